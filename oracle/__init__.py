@@ -1,0 +1,268 @@
+"""CPU oracle for the PointRCNN point-ops hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package.  The product (``pointrcnn_amd``) never does: it fails loudly when its HIP library is missing.
+
+``oracle.cpu``  -- numpy front-end of ``libprcnn_oracle.so`` (``prcnn_oracle.c``: plain-C restatement of
+                   every operator on the path, each citing the reference file:line it follows).
+``oracle.ref``  -- numpy front-end of ``_ref/libprcnn_ref.so`` (the reference's OWN iou3d / roipool3d
+                   sources compiled for the host, see ``build_ref.py``); ``None`` when not built.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_F = ctypes.POINTER(ctypes.c_float)
+_I = ctypes.POINTER(ctypes.c_int32)
+_L = ctypes.POINTER(ctypes.c_int64)
+_U = ctypes.POINTER(ctypes.c_uint64)
+
+
+def build(force=False):
+    """Compile the C restatement (and oracle/_ref when /root/reference is present)."""
+    so = os.path.join(_HERE, "libprcnn_oracle.so")
+    src = os.path.join(_HERE, "prcnn_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "libprcnn_oracle.so"], check=True, stdout=subprocess.DEVNULL)
+    ref_so = os.path.join(_HERE, "_ref", "libprcnn_ref.so")
+    from . import build_ref
+    if build_ref.have_reference() and (force or not os.path.exists(ref_so)):
+        build_ref.build(verbose=False)
+    return so
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class _Cpu:
+    """numpy wrappers around prcnn_cpu_* (shapes follow the reference op surface)."""
+
+    def __init__(self):
+        build()
+        self.lib = ctypes.CDLL(os.path.join(_HERE, "libprcnn_oracle.so"))
+        self.lib.prcnn_cpu_nms.restype = ctypes.c_int
+
+    # ---- PointNet++ ops ----
+    def fps(self, xyz, npoint):
+        xyz = _f32(xyz)
+        B, N, _ = xyz.shape
+        idx = np.zeros((B, npoint), np.int32)
+        self.lib.prcnn_cpu_fps(_p(xyz, _F), B, N, npoint, None, _p(idx, _I))
+        return idx
+
+    def gather(self, feat, idx):
+        feat, idx = _f32(feat), _i32(idx)
+        B, C, N = feat.shape
+        M = idx.shape[1]
+        out = np.zeros((B, C, M), np.float32)
+        self.lib.prcnn_cpu_gather(_p(feat, _F), _p(idx, _I), B, C, N, M, _p(out, _F))
+        return out
+
+    def gather_grad(self, grad_out, idx, N):
+        grad_out, idx = _f32(grad_out), _i32(idx)
+        B, C, M = grad_out.shape
+        out = np.zeros((B, C, N), np.float32)
+        self.lib.prcnn_cpu_gather_grad(_p(grad_out, _F), _p(idx, _I), B, C, N, M, _p(out, _F))
+        return out
+
+    def ball_query(self, radius, nsample, xyz, new_xyz):
+        xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+        B, N, _ = xyz.shape
+        M = new_xyz.shape[1]
+        idx = np.zeros((B, M, nsample), np.int32)
+        self.lib.prcnn_cpu_ball_query(_p(xyz, _F), _p(new_xyz, _F), B, N, M, ctypes.c_float(radius), nsample,
+                                      _p(idx, _I))
+        return idx
+
+    def group(self, feat, idx):
+        feat, idx = _f32(feat), _i32(idx)
+        B, C, N = feat.shape
+        _, M, ns = idx.shape
+        out = np.zeros((B, C, M, ns), np.float32)
+        self.lib.prcnn_cpu_group(_p(feat, _F), _p(idx, _I), B, C, N, M, ns, _p(out, _F))
+        return out
+
+    def group_grad(self, grad_out, idx, N):
+        grad_out, idx = _f32(grad_out), _i32(idx)
+        B, C, M, ns = grad_out.shape
+        out = np.zeros((B, C, N), np.float32)
+        self.lib.prcnn_cpu_group_grad(_p(grad_out, _F), _p(idx, _I), B, C, N, M, ns, _p(out, _F))
+        return out
+
+    def three_nn(self, unknown, known):
+        """returns (dist2 (B,n,3), idx (B,n,3)); the op surface returns sqrt(dist2)."""
+        unknown, known = _f32(unknown), _f32(known)
+        B, n, _ = unknown.shape
+        m = known.shape[1]
+        d2 = np.zeros((B, n, 3), np.float32)
+        idx = np.zeros((B, n, 3), np.int32)
+        self.lib.prcnn_cpu_three_nn(_p(unknown, _F), _p(known, _F), B, n, m, _p(d2, _F), _p(idx, _I))
+        return d2, idx
+
+    def three_weights(self, dist2):
+        dist2 = _f32(dist2)
+        w = np.zeros_like(dist2)
+        self.lib.prcnn_cpu_three_weights(_p(dist2, _F), dist2.size // 3, _p(w, _F))
+        return w
+
+    def three_interp(self, feat, idx, w):
+        feat, idx, w = _f32(feat), _i32(idx), _f32(w)
+        B, C, m = feat.shape
+        n = idx.shape[1]
+        out = np.zeros((B, C, n), np.float32)
+        self.lib.prcnn_cpu_three_interp(_p(feat, _F), _p(idx, _I), _p(w, _F), B, C, m, n, _p(out, _F))
+        return out
+
+    def three_interp_grad(self, grad_out, idx, w, m):
+        grad_out, idx, w = _f32(grad_out), _i32(idx), _f32(w)
+        B, C, n = grad_out.shape
+        out = np.zeros((B, C, m), np.float32)
+        self.lib.prcnn_cpu_three_interp_grad(_p(grad_out, _F), _p(idx, _I), _p(w, _F), B, C, n, m, _p(out, _F))
+        return out
+
+    def linear_rows(self, a, w, bias=None, relu=False):
+        """a (R,K), w (Nout,K) [torch conv weight layout], bias (Nout) -> (R,Nout); double accumulation."""
+        a, w = _f32(a), _f32(w)
+        R, K = a.shape
+        Nout = w.shape[0]
+        out = np.zeros((R, Nout), np.float32)
+        b = _f32(bias) if bias is not None else None
+        self.lib.prcnn_cpu_linear_rows(_p(a, _F), _p(w, _F), _p(b, _F) if b is not None else None, R, K, Nout,
+                                       int(relu), _p(out, _F))
+        return out
+
+    # ---- roipool3d ----
+    def pts_in_boxes3d(self, pts, boxes3d, trig_mode=1):
+        pts, boxes3d = _f32(pts), _f32(boxes3d)
+        N, M = pts.shape[0], boxes3d.shape[0]
+        flags = np.zeros((M, N), np.int64)
+        self.lib.prcnn_cpu_pts_in_boxes3d(_p(pts, _F), _p(boxes3d, _F), N, M, trig_mode, _p(flags, _L))
+        return flags
+
+    def roipool3d(self, xyz, boxes3d, feat, S, trig_mode=1):
+        """boxes already enlarged.  -> pooled (B,M,S,3+C) f32, empty (B,M) i32"""
+        xyz, boxes3d, feat = _f32(xyz), _f32(boxes3d), _f32(feat)
+        B, N, _ = xyz.shape
+        M, C = boxes3d.shape[1], feat.shape[2]
+        out = np.zeros((B, M, S, 3 + C), np.float32)
+        empty = np.zeros((B, M), np.int32)
+        self.lib.prcnn_cpu_roipool3d(_p(xyz, _F), _p(boxes3d, _F), _p(feat, _F), B, N, M, C, S, trig_mode,
+                                     _p(out, _F), _p(empty, _I))
+        return out, empty
+
+    # ---- iou3d ----
+    def boxes_overlap_bev(self, a, b, trig_mode=1):
+        a, b = _f32(a), _f32(b)
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        self.lib.prcnn_cpu_boxes_overlap_bev(_p(a, _F), a.shape[0], _p(b, _F), b.shape[0], trig_mode, _p(out, _F))
+        return out
+
+    def boxes_iou_bev(self, a, b, trig_mode=1):
+        a, b = _f32(a), _f32(b)
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        self.lib.prcnn_cpu_boxes_iou_bev(_p(a, _F), a.shape[0], _p(b, _F), b.shape[0], trig_mode, _p(out, _F))
+        return out
+
+    def nms(self, boxes_sorted, thresh, kind="rotated", trig_mode=1):
+        """boxes already sorted by descending score -> kept positions (int64)"""
+        boxes = _f32(boxes_sorted)
+        keep = np.zeros((boxes.shape[0],), np.int64)
+        n = self.lib.prcnn_cpu_nms(_p(boxes, _F), boxes.shape[0], ctypes.c_float(thresh),
+                                   0 if kind == "rotated" else 1, trig_mode, _p(keep, _L))
+        return keep[:n].copy()
+
+    def nms_mask(self, boxes_sorted, thresh, kind="rotated", trig_mode=1):
+        boxes = _f32(boxes_sorted)
+        N = boxes.shape[0]
+        mask = np.zeros((N, (N + 63) // 64), np.uint64)
+        self.lib.prcnn_cpu_nms_mask(_p(boxes, _F), N, ctypes.c_float(thresh), 0 if kind == "rotated" else 1,
+                                    trig_mode, _p(mask, _U))
+        return mask
+
+
+class _Ref:
+    """numpy wrappers around the reference's own functions compiled for the host (oracle/_ref)."""
+
+    def __init__(self, so):
+        self.lib = ctypes.CDLL(so)
+
+    def boxes_overlap_bev(self, a, b):
+        a, b = _f32(a), _f32(b)
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        self.lib.ref_boxes_overlap_bev(_p(a, _F), a.shape[0], _p(b, _F), b.shape[0], _p(out, _F))
+        return out
+
+    def boxes_iou_bev(self, a, b):
+        a, b = _f32(a), _f32(b)
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        self.lib.ref_boxes_iou_bev(_p(a, _F), a.shape[0], _p(b, _F), b.shape[0], _p(out, _F))
+        return out
+
+    def nms(self, boxes_sorted, thresh, kind="rotated"):
+        boxes = _f32(boxes_sorted)
+        keep = np.zeros((boxes.shape[0],), np.int64)
+        fn = self.lib.ref_nms if kind == "rotated" else self.lib.ref_nms_normal
+        n = fn(_p(boxes, _F), boxes.shape[0], ctypes.c_float(thresh), _p(keep, _L))
+        return keep[:n].copy()
+
+    def roipool3d_gpu(self, xyz, boxes3d, feat, S, slow=False):
+        xyz, boxes3d, feat = _f32(xyz), _f32(boxes3d), _f32(feat)
+        B, N, _ = xyz.shape
+        M, C = boxes3d.shape[1], feat.shape[2]
+        out = np.zeros((B, M, S, 3 + C), np.float32)
+        empty = np.zeros((B, M), np.int32)
+        self.lib.ref_roipool3d_gpu(_p(xyz, _F), _p(boxes3d, _F), _p(feat, _F), B, N, M, C, S, _p(out, _F),
+                                   _p(empty, _I), int(slow))
+        return out, empty
+
+    def pts_in_boxes3d_cpu(self, pts, boxes3d):
+        pts, boxes3d = _f32(pts), _f32(boxes3d)
+        N, M = pts.shape[0], boxes3d.shape[0]
+        flags = np.zeros((M, N), np.int64)
+        self.lib.ref_pts_in_boxes3d_cpu(_p(flags, _L), _p(pts, _F), _p(boxes3d, _F), N, M)
+        return flags
+
+    def roipool3d_cpu(self, pts, boxes3d, feat, S):
+        pts, boxes3d, feat = _f32(pts), _f32(boxes3d), _f32(feat)
+        N, M, C = pts.shape[0], boxes3d.shape[0], feat.shape[1]
+        pp = np.zeros((M, S, 3), np.float32)
+        pf = np.zeros((M, S, C), np.float32)
+        empty = np.zeros((M,), np.int64)
+        self.lib.ref_roipool3d_cpu(_p(pts, _F), _p(boxes3d, _F), _p(feat, _F), N, M, C, S, _p(pp, _F), _p(pf, _F),
+                                   _p(empty, _L))
+        return pp, pf, empty
+
+
+_cpu = None
+_ref = None
+
+
+def cpu():
+    global _cpu
+    if _cpu is None:
+        _cpu = _Cpu()
+    return _cpu
+
+
+def ref():
+    """reference-compiled functions, or None when oracle/_ref has not been built."""
+    global _ref
+    if _ref is None:
+        build()
+        so = os.path.join(_HERE, "_ref", "libprcnn_ref.so")
+        if not os.path.exists(so):
+            return None
+        _ref = _Ref(so)
+    return _ref

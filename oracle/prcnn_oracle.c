@@ -1,0 +1,527 @@
+/*
+ * prcnn_oracle.c -- CPU ORACLE for the PointRCNN point-ops hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product path (pointrcnn_amd/) never imports, links or calls anything here.
+ *
+ * Every function restates, single-threaded and in plain C, the algorithm of
+ * one operator on the reference's hot path, citing the reference file:line it
+ * follows (paths relative to the reference checkout).  Build (see Makefile):
+ *     gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC prcnn_oracle.c -lm
+ * -ffp-contract=off matters: every fp32 product/sum below is individually
+ * rounded (no FMA), which is the arithmetic contract the HIP kernels follow.
+ *
+ * PARITY PINNING STATUS
+ *   roipool3d / pts_in_boxes3d : PINNED -- checked bit-for-bit against the
+ *       reference's own lib/utils/roipool3d/src/roipool3d.cpp compiled in
+ *       place (oracle/_ref, tests/test_oracle_vs_ref.py) and via golden
+ *       fixtures generated from it (tests/golden/).
+ *   iou3d (overlap / iou / nms): PINNED -- checked against the reference's
+ *       lib/utils/iou3d/src/iou3d_kernel.cu device functions compiled for the
+ *       host (oracle/_ref, trig_mode 0 == bit-exact) and golden fixtures.
+ *   PointNet++ ops (fps, ball_query, group, gather, three_nn,
+ *       three_interpolate, per-point MLP): PARITY UNPINNED -- the reference
+ *       vendors them as an EMPTY git submodule (.gitmodules:1-4,
+ *       sshaoshuai/Pointnet2.PyTorch, SHA unrecoverable).  The functions below
+ *       restate the published algorithm under the canonical rules of SURVEY.md
+ *       Appendix A, constrained by the reference call sites
+ *       (lib/net/pointnet2_msg.py:27-34,44,61,66-68; lib/net/rcnn_net.py:33-41).
+ *
+ * trig_mode (roipool3d / iou3d):
+ *   0 = "reference libm": cosf/sinf/atan2f exactly as the reference source
+ *       spells them -- used to pin this restatement against oracle/_ref.
+ *   1 = "canonical": cos/sin evaluated in double and rounded once to float,
+ *       polygon vertices ordered by a division-only monotone surrogate of
+ *       atan2 -- the contract the HIP kernels implement bit-for-bit (device
+ *       libm differs from glibc by ULPs, so mode 0 cannot be bit-exact on a
+ *       GPU; mode 1 can).  Mode 0 vs mode 1 agree to ~1e-6 relative.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PRCNN_EXPORT __attribute__((visibility("default")))
+
+static inline float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    /* three rounded products summed left to right, no FMA. */
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    float s = xx + yy;
+    return s + zz;
+}
+
+/* ------------------------------------------------------------------ *
+ * A.1 furthest_point_sample  [UPSTREAM pointnet2 sampling kernel; call
+ * sites lib/net/pointnet2_msg.py:27-34 via PointnetSAModuleMSG]
+ * xyz (B,N,3) f32 -> idx (B,npoint) i32.  tmp (B,N) scratch or NULL.
+ * start index 0, temp=1e10, tie -> lowest point index.
+ * ------------------------------------------------------------------ */
+PRCNN_EXPORT void prcnn_cpu_fps(const float* xyz, int B, int N, int npoint, float* tmp, int* idx) {
+    float* own = NULL;
+    if (!tmp) { own = (float*)malloc(sizeof(float) * (size_t)B * N); tmp = own; }
+    for (int b = 0; b < B; b++) {
+        const float* p = xyz + (size_t)b * N * 3;
+        float* t = tmp + (size_t)b * N;
+        int* o = idx + (size_t)b * npoint;
+        for (int k = 0; k < N; k++) t[k] = 1e10f;
+        if (npoint <= 0) continue;
+        int old = 0;
+        o[0] = 0;
+        for (int j = 1; j < npoint; j++) {
+            float x0 = p[old * 3], y0 = p[old * 3 + 1], z0 = p[old * 3 + 2];
+            float best = -1.0f;
+            int besti = 0;
+            for (int k = 0; k < N; k++) {
+                float d = sqdist3(p[k * 3], p[k * 3 + 1], p[k * 3 + 2], x0, y0, z0);
+                float v = d < t[k] ? d : t[k];
+                t[k] = v;
+                if (v > best) { best = v; besti = k; }
+            }
+            o[j] = besti;
+            old = besti;
+        }
+    }
+    free(own);
+}
+
+/* A.2 gather_operation: out[b,c,m] = feat[b,c,idx[b,m]] */
+PRCNN_EXPORT void prcnn_cpu_gather(const float* feat, const int* idx, int B, int C, int N, int M, float* out) {
+    for (int b = 0; b < B; b++)
+        for (int c = 0; c < C; c++)
+            for (int m = 0; m < M; m++)
+                out[((size_t)b * C + c) * M + m] = feat[((size_t)b * C + c) * N + idx[(size_t)b * M + m]];
+}
+
+/* A.2 backward: scatter-add of grad_out (B,C,M) into grad_feat (B,C,N) (pre-zeroed by caller) */
+PRCNN_EXPORT void prcnn_cpu_gather_grad(const float* grad_out, const int* idx, int B, int C, int N, int M, float* grad_feat) {
+    for (int b = 0; b < B; b++)
+        for (int c = 0; c < C; c++)
+            for (int m = 0; m < M; m++)
+                grad_feat[((size_t)b * C + c) * N + idx[(size_t)b * M + m]] += grad_out[((size_t)b * C + c) * M + m];
+}
+
+/* A.3 ball_query: first <=nsample points with d2 < r2 in ascending index order,
+ * padded with the first hit; no hit -> zeros. */
+PRCNN_EXPORT void prcnn_cpu_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M,
+                                       float radius, int nsample, int* idx) {
+    float r2 = radius * radius;
+    for (int b = 0; b < B; b++) {
+        const float* p = xyz + (size_t)b * N * 3;
+        for (int m = 0; m < M; m++) {
+            const float* q = new_xyz + ((size_t)b * M + m) * 3;
+            int* o = idx + ((size_t)b * M + m) * nsample;
+            for (int s = 0; s < nsample; s++) o[s] = 0;
+            int cnt = 0;
+            for (int k = 0; k < N && cnt < nsample; k++) {
+                float d2 = sqdist3(q[0], q[1], q[2], p[k * 3], p[k * 3 + 1], p[k * 3 + 2]);
+                if (d2 < r2) {
+                    if (cnt == 0)
+                        for (int s = 0; s < nsample; s++) o[s] = k;
+                    o[cnt] = k;
+                    cnt++;
+                }
+            }
+        }
+    }
+}
+
+/* A.4 grouping_operation: out[b,c,m,s] = feat[b,c,idx[b,m,s]] */
+PRCNN_EXPORT void prcnn_cpu_group(const float* feat, const int* idx, int B, int C, int N, int M, int ns, float* out) {
+    for (int b = 0; b < B; b++)
+        for (int c = 0; c < C; c++)
+            for (int m = 0; m < M; m++)
+                for (int s = 0; s < ns; s++)
+                    out[(((size_t)b * C + c) * M + m) * ns + s] =
+                        feat[((size_t)b * C + c) * N + idx[((size_t)b * M + m) * ns + s]];
+}
+
+PRCNN_EXPORT void prcnn_cpu_group_grad(const float* grad_out, const int* idx, int B, int C, int N, int M, int ns,
+                                       float* grad_feat) {
+    for (int b = 0; b < B; b++)
+        for (int c = 0; c < C; c++)
+            for (int m = 0; m < M; m++)
+                for (int s = 0; s < ns; s++)
+                    grad_feat[((size_t)b * C + c) * N + idx[((size_t)b * M + m) * ns + s]] +=
+                        grad_out[(((size_t)b * C + c) * M + m) * ns + s];
+}
+
+/* A.5 three_nn: 3 smallest squared distances, strict '<' insertion (ties keep earlier k).
+ * Returns SQUARED distances (the Python wrapper takes the sqrt, as upstream does). */
+PRCNN_EXPORT void prcnn_cpu_three_nn(const float* unknown, const float* known, int B, int n, int m,
+                                     float* dist2, int* idx) {
+    for (int b = 0; b < B; b++) {
+        const float* kn = known + (size_t)b * m * 3;
+        for (int i = 0; i < n; i++) {
+            const float* u = unknown + ((size_t)b * n + i) * 3;
+            float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+            int i1 = 0, i2 = 0, i3 = 0;
+            for (int k = 0; k < m; k++) {
+                float d = sqdist3(u[0], u[1], u[2], kn[k * 3], kn[k * 3 + 1], kn[k * 3 + 2]);
+                if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+                else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+                else if (d < b3) { b3 = d; i3 = k; }
+            }
+            float* od = dist2 + ((size_t)b * n + i) * 3;
+            int* oi = idx + ((size_t)b * n + i) * 3;
+            od[0] = b1; od[1] = b2; od[2] = b3;
+            oi[0] = i1; oi[1] = i2; oi[2] = i3;
+        }
+    }
+}
+
+/* A.6 three_interpolate: out[b,c,i] = (w0*f[i0] + w1*f[i1]) + w2*f[i2] */
+PRCNN_EXPORT void prcnn_cpu_three_interp(const float* feat, const int* idx, const float* w, int B, int C, int m, int n,
+                                         float* out) {
+    for (int b = 0; b < B; b++)
+        for (int c = 0; c < C; c++) {
+            const float* f = feat + ((size_t)b * C + c) * m;
+            for (int i = 0; i < n; i++) {
+                const int* ii = idx + ((size_t)b * n + i) * 3;
+                const float* ww = w + ((size_t)b * n + i) * 3;
+                float a0 = ww[0] * f[ii[0]], a1 = ww[1] * f[ii[1]], a2 = ww[2] * f[ii[2]];
+                float s = a0 + a1;
+                out[((size_t)b * C + c) * n + i] = s + a2;
+            }
+        }
+}
+
+PRCNN_EXPORT void prcnn_cpu_three_interp_grad(const float* grad_out, const int* idx, const float* w, int B, int C, int n,
+                                              int m, float* grad_feat) {
+    for (int b = 0; b < B; b++)
+        for (int c = 0; c < C; c++)
+            for (int i = 0; i < n; i++) {
+                const int* ii = idx + ((size_t)b * n + i) * 3;
+                const float* ww = w + ((size_t)b * n + i) * 3;
+                float g = grad_out[((size_t)b * C + c) * n + i];
+                float* gf = grad_feat + ((size_t)b * C + c) * m;
+                gf[ii[0]] += g * ww[0];
+                gf[ii[1]] += g * ww[1];
+                gf[ii[2]] += g * ww[2];
+            }
+}
+
+/* FP-module interpolation weights: w = 1/(sqrt(d2)+1e-8), normalised. */
+PRCNN_EXPORT void prcnn_cpu_three_weights(const float* dist2, int count, float* w) {
+    for (int i = 0; i < count; i++) {
+        float r0 = 1.0f / (sqrtf(dist2[i * 3]) + 1e-8f);
+        float r1 = 1.0f / (sqrtf(dist2[i * 3 + 1]) + 1e-8f);
+        float r2 = 1.0f / (sqrtf(dist2[i * 3 + 2]) + 1e-8f);
+        float s = r0 + r1;
+        s = s + r2;
+        w[i * 3] = r0 / s; w[i * 3 + 1] = r1 / s; w[i * 3 + 2] = r2 / s;
+    }
+}
+
+/* Per-point MLP layer on row-major rows (channels-last): out[r,n] = act(sum_k a[r,k]*w[n,k] + bias[n]).
+ * Accumulated in DOUBLE: this is the "true value" the fp32-MFMA kernel is compared to with a
+ * tolerance (the kernel sums in a different k order, so bit-exactness is not the contract here). */
+PRCNN_EXPORT void prcnn_cpu_linear_rows(const float* a, const float* w, const float* bias, int R, int K, int Nout,
+                                        int relu, float* out) {
+    for (int r = 0; r < R; r++)
+        for (int n = 0; n < Nout; n++) {
+            double acc = bias ? (double)bias[n] : 0.0;
+            const float* ar = a + (size_t)r * K;
+            const float* wr = w + (size_t)n * K;
+            for (int k = 0; k < K; k++) acc += (double)ar[k] * (double)wr[k];
+            float v = (float)acc;
+            if (relu && v < 0.0f) v = 0.0f;
+            out[(size_t)r * Nout + n] = v;
+        }
+}
+
+/* ------------------------------------------------------------------ *
+ * roipool3d  (lib/utils/roipool3d/src/roipool3d.cpp:82-195 is the
+ * authoritative CPU code; GPU twin roipool3d_kernel.cu:14-28,97-194)
+ * ------------------------------------------------------------------ */
+static void box_trig(float angle, int trig_mode, float* cosa, float* sina) {
+    if (trig_mode == 0) { *cosa = cosf(angle); *sina = sinf(angle); }      /* roipool3d.cpp:89 */
+    else { *cosa = (float)cos((double)angle); *sina = (float)sin((double)angle); }
+}
+
+/* roipool3d.cpp:82-95 pt_in_box3d_cpu */
+static int pt_in_box3d(float x, float y, float z, float cx, float bottom_y, float cz, float h, float w, float l,
+                       float cosa, float sina) {
+    float max_dis = 10.0f, x_rot, z_rot, cy;
+    cy = (float)((double)bottom_y - (double)h / 2.0);
+    if ((fabsf(x - cx) > max_dis) || ((double)fabsf(y - cy) > (double)h / 2.0) || (fabsf(z - cz) > max_dis)) return 0;
+    {
+        float dx = x - cx, dz = z - cz;
+        float a = dx * cosa, b = dz * (-sina);
+        x_rot = a + b;
+        a = dx * sina; b = dz * cosa;
+        z_rot = a + b;
+    }
+    return ((double)x_rot >= -(double)l / 2.0) & ((double)x_rot <= (double)l / 2.0) &
+           ((double)z_rot >= -(double)w / 2.0) & ((double)z_rot <= (double)w / 2.0);
+}
+
+/* roipool3d.cpp:97-125 pts_in_boxes3d_cpu: flags (M,N) int64 */
+PRCNN_EXPORT void prcnn_cpu_pts_in_boxes3d(const float* pts, const float* boxes3d, int N, int M, int trig_mode,
+                                           int64_t* flags) {
+    for (int i = 0; i < M; i++) {
+        const float* bx = boxes3d + (size_t)i * 7;
+        float ca, sa;
+        box_trig(bx[6], trig_mode, &ca, &sa);
+        for (int j = 0; j < N; j++)
+            flags[(size_t)i * N + j] =
+                pt_in_box3d(pts[j * 3], pts[j * 3 + 1], pts[j * 3 + 2], bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], ca, sa);
+    }
+}
+
+/* Batched pooling with the GPU op's output layout (roipool3d_kernel.cu:97-194 ==
+ * roipool3d.cpp:127-195 semantics): out (B,M,S,3+C) f32 pre-zeroed, empty (B,M) i32.
+ * boxes are ALREADY enlarged (roipool3d_utils.py:19). */
+PRCNN_EXPORT void prcnn_cpu_roipool3d(const float* xyz, const float* boxes3d, const float* feat, int B, int N, int M,
+                                      int C, int S, int trig_mode, float* out, int* empty) {
+    int* sel = (int*)malloc(sizeof(int) * (size_t)(S > 0 ? S : 1));
+    for (int b = 0; b < B; b++)
+        for (int m = 0; m < M; m++) {
+            const float* bx = boxes3d + ((size_t)b * M + m) * 7;
+            const float* p = xyz + (size_t)b * N * 3;
+            float ca, sa;
+            box_trig(bx[6], trig_mode, &ca, &sa);
+            int cnt = 0;
+            for (int k = 0; k < N && cnt < S; k++)
+                if (pt_in_box3d(p[k * 3], p[k * 3 + 1], p[k * 3 + 2], bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], ca, sa))
+                    sel[cnt++] = k;
+            float* o = out + ((size_t)b * M + m) * S * (3 + C);
+            if (cnt == 0) {
+                empty[(size_t)b * M + m] = 1;
+                memset(o, 0, sizeof(float) * (size_t)S * (3 + C));
+                continue;
+            }
+            empty[(size_t)b * M + m] = 0;
+            for (int s = 0; s < S; s++) {
+                int k = sel[s < cnt ? s : s % cnt];
+                float* row = o + (size_t)s * (3 + C);
+                row[0] = p[k * 3]; row[1] = p[k * 3 + 1]; row[2] = p[k * 3 + 2];
+                memcpy(row + 3, feat + ((size_t)b * N + k) * C, sizeof(float) * C);
+            }
+        }
+    free(sel);
+}
+
+/* ------------------------------------------------------------------ *
+ * iou3d  (lib/utils/iou3d/src/iou3d_kernel.cu:14-303)
+ * ------------------------------------------------------------------ */
+typedef struct { float x, y; } pt2;
+
+static inline float cross2(pt2 a, pt2 b) {                 /* iou3d_kernel.cu:34-36 */
+    float u = a.x * b.y, v = a.y * b.x;
+    return u - v;
+}
+static inline float cross3(pt2 p1, pt2 p2, pt2 p0) {       /* iou3d_kernel.cu:38-40 */
+    float a = (p1.x - p0.x) * (p2.y - p0.y);
+    float b = (p2.x - p0.x) * (p1.y - p0.y);
+    return a - b;
+}
+static inline float fmin2(float a, float b) { return a < b ? a : b; }   /* CUDA min/max(float,float) */
+static inline float fmax2(float a, float b) { return a > b ? a : b; }
+
+static int check_rect_cross(pt2 p1, pt2 p2, pt2 q1, pt2 q2) {           /* iou3d_kernel.cu:42-48 */
+    return fmin2(p1.x, p2.x) <= fmax2(q1.x, q2.x) && fmin2(q1.x, q2.x) <= fmax2(p1.x, p2.x) &&
+           fmin2(p1.y, p2.y) <= fmax2(q1.y, q2.y) && fmin2(q1.y, q2.y) <= fmax2(p1.y, p2.y);
+}
+
+/* iou3d_kernel.cu:50-65 check_in_box2d; (c,s) = (cos(-angle), sin(-angle)) */
+static int check_in_box2d(const float* box, pt2 p, float c, float s) {
+    const float MARGIN = 1e-5f;
+    float center_x = (box[0] + box[2]) / 2, center_y = (box[1] + box[3]) / 2;
+    float dx = p.x - center_x, dy = p.y - center_y;
+    float t0 = dx * c, t1 = dy * s;
+    float rot_x = (t0 + t1) + center_x;
+    float t2 = (-dx) * s, t3 = dy * c;
+    float rot_y = (t2 + t3) + center_y;
+    return (rot_x > box[0] - MARGIN && rot_x < box[2] + MARGIN && rot_y > box[1] - MARGIN && rot_y < box[3] + MARGIN);
+}
+
+/* iou3d_kernel.cu:67-96 intersection */
+static int seg_intersection(pt2 p1, pt2 p0, pt2 q1, pt2 q0, pt2* ans) {
+    const float EPS = 1e-8f;
+    if (check_rect_cross(p0, p1, q0, q1) == 0) return 0;
+    float s1 = cross3(q0, p1, p0), s2 = cross3(p1, q1, p0), s3 = cross3(p0, q1, q0), s4 = cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+    float s5 = cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > EPS) {
+        float a = s5 * q0.x, b = s1 * q1.x;
+        ans->x = (a - b) / (s5 - s1);
+        a = s5 * q0.y; b = s1 * q1.y;
+        ans->y = (a - b) / (s5 - s1);
+    } else {
+        float a0 = p0.y - p1.y, b0 = p1.x - p0.x;
+        float u = p0.x * p1.y, v = p1.x * p0.y;
+        float c0 = u - v;
+        float a1 = q0.y - q1.y, b1 = q1.x - q0.x;
+        u = q0.x * q1.y; v = q1.x * q0.y;
+        float c1 = u - v;
+        u = a0 * b1; v = a1 * b0;
+        float D = u - v;
+        u = b0 * c1; v = b1 * c0;
+        ans->x = (u - v) / D;
+        u = a1 * c0; v = a0 * c1;
+        ans->y = (u - v) / D;
+    }
+    return 1;
+}
+
+/* iou3d_kernel.cu:98-102 rotate_around_center */
+static pt2 rotate_around_center(pt2 center, float c, float s, pt2 p) {
+    float dx = p.x - center.x, dy = p.y - center.y;
+    float t0 = dx * c, t1 = dy * s;
+    float nx = (t0 + t1) + center.x;
+    float t2 = (-dx) * s, t3 = dy * c;
+    float ny = (t2 + t3) + center.y;
+    pt2 r = { nx, ny };
+    return r;
+}
+
+/* canonical ordering key: strictly increasing in atan2(dy,dx) over (-pi, pi], IEEE +,-,/ only */
+static float angle_key(float dx, float dy) {
+    float ax = fabsf(dx), ay = fabsf(dy);
+    float s = ax + ay;
+    if (!(s > 0.0f)) return 0.0f;
+    float t = dy / s;
+    if (dx >= 0.0f) return t;
+    return dy >= 0.0f ? 2.0f - t : -2.0f - t;
+}
+
+static void iou_trig(float angle, int trig_mode, float* c, float* s) {
+    if (trig_mode == 0) { *c = cosf(angle); *s = sinf(angle); }             /* iou3d_kernel.cu:135-136 */
+    else { *c = (float)cos((double)angle); *s = (float)sin((double)angle); }
+}
+
+/* iou3d_kernel.cu:108-212 box_overlap */
+static float box_overlap(const float* box_a, const float* box_b, int trig_mode) {
+    float a_x1 = box_a[0], a_y1 = box_a[1], a_x2 = box_a[2], a_y2 = box_a[3], a_angle = box_a[4];
+    float b_x1 = box_b[0], b_y1 = box_b[1], b_x2 = box_b[2], b_y2 = box_b[3], b_angle = box_b[4];
+    pt2 center_a = { (a_x1 + a_x2) / 2, (a_y1 + a_y2) / 2 };
+    pt2 center_b = { (b_x1 + b_x2) / 2, (b_y1 + b_y2) / 2 };
+    pt2 A[5] = { { a_x1, a_y1 }, { a_x2, a_y1 }, { a_x2, a_y2 }, { a_x1, a_y2 } };
+    pt2 Bc[5] = { { b_x1, b_y1 }, { b_x2, b_y1 }, { b_x2, b_y2 }, { b_x1, b_y2 } };
+    float ac, as, bc, bs, acn, asn, bcn, bsn;
+    iou_trig(a_angle, trig_mode, &ac, &as);
+    iou_trig(b_angle, trig_mode, &bc, &bs);
+    if (trig_mode == 0) {   /* check_in_box2d evaluates cos(-angle), sin(-angle) itself (iou3d_kernel.cu:56) */
+        acn = cosf(-a_angle); asn = sinf(-a_angle); bcn = cosf(-b_angle); bsn = sinf(-b_angle);
+    } else {
+        acn = ac; asn = -as; bcn = bc; bsn = -bs;
+    }
+    for (int k = 0; k < 4; k++) {
+        A[k] = rotate_around_center(center_a, ac, as, A[k]);
+        Bc[k] = rotate_around_center(center_b, bc, bs, Bc[k]);
+    }
+    A[4] = A[0];
+    Bc[4] = Bc[0];
+
+    pt2 cp[24];            /* the reference declares 16 (iou3d_kernel.cu:154); 24 = hard upper bound 16+8, avoids UB */
+    pt2 poly_center = { 0, 0 };
+    int cnt = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            if (seg_intersection(A[i + 1], A[i], Bc[j + 1], Bc[j], &cp[cnt])) {
+                poly_center.x = poly_center.x + cp[cnt].x;
+                poly_center.y = poly_center.y + cp[cnt].y;
+                cnt++;
+            }
+    for (int k = 0; k < 4; k++) {
+        if (check_in_box2d(box_a, Bc[k], acn, asn)) {
+            poly_center.x = poly_center.x + Bc[k].x; poly_center.y = poly_center.y + Bc[k].y;
+            cp[cnt++] = Bc[k];
+        }
+        if (check_in_box2d(box_b, A[k], bcn, bsn)) {
+            poly_center.x = poly_center.x + A[k].x; poly_center.y = poly_center.y + A[k].y;
+            cp[cnt++] = A[k];
+        }
+    }
+    if (cnt == 0) return 0.0f;     /* reference: 0/0 centre, empty loops, area 0 (iou3d_kernel.cu:184-211) */
+    poly_center.x /= cnt;
+    poly_center.y /= cnt;
+
+    float key[24];
+    for (int i = 0; i < cnt; i++) {
+        float dy = cp[i].y - poly_center.y, dx = cp[i].x - poly_center.x;
+        key[i] = trig_mode == 0 ? atan2f(dy, dx) : angle_key(dx, dy);      /* iou3d_kernel.cu:104-106 */
+    }
+    for (int j = 0; j < cnt - 1; j++)                                        /* iou3d_kernel.cu:188-196 */
+        for (int i = 0; i < cnt - j - 1; i++)
+            if (key[i] > key[i + 1]) {
+                pt2 t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
+                float tk = key[i]; key[i] = key[i + 1]; key[i + 1] = tk;
+            }
+    float area = 0;
+    for (int k = 0; k < cnt - 1; k++) {                                      /* iou3d_kernel.cu:206-211 */
+        pt2 u = { cp[k].x - cp[0].x, cp[k].y - cp[0].y };
+        pt2 v = { cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y };
+        area += cross2(u, v);
+    }
+    return fabsf(area) / 2.0f;
+}
+
+static float iou_bev(const float* a, const float* b, int trig_mode) {      /* iou3d_kernel.cu:214-221 */
+    float sa = (a[2] - a[0]) * (a[3] - a[1]);
+    float sb = (b[2] - b[0]) * (b[3] - b[1]);
+    float s_overlap = box_overlap(a, b, trig_mode);
+    return s_overlap / fmaxf(sa + sb - s_overlap, 1e-8f);
+}
+
+static float iou_normal(const float* a, const float* b) {                  /* iou3d_kernel.cu:295-303 */
+    float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    float interS = width * height;
+    float Sa = (a[2] - a[0]) * (a[3] - a[1]);
+    float Sb = (b[2] - b[0]) * (b[3] - b[1]);
+    return interS / fmaxf(Sa + Sb - interS, 1e-8f);
+}
+
+/* iou3d_kernel.cu:223-234 / iou3d.cpp:31-50 */
+PRCNN_EXPORT void prcnn_cpu_boxes_overlap_bev(const float* a, int Na, const float* b, int Nb, int trig_mode, float* out) {
+    for (int i = 0; i < Na; i++)
+        for (int j = 0; j < Nb; j++) out[(size_t)i * Nb + j] = box_overlap(a + i * 5, b + j * 5, trig_mode);
+}
+/* iou3d_kernel.cu:236-248 / iou3d.cpp:52-71 */
+PRCNN_EXPORT void prcnn_cpu_boxes_iou_bev(const float* a, int Na, const float* b, int Nb, int trig_mode, float* out) {
+    for (int i = 0; i < Na; i++)
+        for (int j = 0; j < Nb; j++) out[(size_t)i * Nb + j] = iou_bev(a + i * 5, b + j * 5, trig_mode);
+}
+
+/* Greedy NMS on boxes ALREADY sorted by descending score (iou3d_utils.py:64-66):
+ * iou3d_kernel.cu:250-292 (mask: row i vs col j>i, strict '>') + iou3d.cpp:100-119 (sweep).
+ * kind 0 = rotated (iou_bev), 1 = normal (iou_normal).  Returns num_to_keep. */
+PRCNN_EXPORT int prcnn_cpu_nms(const float* boxes, int N, float thresh, int kind, int trig_mode, int64_t* keep) {
+    unsigned char* removed = (unsigned char*)calloc((size_t)(N > 0 ? N : 1), 1);
+    int num = 0;
+    for (int i = 0; i < N; i++) {
+        if (removed[i]) continue;
+        keep[num++] = i;
+        for (int j = i + 1; j < N; j++) {
+            if (removed[j]) continue;     /* OR-ing an already set bit is a no-op in the reference sweep */
+            float v = kind == 0 ? iou_bev(boxes + (size_t)i * 5, boxes + (size_t)j * 5, trig_mode)
+                                : iou_normal(boxes + (size_t)i * 5, boxes + (size_t)j * 5);
+            if (v > thresh) removed[j] = 1;
+        }
+    }
+    free(removed);
+    return num;
+}
+
+/* full pairwise mask words exactly as the reference kernel lays them out
+ * (iou3d_kernel.cu:250-292): mask[i*col_blocks + cb] bit t = iou(i, cb*64+t) > thr,
+ * diagonal tile only t > i%64.  Used to pin the HIP mask kernel's upper triangle. */
+PRCNN_EXPORT void prcnn_cpu_nms_mask(const float* boxes, int N, float thresh, int kind, int trig_mode, uint64_t* mask) {
+    int cbn = (N + 63) / 64;
+    for (int i = 0; i < N; i++)
+        for (int cb = 0; cb < cbn; cb++) {
+            uint64_t t = 0;
+            int start = (i / 64 == cb) ? (i % 64) + 1 : 0;
+            for (int tt = start; tt < 64 && cb * 64 + tt < N; tt++) {
+                int j = cb * 64 + tt;
+                float v = kind == 0 ? iou_bev(boxes + (size_t)i * 5, boxes + (size_t)j * 5, trig_mode)
+                                    : iou_normal(boxes + (size_t)i * 5, boxes + (size_t)j * 5);
+                if (v > thresh) t |= 1ULL << tt;
+            }
+            mask[(size_t)i * cbn + cb] = t;
+        }
+}
