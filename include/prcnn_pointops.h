@@ -1,0 +1,174 @@
+/*
+ * prcnn_pointops.h -- C ABI of libprcnn_pointops.so, the MI355X (gfx950) implementation of
+ * PointRCNN's point-ops hot path (PointNet++ set-abstraction / feature-propagation operators,
+ * roipool3d, iou3d).
+ *
+ * This is the drop-in boundary: what the reference binds through its three pybind modules
+ * (`pointnet2_cuda` [un-vendored submodule, .gitmodules:1-4], `iou3d_cuda`
+ * lib/utils/iou3d/src/iou3d.cpp:174-179, `roipool3d_cuda` lib/utils/roipool3d/src/roipool3d.cpp:198-203)
+ * is exactly this set of entry points.  INTEGRATION.md shows the ctypes binding
+ * (pointrcnn_amd/_cabi.py is that binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in `_host`;
+ *   - tensors are dense row-major fp32 / int32 / int64 exactly as the reference op surface lays
+ *     them out; the caller allocates every output (reference: iou3d_utils.py:14,32,68;
+ *     roipool3d_utils.py:21-23); callees keep no reference to any buffer after return;
+ *   - `stream` is a hipStream_t (NULL = the null stream).  All work is enqueued on it and the call
+ *     returns without synchronising (the reference launches on the legacy default stream and
+ *     nms_* blocks on a D2H copy: iou3d.cpp:93-94 -- the sync lives in the Python shim only);
+ *   - return value: 0 on success, <0 on error (never exit(): contrast iou3d.cpp:13-21);
+ *     prcnn_last_error() returns a thread-local message for the last failing call;
+ *   - no global mutable state; every entry point is re-entrant.
+ *
+ * Arithmetic contract (shared bit-for-bit with oracle/prcnn_oracle.c, trig_mode 1):
+ *   squared distances are ((dx*dx + dy*dy) + dz*dz) with individually rounded fp32 operations (no
+ *   FMA); box angles use cos/sin evaluated in double and rounded once to fp32; polygon vertices are
+ *   ordered by a division-only monotone surrogate of atan2.
+ */
+#ifndef PRCNN_POINTOPS_H
+#define PRCNN_POINTOPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* prcnn_stream_t; /* hipStream_t */
+
+#define PRCNN_OK 0
+#define PRCNN_EINVAL (-1)       /* bad argument (shape, null pointer, unsupported size) */
+#define PRCNN_EHIP (-2)         /* HIP runtime / launch failure */
+#define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
+
+int prcnn_abi_version(void);
+const char* prcnn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * PointNet++ operators.  Replace pointnet2_cuda.* [UPSTREAM sshaoshuai/Pointnet2.PyTorch, not in
+ * tree]; reference call sites: lib/net/pointnet2_msg.py:27-34,44,61,66-68, lib/net/rcnn_net.py:33-41.
+ * ------------------------------------------------------------------------------------------- */
+
+/* furthest_point_sampling_wrapper(B,N,npoint,xyz,temp,idx): xyz (B,N,3) -> idx (B,npoint) i32.
+ * Start index 0, ties -> lowest point index.  `tmp` (B,N) f32 scratch is only needed when
+ * N > 16384 (HBM-resident variant); may be NULL otherwise. */
+int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, int32_t* idx, prcnn_stream_t stream);
+
+/* gather_points_wrapper(B,C,N,npoint,feat,idx,out): out[b,c,m] = feat[b,c,idx[b,m]] */
+int prcnn_gather(const float* feat, const int32_t* idx, int B, int C, int N, int M, float* out, prcnn_stream_t stream);
+/* gather_points_grad_wrapper: grad_feat (B,C,N) += scatter(grad_out (B,C,M)); grad_feat pre-zeroed by caller */
+int prcnn_gather_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M, float* grad_feat,
+                      prcnn_stream_t stream);
+
+/* channels-last twin of gather: out[b,m,0:C] = in_cl[b, idx[b,m], 0:C]; in_cl rows have stride ld_in floats.
+ * (new_xyz = xyz[fps_idx] without the two transposes upstream needs around gather_operation.) */
+int prcnn_gather_rows(const float* in_cl, int ld_in, const int32_t* idx, int B, int N, int M, int C, float* out,
+                      prcnn_stream_t stream);
+
+/* ball_query_wrapper(B,N,M,radius,nsample,new_xyz,xyz,idx): idx (B,M,nsample) i32; first <=nsample
+ * points with d2 < radius^2 in ascending index order, padded with the first hit; no hit -> zeros. */
+int prcnn_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample,
+                     int32_t* idx, prcnn_stream_t stream);
+/* Two radii in ONE scan of xyz (the MSG level's two groupers share new_xyz): same results as two
+ * prcnn_ball_query calls. */
+int prcnn_ball_query2(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a,
+                      int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, prcnn_stream_t stream);
+
+/* group_points_wrapper(B,C,N,npoint,nsample,feat,idx,out): out[b,c,m,s] = feat[b,c,idx[b,m,s]] */
+int prcnn_group(const float* feat, const int32_t* idx, int B, int C, int N, int M, int nsample, float* out,
+                prcnn_stream_t stream);
+int prcnn_group_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M, int nsample,
+                     float* grad_feat, prcnn_stream_t stream);
+
+/* three_nn_wrapper(B,n,m,unknown,known,dist2,idx): 3 nearest known points per unknown point, SQUARED
+ * distances (the Python wrapper takes the sqrt, as upstream does), strict-< insertion (ties keep the
+ * earlier index).  `weight` (B,n,3), optional (NULL to skip): the FP module's normalised
+ * inverse-distance weights w_k = r_k / (r_0+r_1+r_2), r_k = 1/(sqrt(dist2_k)+1e-8). */
+int prcnn_three_nn(const float* unknown, const float* known, int B, int n, int m, float* dist2, int32_t* idx,
+                   float* weight, prcnn_stream_t stream);
+
+/* three_interpolate_wrapper(B,C,m,n,feat,idx,weight,out): out[b,c,i] = (w0*f[i0] + w1*f[i1]) + w2*f[i2] */
+int prcnn_three_interp(const float* feat, const int32_t* idx, const float* weight, int B, int C, int m, int n,
+                       float* out, prcnn_stream_t stream);
+int prcnn_three_interp_grad(const float* grad_out, const int32_t* idx, const float* weight, int B, int C, int n,
+                            int m, float* grad_feat, prcnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused per-point MLP layers (new; replaces the SharedMLP = Conv2d1x1+BN+ReLU (+max_pool2d) chain
+ * that upstream runs through cuDNN on a materialised (B,C+3,npoint,nsample) tensor; specs at
+ * lib/net/pointnet2_msg.py:20-45, lib/net/rpn.py:20-46, lib/net/rcnn_net.py:23-41).
+ *
+ * All activations are CHANNELS-LAST rows: a row is one point (or one (centroid,sample) pair) and
+ * holds its channels contiguously.  One call = one layer:
+ *      out[row, col_off + n] = act( sum_k A[row,k] * W[n,k] + bias[n] ),   n < Nout
+ * computed with fp32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
+ * BatchNorm (eval) is folded into W/bias by the caller.  `wpack` is W re-laid for the MFMA operand
+ * order by prcnn_pack_weight.  If pool_ns > 0 the epilogue max-reduces every pool_ns consecutive
+ * rows (max_pool2d(kernel=[1,nsample])) and writes rows/pool_ns rows; pool_ns must be 16, 32 or 64.
+ * `ld_*` are row strides in floats.
+ * ------------------------------------------------------------------------------------------- */
+
+/* floats needed for the packed image of a (Nout,K) weight */
+size_t prcnn_wpack_floats(int Nout, int K);
+/* w: (Nout,K) row-major (torch conv weight).  k_rot: the first k_rot input channels of W are moved
+ * to the END of the packed K order (grouped rows are laid out [features(C), dxyz(3)] while torch's
+ * QueryAndGroup order is [dxyz(3), features(C)]: pass k_rot=3 for those layers, 0 otherwise). */
+int prcnn_pack_weight(const float* w, int Nout, int K, int k_rot, float* wpack, prcnn_stream_t stream);
+
+/* A = in (rows, K), row stride ld_in */
+int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const float* bias, int Nout,
+                   int relu, float* out, int ld_out, int col_off, int pool_ns, prcnn_stream_t stream);
+
+/* A row (b,m,s) = [ feat_cl[b, idx[b,m,s], 0:C],  xyz[b, idx[b,m,s]] - new_xyz[b,m] ]  (K = C+3;
+ * C may be 0 with feat_cl NULL).  new_xyz NULL => GroupAll semantics (no centroid subtraction).
+ * rows = B*M*nsample. */
+int prcnn_mlp_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl, int ld_feat,
+                    int B, int N, int M, int nsample, int C, const float* wpack, const float* bias, int Nout,
+                    int relu, float* out, int ld_out, int col_off, int pool_ns, prcnn_stream_t stream);
+
+/* A row (b,i) = [ sum_j w3[b,i,j] * known_cl[b, idx3[b,i,j], 0:C2],  skip_cl[b,i,0:C1] ]  (K = C2+C1;
+ * C1 may be 0 with skip_cl NULL).  rows = B*n. */
+int prcnn_mlp_interp(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3, const float* skip_cl,
+                     int ld_skip, int B, int n, int m, int C2, int C1, const float* wpack, const float* bias,
+                     int Nout, int relu, float* out, int ld_out, int col_off, prcnn_stream_t stream);
+
+/* out[r, col_off + c] = max over ns consecutive rows of in (generic nsample fallback for pooling) */
+int prcnn_maxpool_rows(const float* in, int ld_in, int64_t rows_out, int ns, int C, float* out, int ld_out,
+                       int col_off, prcnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * roipool3d.  Replaces roipool3d_cuda.forward (roipool3d.cpp:48-79 -> roipool3d_kernel.cu:209-237).
+ * xyz (B,N,3), boxes3d (B,M,7) [x,y(bottom),z,h,w,l,ry] ALREADY enlarged (roipool3d_utils.py:19),
+ * feat (B,N,C) -> pooled (B,M,S,3+C), empty (B,M) i32.  One pass, no B*N*M temporary, no allocation.
+ * Every output element is written (empty boxes get zero rows), so `pooled` need not be pre-zeroed.
+ * ------------------------------------------------------------------------------------------- */
+int prcnn_roipool3d(const float* xyz, const float* boxes3d, const float* feat, int B, int N, int M, int C, int S,
+                    float* pooled, int32_t* empty, prcnn_stream_t stream);
+
+/* point-in-box flags on the device: flags (M,N) i32 (device twin of roipool3d.cpp:97-125) */
+int prcnn_pts_in_boxes3d(const float* pts, const float* boxes3d, int N, int M, int32_t* flags, prcnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * iou3d.  Replace iou3d_cuda.{boxes_overlap_bev_gpu,boxes_iou_bev_gpu,nms_gpu,nms_normal_gpu}
+ * (iou3d.cpp:31,52,73,123).  BEV boxes are (N,5) [x1,y1,x2,y2,ry].
+ * ------------------------------------------------------------------------------------------- */
+int prcnn_boxes_overlap_bev(const float* boxes_a, int Na, const float* boxes_b, int Nb, float* out,
+                            prcnn_stream_t stream);
+int prcnn_boxes_iou_bev(const float* boxes_a, int Na, const float* boxes_b, int Nb, float* out, prcnn_stream_t stream);
+
+#define PRCNN_NMS_ROTATED 0
+#define PRCNN_NMS_NORMAL 1
+/* workspace bytes prcnn_nms needs for N boxes */
+size_t prcnn_nms_workspace_bytes(int N);
+/* Greedy NMS over boxes ALREADY sorted by descending score (iou3d_utils.py:64-66): box i suppresses
+ * j>i iff iou(i,j) > thresh.  Entirely on the device: keep (N) i64 receives the kept positions in
+ * ascending order, num_keep (1) i32 their count.  No host synchronisation. */
+int prcnn_nms(const float* boxes, int N, float thresh, int kind, int64_t* keep, int32_t* num_keep, void* workspace,
+              size_t workspace_bytes, prcnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRCNN_POINTOPS_H */

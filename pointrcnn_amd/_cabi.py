@@ -1,0 +1,87 @@
+"""ctypes binding of libprcnn_pointops.so -- exactly the entry points declared in include/prcnn_pointops.h.
+
+This is the reference-side binding a maintainer would add: raw device pointers + sizes +
+a hipStream_t, no torch types cross the boundary.  The product path FAILS LOUDLY when the library is
+missing: there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_L = ctypes.c_int64
+_Z = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/prcnn_pointops.h one for one
+SIGNATURES = {
+    "prcnn_abi_version": (_I, []),
+    "prcnn_last_error": (ctypes.c_char_p, []),
+    "prcnn_fps": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "prcnn_gather": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "prcnn_gather_grad": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "prcnn_gather_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "prcnn_ball_query": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P]),
+    "prcnn_ball_query2": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _F, _I, _P, _P]),
+    "prcnn_group": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "prcnn_group_grad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "prcnn_three_nn": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "prcnn_three_interp": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "prcnn_three_interp_grad": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "prcnn_wpack_floats": (_Z, [_I, _I]),
+    "prcnn_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
+    "prcnn_mlp_rows": (_I, [_P, _I, _L, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
+    "prcnn_mlp_group": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
+    "prcnn_mlp_interp": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P]),
+    "prcnn_maxpool_rows": (_I, [_P, _I, _L, _I, _I, _P, _I, _I, _P]),
+    "prcnn_roipool3d": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "prcnn_pts_in_boxes3d": (_I, [_P, _P, _I, _I, _P, _P]),
+    "prcnn_boxes_overlap_bev": (_I, [_P, _I, _P, _I, _P, _P]),
+    "prcnn_boxes_iou_bev": (_I, [_P, _I, _P, _I, _P, _P]),
+    "prcnn_nms_workspace_bytes": (_Z, [_I]),
+    "prcnn_nms": (_I, [_P, _I, _F, _I, _P, _P, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+class PointOpsError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _build.LIB
+
+
+def lib():
+    """Load (building first if hipcc is available and the .so is missing/stale) and type the library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path) or (os.path.exists(_build.HIPCC) and _build._stale()):
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise PointOpsError(
+                    "libprcnn_pointops.so is missing and could not be built (%s). The HIP extension is "
+                    "mandatory: there is no CPU fallback. Run `python -m pointrcnn_amd.build`." % e)
+    try:
+        handle = ctypes.CDLL(path)
+    except OSError as e:
+        raise PointOpsError("cannot load %s: %s" % (path, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)      # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return handle
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().prcnn_last_error()
+        raise PointOpsError("%s failed (code %d): %s" % (what or "prcnn call", rc, msg.decode() if msg else "?"))

@@ -1,0 +1,69 @@
+// common.h -- shared helpers for the gfx950 point-ops kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/prcnn_pointops.h"
+
+#define PRCNN_API extern "C" __attribute__((visibility("default")))
+
+int prcnn_fail(int code, const char* fmt, ...);
+
+#define PRCNN_REQUIRE(cond, ...)                              \
+    do {                                                      \
+        if (!(cond)) return prcnn_fail(PRCNN_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define PRCNN_LAUNCH_CHECK(name)                                                                        \
+    do {                                                                                                \
+        hipError_t e_ = hipGetLastError();                                                              \
+        if (e_ != hipSuccess) return prcnn_fail(PRCNN_EHIP, "%s: launch failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int prcnn_divup(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave64 cross-lane reductions on the VALU (DPP), no LDS ---------------------------------
+// row_shr:1,2,4,8 builds an inclusive scan inside each 16-lane row, row_bcast:15 / row_bcast:31
+// fold the rows; lane 63 ends up with the wave-wide result, returned in an SGPR (wave-uniform).
+#define PRCNN_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp((v), (v), (ctrl), (rmask), 0xf, false)
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = max(v, PRCNN_DPP(v, 0x111, 0xf));
+    v = max(v, PRCNN_DPP(v, 0x112, 0xf));
+    v = max(v, PRCNN_DPP(v, 0x114, 0xf));
+    v = max(v, PRCNN_DPP(v, 0x118, 0xf));
+    v = max(v, PRCNN_DPP(v, 0x142, 0xa));
+    v = max(v, PRCNN_DPP(v, 0x143, 0xc));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, PRCNN_DPP(v, 0x111, 0xf));
+    v = min(v, PRCNN_DPP(v, 0x112, 0xf));
+    v = min(v, PRCNN_DPP(v, 0x114, 0xf));
+    v = min(v, PRCNN_DPP(v, 0x118, 0xf));
+    v = min(v, PRCNN_DPP(v, 0x142, 0xa));
+    v = min(v, PRCNN_DPP(v, 0x143, 0xc));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// reductions over the first 16 lanes only (one DPP row); result read from lane 15
+__device__ __forceinline__ int row0_max_i32(int v) {
+    v = max(v, PRCNN_DPP(v, 0x111, 0xf));
+    v = max(v, PRCNN_DPP(v, 0x112, 0xf));
+    v = max(v, PRCNN_DPP(v, 0x114, 0xf));
+    v = max(v, PRCNN_DPP(v, 0x118, 0xf));
+    return __builtin_amdgcn_readlane(v, 15);
+}
+__device__ __forceinline__ int row0_min_i32(int v) {
+    v = min(v, PRCNN_DPP(v, 0x111, 0xf));
+    v = min(v, PRCNN_DPP(v, 0x112, 0xf));
+    v = min(v, PRCNN_DPP(v, 0x114, 0xf));
+    v = min(v, PRCNN_DPP(v, 0x118, 0xf));
+    return __builtin_amdgcn_readlane(v, 15);
+}
+
+// squared distance under the canonical arithmetic contract: individually rounded, left to right.
+// (the library is also built with -ffp-contract=off; the intrinsics make the intent explicit)
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}

@@ -1,0 +1,443 @@
+// mlp.hip -- fused per-point MLP layer for gfx950: [gather | interpolate | plain] A-tile -> fp32 MFMA ->
+// bias + ReLU (+ max-pool over nsample) epilogue.
+//
+// Replaces the SharedMLP chain (Conv2d 1x1 + BatchNorm2d + ReLU, then F.max_pool2d(kernel=[1,nsample]))
+// that upstream PointNet++ modules run through cuDNN on a materialised (B, C+3, npoint, nsample) grouped
+// tensor [UPSTREAM, not in tree]; layer specs: lib/net/pointnet2_msg.py:20-45, lib/net/rpn.py:20-46,
+// lib/net/rcnn_net.py:23-41.  The grouped tensor never exists here: rows of the GEMM A operand are
+// gathered (or 3-NN-interpolated) from channels-last features straight into LDS.
+//
+// GEMM view: out[rows x Nout] = A[rows x K] * W^T[K x Nout].  Workgroup tile 128 rows x 64 cols, 4 waves
+// as 2(M) x 2(N); each wave owns 64 rows x 32 cols = two v_mfma_f32_32x32x2_f32 accumulators (exact fp32
+// products, fp32 accumulation: the result is an fp32 FMA chain, no reduced precision anywhere).
+// K is walked in chunks of 32 (four 8-wide k-blocks).  Inside a k-block the MFMA step s pairs
+// k = 8*kb + s (lanes 0-31) with k = 8*kb + 4 + s (lanes 32-63): a lane's four A values for the block
+// are then 16 contiguous bytes of its LDS row (one ds_read_b128), and the matching B values are
+// 16 contiguous bytes of the pre-packed weight image (prcnn_pack_weight), which is staged into LDS by a
+// straight linear copy.  A rows are padded to 36 floats so the 16 rows of each ds_read_b128 lane group
+// land on 16 distinct 16-byte bank slots.
+// Pipeline: global loads for chunk c+1 are issued before the MFMAs of chunk c and written to the other
+// LDS buffer after them (one barrier per chunk).
+#include "common.h"
+
+#define MLP_BM 128
+#define MLP_BN 64
+#define MLP_BK 32
+#define MLP_THREADS 256
+#define MLP_ALD 36
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { MODE_PLAIN = 0, MODE_GROUP = 1, MODE_INTERP = 2 };
+
+struct MlpParams {
+    long rows;            // total A rows
+    int K, KB, NB;        // logical K, number of 8-wide k-blocks, number of 32-wide n-blocks
+    const float* wpack;
+    const float* bias;
+    int Nout, relu;
+    float* out;
+    int ld_out, col_off, pool_ns;
+    // MODE_PLAIN
+    const float* in;
+    int ld_in;
+    // MODE_GROUP
+    const float* xyz;
+    const float* new_xyz;
+    const int32_t* idx;
+    const float* feat;
+    int ld_feat, N, M, ns, C;
+    // MODE_INTERP
+    const float* known;
+    const int32_t* idx3;
+    const float* w3;
+    const float* skip;
+    int ld_known, ld_skip, n, m, C2, C1;
+    int vec_a, vec_b;     // 16-byte vector loads legal for source a (feat/known/in) / source b (skip)
+};
+
+template <int MODE> struct RowMeta;
+template <> struct RowMeta<MODE_PLAIN> { long off; bool valid; };
+template <> struct RowMeta<MODE_GROUP> { long off; float dx, dy, dz; bool valid; };
+template <> struct RowMeta<MODE_INTERP> { long o0, o1, o2, os; float w0, w1, w2; bool valid; };
+
+template <int MODE> struct Raw;
+template <> struct Raw<MODE_PLAIN> { float4 a; };
+template <> struct Raw<MODE_GROUP> { float4 a; };
+template <> struct Raw<MODE_INTERP> { float4 a, b, c; };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ---- per-row metadata (computed once per thread for its 4 rows) -------------------------------
+template <int MODE> __device__ __forceinline__ void make_meta(const MlpParams& P, long grow, RowMeta<MODE>& r);
+
+template <> __device__ __forceinline__ void make_meta<MODE_PLAIN>(const MlpParams& P, long grow, RowMeta<MODE_PLAIN>& r) {
+    r.valid = grow < P.rows;
+    r.off = r.valid ? grow * (long)P.ld_in : 0;
+}
+template <> __device__ __forceinline__ void make_meta<MODE_GROUP>(const MlpParams& P, long grow, RowMeta<MODE_GROUP>& r) {
+    r.valid = grow < P.rows;
+    r.off = 0; r.dx = r.dy = r.dz = 0.f;
+    if (r.valid) {
+        long per_b = (long)P.M * P.ns;
+        int b = (int)(grow / per_b);
+        int m_ = (int)((grow - (long)b * per_b) / P.ns);
+        int p = P.idx[grow];
+        long pt = (long)b * P.N + p;
+        r.off = pt * (long)P.ld_feat;
+        float x = P.xyz[pt * 3], y = P.xyz[pt * 3 + 1], z = P.xyz[pt * 3 + 2];
+        if (P.new_xyz) {
+            const float* q = P.new_xyz + ((long)b * P.M + m_) * 3;
+            x = x - q[0]; y = y - q[1]; z = z - q[2];
+        }
+        r.dx = x; r.dy = y; r.dz = z;
+    }
+}
+template <> __device__ __forceinline__ void make_meta<MODE_INTERP>(const MlpParams& P, long grow, RowMeta<MODE_INTERP>& r) {
+    r.valid = grow < P.rows;
+    r.o0 = r.o1 = r.o2 = r.os = 0; r.w0 = r.w1 = r.w2 = 0.f;
+    if (r.valid) {
+        int b = (int)(grow / P.n);
+        const int32_t* id = P.idx3 + grow * 3;
+        const float* w = P.w3 + grow * 3;
+        long base = (long)b * P.m;
+        r.o0 = (base + id[0]) * (long)P.ld_known;
+        r.o1 = (base + id[1]) * (long)P.ld_known;
+        r.o2 = (base + id[2]) * (long)P.ld_known;
+        r.os = grow * (long)P.ld_skip;
+        r.w0 = w[0]; r.w1 = w[1]; r.w2 = w[2];
+    }
+}
+
+// ---- raw global fetch of 4 consecutive k (k % 4 == 0) for one row; finish() turns it into A values
+template <int MODE> __device__ __forceinline__ void fetch(const MlpParams& P, const RowMeta<MODE>& r, int k, Raw<MODE>& v);
+template <int MODE> __device__ __forceinline__ float4 finish(const MlpParams& P, const RowMeta<MODE>& r, int k, const Raw<MODE>& v);
+
+template <> __device__ __forceinline__ void fetch<MODE_PLAIN>(const MlpParams& P, const RowMeta<MODE_PLAIN>& r, int k, Raw<MODE_PLAIN>& v) {
+    v.a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!r.valid || k >= P.K) return;
+    const float* s = P.in + r.off + k;
+    if (P.vec_a && k + 4 <= P.K) { v.a = ld4(s); return; }
+    v.a.x = s[0];
+    if (k + 1 < P.K) v.a.y = s[1];
+    if (k + 2 < P.K) v.a.z = s[2];
+    if (k + 3 < P.K) v.a.w = s[3];
+}
+template <> __device__ __forceinline__ float4 finish<MODE_PLAIN>(const MlpParams&, const RowMeta<MODE_PLAIN>&, int, const Raw<MODE_PLAIN>& v) {
+    return v.a;
+}
+
+__device__ __forceinline__ float group_elem(const MlpParams& P, const RowMeta<MODE_GROUP>& r, int kk) {
+    if (kk < P.C) return P.feat[r.off + kk];
+    int t = kk - P.C;
+    return t == 0 ? r.dx : (t == 1 ? r.dy : (t == 2 ? r.dz : 0.f));
+}
+template <> __device__ __forceinline__ void fetch<MODE_GROUP>(const MlpParams& P, const RowMeta<MODE_GROUP>& r, int k, Raw<MODE_GROUP>& v) {
+    v.a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!r.valid || k >= P.K) return;
+    if (P.vec_a && k + 4 <= P.C) { v.a = ld4(P.feat + r.off + k); return; }
+    v.a.x = group_elem(P, r, k);
+    v.a.y = group_elem(P, r, k + 1);
+    v.a.z = group_elem(P, r, k + 2);
+    v.a.w = group_elem(P, r, k + 3);
+}
+template <> __device__ __forceinline__ float4 finish<MODE_GROUP>(const MlpParams&, const RowMeta<MODE_GROUP>&, int, const Raw<MODE_GROUP>& v) {
+    return v.a;
+}
+
+__device__ __forceinline__ float interp1(float w0, float f0, float w1, float f1, float w2, float f2) {
+    // (w0*f0 + w1*f1) + w2*f2, individually rounded: bit-identical to three_interpolate
+    return __fadd_rn(__fadd_rn(__fmul_rn(w0, f0), __fmul_rn(w1, f1)), __fmul_rn(w2, f2));
+}
+template <> __device__ __forceinline__ void fetch<MODE_INTERP>(const MlpParams& P, const RowMeta<MODE_INTERP>& r, int k, Raw<MODE_INTERP>& v) {
+    v.a = v.b = v.c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!r.valid || k >= P.K) return;
+    if (k + 4 <= P.C2) {
+        if (P.vec_a) {
+            v.a = ld4(P.known + r.o0 + k); v.b = ld4(P.known + r.o1 + k); v.c = ld4(P.known + r.o2 + k);
+        } else {
+            const float *a = P.known + r.o0 + k, *b = P.known + r.o1 + k, *c = P.known + r.o2 + k;
+            v.a = make_float4(a[0], a[1], a[2], a[3]);
+            v.b = make_float4(b[0], b[1], b[2], b[3]);
+            v.c = make_float4(c[0], c[1], c[2], c[3]);
+        }
+        return;
+    }
+    if (k >= P.C2) {        // skip-connection part: stored in v.a, passed through by finish()
+        int ks = k - P.C2;
+        const float* s = P.skip + r.os + ks;
+        if (P.vec_b && ks + 4 <= P.C1) { v.a = ld4(s); return; }
+        if (ks < P.C1) v.a.x = s[0];
+        if (ks + 1 < P.C1) v.a.y = s[1];
+        if (ks + 2 < P.C1) v.a.z = s[2];
+        if (ks + 3 < P.C1) v.a.w = s[3];
+        return;
+    }
+    // 4-group straddling the C2 boundary (C2 % 4 != 0): element-wise, v.b/v.c carry the neighbours
+    auto one = [&](int kk, float& a, float& b, float& c) {
+        if (kk < P.C2) { a = P.known[r.o0 + kk]; b = P.known[r.o1 + kk]; c = P.known[r.o2 + kk]; }
+        else if (kk - P.C2 < P.C1) { a = P.skip[r.os + kk - P.C2]; }
+    };
+    one(k, v.a.x, v.b.x, v.c.x);
+    one(k + 1, v.a.y, v.b.y, v.c.y);
+    one(k + 2, v.a.z, v.b.z, v.c.z);
+    one(k + 3, v.a.w, v.b.w, v.c.w);
+}
+template <> __device__ __forceinline__ float4 finish<MODE_INTERP>(const MlpParams& P, const RowMeta<MODE_INTERP>& r, int k, const Raw<MODE_INTERP>& v) {
+    if (k >= P.C2) return v.a;
+    float4 o;
+    o.x = interp1(r.w0, v.a.x, r.w1, v.b.x, r.w2, v.c.x);
+    o.y = (k + 1 < P.C2) ? interp1(r.w0, v.a.y, r.w1, v.b.y, r.w2, v.c.y) : v.a.y;
+    o.z = (k + 2 < P.C2) ? interp1(r.w0, v.a.z, r.w1, v.b.z, r.w2, v.c.z) : v.a.z;
+    o.w = (k + 3 < P.C2) ? interp1(r.w0, v.a.w, r.w1, v.b.w, r.w2, v.c.w) : v.a.w;
+    return o;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams P) {
+    __shared__ __attribute__((aligned(16))) float As[2][MLP_BM * MLP_ALD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][2 * 4 * 256];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, j = lane & 31;
+    const long row0 = (long)blockIdx.x * MLP_BM;
+    const int nb0 = blockIdx.y * 2;
+    const int nchunks = (P.KB + 3) >> 2;
+
+    // fill-phase assignment: thread -> float4 column c4 of rows r0 + 32*u
+    const int c4 = tid & 7, r0 = tid >> 3;
+    RowMeta<MODE> meta[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) make_meta<MODE>(P, row0 + r0 + 32 * u, meta[u]);
+
+    Raw<MODE> ra[4];
+    float4 rb[2];
+    auto load_chunk = [&](int c) {
+        const int k = c * MLP_BK + c4 * 4;
+#pragma unroll
+        for (int u = 0; u < 4; u++) fetch<MODE>(P, meta[u], k, ra[u]);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            int f = tid + 256 * u;                 // float4 index inside the [q][kbl][64] image
+            int q = f >> 8, rr = f & 255, kbl = rr >> 6, o4 = rr & 63;
+            int nb = nb0 + q, kb = c * 4 + kbl;
+            rb[u] = (nb < P.NB && kb < P.KB) ? ld4(P.wpack + ((long)nb * P.KB + kb) * 256 + o4 * 4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_chunk = [&](int c, int buf) {
+        const int k = c * MLP_BK + c4 * 4;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float4 v = finish<MODE>(P, meta[u], k, ra[u]);
+            *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * u) * MLP_ALD + c4 * 4]) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(&Bs[buf][(tid + 256 * u) * 4]) = rb[u];
+    };
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    const bool n_active = (nb0 + wn) < P.NB;
+
+    load_chunk(0);
+    store_chunk(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        if (n_active) {
+            const int nkb = min(4, P.KB - c * 4);
+            const float* a_base = &As[buf][(wm * 64 + j) * MLP_ALD + 4 * h];
+            const float* b_base = &Bs[buf][wn * 1024 + lane * 4];
+            for (int kbl = 0; kbl < nkb; kbl++) {
+                float4 a0 = *reinterpret_cast<const float4*>(a_base + kbl * 8);
+                float4 a1 = *reinterpret_cast<const float4*>(a_base + 32 * MLP_ALD + kbl * 8);
+                float4 bq = *reinterpret_cast<const float4*>(b_base + kbl * 256);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bq.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bq.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bq.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bq.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bq.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bq.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bq.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bq.w, acc1, 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) store_chunk(c + 1, buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    if (!n_active) return;
+    const int n = (nb0 + wn) * 32 + j;
+    const bool n_ok = n < P.Nout;
+    const float bias = (P.bias && n_ok) ? P.bias[n] : 0.f;
+    const long wrow0 = row0 + wm * 64;
+    if (P.pool_ns == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+            long g0 = wrow0 + rin, g1 = wrow0 + 32 + rin;
+            float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
+            if (P.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            if (n_ok && g0 < P.rows) P.out[g0 * P.ld_out + P.col_off + n] = v0;
+            if (n_ok && g1 < P.rows) P.out[g1 * P.ld_out + P.col_off + n] = v1;
+        }
+    } else {
+        // max over nsample consecutive rows.  max commutes with the (monotone) bias add and ReLU, so
+        // they are applied once per pooled value: bit-identical to pooling the activated rows.
+        float lo0 = acc0[0], hi0 = acc0[8], lo1 = acc1[0], hi1 = acc1[8];
+#pragma unroll
+        for (int r = 1; r < 8; r++) {
+            lo0 = fmaxf(lo0, acc0[r]); hi0 = fmaxf(hi0, acc0[8 + r]);
+            lo1 = fmaxf(lo1, acc1[r]); hi1 = fmaxf(hi1, acc1[8 + r]);
+        }
+        lo0 = fmaxf(lo0, __shfl_xor(lo0, 32)); hi0 = fmaxf(hi0, __shfl_xor(hi0, 32));
+        lo1 = fmaxf(lo1, __shfl_xor(lo1, 32)); hi1 = fmaxf(hi1, __shfl_xor(hi1, 32));
+        const long groups = P.rows / P.pool_ns;
+        float v[4]; long g[4]; int cnt;
+        if (P.pool_ns == 16) {
+            long g0 = wrow0 / 16;
+            v[0] = lo0; v[1] = hi0; v[2] = lo1; v[3] = hi1; g[0] = g0; g[1] = g0 + 1; g[2] = g0 + 2; g[3] = g0 + 3; cnt = 4;
+        } else if (P.pool_ns == 32) {
+            long g0 = wrow0 / 32;
+            v[0] = fmaxf(lo0, hi0); v[1] = fmaxf(lo1, hi1); g[0] = g0; g[1] = g0 + 1; cnt = 2;
+        } else {
+            v[0] = fmaxf(fmaxf(lo0, hi0), fmaxf(lo1, hi1)); g[0] = wrow0 / 64; cnt = 1;
+        }
+        if (h == 0 && n_ok) {
+            for (int t = 0; t < cnt; t++) {
+                float o = v[t] + bias;
+                if (P.relu) o = fmaxf(o, 0.f);
+                if (g[t] < groups) P.out[g[t] * P.ld_out + P.col_off + n] = o;
+            }
+        }
+    }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, int Nout, int K, int k_rot, int KB, int NB,
+                                   float* __restrict__ wpack) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)NB * KB * 256;
+    if (e >= total) return;
+    int s = e & 3, jj = (e >> 2) & 31, hh = (e >> 7) & 1;
+    long blk = e >> 8;
+    int kb = (int)(blk % KB), nb = (int)(blk / KB);
+    int n = nb * 32 + jj, kp = kb * 8 + 4 * hh + s;
+    float val = 0.f;
+    if (n < Nout && kp < K) {
+        int ko = kp < K - k_rot ? kp + k_rot : kp - (K - k_rot);
+        val = w[(long)n * K + ko];
+    }
+    wpack[e] = val;
+}
+
+__global__ void maxpool_rows_kernel(const float* __restrict__ in, int ld_in, long rows_out, int ns, int C,
+                                    float* __restrict__ out, int ld_out, int col_off) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows_out * C) return;
+    long r = e / C; int c = (int)(e - r * C);
+    const float* p = in + r * ns * (long)ld_in + c;
+    float m = p[0];
+    for (int s = 1; s < ns; s++) m = fmaxf(m, p[(long)s * ld_in]);
+    out[r * ld_out + col_off + c] = m;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
+    PRCNN_REQUIRE(P.wpack && P.out, "prcnn_mlp: null weight/output pointer");
+    PRCNN_REQUIRE(P.rows >= 0 && P.K > 0 && P.Nout > 0, "prcnn_mlp: bad shape rows=%ld K=%d Nout=%d", P.rows, P.K, P.Nout);
+    PRCNN_REQUIRE(P.pool_ns == 0 || P.pool_ns == 16 || P.pool_ns == 32 || P.pool_ns == 64,
+                  "prcnn_mlp: pool_ns=%d unsupported (use 16/32/64, or store + prcnn_maxpool_rows)", P.pool_ns);
+    PRCNN_REQUIRE(P.pool_ns == 0 || P.rows % P.pool_ns == 0, "prcnn_mlp: rows %ld not a multiple of pool_ns %d", P.rows, P.pool_ns);
+    PRCNN_REQUIRE(aligned16(P.wpack), "prcnn_mlp: wpack must be 16-byte aligned");
+    if (P.rows == 0) return PRCNN_OK;
+    P.KB = (P.K + 7) / 8;
+    P.NB = (P.Nout + 31) / 32;
+    dim3 grid(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, 2));
+    if (mode == MODE_PLAIN) hipLaunchKernelGGL(mlp_layer_kernel<MODE_PLAIN>, grid, dim3(MLP_THREADS), 0, s, P);
+    else if (mode == MODE_GROUP) hipLaunchKernelGGL(mlp_layer_kernel<MODE_GROUP>, grid, dim3(MLP_THREADS), 0, s, P);
+    else hipLaunchKernelGGL(mlp_layer_kernel<MODE_INTERP>, grid, dim3(MLP_THREADS), 0, s, P);
+    PRCNN_LAUNCH_CHECK("prcnn_mlp");
+    return PRCNN_OK;
+}
+
+PRCNN_API size_t prcnn_wpack_floats(int Nout, int K) {
+    if (Nout <= 0 || K <= 0) return 0;
+    return (size_t)((Nout + 31) / 32) * ((K + 7) / 8) * 256;
+}
+
+PRCNN_API int prcnn_pack_weight(const float* w, int Nout, int K, int k_rot, float* wpack, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(w && wpack, "prcnn_pack_weight: null pointer");
+    PRCNN_REQUIRE(Nout > 0 && K > 0 && k_rot >= 0 && k_rot <= K, "prcnn_pack_weight: bad shape Nout=%d K=%d k_rot=%d", Nout, K, k_rot);
+    int KB = (K + 7) / 8, NB = (Nout + 31) / 32;
+    long total = (long)NB * KB * 256;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(prcnn_divup(total, 256)), dim3(256), 0, (hipStream_t)stream, w, Nout, K,
+                       k_rot, KB, NB, wpack);
+    PRCNN_LAUNCH_CHECK("prcnn_pack_weight");
+    return PRCNN_OK;
+}
+
+PRCNN_API int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const float* bias,
+                             int Nout, int relu, float* out, int ld_out, int col_off, int pool_ns,
+                             prcnn_stream_t stream) {
+    PRCNN_REQUIRE(in, "prcnn_mlp_rows: null input");
+    PRCNN_REQUIRE(ld_in >= K && ld_out >= col_off + Nout, "prcnn_mlp_rows: bad strides ld_in=%d K=%d ld_out=%d", ld_in, K, ld_out);
+    MlpParams P = {};
+    P.rows = rows; P.K = K; P.wpack = wpack; P.bias = bias; P.Nout = Nout; P.relu = relu;
+    P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.pool_ns = pool_ns;
+    P.in = in; P.ld_in = ld_in;
+    P.vec_a = aligned16(in) && (ld_in % 4 == 0);
+    return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
+}
+
+PRCNN_API int prcnn_mlp_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl,
+                              int ld_feat, int B, int N, int M, int nsample, int C, const float* wpack,
+                              const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, int pool_ns,
+                              prcnn_stream_t stream) {
+    PRCNN_REQUIRE(xyz && idx, "prcnn_mlp_group: null pointer");
+    PRCNN_REQUIRE(C == 0 || feat_cl, "prcnn_mlp_group: C=%d but feat_cl is null", C);
+    PRCNN_REQUIRE(B >= 0 && N > 0 && M > 0 && nsample > 0 && C >= 0 && (C == 0 || ld_feat >= C),
+                  "prcnn_mlp_group: bad shape B=%d N=%d M=%d ns=%d C=%d ld=%d", B, N, M, nsample, C, ld_feat);
+    PRCNN_REQUIRE(ld_out >= col_off + Nout, "prcnn_mlp_group: ld_out=%d < col_off+Nout", ld_out);
+    MlpParams P = {};
+    P.rows = (long)B * M * nsample; P.K = C + 3; P.wpack = wpack; P.bias = bias; P.Nout = Nout; P.relu = relu;
+    P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.pool_ns = pool_ns;
+    P.xyz = xyz; P.new_xyz = new_xyz; P.idx = idx; P.feat = feat_cl; P.ld_feat = ld_feat;
+    P.N = N; P.M = M; P.ns = nsample; P.C = C;
+    P.vec_a = C > 0 && aligned16(feat_cl) && (ld_feat % 4 == 0);
+    return launch_mlp(MODE_GROUP, P, (hipStream_t)stream);
+}
+
+PRCNN_API int prcnn_mlp_interp(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3,
+                               const float* skip_cl, int ld_skip, int B, int n, int m, int C2, int C1,
+                               const float* wpack, const float* bias, int Nout, int relu, float* out, int ld_out,
+                               int col_off, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(known_cl && idx3 && w3, "prcnn_mlp_interp: null pointer");
+    PRCNN_REQUIRE(C1 == 0 || skip_cl, "prcnn_mlp_interp: C1=%d but skip_cl is null", C1);
+    PRCNN_REQUIRE(B >= 0 && n > 0 && m > 0 && C2 > 0 && C1 >= 0 && ld_known >= C2 && (C1 == 0 || ld_skip >= C1),
+                  "prcnn_mlp_interp: bad shape B=%d n=%d m=%d C2=%d C1=%d", B, n, m, C2, C1);
+    PRCNN_REQUIRE(ld_out >= col_off + Nout, "prcnn_mlp_interp: ld_out=%d < col_off+Nout", ld_out);
+    MlpParams P = {};
+    P.rows = (long)B * n; P.K = C2 + C1; P.wpack = wpack; P.bias = bias; P.Nout = Nout; P.relu = relu;
+    P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.pool_ns = 0;
+    P.known = known_cl; P.idx3 = idx3; P.w3 = w3; P.skip = skip_cl; P.ld_known = ld_known; P.ld_skip = ld_skip;
+    P.n = n; P.m = m; P.C2 = C2; P.C1 = C1;
+    P.vec_a = aligned16(known_cl) && (ld_known % 4 == 0);
+    P.vec_b = C1 > 0 && aligned16(skip_cl) && (ld_skip % 4 == 0) && (C2 % 4 == 0);
+    return launch_mlp(MODE_INTERP, P, (hipStream_t)stream);
+}
+
+PRCNN_API int prcnn_maxpool_rows(const float* in, int ld_in, int64_t rows_out, int ns, int C, float* out, int ld_out,
+                                 int col_off, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(in && out, "prcnn_maxpool_rows: null pointer");
+    PRCNN_REQUIRE(rows_out >= 0 && ns > 0 && C > 0 && ld_in >= C && ld_out >= col_off + C, "prcnn_maxpool_rows: bad shape");
+    if (rows_out == 0) return PRCNN_OK;
+    hipLaunchKernelGGL(maxpool_rows_kernel, dim3(prcnn_divup(rows_out * C, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       ld_in, (long)rows_out, ns, C, out, ld_out, col_off);
+    PRCNN_LAUNCH_CHECK("prcnn_maxpool_rows");
+    return PRCNN_OK;
+}

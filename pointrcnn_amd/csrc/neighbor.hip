@@ -1,0 +1,171 @@
+// neighbor.hip -- ball_query (one or two radii per scan) and three_nn for gfx950.
+//
+// Replaces pointnet2_cuda.ball_query_wrapper / three_nn_wrapper [UPSTREAM, not in tree]; semantics per
+// SURVEY Appendix A.3 / A.5 and oracle prcnn_cpu_ball_query / prcnn_cpu_three_nn.
+//
+// Both are brute-force scans (compulsory HBM traffic is tiny: N*12 B per frame; the work is VALU):
+// a workgroup owns 256 query points (one per lane) of one frame and streams the frame's candidate
+// points through LDS in coalesced chunks, expanded to float4 so that the inner loop is ONE
+// ds_read_b128 broadcast (all lanes read the same address: conflict-free) per candidate.  Scanning
+// candidates in ascending index order makes the "first nsample hits in index order" contract fall
+// out by construction -- no sort, no compaction pass.  The MSG levels query two radii around the
+// same centroids: ball_query2 evaluates both in the same pass (half the scans).
+#include "common.h"
+
+#define NB_THREADS 256
+#define NB_CHUNK 2048      // candidates staged per LDS chunk: 2048 * 16 B = 32 KB
+
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ p, int c0, int N, float4* spts, int tid) {
+    // p: frame base (N,3).  Coalesced dword loads of the flat xyz stream, expanded to float4 in LDS.
+    int cnt = min(NB_CHUNK, N - c0);
+    const float* src = p + (size_t)c0 * 3;
+    float* s = reinterpret_cast<float*>(spts);
+    for (int i = tid; i < cnt * 3; i += NB_THREADS) {
+        int pt = i / 3, c = i - pt * 3;
+        s[pt * 4 + c] = src[i];
+    }
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(NB_THREADS) void ball_query_kernel(const float* __restrict__ xyz,
+                                                                const float* __restrict__ new_xyz, int N, int M,
+                                                                float r2a, int nsa, int32_t* __restrict__ idxa,
+                                                                float r2b, int nsb, int32_t* __restrict__ idxb) {
+    __shared__ float4 spts[NB_CHUNK];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int m = blockIdx.x * NB_THREADS + tid;
+    const bool valid = m < M;
+    const float* __restrict__ p = xyz + (size_t)b * N * 3;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (valid) {
+        const float* q = new_xyz + ((size_t)b * M + m) * 3;
+        qx = q[0]; qy = q[1]; qz = q[2];
+    }
+    int32_t* oa = idxa + ((size_t)b * M + (valid ? m : 0)) * nsa;
+    int32_t* ob = DUAL ? idxb + ((size_t)b * M + (valid ? m : 0)) * nsb : nullptr;
+    int cnta = 0, cntb = 0, firsta = 0, firstb = 0;
+    const float r2max = DUAL ? fmaxf(r2a, r2b) : r2a;
+    bool done = !valid;
+
+    for (int c0 = 0; c0 < N; c0 += NB_CHUNK) {
+        __syncthreads();
+        stage_chunk(p, c0, N, spts, tid);
+        __syncthreads();
+        const int cnt = min(NB_CHUNK, N - c0);
+        if (__all(done)) continue;                 // this wave is finished; still helps staging
+        if (!done) {
+#pragma unroll 4
+            for (int i = 0; i < cnt; i++) {
+                float4 c = spts[i];
+                float d2 = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+                if (d2 < r2max) {
+                    int k = c0 + i;
+                    if (d2 < r2a && cnta < nsa) {
+                        if (cnta == 0) firsta = k;
+                        oa[cnta++] = k;
+                    }
+                    if (DUAL && d2 < r2b && cntb < nsb) {
+                        if (cntb == 0) firstb = k;
+                        ob[cntb++] = k;
+                    }
+                    if (cnta >= nsa && (!DUAL || cntb >= nsb)) { done = true; break; }
+                }
+            }
+        }
+    }
+    if (valid) {
+        for (int s = cnta; s < nsa; s++) oa[s] = firsta;      // pad with the first hit (0 if none)
+        if (DUAL)
+            for (int s = cntb; s < nsb; s++) ob[s] = firstb;
+    }
+}
+
+__global__ __launch_bounds__(NB_THREADS) void three_nn_kernel(const float* __restrict__ unknown,
+                                                              const float* __restrict__ known, int n, int m,
+                                                              float* __restrict__ dist2, int32_t* __restrict__ idx,
+                                                              float* __restrict__ weight) {
+    __shared__ float4 spts[NB_CHUNK];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int i = blockIdx.x * NB_THREADS + tid;
+    const bool valid = i < n;
+    const float* __restrict__ p = known + (size_t)b * m * 3;
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    if (valid) {
+        const float* u = unknown + ((size_t)b * n + i) * 3;
+        ux = u[0]; uy = u[1]; uz = u[2];
+    }
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int c0 = 0; c0 < m; c0 += NB_CHUNK) {
+        __syncthreads();
+        stage_chunk(p, c0, m, spts, tid);
+        __syncthreads();
+        const int cnt = min(NB_CHUNK, m - c0);
+#pragma unroll 4
+        for (int j = 0; j < cnt; j++) {
+            float4 c = spts[j];
+            float d = sqdist3(ux, uy, uz, c.x, c.y, c.z);
+            if (d < b3) {                       // rare after warm-up: keeps the common path to one compare
+                int k = c0 + j;
+                if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+                else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+                else { b3 = d; i3 = k; }
+            }
+        }
+    }
+    if (valid) {
+        size_t o = ((size_t)b * n + i) * 3;
+        dist2[o] = b1; dist2[o + 1] = b2; dist2[o + 2] = b3;
+        idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+        if (weight) {
+            // PointnetFPModule: w = 1/(dist+1e-8), normalised; sqrt and divide are
+            // correctly rounded on gfx950 under hipcc defaults, as in the oracle.
+            float r0 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(b1), 1e-8f));
+            float r1 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(b2), 1e-8f));
+            float r2 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(b3), 1e-8f));
+            float s = __fadd_rn(__fadd_rn(r0, r1), r2);
+            weight[o] = __fdiv_rn(r0, s); weight[o + 1] = __fdiv_rn(r1, s); weight[o + 2] = __fdiv_rn(r2, s);
+        }
+    }
+}
+
+static int ball_query_impl(const float* xyz, const float* new_xyz, int B, int N, int M, float ra, int nsa, int32_t* ia,
+                           float rb, int nsb, int32_t* ib, bool dual, hipStream_t s) {
+    PRCNN_REQUIRE(xyz && new_xyz && ia && (!dual || ib), "prcnn_ball_query: null pointer");
+    PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && nsa > 0 && (!dual || nsb > 0),
+                  "prcnn_ball_query: bad shape B=%d N=%d M=%d nsample=%d/%d", B, N, M, nsa, nsb);
+    if (B == 0 || M == 0) return PRCNN_OK;
+    dim3 grid(prcnn_divup(M, NB_THREADS), B);
+    float r2a = ra * ra, r2b = rb * rb;        // fp32 product, as the oracle
+    if (dual)
+        hipLaunchKernelGGL(ball_query_kernel<true>, grid, dim3(NB_THREADS), 0, s, xyz, new_xyz, N, M, r2a, nsa, ia, r2b,
+                           nsb, ib);
+    else
+        hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(NB_THREADS), 0, s, xyz, new_xyz, N, M, r2a, nsa, ia,
+                           0.f, 0, (int32_t*)nullptr);
+    PRCNN_LAUNCH_CHECK("prcnn_ball_query");
+    return PRCNN_OK;
+}
+
+PRCNN_API int prcnn_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample,
+                               int32_t* idx, prcnn_stream_t stream) {
+    return ball_query_impl(xyz, new_xyz, B, N, M, radius, nsample, idx, 0.f, 0, nullptr, false, (hipStream_t)stream);
+}
+
+PRCNN_API int prcnn_ball_query2(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a,
+                                int nsample_a, int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b,
+                                prcnn_stream_t stream) {
+    return ball_query_impl(xyz, new_xyz, B, N, M, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, true,
+                           (hipStream_t)stream);
+}
+
+PRCNN_API int prcnn_three_nn(const float* unknown, const float* known, int B, int n, int m, float* dist2, int32_t* idx,
+                             float* weight, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(unknown && known && dist2 && idx, "prcnn_three_nn: null pointer");
+    PRCNN_REQUIRE(B >= 0 && n >= 0 && m > 0, "prcnn_three_nn: bad shape B=%d n=%d m=%d", B, n, m);
+    if (B == 0 || n == 0) return PRCNN_OK;
+    hipLaunchKernelGGL(three_nn_kernel, dim3(prcnn_divup(n, NB_THREADS), B), dim3(NB_THREADS), 0, (hipStream_t)stream,
+                       unknown, known, n, m, dist2, idx, weight);
+    PRCNN_LAUNCH_CHECK("prcnn_three_nn");
+    return PRCNN_OK;
+}

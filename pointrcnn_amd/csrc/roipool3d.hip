@@ -1,0 +1,134 @@
+// roipool3d.hip -- canonical-RoI point pooling for gfx950, one fused pass.
+//
+// Replaces roipool3d_cuda.forward (lib/utils/roipool3d/src/roipool3d.cpp:48-79 ->
+// roipool3d_kernel.cu:209-237: assign_pts_to_box3d + get_pooled_idx + roipool3d_forward with a
+// B*N*M int32 temporary and two cudaMalloc/cudaFree per call).  Semantics follow the reference's CPU
+// code, which is the authoritative statement (roipool3d.cpp:82-195): first <= S in-box points in
+// ascending index order, wrap-duplicated (slot k >= cnt copies slot k % cnt), empty boxes flagged.
+//
+// One workgroup per (frame, box).  Each of the 4 waves scans a contiguous quarter of the frame's points;
+// a wave-wide __ballot + prefix popcount compacts its hits in index order into its own LDS list (no
+// barrier inside the scan).  The four lists are concatenated in wave order == index order, truncated at
+// S.  The gather then writes the box's S x (3+C) output block with one wave per row: reads are
+// contiguous within a point's feature row, writes are fully coalesced.  Nothing but the inputs and the
+// output touches HBM.
+#include "common.h"
+
+#define RP_THREADS 256
+#define RP_WAVES 4
+
+struct BoxConst { float cx, cy, cz, hh, hw, hl, cosa, sina; };
+
+__device__ __forceinline__ BoxConst make_box(const float* bx) {
+    // roipool3d.cpp:82-95.  cy = bottom_y - h/2 in double then rounded (exactly what the reference's
+    // `h / 2.0` expression does); cos/sin in double rounded once to fp32 (canonical trig contract).
+    BoxConst b;
+    b.cx = bx[0]; b.cz = bx[2];
+    b.cy = (float)((double)bx[1] - (double)bx[3] / 2.0);
+    b.hh = bx[3] * 0.5f; b.hw = bx[4] * 0.5f; b.hl = bx[5] * 0.5f;      // exact halvings
+    b.cosa = (float)cos((double)bx[6]);
+    b.sina = (float)sin((double)bx[6]);
+    return b;
+}
+
+__device__ __forceinline__ bool pt_in_box(const BoxConst& b, float x, float y, float z) {
+    if (fabsf(x - b.cx) > 10.0f || fabsf(y - b.cy) > b.hh || fabsf(z - b.cz) > 10.0f) return false;
+    float dx = x - b.cx, dz = z - b.cz;
+    float x_rot = __fadd_rn(__fmul_rn(dx, b.cosa), __fmul_rn(dz, -b.sina));
+    float z_rot = __fadd_rn(__fmul_rn(dx, b.sina), __fmul_rn(dz, b.cosa));
+    return (x_rot >= -b.hl) & (x_rot <= b.hl) & (z_rot >= -b.hw) & (z_rot <= b.hw);
+}
+
+__global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(const float* __restrict__ xyz,
+                                                               const float* __restrict__ boxes3d,
+                                                               const float* __restrict__ feat, int N, int M, int C,
+                                                               int S, float* __restrict__ pooled,
+                                                               int32_t* __restrict__ empty) {
+    extern __shared__ int32_t lds[];          // RP_WAVES lists of S indices, then the merged list of S
+    __shared__ BoxConst sbox;
+    __shared__ int wcnt[RP_WAVES];
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sbox = make_box(boxes3d + ((size_t)b * M + m) * 7);
+    __syncthreads();
+    const BoxConst box = sbox;
+    const float* __restrict__ p = xyz + (size_t)b * N * 3;
+    int32_t* mylist = lds + wave * S;
+
+    // each wave scans points [k_begin, k_end) in index order
+    const int per_wave = (((N + RP_WAVES - 1) / RP_WAVES) + 63) & ~63;
+    const int k_begin = wave * per_wave, k_end = min(N, k_begin + per_wave);
+    int cnt = 0;                               // wave-uniform
+    for (int k0 = k_begin; k0 < k_end && cnt < S; k0 += 64) {
+        int k = k0 + lane;
+        bool in = false;
+        if (k < k_end) in = pt_in_box(box, p[k * 3], p[k * 3 + 1], p[k * 3 + 2]);
+        unsigned long long mask = __ballot(in);
+        int pos = cnt + __popcll(mask & ((1ULL << lane) - 1ULL));
+        if (in && pos < S) mylist[pos] = k;
+        cnt += __popcll(mask);
+    }
+    if (lane == 0) wcnt[wave] = min(cnt, S);
+    __syncthreads();
+    // merge in wave order (== ascending point index), truncate at S
+    int32_t* sel = lds + RP_WAVES * S;
+    int off = 0;
+    for (int w = 0; w < wave; w++) off += wcnt[w];
+    int total = 0;
+    for (int w = 0; w < RP_WAVES; w++) total += wcnt[w];
+    total = min(total, S);
+    for (int i = lane; i < wcnt[wave]; i += 64)
+        if (off + i < S) sel[off + i] = mylist[i];
+    __syncthreads();
+
+    const int W = 3 + C;
+    float* __restrict__ o = pooled + ((size_t)b * M + m) * S * W;
+    if (tid == 0) empty[(size_t)b * M + m] = total == 0 ? 1 : 0;
+    if (total == 0) {
+        for (size_t e = tid; e < (size_t)S * W; e += RP_THREADS) o[e] = 0.f;
+        return;
+    }
+    const float* __restrict__ f = feat + (size_t)b * N * C;
+    for (int s = wave; s < S; s += RP_WAVES) {
+        int k = sel[s < total ? s : s % total];
+        float* row = o + (size_t)s * W;
+        const float* src = f + (size_t)k * C;
+        for (int c = lane; c < W; c += 64) row[c] = c < 3 ? p[k * 3 + c] : src[c - 3];
+    }
+}
+
+__global__ __launch_bounds__(256) void pts_in_boxes3d_kernel(const float* __restrict__ pts,
+                                                            const float* __restrict__ boxes3d, int N, int M,
+                                                            int32_t* __restrict__ flags) {
+    __shared__ BoxConst sbox;
+    const int m = blockIdx.y;
+    if (threadIdx.x == 0) sbox = make_box(boxes3d + (size_t)m * 7);
+    __syncthreads();
+    const BoxConst box = sbox;
+    int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < N) flags[(size_t)m * N + k] = pt_in_box(box, pts[k * 3], pts[k * 3 + 1], pts[k * 3 + 2]) ? 1 : 0;
+}
+
+PRCNN_API int prcnn_roipool3d(const float* xyz, const float* boxes3d, const float* feat, int B, int N, int M, int C,
+                              int S, float* pooled, int32_t* empty, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(xyz && boxes3d && pooled && empty && (C == 0 || feat), "prcnn_roipool3d: null pointer");
+    PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && C >= 0 && S > 0, "prcnn_roipool3d: bad shape B=%d N=%d M=%d C=%d S=%d", B, N, M, C, S);
+    size_t lds_bytes = (size_t)(RP_WAVES + 1) * S * sizeof(int32_t);
+    PRCNN_REQUIRE(lds_bytes <= 60 * 1024, "prcnn_roipool3d: sampled_pt_num %d too large for the LDS index lists", S);
+    if (B == 0 || M == 0) return PRCNN_OK;
+    hipLaunchKernelGGL(roipool3d_kernel, dim3(M, B), dim3(RP_THREADS), lds_bytes, (hipStream_t)stream, xyz, boxes3d, feat,
+                       N, M, C, S, pooled, empty);
+    PRCNN_LAUNCH_CHECK("prcnn_roipool3d");
+    return PRCNN_OK;
+}
+
+PRCNN_API int prcnn_pts_in_boxes3d(const float* pts, const float* boxes3d, int N, int M, int32_t* flags,
+                                   prcnn_stream_t stream) {
+    PRCNN_REQUIRE(pts && boxes3d && flags, "prcnn_pts_in_boxes3d: null pointer");
+    PRCNN_REQUIRE(N >= 0 && M >= 0, "prcnn_pts_in_boxes3d: bad shape");
+    if (N == 0 || M == 0) return PRCNN_OK;
+    hipLaunchKernelGGL(pts_in_boxes3d_kernel, dim3(prcnn_divup(N, 256), M), dim3(256), 0, (hipStream_t)stream, pts,
+                       boxes3d, N, M, flags);
+    PRCNN_LAUNCH_CHECK("prcnn_pts_in_boxes3d");
+    return PRCNN_OK;
+}

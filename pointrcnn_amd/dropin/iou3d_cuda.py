@@ -1,0 +1,49 @@
+"""`iou3d_cuda` -- Python stand-in for the reference's pybind module (lib/utils/iou3d/src/iou3d.cpp:174-179):
+same four functions, same argument order and ownership (caller allocates; `keep` is a CPU int64 tensor for
+the nms functions, iou3d_utils.py:68,85), argument errors raise RuntimeError (AT_CHECK, iou3d.cpp:7-9).
+All computation is in libprcnn_pointops.so.  The NMS sweep runs on the device; the only host
+synchronisation is the copy of the kept indices into the caller's CPU `keep`, which this API shape forces
+(pointrcnn_amd.ops.nms_sorted is the sync-free form)."""
+import torch
+
+from pointrcnn_amd import ops
+
+
+def _check_input(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDAtensor " % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous " % name)
+
+
+def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
+    for t, n in ((boxes_a, "boxes_a"), (boxes_b, "boxes_b"), (ans_overlap, "ans_overlap")):
+        _check_input(t, n)
+    ops.boxes_overlap_bev(boxes_a, boxes_b, out=ans_overlap)
+    return 1
+
+
+def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
+    for t, n in ((boxes_a, "boxes_a"), (boxes_b, "boxes_b"), (ans_iou, "ans_iou")):
+        _check_input(t, n)
+    ops.boxes_iou_bev(boxes_a, boxes_b, out=ans_iou)
+    return 1
+
+
+def _nms(boxes, keep, thresh, rotated):
+    _check_input(boxes, "boxes")
+    if not keep.is_contiguous():
+        raise RuntimeError("keep must be contiguous ")
+    keep_dev, num = ops.nms_sorted(boxes, thresh, rotated=rotated)
+    n = int(num.item())
+    if n:
+        keep[:n].copy_(keep_dev[:n])
+    return n
+
+
+def nms_gpu(boxes, keep, nms_overlap_thresh):
+    return _nms(boxes, keep, nms_overlap_thresh, True)
+
+
+def nms_normal_gpu(boxes, keep, nms_overlap_thresh):
+    return _nms(boxes, keep, nms_overlap_thresh, False)

@@ -1,0 +1,194 @@
+"""`pointnet2_lib.pointnet2.pointnet2_modules` -- PointnetSAModuleMSG / PointnetSAModule / PointnetFPModule with
+the constructor and forward signatures the reference uses (lib/net/pointnet2_msg.py:27-34,44,61,66-68;
+lib/net/rcnn_net.py:33-41,180) [UPSTREAM module, absent from the tree; semantics per SURVEY.md Appendix A].
+
+Two execution paths with identical results:
+  * composed path (training / autograd): FPS -> gather -> ball_query -> grouping -> SharedMLP -> max_pool,
+    every point op a HIP kernel behind an autograd Function (pointnet2_utils);
+  * fused inference path (no autograd, BN in eval mode): features stay channels-last, the two radii of an MSG
+    level are queried in one scan, grouping / 3-NN interpolation is folded into the first MLP layer's MFMA
+    A-tile, max-pool into the last layer's epilogue, and both scales write straight into the concatenated
+    output -- no (B,C+3,npoint,nsample) tensor, no cat, no transposes.  Outputs are returned as (B,C,N)
+    VIEWS of channels-last buffers so the next module picks them up without a copy.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pointrcnn_amd import ops
+from . import pointnet2_utils
+from . import pytorch_utils as pt_utils
+
+_POOL_FUSED = (16, 32, 64)
+
+
+def _channels_last(features):
+    """(B,C,N) -> (B,N,C) tensor with unit last stride and uniform row stride (view when possible)."""
+    if features is None:
+        return None
+    return pt_utils._rows_view(features.transpose(1, 2))
+
+
+def _run_mlp_tail(x_rows, layers, start, out, pool_ns):
+    """layers[start:] applied to channels-last rows; the last layer pools/stores into `out`."""
+    n = len(layers)
+    for li in range(start, n):
+        last = li == n - 1
+        x_rows = ops.mlp_rows(x_rows, layers[li], out=out if last else None, pool_ns=pool_ns if last else 0)
+    return x_rows
+
+
+class _PointnetSAModuleBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+        self.pool_method = "max_pool"
+
+    def _fused_ok(self, xyz, features):
+        if torch.is_grad_enabled() or not xyz.is_cuda or self.pool_method != "max_pool":
+            return False
+        if xyz.dtype != torch.float32 or (features is not None and features.dtype != torch.float32):
+            return False
+        for g, m in zip(self.groupers, self.mlps):
+            if not getattr(g, "use_xyz", True) or not m.fusable():
+                return False
+        return True
+
+    def forward(self, xyz, features=None, new_xyz=None):
+        """xyz (B,N,3), features (B,C,N) or None -> new_xyz (B,npoint,3) or None, new_features (B,sum C_out,npoint)"""
+        if self._fused_ok(xyz, features):
+            return self._forward_fused(xyz, features, new_xyz)
+        new_features_list = []
+        xyz_flipped = xyz.transpose(1, 2).contiguous()
+        if new_xyz is None:
+            new_xyz = pointnet2_utils.gather_operation(
+                xyz_flipped, pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            ).transpose(1, 2).contiguous() if self.npoint is not None else None
+        for i in range(len(self.groupers)):
+            new_features = self.groupers[i](xyz, new_xyz, features)         # (B,C,npoint,nsample)
+            new_features = self.mlps[i](new_features)
+            if self.pool_method == "max_pool":
+                new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)])
+            elif self.pool_method == "avg_pool":
+                new_features = F.avg_pool2d(new_features, kernel_size=[1, new_features.size(3)])
+            else:
+                raise NotImplementedError
+            new_features_list.append(new_features.squeeze(-1))
+        return new_xyz, torch.cat(new_features_list, dim=1)
+
+    # ---- fused inference path -----------------------------------------------------------------
+    def _forward_fused(self, xyz, features, new_xyz):
+        xyz = xyz.contiguous()
+        B, N, _ = xyz.shape
+        feat_cl = _channels_last(features)
+        if new_xyz is None and self.npoint is not None:
+            new_xyz = ops.gather_rows(xyz, ops.furthest_point_sample(xyz, self.npoint))
+        M = new_xyz.shape[1] if new_xyz is not None else 1
+        c_outs = [m.layers()[-1]._parts()[0].out_channels for m in self.mlps]
+        out_cl = torch.empty((B, M, sum(c_outs)), dtype=torch.float32, device=xyz.device)
+
+        # neighbour search: both radii of an MSG level in one scan
+        idxs = [None] * len(self.groupers)
+        qg = [i for i, g in enumerate(self.groupers) if isinstance(g, pointnet2_utils.QueryAndGroup)]
+        if len(qg) == 2 and new_xyz is not None:
+            a, b = self.groupers[qg[0]], self.groupers[qg[1]]
+            idxs[qg[0]], idxs[qg[1]] = ops.ball_query2(a.radius, a.nsample, b.radius, b.nsample, xyz, new_xyz)
+        for i, g in enumerate(self.groupers):
+            if idxs[i] is not None:
+                continue
+            if isinstance(g, pointnet2_utils.QueryAndGroup):
+                idxs[i] = ops.ball_query(g.radius, g.nsample, xyz, new_xyz)
+            else:                                   # GroupAll: one group holding every point, no centring
+                idxs[i] = torch.arange(N, dtype=torch.int32, device=xyz.device).view(1, 1, N).expand(B, 1, N).contiguous()
+
+        col = 0
+        for i, (g, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            group_all = not isinstance(g, pointnet2_utils.QueryAndGroup)
+            ns = idxs[i].shape[2]
+            mods = mlp.layers()
+            # torch's grouped channel order is [dxyz(3), feat(C)]; the kernel's A row is [feat(C), dxyz(3)]
+            layers = [mods[0].packed(k_rot=3 if feat_cl is not None else 0)] + [m.packed() for m in mods[1:]]
+            fused_pool = ns in _POOL_FUSED
+            dst = (out_cl.view(B * M, -1), col)
+            ctr = None if group_all else new_xyz
+            if len(layers) == 1:
+                x = ops.mlp_group(xyz, ctr, idxs[i], feat_cl, layers[0], out=dst if fused_pool else None,
+                                  pool_ns=ns if fused_pool else 0)
+            else:
+                x = ops.mlp_group(xyz, ctr, idxs[i], feat_cl, layers[0])
+                x = _run_mlp_tail(x, layers, 1, dst if fused_pool else None, ns if fused_pool else 0)
+            if not fused_pool:
+                ops.maxpool_rows(x, ns, out=dst)
+            col += c_outs[i]
+        return new_xyz, out_cl.transpose(1, 2)
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """Set abstraction with multi-scale grouping (lib/net/pointnet2_msg.py:27-34)."""
+
+    def __init__(self, *, npoint, radii, nsamples, mlps, bn=True, use_xyz=True, pool_method="max_pool",
+                 instance_norm=False):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for i in range(len(radii)):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radii[i], nsamples[i], use_xyz=use_xyz)
+                                 if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
+            mlp_spec = list(mlps[i])
+            if use_xyz:
+                mlp_spec[0] += 3
+            self.mlps.append(pt_utils.SharedMLP(mlp_spec, bn=bn, instance_norm=instance_norm))
+        self.pool_method = pool_method
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """Single-scale set abstraction; npoint=None groups all points (lib/net/rcnn_net.py:31-41)."""
+
+    def __init__(self, *, mlp, npoint=None, radius=None, nsample=None, bn=True, use_xyz=True,
+                 pool_method="max_pool", instance_norm=False):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz,
+                         pool_method=pool_method, instance_norm=instance_norm)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation: 3-NN inverse-distance interpolation + skip concat + SharedMLP
+    (lib/net/pointnet2_msg.py:43-45,66-68)."""
+
+    def __init__(self, *, mlp, bn=True):
+        super().__init__()
+        self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n) or None, known_feats (B,C2,m) -> (B,mlp[-1],n)"""
+        if (not torch.is_grad_enabled()) and known is not None and unknown.is_cuda and self.mlp.fusable() \
+                and known_feats.dtype == torch.float32:
+            return self._forward_fused(unknown, known, unknow_feats, known_feats)
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)
+            norm = torch.sum(dist_recip, dim=2, keepdim=True)
+            weight = dist_recip / norm
+            interpolated_feats = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            interpolated_feats = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        if unknow_feats is not None:
+            new_features = torch.cat([interpolated_feats, unknow_feats], dim=1)
+        else:
+            new_features = interpolated_feats
+        new_features = self.mlp(new_features.unsqueeze(-1))
+        return new_features.squeeze(-1)
+
+    def _forward_fused(self, unknown, known, unknow_feats, known_feats):
+        unknown, known = unknown.contiguous(), known.contiguous()
+        B, n, _ = unknown.shape
+        _, idx3, w3 = ops.three_nn(unknown, known, want_weight=True)
+        known_cl = _channels_last(known_feats)
+        skip_cl = _channels_last(unknow_feats)
+        layers = [m.packed() for m in self.mlp.layers()]
+        x = ops.mlp_interp(known_cl, idx3, w3, skip_cl, layers[0])
+        x = _run_mlp_tail(x, layers, 1, None, 0)
+        return x.view(B, n, -1).transpose(1, 2)

@@ -1,0 +1,207 @@
+"""`pointnet2_lib.pointnet2.pytorch_utils` -- SharedMLP / Conv1d / Conv2d / FC building blocks with the
+attribute names the released checkpoint's state-dict keys need (`layer{k}.conv.weight`, `layer{k}.bn.bn.*`;
+in-tree evidence lib/net/rpn.py:64,66, lib/net/rcnn_net.py:104) [UPSTREAM module, absent from the tree].
+
+Inference fast path (MI355X): when autograd is off, BatchNorm is in eval mode and the input lives on the GPU,
+a 1x1 conv (+BN +ReLU) layer is ONE fused fp32-MFMA kernel on channels-last rows (pointrcnn_amd.ops.mlp_rows)
+with BN folded into the packed weights; activations stay channels-last between layers and are handed to the
+caller as transposed VIEWS, so a chain of these modules never pays a layout change.  Otherwise (training,
+CPU construction) the modules behave as plain torch Conv/BN/ReLU stacks.
+"""
+import torch
+import torch.nn as nn
+
+from pointrcnn_amd import ops
+
+
+def _fold_bn(conv, bn):
+    """(Nout,K) weight and (Nout) bias of conv followed by eval-mode batch norm."""
+    w = conv.weight.detach().reshape(conv.out_channels, -1).float()
+    b = conv.bias.detach().float() if conv.bias is not None else None
+    if bn is not None:
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+        w = w * scale[:, None]
+        b = shift if b is None else b * scale + shift
+    return w.contiguous(), (None if b is None else b.contiguous())
+
+
+def _rows_view(x_cl):
+    """x_cl: (..., C) view with unit last stride -> tensor usable as uniformly strided rows (copy if needed)."""
+    if x_cl.stride(-1) != 1:
+        return x_cl.contiguous()
+    ld = None
+    expect = None
+    for size, stride in zip(reversed(x_cl.shape[:-1]), reversed(x_cl.stride()[:-1])):
+        if size == 1:
+            continue
+        if ld is None:
+            ld, expect = stride, stride * size
+        elif stride != expect:
+            return x_cl.contiguous()
+        else:
+            expect = stride * size
+    if ld is not None and ld < x_cl.shape[-1]:
+        return x_cl.contiguous()
+    return x_cl
+
+
+class _BNBase(nn.Sequential):
+    def __init__(self, in_size, batch_norm=None, name=""):
+        super().__init__()
+        self.add_module(name + "bn", batch_norm(in_size))
+        nn.init.constant_(self[0].weight, 1.0)
+        nn.init.constant_(self[0].bias, 0)
+
+
+class BatchNorm1d(_BNBase):
+    def __init__(self, in_size, *, name=""):
+        super().__init__(in_size, batch_norm=nn.BatchNorm1d, name=name)
+
+
+class BatchNorm2d(_BNBase):
+    def __init__(self, in_size, name=""):
+        super().__init__(in_size, batch_norm=nn.BatchNorm2d, name=name)
+
+
+class _ConvBase(nn.Sequential):
+    def __init__(self, in_size, out_size, kernel_size, stride, padding, activation, bn, init, conv=None,
+                 batch_norm=None, bias=True, preact=False, name="", instance_norm=False, instance_norm_func=None):
+        super().__init__()
+        bias = bias and (not bn)
+        conv_unit = conv(in_size, out_size, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias)
+        init(conv_unit.weight)
+        if bias:
+            nn.init.constant_(conv_unit.bias, 0)
+        bn_unit = None
+        if bn:
+            bn_unit = batch_norm(out_size if not preact else in_size)
+        in_unit = None
+        if instance_norm:
+            in_unit = instance_norm_func(out_size if not preact else in_size, affine=False,
+                                         track_running_stats=False)
+        if preact:
+            if bn:
+                self.add_module(name + "bn", bn_unit)
+            if activation is not None:
+                self.add_module(name + "activation", activation)
+            if not bn and instance_norm:
+                self.add_module(name + "in", in_unit)
+        self.add_module(name + "conv", conv_unit)
+        if not preact:
+            if bn:
+                self.add_module(name + "bn", bn_unit)
+            if activation is not None:
+                self.add_module(name + "activation", activation)
+            if not bn and instance_norm:
+                self.add_module(name + "in", in_unit)
+        self._prcnn_name = name
+        self._prcnn_fusable = (not preact) and (not instance_norm) and \
+            (activation is None or isinstance(activation, nn.ReLU))
+        self._prcnn_cache = {}
+
+    # ---- fused inference path -------------------------------------------------------------
+    def _parts(self):
+        n = self._prcnn_name
+        conv = getattr(self, n + "conv")
+        bnw = getattr(self, n + "bn", None)
+        bn = bnw[0] if bnw is not None else None
+        act = getattr(self, n + "activation", None)
+        return conv, bn, act
+
+    def fusable(self):
+        if not self._prcnn_fusable:
+            return False
+        conv, bn, _ = self._parts()
+        ks = conv.kernel_size if isinstance(conv.kernel_size, tuple) else (conv.kernel_size,)
+        st = conv.stride if isinstance(conv.stride, tuple) else (conv.stride,)
+        pd = conv.padding if isinstance(conv.padding, tuple) else (conv.padding,)
+        if any(k != 1 for k in ks) or any(s != 1 for s in st) or any(p != 0 for p in pd):
+            return False
+        if bn is not None and bn.training:
+            return False
+        return conv.weight.is_cuda and conv.weight.dtype == torch.float32
+
+    def packed(self, k_rot=0):
+        """PackedLinear of this layer (BN folded); cached until a parameter/buffer changes."""
+        conv, bn, act = self._parts()
+        tensors = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
+        if bn is not None:
+            tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = (k_rot,) + tuple((t.data_ptr(), t._version) for t in tensors)
+        hit = self._prcnn_cache.get(k_rot)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w, b = _fold_bn(conv, bn)
+        lin = ops.PackedLinear(w, b, relu=act is not None, k_rot=k_rot)
+        self._prcnn_cache[k_rot] = (key, lin)
+        return lin
+
+    def forward(self, x):
+        if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or not self.fusable():
+            return super().forward(x)
+        # (B,C,L) or (B,C,H,W) -> channels-last rows; zero-copy when x is a transposed channels-last view
+        nd = x.dim()
+        perm = (0, 2, 1) if nd == 3 else (0, 2, 3, 1)
+        x_cl = _rows_view(x.permute(*perm))
+        y = ops.mlp_rows(x_cl, self.packed())
+        y = y.view(*x_cl.shape[:-1], y.shape[-1])
+        return y.permute(0, 2, 1) if nd == 3 else y.permute(0, 3, 1, 2)
+
+
+class Conv1d(_ConvBase):
+    def __init__(self, in_size, out_size, *, kernel_size=1, stride=1, padding=0, activation=nn.ReLU(inplace=True),
+                 bn=False, init=nn.init.kaiming_normal_, bias=True, preact=False, name="", instance_norm=False):
+        super().__init__(in_size, out_size, kernel_size, stride, padding, activation, bn, init, conv=nn.Conv1d,
+                         batch_norm=BatchNorm1d, bias=bias, preact=preact, name=name,
+                         instance_norm=instance_norm, instance_norm_func=nn.InstanceNorm1d)
+
+
+class Conv2d(_ConvBase):
+    def __init__(self, in_size, out_size, *, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0),
+                 activation=nn.ReLU(inplace=True), bn=False, init=nn.init.kaiming_normal_, bias=True, preact=False,
+                 name="", instance_norm=False):
+        super().__init__(in_size, out_size, kernel_size, stride, padding, activation, bn, init, conv=nn.Conv2d,
+                         batch_norm=BatchNorm2d, bias=bias, preact=preact, name=name,
+                         instance_norm=instance_norm, instance_norm_func=nn.InstanceNorm2d)
+
+
+class SharedMLP(nn.Sequential):
+    """args = [C_in, C_1, ..., C_out]: a stack of 1x1 Conv2d(+BN)+ReLU layers named layer0, layer1, ..."""
+
+    def __init__(self, args, *, bn=False, activation=nn.ReLU(inplace=True), preact=False, first=False, name="",
+                 instance_norm=False):
+        super().__init__()
+        for i in range(len(args) - 1):
+            plain = (not first) or (not preact) or (i != 0)
+            self.add_module(name + "layer{}".format(i),
+                            Conv2d(args[i], args[i + 1], bn=plain and bn, activation=activation if plain else None,
+                                   preact=preact, instance_norm=instance_norm))
+
+    def layers(self):
+        return [m for m in self.children()]
+
+    def fusable(self):
+        return all(isinstance(m, _ConvBase) and m.fusable() for m in self.children())
+
+
+class FC(nn.Sequential):
+    def __init__(self, in_size, out_size, *, activation=nn.ReLU(inplace=True), bn=False, init=None, preact=False,
+                 name=""):
+        super().__init__()
+        fc = nn.Linear(in_size, out_size, bias=not bn)
+        if init is not None:
+            init(fc.weight)
+        if not bn:
+            nn.init.constant_(fc.bias, 0)
+        if preact:
+            if bn:
+                self.add_module(name + "bn", BatchNorm1d(in_size))
+            if activation is not None:
+                self.add_module(name + "activation", activation)
+        self.add_module(name + "fc", fc)
+        if not preact:
+            if bn:
+                self.add_module(name + "bn", BatchNorm1d(out_size))
+            if activation is not None:
+                self.add_module(name + "activation", activation)

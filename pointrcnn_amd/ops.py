@@ -1,0 +1,293 @@
+"""Tensor-level host layer over the C ABI: argument checking, output allocation, stream plumbing.
+
+PyTorch is used for device memory and streams only; every computation below is one call into
+libprcnn_pointops.so on torch's CURRENT stream (so it composes with torch.cuda.graphs and side streams).
+Shapes and argument meaning mirror the reference op surface (see each function's citation).
+"""
+import torch
+
+from . import _cabi
+
+_INT = torch.int32
+_F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=_F32, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA(HIP) tensor: the HIP kernels are the only implementation" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError("%s must have %d dims, got shape %s" % (name, ndim, tuple(t.shape)))
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------ PointNet++ operators
+def furthest_point_sample(xyz, npoint):
+    """xyz (B,N,3) f32 -> idx (B,npoint) i32   [pointnet2_utils.furthest_point_sample]"""
+    _chk(xyz, "xyz", ndim=3)
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, npoint), dtype=_INT, device=xyz.device)
+    tmp = torch.empty((B, N), dtype=_F32, device=xyz.device) if N > 16384 else None
+    L = _cabi.lib()
+    _cabi.check(L.prcnn_fps(_p(xyz), B, N, npoint, _p(tmp), _p(idx), _stream()), "prcnn_fps")
+    return idx
+
+
+def gather(features, idx):
+    """features (B,C,N), idx (B,M) i32 -> (B,C,M)   [gather_operation]"""
+    _chk(features, "features", ndim=3); _chk(idx, "idx", _INT, 2)
+    B, C, N = features.shape
+    M = idx.shape[1]
+    out = torch.empty((B, C, M), dtype=_F32, device=features.device)
+    _cabi.check(_cabi.lib().prcnn_gather(_p(features), _p(idx), B, C, N, M, _p(out), _stream()), "prcnn_gather")
+    return out
+
+
+def gather_grad(grad_out, idx, N):
+    _chk(grad_out, "grad_out", ndim=3); _chk(idx, "idx", _INT, 2)
+    B, C, M = grad_out.shape
+    g = torch.zeros((B, C, N), dtype=_F32, device=grad_out.device)
+    _cabi.check(_cabi.lib().prcnn_gather_grad(_p(grad_out), _p(idx), B, C, N, M, _p(g), _stream()), "prcnn_gather_grad")
+    return g
+
+
+def gather_rows(in_cl, idx):
+    """in_cl (B,N,C) channels-last (row stride may exceed C), idx (B,M) i32 -> (B,M,C)"""
+    _chk(idx, "idx", _INT, 2)
+    B, N, C = in_cl.shape
+    M = idx.shape[1]
+    out = torch.empty((B, M, C), dtype=_F32, device=in_cl.device)
+    _cabi.check(_cabi.lib().prcnn_gather_rows(_p(in_cl), in_cl.stride(-2), _p(idx), B, N, M, C, _p(out), _stream()),
+                "prcnn_gather_rows")
+    return out
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """xyz (B,N,3), new_xyz (B,M,3) -> idx (B,M,nsample) i32   [ball_query]"""
+    _chk(xyz, "xyz", ndim=3); _chk(new_xyz, "new_xyz", ndim=3)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.empty((B, M, nsample), dtype=_INT, device=xyz.device)
+    _cabi.check(_cabi.lib().prcnn_ball_query(_p(xyz), _p(new_xyz), B, N, M, float(radius), nsample, _p(idx), _stream()),
+                "prcnn_ball_query")
+    return idx
+
+
+def ball_query2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz):
+    """two radii in one scan -> (idx_a, idx_b)"""
+    _chk(xyz, "xyz", ndim=3); _chk(new_xyz, "new_xyz", ndim=3)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    ia = torch.empty((B, M, nsample_a), dtype=_INT, device=xyz.device)
+    ib = torch.empty((B, M, nsample_b), dtype=_INT, device=xyz.device)
+    _cabi.check(_cabi.lib().prcnn_ball_query2(_p(xyz), _p(new_xyz), B, N, M, float(radius_a), nsample_a, _p(ia),
+                                              float(radius_b), nsample_b, _p(ib), _stream()), "prcnn_ball_query2")
+    return ia, ib
+
+
+def group(features, idx):
+    """features (B,C,N), idx (B,M,ns) -> (B,C,M,ns)   [grouping_operation]"""
+    _chk(features, "features", ndim=3); _chk(idx, "idx", _INT, 3)
+    B, C, N = features.shape
+    _, M, ns = idx.shape
+    out = torch.empty((B, C, M, ns), dtype=_F32, device=features.device)
+    _cabi.check(_cabi.lib().prcnn_group(_p(features), _p(idx), B, C, N, M, ns, _p(out), _stream()), "prcnn_group")
+    return out
+
+
+def group_grad(grad_out, idx, N):
+    _chk(grad_out, "grad_out", ndim=4); _chk(idx, "idx", _INT, 3)
+    B, C, M, ns = grad_out.shape
+    g = torch.zeros((B, C, N), dtype=_F32, device=grad_out.device)
+    _cabi.check(_cabi.lib().prcnn_group_grad(_p(grad_out), _p(idx), B, C, N, M, ns, _p(g), _stream()), "prcnn_group_grad")
+    return g
+
+
+def three_nn(unknown, known, want_weight=False):
+    """unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3), idx (B,n,3) i32 [, weight (B,n,3)]"""
+    _chk(unknown, "unknown", ndim=3); _chk(known, "known", ndim=3)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = torch.empty((B, n, 3), dtype=_F32, device=unknown.device)
+    idx = torch.empty((B, n, 3), dtype=_INT, device=unknown.device)
+    w = torch.empty((B, n, 3), dtype=_F32, device=unknown.device) if want_weight else None
+    _cabi.check(_cabi.lib().prcnn_three_nn(_p(unknown), _p(known), B, n, m, _p(d2), _p(idx), _p(w), _stream()),
+                "prcnn_three_nn")
+    return (d2, idx, w) if want_weight else (d2, idx)
+
+
+def three_interpolate(features, idx, weight):
+    """features (B,C,m), idx (B,n,3), weight (B,n,3) -> (B,C,n)"""
+    _chk(features, "features", ndim=3); _chk(idx, "idx", _INT, 3); _chk(weight, "weight", ndim=3)
+    B, C, m = features.shape
+    n = idx.shape[1]
+    out = torch.empty((B, C, n), dtype=_F32, device=features.device)
+    _cabi.check(_cabi.lib().prcnn_three_interp(_p(features), _p(idx), _p(weight), B, C, m, n, _p(out), _stream()),
+                "prcnn_three_interp")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    _chk(grad_out, "grad_out", ndim=3); _chk(idx, "idx", _INT, 3); _chk(weight, "weight", ndim=3)
+    B, C, n = grad_out.shape
+    g = torch.zeros((B, C, m), dtype=_F32, device=grad_out.device)
+    _cabi.check(_cabi.lib().prcnn_three_interp_grad(_p(grad_out), _p(idx), _p(weight), B, C, n, m, _p(g), _stream()),
+                "prcnn_three_interp_grad")
+    return g
+
+
+# ------------------------------------------------------------------ fused per-point MLP layers
+class PackedLinear:
+    """One 1x1-conv layer with (eval-mode) BatchNorm folded in, packed for the MFMA kernel.
+
+    weight: (Nout, K) f32 device tensor in torch conv layout; bias: (Nout) or None.
+    k_rot: leading input channels moved to the end of K (3 for grouped [dxyz, feat] layers).
+    """
+
+    def __init__(self, weight, bias=None, relu=True, k_rot=0):
+        _chk(weight, "weight", ndim=2)
+        self.nout, self.k = weight.shape
+        self.relu = bool(relu)
+        L = _cabi.lib()
+        self.wpack = torch.empty((L.prcnn_wpack_floats(self.nout, self.k),), dtype=_F32, device=weight.device)
+        _cabi.check(L.prcnn_pack_weight(_p(weight), self.nout, self.k, k_rot, _p(self.wpack), _stream()),
+                    "prcnn_pack_weight")
+        self.bias = None if bias is None else _chk(bias.contiguous(), "bias", ndim=1)
+
+
+def _out_buf(out, rows, lin, device):
+    if out is None:
+        return torch.empty((rows, lin.nout), dtype=_F32, device=device), lin.nout, 0
+    buf, col_off = out
+    return buf, buf.stride(-2), col_off
+
+
+def mlp_rows(x, lin, out=None, pool_ns=0):
+    """x (..., K) channels-last rows (last dim contiguous, uniform row stride) -> (rows[/pool_ns], Nout).
+    out = (buffer, col_off) writes into a wider channels-last buffer instead of allocating."""
+    if x.stride(-1) != 1:
+        raise RuntimeError("mlp_rows: last dim must be contiguous")
+    K = x.shape[-1]
+    rows = x.numel() // K
+    ld_in = x.stride(-2) if x.dim() > 1 else K
+    rows_out = rows // pool_ns if pool_ns else rows
+    buf, ld_out, col_off = _out_buf(out, rows_out, lin, x.device)
+    _cabi.check(_cabi.lib().prcnn_mlp_rows(_p(x), ld_in, rows, K, _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu),
+                                           _p(buf), ld_out, col_off, pool_ns, _stream()), "prcnn_mlp_rows")
+    return buf
+
+
+def mlp_group(xyz, new_xyz, idx, feat_cl, lin, out=None, pool_ns=0):
+    """First SA layer fused with ball-query grouping.  xyz (B,N,3), new_xyz (B,M,3) or None (GroupAll),
+    idx (B,M,ns) i32, feat_cl (B,N,C) channels-last or None -> (B*M*ns[/pool_ns], Nout)."""
+    B, N, _ = xyz.shape
+    _, M, ns = idx.shape
+    C = 0 if feat_cl is None else feat_cl.shape[-1]
+    ld_feat = 0 if feat_cl is None else feat_cl.stride(-2)
+    rows = B * M * ns
+    rows_out = rows // pool_ns if pool_ns else rows
+    buf, ld_out, col_off = _out_buf(out, rows_out, lin, xyz.device)
+    _cabi.check(_cabi.lib().prcnn_mlp_group(_p(xyz), _p(new_xyz), _p(idx), _p(feat_cl), ld_feat, B, N, M, ns, C,
+                                            _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu), _p(buf), ld_out,
+                                            col_off, pool_ns, _stream()), "prcnn_mlp_group")
+    return buf
+
+
+def mlp_interp(known_cl, idx3, w3, skip_cl, lin, out=None):
+    """First FP layer fused with three_interpolate + skip concat.  known_cl (B,m,C2), idx3/w3 (B,n,3),
+    skip_cl (B,n,C1) or None -> (B*n, Nout)."""
+    B, m, C2 = known_cl.shape
+    n = idx3.shape[1]
+    C1 = 0 if skip_cl is None else skip_cl.shape[-1]
+    ld_skip = 0 if skip_cl is None else skip_cl.stride(-2)
+    buf, ld_out, col_off = _out_buf(out, B * n, lin, known_cl.device)
+    _cabi.check(_cabi.lib().prcnn_mlp_interp(_p(known_cl), known_cl.stride(-2), _p(idx3), _p(w3), _p(skip_cl), ld_skip,
+                                             B, n, m, C2, C1, _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu),
+                                             _p(buf), ld_out, col_off, _stream()), "prcnn_mlp_interp")
+    return buf
+
+
+def maxpool_rows(x, ns, out=None):
+    """x (rows, C) -> (rows/ns, C): max over every ns consecutive rows (generic nsample fallback)."""
+    rows, C = x.shape
+    rows_out = rows // ns
+    if out is None:
+        buf, ld_out, col_off = torch.empty((rows_out, C), dtype=_F32, device=x.device), C, 0
+    else:
+        buf, col_off = out
+        ld_out = buf.stride(-2)
+    _cabi.check(_cabi.lib().prcnn_maxpool_rows(_p(x), x.stride(0), rows_out, ns, C, _p(buf), ld_out, col_off, _stream()),
+                "prcnn_maxpool_rows")
+    return buf
+
+
+# ------------------------------------------------------------------ roipool3d
+def roipool3d(xyz, boxes3d_enlarged, pts_feature, sampled_pt_num):
+    """xyz (B,N,3), boxes (B,M,7) already enlarged, pts_feature (B,N,C) -> pooled (B,M,S,3+C), empty (B,M) i32
+    [roipool3d_cuda.forward, lib/utils/roipool3d/src/roipool3d.cpp:48-79]"""
+    _chk(xyz, "xyz", ndim=3); _chk(boxes3d_enlarged, "boxes3d", ndim=3); _chk(pts_feature, "pts_feature", ndim=3)
+    B, N, _ = xyz.shape
+    M, C = boxes3d_enlarged.shape[1], pts_feature.shape[2]
+    pooled = torch.empty((B, M, sampled_pt_num, 3 + C), dtype=_F32, device=xyz.device)
+    empty = torch.empty((B, M), dtype=_INT, device=xyz.device)
+    _cabi.check(_cabi.lib().prcnn_roipool3d(_p(xyz), _p(boxes3d_enlarged), _p(pts_feature), B, N, M, C, sampled_pt_num,
+                                            _p(pooled), _p(empty), _stream()), "prcnn_roipool3d")
+    return pooled, empty
+
+
+def pts_in_boxes3d(pts, boxes3d):
+    """pts (N,3), boxes3d (M,7) -> flags (M,N) i32"""
+    _chk(pts, "pts", ndim=2); _chk(boxes3d, "boxes3d", ndim=2)
+    N, M = pts.shape[0], boxes3d.shape[0]
+    flags = torch.empty((M, N), dtype=_INT, device=pts.device)
+    _cabi.check(_cabi.lib().prcnn_pts_in_boxes3d(_p(pts), _p(boxes3d), N, M, _p(flags), _stream()), "prcnn_pts_in_boxes3d")
+    return flags
+
+
+# ------------------------------------------------------------------ iou3d
+def boxes_overlap_bev(boxes_a, boxes_b, out=None):
+    _chk(boxes_a, "boxes_a", ndim=2); _chk(boxes_b, "boxes_b", ndim=2)
+    na, nb = boxes_a.shape[0], boxes_b.shape[0]
+    if out is None:
+        out = torch.empty((na, nb), dtype=_F32, device=boxes_a.device)
+    _cabi.check(_cabi.lib().prcnn_boxes_overlap_bev(_p(boxes_a), na, _p(boxes_b), nb, _p(out), _stream()),
+                "prcnn_boxes_overlap_bev")
+    return out
+
+
+def boxes_iou_bev(boxes_a, boxes_b, out=None):
+    _chk(boxes_a, "boxes_a", ndim=2); _chk(boxes_b, "boxes_b", ndim=2)
+    na, nb = boxes_a.shape[0], boxes_b.shape[0]
+    if out is None:
+        out = torch.empty((na, nb), dtype=_F32, device=boxes_a.device)
+    _cabi.check(_cabi.lib().prcnn_boxes_iou_bev(_p(boxes_a), na, _p(boxes_b), nb, _p(out), _stream()),
+                "prcnn_boxes_iou_bev")
+    return out
+
+
+def nms_sorted(boxes_sorted, thresh, rotated=True):
+    """Greedy NMS over boxes already sorted by descending score, fully on device.
+    -> keep (N) int64 (first num entries valid), num (1) int32.  No host sync."""
+    _chk(boxes_sorted, "boxes", ndim=2)
+    N = boxes_sorted.shape[0]
+    L = _cabi.lib()
+    keep = torch.empty((max(N, 1),), dtype=torch.int64, device=boxes_sorted.device)
+    num = torch.empty((1,), dtype=_INT, device=boxes_sorted.device)
+    wsb = L.prcnn_nms_workspace_bytes(N)
+    ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=boxes_sorted.device)
+    _cabi.check(L.prcnn_nms(_p(boxes_sorted), N, float(thresh), 0 if rotated else 1, _p(keep), _p(num), _p(ws), wsb,
+                            _stream()), "prcnn_nms")
+    return keep, num

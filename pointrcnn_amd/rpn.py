@@ -1,0 +1,172 @@
+"""Host-side mirror of the reference's RPN inference graph, built from the drop-in modules.
+
+Mirrors lib/net/pointnet2_msg.py:12-70 (Pointnet2MSG: 4 SA-MSG + 4 FP) and lib/net/rpn.py:12-82 (RPN: backbone
++ classification / regression Conv1d heads) with the shapes of tools/cfgs/default.yaml:23-64, using the SAME
+attribute names (`backbone_net.SA_modules`, `FP_modules`, `rpn_cls_layer`, `rpn_reg_layer`) so that the `rpn.*`
+entries of a reference checkpoint load with `load_state_dict`.  Only the inference subset is mirrored: losses
+and the proposal layer are torch glue outside the hot path.
+
+This is what bench.py times; the reference's own unchanged lib/net/rpn.py builds the same graph through
+`pointrcnn_amd.install()`.
+"""
+import torch
+import torch.nn as nn
+
+import pointrcnn_amd
+
+pointrcnn_amd.install()
+from pointnet2_lib.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG  # noqa: E402
+import pointnet2_lib.pointnet2.pytorch_utils as pt_utils  # noqa: E402
+
+
+class RPNConfig:
+    """tools/cfgs/default.yaml:23-64 (RPN section), the values that fix every shape on the path."""
+    USE_INTENSITY = False
+    USE_BN = True
+    NUM_POINTS = 16384
+    SA_NPOINTS = [4096, 1024, 256, 64]
+    SA_RADIUS = [[0.1, 0.5], [0.5, 1.0], [1.0, 2.0], [2.0, 4.0]]
+    SA_NSAMPLE = [[16, 32], [16, 32], [16, 32], [16, 32]]
+    SA_MLPS = [[[16, 16, 32], [32, 32, 64]],
+               [[64, 64, 128], [64, 96, 128]],
+               [[128, 196, 256], [128, 196, 256]],
+               [[256, 256, 512], [256, 384, 512]]]
+    FP_MLPS = [[128, 128], [256, 256], [512, 512], [512, 512]]
+    CLS_FC = [128]
+    REG_FC = [128]
+    DP_RATIO = 0.5
+    LOC_XZ_FINE = True
+    LOC_SCOPE = 3.0
+    LOC_BIN_SIZE = 0.5
+    NUM_HEAD_BIN = 12
+
+
+class Pointnet2MSG(nn.Module):
+    def __init__(self, input_channels=0, use_xyz=True, cfg=RPNConfig):
+        super().__init__()
+        self.SA_modules = nn.ModuleList()
+        channel_in = input_channels
+        skip_channel_list = [input_channels]
+        for k in range(len(cfg.SA_NPOINTS)):
+            mlps = [list(m) for m in cfg.SA_MLPS[k]]
+            channel_out = 0
+            for idx in range(len(mlps)):
+                mlps[idx] = [channel_in] + mlps[idx]
+                channel_out += mlps[idx][-1]
+            self.SA_modules.append(PointnetSAModuleMSG(npoint=cfg.SA_NPOINTS[k], radii=cfg.SA_RADIUS[k],
+                                                       nsamples=cfg.SA_NSAMPLE[k], mlps=mlps, use_xyz=use_xyz,
+                                                       bn=cfg.USE_BN))
+            skip_channel_list.append(channel_out)
+            channel_in = channel_out
+        self.FP_modules = nn.ModuleList()
+        for k in range(len(cfg.FP_MLPS)):
+            pre_channel = cfg.FP_MLPS[k + 1][-1] if k + 1 < len(cfg.FP_MLPS) else channel_out
+            self.FP_modules.append(PointnetFPModule(mlp=[pre_channel + skip_channel_list[k]] + cfg.FP_MLPS[k]))
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, pointcloud):
+        xyz, features = self._break_up_pc(pointcloud)
+        l_xyz, l_features = [xyz], [features]
+        for i in range(len(self.SA_modules)):
+            li_xyz, li_features = self.SA_modules[i](l_xyz[i], l_features[i])
+            l_xyz.append(li_xyz)
+            l_features.append(li_features)
+        for i in range(-1, -(len(self.FP_modules) + 1), -1):
+            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
+        return l_xyz[0], l_features[0]
+
+
+class RPN(nn.Module):
+    """Inference subset of lib/net/rpn.py:12-82."""
+
+    def __init__(self, use_xyz=True, cfg=RPNConfig):
+        super().__init__()
+        self.backbone_net = Pointnet2MSG(input_channels=int(cfg.USE_INTENSITY), use_xyz=use_xyz, cfg=cfg)
+        cls_layers = []
+        pre_channel = cfg.FP_MLPS[0][-1]
+        for k in range(len(cfg.CLS_FC)):
+            cls_layers.append(pt_utils.Conv1d(pre_channel, cfg.CLS_FC[k], bn=cfg.USE_BN))
+            pre_channel = cfg.CLS_FC[k]
+        cls_layers.append(pt_utils.Conv1d(pre_channel, 1, activation=None))
+        if cfg.DP_RATIO >= 0:
+            cls_layers.insert(1, nn.Dropout(cfg.DP_RATIO))
+        self.rpn_cls_layer = nn.Sequential(*cls_layers)
+
+        per_loc_bin_num = int(cfg.LOC_SCOPE / cfg.LOC_BIN_SIZE) * 2
+        if cfg.LOC_XZ_FINE:
+            reg_channel = per_loc_bin_num * 4 + cfg.NUM_HEAD_BIN * 2 + 3
+        else:
+            reg_channel = per_loc_bin_num * 2 + cfg.NUM_HEAD_BIN * 2 + 3
+        reg_channel += 1
+        self.reg_channel = reg_channel
+        reg_layers = []
+        pre_channel = cfg.FP_MLPS[0][-1]
+        for k in range(len(cfg.REG_FC)):
+            reg_layers.append(pt_utils.Conv1d(pre_channel, cfg.REG_FC[k], bn=cfg.USE_BN))
+            pre_channel = cfg.REG_FC[k]
+        reg_layers.append(pt_utils.Conv1d(pre_channel, reg_channel, activation=None))
+        if cfg.DP_RATIO >= 0:
+            reg_layers.insert(1, nn.Dropout(cfg.DP_RATIO))
+        self.rpn_reg_layer = nn.Sequential(*reg_layers)
+
+    def forward(self, input_data):
+        pts_input = input_data["pts_input"]
+        backbone_xyz, backbone_features = self.backbone_net(pts_input)                     # (B,N,3), (B,C,N)
+        rpn_cls = self.rpn_cls_layer(backbone_features).transpose(1, 2).contiguous()      # (B,N,1)
+        rpn_reg = self.rpn_reg_layer(backbone_features).transpose(1, 2).contiguous()      # (B,N,reg)
+        return {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": backbone_xyz,
+                "backbone_features": backbone_features}
+
+
+def randomize_bn_stats(module, seed=0):
+    """Give every BatchNorm non-trivial running statistics / affine terms (seeded): a random-init network with
+    identity BN would not exercise the folded-BN path."""
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            with torch.no_grad():
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+                m.weight.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+                m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    return module
+
+
+def synthetic_clouds(batch, npoints=16384, seed0=100, device="cpu"):
+    """Per frame x~U(-40,40), y~U(-1,3), z~U(0,70.4) (PC_AREA_SCOPE, tools/cfgs/default.yaml:18), seed 100+frame."""
+    out = torch.empty((batch, npoints, 3), dtype=torch.float32)
+    lo = torch.tensor([-40.0, -1.0, 0.0])
+    hi = torch.tensor([40.0, 3.0, 70.4])
+    for f in range(batch):
+        g = torch.Generator().manual_seed(seed0 + f)
+        out[f] = torch.rand((npoints, 3), generator=g) * (hi - lo) + lo
+    return out.to(device)
+
+
+def rpn_flops_per_frame(cfg=RPNConfig):
+    """Algorithmic MLP FLOPs per frame (2*MACs) of the RPN inference graph -- SURVEY.md 8(d): 14.95 GFLOP."""
+    macs = 0
+    cin = int(cfg.USE_INTENSITY)
+    skip = [cin]
+    for k, npoint in enumerate(cfg.SA_NPOINTS):
+        cout = 0
+        for ns, spec in zip(cfg.SA_NSAMPLE[k], cfg.SA_MLPS[k]):
+            chans = [cin + 3] + list(spec)
+            macs += npoint * ns * sum(a * b for a, b in zip(chans[:-1], chans[1:]))
+            cout += spec[-1]
+        skip.append(cout)
+        cin = cout
+    n_at = [cfg.NUM_POINTS] + list(cfg.SA_NPOINTS)
+    for k in range(len(cfg.FP_MLPS)):
+        pre = cfg.FP_MLPS[k + 1][-1] if k + 1 < len(cfg.FP_MLPS) else cin
+        chans = [pre + skip[k]] + list(cfg.FP_MLPS[k])
+        macs += n_at[k] * sum(a * b for a, b in zip(chans[:-1], chans[1:]))
+    c = cfg.FP_MLPS[0][-1]
+    reg = int(cfg.LOC_SCOPE / cfg.LOC_BIN_SIZE) * 2 * (4 if cfg.LOC_XZ_FINE else 2) + cfg.NUM_HEAD_BIN * 2 + 3 + 1
+    macs += cfg.NUM_POINTS * (c * cfg.CLS_FC[0] + cfg.CLS_FC[0] * 1 + c * cfg.REG_FC[0] + cfg.REG_FC[0] * reg)
+    return 2 * macs

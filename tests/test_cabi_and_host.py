@@ -1,0 +1,182 @@
+"""CPU: the C-ABI library loads and exports every symbol include/prcnn_pointops.h declares; argument
+validation; host-side logic (module structure, state-dict names, BN folding, layout helpers); product/oracle
+separation.  No GPU computation is issued here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_decls():
+    text = open(os.path.join(ROOT, "include", "prcnn_pointops.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.findall(r"^(?:int|size_t|const char\*)\s+(prcnn_\w+)\s*\(", text, flags=re.M)
+
+
+def test_library_exports_every_declared_symbol():
+    from pointrcnn_amd import _cabi
+    lib = _cabi.lib()
+    names = header_decls()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+    assert sorted(names) == sorted(_cabi.SIGNATURES), "ctypes binding and header disagree"
+    out = subprocess.run(["nm", "-D", "--defined-only", _cabi.library_path()], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (prcnn_\w+)", out))
+    assert exported == set(names), "library exports differ from the header: %s" % (exported ^ set(names))
+
+
+def test_abi_version_and_pure_host_queries():
+    from pointrcnn_amd import _cabi
+    lib = _cabi.lib()
+    assert lib.prcnn_abi_version() == 1
+    assert lib.prcnn_wpack_floats(64, 99) == 2 * 13 * 256
+    assert lib.prcnn_wpack_floats(0, 5) == 0
+    assert lib.prcnn_nms_workspace_bytes(6300) == 6300 * 99 * 8
+    assert lib.prcnn_nms_workspace_bytes(0) == 0
+
+
+def test_argument_errors_return_codes_not_exit():
+    """bad arguments come back as PRCNN_EINVAL with a message (the reference exit()s: iou3d.cpp:13-21)"""
+    from pointrcnn_amd import _cabi
+    lib = _cabi.lib()
+    assert lib.prcnn_fps(None, 1, 16, 4, None, None, None) == -1
+    assert b"null" in lib.prcnn_last_error()
+    dummy = ctypes.c_void_p(16)
+    assert lib.prcnn_fps(dummy, 1, 16, 32, None, dummy, None) == -1           # npoint > N
+    assert b"npoint" in lib.prcnn_last_error()
+    assert lib.prcnn_fps(dummy, 1, 20000, 4, None, dummy, None) == -1         # large N needs tmp
+    assert lib.prcnn_mlp_rows(dummy, 8, 128, 8, dummy, None, 16, 1, dummy, 16, 0, 20, None) == -1   # pool_ns=20
+    assert b"pool_ns" in lib.prcnn_last_error()
+    assert lib.prcnn_nms(dummy, 10, 0.5, 7, dummy, dummy, dummy, 1 << 20, None) == -1               # bad kind
+    assert lib.prcnn_nms(dummy, 100, 0.5, 0, dummy, dummy, dummy, 8, None) == -1                     # workspace too small
+    with pytest.raises(_cabi.PointOpsError):
+        _cabi.check(-1, "x")
+
+
+def test_product_has_no_cpu_fallback_and_never_touches_the_oracle():
+    from pointrcnn_amd import ops
+    with pytest.raises(RuntimeError, match="HIP"):
+        ops.furthest_point_sample(torch.zeros(1, 8, 3), 2)
+    with pytest.raises(RuntimeError):
+        ops.boxes_iou_bev(torch.zeros(2, 5), torch.zeros(2, 5))
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pointrcnn_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "libprcnn_oracle" not in src and "oracle/" not in src.replace("oracle/prcnn_oracle.c", ""), f
+
+
+def test_dropin_module_names_and_state_dict_keys():
+    import pointrcnn_amd
+    pointrcnn_amd.install()
+    import iou3d_cuda, roipool3d_cuda, pointnet2_cuda   # noqa: F401,E401
+    from pointnet2_lib.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
+    import pointnet2_lib.pointnet2.pytorch_utils as pt_utils
+    for fn in ("boxes_overlap_bev_gpu", "boxes_iou_bev_gpu", "nms_gpu", "nms_normal_gpu"):      # iou3d.cpp:174-179
+        assert callable(getattr(iou3d_cuda, fn))
+    for fn in ("forward", "forward_slow", "pts_in_boxes3d_cpu", "roipool3d_cpu"):               # roipool3d.cpp:198-203
+        assert callable(getattr(roipool3d_cuda, fn))
+    for fn in ("furthest_point_sampling_wrapper", "gather_points_wrapper", "gather_points_grad_wrapper",
+               "ball_query_wrapper", "group_points_wrapper", "group_points_grad_wrapper", "three_nn_wrapper",
+               "three_interpolate_wrapper", "three_interpolate_grad_wrapper"):
+        assert callable(getattr(pointnet2_cuda, fn))
+    sa = PointnetSAModuleMSG(npoint=64, radii=[0.1, 0.5], nsamples=[16, 32], mlps=[[0, 16, 16, 32], [0, 32, 32, 64]],
+                             use_xyz=True, bn=True)
+    keys = set(sa.state_dict())
+    assert "mlps.0.layer0.conv.weight" in keys and "mlps.1.layer2.bn.bn.running_var" in keys
+    assert sa.state_dict()["mlps.0.layer0.conv.weight"].shape == (16, 3, 1, 1)          # +3 for use_xyz
+    assert "mlps.0.layer0.conv.bias" not in keys                                         # bias = not bn
+    s1 = PointnetSAModule(npoint=None, radius=100, nsample=64, mlp=[256, 256, 512], use_xyz=True, bn=False)
+    assert "mlps.0.layer0.conv.bias" in s1.state_dict() and s1.npoint is None
+    fp = PointnetFPModule(mlp=[257, 128, 128])
+    assert "mlp.layer1.bn.bn.weight" in fp.state_dict()
+    c = pt_utils.Conv1d(128, 1, activation=None)
+    assert list(c.state_dict()) == ["conv.weight", "conv.bias"] and c.conv.bias is not None    # rpn.py:64 access
+
+
+def test_composed_cpu_modules_are_plain_torch():
+    """on CPU tensors the conv stacks run as ordinary torch modules (construction / training-time path)"""
+    import pointrcnn_amd
+    pointrcnn_amd.install()
+    import pointnet2_lib.pointnet2.pytorch_utils as pt_utils
+    mlp = pt_utils.SharedMLP([6, 8, 4], bn=True).eval()
+    x = torch.randn(2, 6, 5, 3)
+    y = mlp(x)
+    assert y.shape == (2, 4, 5, 3) and (y >= 0).all()
+    assert not mlp.fusable()         # CPU weights: the fused path is never taken
+
+
+def test_bn_folding_math():
+    import pointrcnn_amd
+    pointrcnn_amd.install()
+    import pointnet2_lib.pointnet2.pytorch_utils as pt_utils
+    from pointrcnn_amd.rpn import randomize_bn_stats
+    layer = randomize_bn_stats(pt_utils.Conv2d(7, 5, bn=True), seed=3).eval()
+    conv, bn, act = layer._parts()
+    w, b = pt_utils._fold_bn(conv, bn)
+    x = torch.randn(4, 7, 3, 2)
+    want = bn(conv(x))
+    got = torch.einsum("bkhw,nk->bnhw", x, w) + b[None, :, None, None]
+    torch.testing.assert_close(got, want, atol=1e-5, rtol=1e-5)
+    assert act is not None
+
+
+def test_rows_view_detects_uniform_strides():
+    import pointrcnn_amd
+    pointrcnn_amd.install()
+    from pointnet2_lib.pointnet2.pytorch_utils import _rows_view
+    base = torch.randn(3, 10, 133)
+    v = base[..., 0:5]                                     # rcnn_net.py:168 slicing pattern
+    assert _rows_view(v).data_ptr() == base.data_ptr()     # rows with ld=133: no copy
+    t = torch.randn(2, 6, 50).transpose(1, 2)              # (B,N,C) view of channel-first data: needs a copy
+    assert _rows_view(t).is_contiguous() and _rows_view(t).data_ptr() != t.data_ptr()
+    cl = torch.randn(2, 50, 6).transpose(1, 2)             # (B,C,N) view of channels-last data
+    back = cl.permute(0, 2, 1)
+    assert _rows_view(back).data_ptr() == back.data_ptr()
+    x4 = torch.randn(2, 50, 1, 6).permute(0, 3, 1, 2)      # conv2d-shaped view of channels-last rows
+    assert _rows_view(x4.permute(0, 2, 3, 1)).data_ptr() == x4.data_ptr()
+
+
+def test_rpn_mirror_shapes_and_flops():
+    from pointrcnn_amd import rpn
+    m = rpn.RPN()
+    nparam = sum(p.numel() for p in m.parameters())
+    assert 3.0e6 < nparam < 3.1e6                                   # ~3.0 M
+    assert abs(rpn.rpn_flops_per_frame() / 1e9 - 14.95) < 0.01      # 14.95 GFLOP / frame
+    assert m.reg_channel == 76
+    sd = m.state_dict()
+    assert sd["backbone_net.SA_modules.1.mlps.1.layer0.conv.weight"].shape == (64, 99, 1, 1)
+    assert sd["backbone_net.FP_modules.3.mlp.layer0.conv.weight"].shape == (512, 1536, 1, 1)
+    assert sd["rpn_reg_layer.2.conv.weight"].shape == (76, 128, 1)
+    pts = rpn.synthetic_clouds(2, 64)
+    assert pts.shape == (2, 64, 3) and float(pts[..., 2].min()) >= 0 and float(pts[..., 0].abs().max()) <= 40
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib/net"), reason="reference checkout absent")
+def test_reference_backbone_builds_unchanged_on_the_dropin_surface():
+    """the reference's own lib/net/pointnet2_msg.py, imported UNCHANGED, constructs its Pointnet2MSG on our
+    modules and yields the same state-dict keys/shapes as the host mirror (checkpoint compatibility)"""
+    code = r"""
+import sys
+sys.path[:0] = ['/root/reference', %r, %r]
+import pointrcnn_amd; pointrcnn_amd.install()
+from lib.net.pointnet2_msg import Pointnet2MSG
+from lib.config import cfg
+from pointrcnn_amd import rpn
+a = Pointnet2MSG(input_channels=0, use_xyz=True).state_dict()
+b = rpn.Pointnet2MSG().state_dict()
+assert list(a) == list(b), 'key mismatch'
+assert all(a[k].shape == b[k].shape for k in a)
+print('OK', len(a))
+""" % (os.path.join(ROOT, "tests", "compat"), ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]

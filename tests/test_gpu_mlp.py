@@ -1,0 +1,137 @@
+"""GPU parity: fused per-point MLP layers (fp32 MFMA) vs the double-accumulated CPU oracle.
+The gathered / interpolated A rows are exact; the GEMM sums in a different k order than a sequential
+reference, so the contract is |hip - oracle| <= 1e-5 * max(1, max|oracle|) (util.mlp_tol)."""
+import numpy as np
+import pytest
+import torch
+
+from util import mlp_tol, unit_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def lin(dev, w, b, relu, k_rot=0):
+    from pointrcnn_amd import ops
+    return ops.PackedLinear(T(w, dev), None if b is None else T(b, dev), relu=relu, k_rot=k_rot)
+
+
+@pytest.mark.parametrize("rows,K,Nout,relu,bias", [(128, 32, 64, True, True), (1000, 3, 16, True, False),
+                                                   (77, 5, 1, False, True), (300, 99, 76, False, True),
+                                                   (513, 131, 196, True, True), (256, 515, 512, True, True),
+                                                   (40, 1536, 33, True, False), (129, 8, 32, False, False)])
+def test_mlp_rows_matches_oracle(dev, cpu, rows, K, Nout, relu, bias):
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(rows + K)
+    a = r.normal(size=(rows, K)).astype(np.float32)
+    w = (r.normal(size=(Nout, K)) * 0.2).astype(np.float32)
+    b = r.normal(size=(Nout,)).astype(np.float32) if bias else None
+    want = cpu.linear_rows(a, w, b, relu)
+    got = ops.mlp_rows(T(a, dev), lin(dev, w, b, relu)).cpu().numpy()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=mlp_tol(want), rtol=0)
+
+
+def test_mlp_rows_identity_is_transpose_safe(dev):
+    """A = identity with an ASYMMETRIC W: catches row/col swaps in the MFMA output mapping"""
+    from pointrcnn_amd import ops
+    K, Nout = 64, 96
+    w = (np.arange(Nout * K, dtype=np.float32).reshape(Nout, K) % 251) / 16.0
+    got = ops.mlp_rows(T(np.eye(K, dtype=np.float32), dev), lin(dev, w, None, False)).cpu().numpy()
+    assert np.array_equal(got, w.T)      # single non-zero product per output: exact
+
+
+def test_mlp_rows_strided_io_and_col_offset(dev, cpu):
+    """input rows taken out of a wider buffer (ld_in > K, unaligned) and output written at a column offset"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(7)
+    wide = r.normal(size=(2, 150, 133)).astype(np.float32)
+    w = (r.normal(size=(40, 5)) * 0.3).astype(np.float32)
+    b = r.normal(size=(40,)).astype(np.float32)
+    x = T(wide, dev)[..., 0:5]                       # (2,150,5) view, row stride 133
+    out = torch.full((300, 100), -7.0, device=dev)
+    ops.mlp_rows(x, lin(dev, w, b, True), out=(out, 30))
+    want = cpu.linear_rows(wide[..., 0:5].reshape(-1, 5), w, b, True)
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got[:, 30:70], want, atol=mlp_tol(want), rtol=0)
+    assert (got[:, :30] == -7.0).all() and (got[:, 70:] == -7.0).all()
+
+
+@pytest.mark.parametrize("ns", [16, 32, 64])
+def test_mlp_rows_fused_maxpool(dev, cpu, ns):
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(ns)
+    groups, K, Nout = 37, 24, 70
+    a = r.normal(size=(groups * ns, K)).astype(np.float32)
+    w = (r.normal(size=(Nout, K)) * 0.3).astype(np.float32)
+    b = r.normal(size=(Nout,)).astype(np.float32)
+    want = cpu.linear_rows(a, w, b, True).reshape(groups, ns, Nout).max(1)
+    got = ops.mlp_rows(T(a, dev), lin(dev, w, b, True), pool_ns=ns).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=mlp_tol(want), rtol=0)
+    # generic pooling kernel (any nsample) agrees with the fused epilogue bit for bit
+    full = ops.mlp_rows(T(a, dev), lin(dev, w, b, True))
+    assert np.array_equal(ops.maxpool_rows(full, ns).cpu().numpy(), got)
+
+
+@pytest.mark.parametrize("C,Nout,ns", [(0, 16, 16), (3, 32, 32), (96, 64, 16), (13, 40, 8), (256, 128, 64)])
+def test_mlp_group_matches_oracle(dev, cpu, C, Nout, ns):
+    """first SA layer fused with grouping: rows = [dxyz, feat] in torch order, weights in torch order"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(C + ns)
+    B, N, M = 2, 600, 50
+    xyz = unit_cloud(B, N, seed=C)
+    new_xyz = xyz[:, :M].copy()
+    idx = cpu.ball_query(0.25, ns, xyz, new_xyz)
+    feat = r.normal(size=(B, C, N)).astype(np.float32) if C else None
+    w = (r.normal(size=(Nout, C + 3)) * 0.3).astype(np.float32)
+    b = r.normal(size=(Nout,)).astype(np.float32)
+    # oracle: grouping_operation on xyz^T and features, centre, concat [dxyz, feat], then the layer
+    gx = cpu.group(xyz.transpose(0, 2, 1), idx) - new_xyz.transpose(0, 2, 1)[..., None]
+    g = gx if feat is None else np.concatenate([gx, cpu.group(feat, idx)], 1)      # (B,3+C,M,ns)
+    rows = g.transpose(0, 2, 3, 1).reshape(-1, C + 3)
+    want = cpu.linear_rows(rows, w, b, True)
+    feat_cl = None if feat is None else T(feat.transpose(0, 2, 1), dev)
+    got = ops.mlp_group(T(xyz, dev), T(new_xyz, dev), T(idx, dev), feat_cl, lin(dev, w, b, True, k_rot=3 if C else 0))
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=mlp_tol(want), rtol=0)
+
+
+def test_mlp_group_gathered_rows_are_exact(dev, cpu):
+    """identity weights expose the A tile itself: grouped features must be EXACT copies (north star: 1e-5;
+    here bit equal), dxyz an exactly rounded fp32 subtraction"""
+    from pointrcnn_amd import ops
+    B, N, M, ns, C = 1, 400, 30, 16, 29
+    r = np.random.default_rng(3)
+    xyz = unit_cloud(B, N, seed=8)
+    new_xyz = xyz[:, :M].copy()
+    idx = cpu.ball_query(0.3, ns, xyz, new_xyz)
+    feat = r.normal(size=(B, C, N)).astype(np.float32)
+    w = np.eye(C + 3, dtype=np.float32)
+    got = ops.mlp_group(T(xyz, dev), T(new_xyz, dev), T(idx, dev), T(feat.transpose(0, 2, 1), dev),
+                        lin(dev, w, None, False, k_rot=3)).cpu().numpy()
+    gx = cpu.group(xyz.transpose(0, 2, 1), idx) - new_xyz.transpose(0, 2, 1)[..., None]
+    g = np.concatenate([gx, cpu.group(feat, idx)], 1).transpose(0, 2, 3, 1).reshape(-1, C + 3)
+    assert np.array_equal(got, g)
+
+
+@pytest.mark.parametrize("C2,C1,Nout", [(64, 0, 32), (256, 96, 128), (30, 7, 20), (512, 256, 64)])
+def test_mlp_interp_matches_oracle(dev, cpu, C2, C1, Nout):
+    """first FP layer fused with three_interpolate + skip concat"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(C2 + C1)
+    B, n, m = 2, 333, 80
+    unk, kn = unit_cloud(B, n, seed=1), unit_cloud(B, m, seed=2)
+    d2, idx3 = cpu.three_nn(unk, kn)
+    w3 = cpu.three_weights(d2)
+    kf = r.normal(size=(B, C2, m)).astype(np.float32)
+    sf = r.normal(size=(B, C1, n)).astype(np.float32) if C1 else None
+    w = (r.normal(size=(Nout, C2 + C1)) * 0.2).astype(np.float32)
+    b = r.normal(size=(Nout,)).astype(np.float32)
+    interp = cpu.three_interp(kf, idx3, w3)
+    cat = interp if sf is None else np.concatenate([interp, sf], 1)
+    want = cpu.linear_rows(cat.transpose(0, 2, 1).reshape(-1, C2 + C1), w, b, True)
+    got = ops.mlp_interp(T(kf.transpose(0, 2, 1), dev), T(idx3, dev), T(w3, dev),
+                         None if sf is None else T(sf.transpose(0, 2, 1), dev), lin(dev, w, b, True))
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=mlp_tol(want), rtol=0)

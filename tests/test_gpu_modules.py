@@ -1,0 +1,153 @@
+"""GPU parity at module level: the drop-in PointNet++ modules' fused inference path vs (a) the oracle
+pipeline op by op and (b) the composed torch path of the same module, and the full RPN graph."""
+import numpy as np
+import pytest
+import torch
+
+from util import kitti_cloud, mlp_tol, unit_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def oracle_sa(cpu, xyz, feat, npoint, radius, ns, ws):
+    """SA module restated with oracle ops: fps -> gather -> ball_query -> group -> MLP(relu) -> max"""
+    fidx = cpu.fps(xyz, npoint)
+    new_xyz = cpu.gather(xyz.transpose(0, 2, 1), fidx).transpose(0, 2, 1)
+    idx = cpu.ball_query(radius, ns, xyz, new_xyz)
+    gx = cpu.group(xyz.transpose(0, 2, 1), idx) - new_xyz.transpose(0, 2, 1)[..., None]
+    g = gx if feat is None else np.concatenate([gx, cpu.group(feat, idx)], 1)
+    B, K, M, _ = g.shape
+    rows = g.transpose(0, 2, 3, 1).reshape(-1, K)
+    for w in ws:
+        rows = cpu.linear_rows(rows, w, None, True)
+    return fidx, new_xyz, idx, rows.reshape(B, M, ns, -1).max(2).transpose(0, 2, 1)
+
+
+def test_config1_single_sa_layer(dev, cpu):
+    """BASELINE.json configs[0]: single SA layer (npoint=512, r=0.2, nsample=32, C=3) on 1x4096 random points;
+    FPS / ball-query indices bit-exact, output within 1e-5"""
+    from pointnet2_lib.pointnet2.pointnet2_modules import PointnetSAModule
+    from pointrcnn_amd import ops
+    xyz = torch.rand(1, 4096, 3, generator=torch.Generator().manual_seed(0)).numpy()
+    feat = torch.randn(1, 3, 4096, generator=torch.Generator().manual_seed(1)).numpy()
+    mod = PointnetSAModule(npoint=512, radius=0.2, nsample=32, mlp=[3, 32, 32, 64], use_xyz=True, bn=False).to(dev).eval()
+    g = torch.Generator().manual_seed(2)
+    ws = []
+    for layer in mod.mlps[0].layers():
+        w = torch.randn(layer.conv.weight.shape, generator=g) * 0.1
+        with torch.no_grad():
+            layer.conv.weight.copy_(w)
+            layer.conv.bias.zero_()
+        ws.append(w.reshape(w.shape[0], -1).numpy())
+    fidx, new_xyz, idx, want = oracle_sa(cpu, xyz, feat, 512, 0.2, 32, ws)
+    txyz = T(xyz, dev)
+    assert np.array_equal(ops.furthest_point_sample(txyz, 512).cpu().numpy(), fidx)
+    assert np.array_equal(ops.ball_query(0.2, 32, txyz, T(new_xyz, dev)).cpu().numpy(), idx)
+    with torch.no_grad():
+        nx, nf = mod(txyz, T(feat, dev))
+    assert np.array_equal(nx.cpu().numpy(), new_xyz)
+    assert nf.shape == (1, 64, 512)
+    np.testing.assert_allclose(nf.cpu().numpy(), want, atol=mlp_tol(want), rtol=0)
+
+
+def test_sa_msg_fused_equals_composed(dev):
+    """same module, same weights: fused inference path (no_grad) == composed autograd path (MIOpen conv/BN)"""
+    from pointnet2_lib.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    from pointrcnn_amd.rpn import randomize_bn_stats
+    torch.manual_seed(0)
+    mod = PointnetSAModuleMSG(npoint=256, radii=[0.2, 0.4], nsamples=[16, 32], mlps=[[24, 32, 48], [24, 40, 64]],
+                              use_xyz=True, bn=True)
+    randomize_bn_stats(mod).to(dev).eval()
+    xyz = T(unit_cloud(2, 2000, seed=3), dev)
+    feat = torch.randn(2, 24, 2000, device=dev)
+    with torch.no_grad():
+        nx_f, nf_f = mod(xyz, feat)
+    with torch.enable_grad():
+        nx_c, nf_c = mod(xyz, feat.clone().requires_grad_(True))
+    assert torch.equal(nx_f, nx_c)
+    assert nf_f.shape == nf_c.shape == (2, 112, 256)
+    np.testing.assert_allclose(nf_f.cpu().numpy(), nf_c.detach().cpu().numpy(), atol=2e-4, rtol=1e-4)
+
+
+def test_sa_group_all_and_odd_nsample(dev):
+    """npoint=None (GroupAll, rcnn_net.py:31) and an nsample outside {16,32,64} (generic pooling kernel)"""
+    from pointnet2_lib.pointnet2.pointnet2_modules import PointnetSAModule
+    torch.manual_seed(1)
+    xyz = T(unit_cloud(3, 32, seed=5), dev)
+    feat = torch.randn(3, 20, 32, device=dev)
+    ga = PointnetSAModule(npoint=None, radius=100, nsample=64, mlp=[20, 32, 48], use_xyz=True, bn=False).to(dev).eval()
+    with torch.no_grad():
+        nx, nf = ga(xyz, feat)
+    with torch.enable_grad():
+        nx_c, nf_c = ga(xyz, feat.clone().requires_grad_(True))
+    assert nx is None and nx_c is None and nf.shape == (3, 48, 1)
+    np.testing.assert_allclose(nf.cpu().numpy(), nf_c.detach().cpu().numpy(), atol=2e-4, rtol=1e-4)
+    odd = PointnetSAModule(npoint=10, radius=0.5, nsample=12, mlp=[20, 16], use_xyz=True, bn=False).to(dev).eval()
+    with torch.no_grad():
+        _, nf = odd(xyz, feat)
+    with torch.enable_grad():
+        _, nf_c = odd(xyz, feat.clone().requires_grad_(True))
+    np.testing.assert_allclose(nf.cpu().numpy(), nf_c.detach().cpu().numpy(), atol=2e-4, rtol=1e-4)
+
+
+def test_fp_module_fused_equals_composed_and_oracle(dev, cpu):
+    from pointnet2_lib.pointnet2.pointnet2_modules import PointnetFPModule
+    from pointrcnn_amd.rpn import randomize_bn_stats
+    torch.manual_seed(2)
+    mod = randomize_bn_stats(PointnetFPModule(mlp=[96 + 40, 64, 32])).to(dev).eval()
+    unk, kn = unit_cloud(2, 700, seed=1), unit_cloud(2, 150, seed=2)
+    uf = torch.randn(2, 40, 700, device=dev)
+    kf = torch.randn(2, 96, 150, device=dev)
+    with torch.no_grad():
+        out_f = mod(T(unk, dev), T(kn, dev), uf, kf)
+    with torch.enable_grad():
+        out_c = mod(T(unk, dev), T(kn, dev), uf.clone().requires_grad_(True), kf)
+    assert out_f.shape == (2, 32, 700)
+    np.testing.assert_allclose(out_f.cpu().numpy(), out_c.detach().cpu().numpy(), atol=2e-4, rtol=1e-4)
+    # no skip features (level-0 of the RPN: pointnet2_msg.py:18,42-45)
+    mod0 = PointnetFPModule(mlp=[96, 32], bn=False).to(dev).eval()
+    with torch.no_grad():
+        o_f = mod0(T(unk, dev), T(kn, dev), None, kf)
+    with torch.enable_grad():
+        o_c = mod0(T(unk, dev), T(kn, dev), None, kf.clone().requires_grad_(True))
+    np.testing.assert_allclose(o_f.cpu().numpy(), o_c.detach().cpu().numpy(), atol=2e-4, rtol=1e-4)
+
+
+def test_conv1d_heads_fused_equals_torch(dev):
+    """pt_utils.Conv1d stacks as the RPN heads build them (rpn.py:20-46): fused path == torch path"""
+    import pointnet2_lib.pointnet2.pytorch_utils as pt_utils
+    from pointrcnn_amd.rpn import randomize_bn_stats
+    torch.manual_seed(3)
+    head = torch.nn.Sequential(pt_utils.Conv1d(128, 128, bn=True), torch.nn.Dropout(0.5),
+                               pt_utils.Conv1d(128, 76, activation=None))
+    randomize_bn_stats(head).to(dev).eval()
+    x = torch.randn(2, 128, 1000, device=dev)
+    with torch.no_grad():
+        y_f = head(x)
+    with torch.enable_grad():
+        y_c = head(x.clone().requires_grad_(True))
+    assert y_f.shape == (2, 76, 1000)
+    np.testing.assert_allclose(y_f.cpu().numpy(), y_c.detach().cpu().numpy(), atol=2e-4, rtol=1e-4)
+
+
+def test_full_rpn_fused_equals_composed(dev):
+    """the benchmark graph (default.yaml RPN, 16384 points): fused inference path vs the composed op-by-op path
+    of the very same modules (HIP index ops + MIOpen conv/BN); index ops are shared so only fp32 summation
+    order differs"""
+    from pointrcnn_amd import rpn
+    torch.manual_seed(4)
+    model = rpn.randomize_bn_stats(rpn.RPN()).to(dev).eval()
+    pts = rpn.synthetic_clouds(1, 16384, device=dev)
+    with torch.no_grad():
+        out_f = model({"pts_input": pts})
+    with torch.enable_grad():
+        out_c = model({"pts_input": pts.clone().requires_grad_(True)})
+    assert out_f["rpn_cls"].shape == (1, 16384, 1) and out_f["rpn_reg"].shape == (1, 16384, 76)
+    assert out_f["backbone_features"].shape == (1, 128, 16384)
+    for k in ("backbone_features", "rpn_cls", "rpn_reg"):
+        a, b = out_f[k].cpu().numpy(), out_c[k].detach().cpu().numpy()
+        np.testing.assert_allclose(a, b, atol=5e-4 * max(1.0, float(np.abs(b).max())), rtol=0)

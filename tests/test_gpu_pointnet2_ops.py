@@ -1,0 +1,172 @@
+"""GPU parity: PointNet++ index/gather operators through the C ABI vs the CPU oracle.
+Indices are BIT-EXACT (north star); gathered values are exact copies; grads within 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from util import kitti_cloud, unit_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("B,N,npoint", [(1, 4096, 512), (3, 64, 64), (2, 100, 37), (2, 512, 128), (3, 1000, 256),
+                                        (2, 1024, 256), (2, 2048, 300), (1, 8192, 512), (2, 16384, 1024),
+                                        (1, 20000, 200), (1, 1, 1), (2, 130, 130)])
+def test_fps_matches_oracle(dev, cpu, B, N, npoint):
+    from pointrcnn_amd import ops
+    xyz = unit_cloud(B, N, seed=N + npoint)
+    got = ops.furthest_point_sample(T(xyz, dev), npoint).cpu().numpy()
+    assert np.array_equal(got, cpu.fps(xyz, npoint))
+
+
+def test_fps_config1_and_full_sa1(dev, cpu):
+    """BASELINE config 1 (1x4096, npoint 512) and one frame of the real SA1 problem (16384 -> 4096)"""
+    from pointrcnn_amd import ops
+    xyz = kitti_cloud(1, 16384)
+    got = ops.furthest_point_sample(T(xyz, dev), 4096).cpu().numpy()
+    assert np.array_equal(got, cpu.fps(xyz, 4096))
+
+
+def test_fps_ties_duplicates(dev, cpu):
+    """duplicated / identical points: arg-max ties must resolve to the LOWEST index"""
+    from pointrcnn_amd import ops
+    base = unit_cloud(1, 300, seed=5)
+    dup = np.concatenate([base, base, base[:, :100]], 1)             # every point 2-3 times
+    same = np.ones((2, 257, 3), np.float32) * 0.25                    # all identical
+    grid = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(4), indexing="ij"), -1)
+    grid = grid.reshape(1, -1, 3).astype(np.float32)                  # lattice: many exact distance ties
+    for xyz, npnt in ((dup, 200), (same, 50), (grid, 512)):
+        got = ops.furthest_point_sample(T(xyz, dev), npnt).cpu().numpy()
+        assert np.array_equal(got, cpu.fps(xyz, npnt))
+
+
+def test_fps_full_size_properties(dev, cpu):
+    """bs32 x 16384 -> 4096 (the benchmark shape): size-independent properties + two frames vs the oracle"""
+    from pointrcnn_amd import ops
+    xyz = kitti_cloud(32, 16384)
+    idx = ops.furthest_point_sample(T(xyz, dev), 4096).cpu().numpy()
+    assert idx.shape == (32, 4096) and idx.min() >= 0 and idx.max() < 16384
+    assert (idx[:, 0] == 0).all()
+    for b in range(32):
+        assert len(np.unique(idx[b])) == 4096          # distinct points => a sample is never repeated
+    want = cpu.fps(xyz[[0, 31]], 4096)
+    assert np.array_equal(idx[[0, 31]], want)
+
+
+# ------------------------------------------------------------------ ball query
+@pytest.mark.parametrize("B,N,M,r,ns", [(1, 4096, 512, 0.2, 32), (2, 1000, 77, 0.15, 16), (2, 3000, 300, 0.05, 64),
+                                        (1, 2049, 257, 0.3, 5), (2, 64, 64, 0.5, 16)])
+def test_ball_query_matches_oracle(dev, cpu, B, N, M, r, ns):
+    from pointrcnn_amd import ops
+    xyz = unit_cloud(B, N, seed=N)
+    new_xyz = xyz[:, cpu.fps(xyz, M)[0]] if M <= N else unit_cloud(B, M, seed=1)
+    got = ops.ball_query(r, ns, T(xyz, dev), T(new_xyz, dev)).cpu().numpy()
+    assert np.array_equal(got, cpu.ball_query(r, ns, xyz, new_xyz))
+
+
+def test_ball_query_edge_cases(dev, cpu):
+    from pointrcnn_amd import ops
+    xyz = unit_cloud(2, 500, seed=3)
+    far = unit_cloud(2, 40, seed=4) + 10.0                 # centroids with no neighbour at all -> zeros
+    got = ops.ball_query(0.2, 8, T(xyz, dev), T(far, dev)).cpu().numpy()
+    assert np.array_equal(got, cpu.ball_query(0.2, 8, xyz, far)) and (got == 0).all()
+    tiny = ops.ball_query(1e-6, 8, T(xyz, dev), T(xyz[:, :100].copy(), dev)).cpu().numpy()   # only self in range
+    assert np.array_equal(tiny, cpu.ball_query(1e-6, 8, xyz, xyz[:, :100]))
+    assert (tiny == np.arange(100)[None, :, None]).all()
+    same = np.zeros((1, 300, 3), np.float32)                # all identical: first nsample indices
+    g = ops.ball_query(0.1, 16, T(same, dev), T(same[:, :10].copy(), dev)).cpu().numpy()
+    assert np.array_equal(g, cpu.ball_query(0.1, 16, same, same[:, :10]))
+
+
+def test_ball_query2_equals_two_single_queries(dev, cpu):
+    from pointrcnn_amd import ops
+    xyz = kitti_cloud(2, 16384)
+    new_xyz = xyz[:, ::4][:, :1024].copy()
+    ia, ib = ops.ball_query2(0.5, 16, 1.0, 32, T(xyz, dev), T(new_xyz, dev))
+    assert np.array_equal(ia.cpu().numpy(), cpu.ball_query(0.5, 16, xyz, new_xyz))
+    assert np.array_equal(ib.cpu().numpy(), cpu.ball_query(1.0, 32, xyz, new_xyz))
+
+
+# ------------------------------------------------------------------ three_nn
+@pytest.mark.parametrize("B,n,m", [(2, 256, 64), (1, 1024, 256), (2, 1000, 333), (1, 4096, 2500), (2, 50, 2), (1, 7, 1)])
+def test_three_nn_matches_oracle(dev, cpu, B, n, m):
+    from pointrcnn_amd import ops
+    unk, kn = unit_cloud(B, n, seed=n), unit_cloud(B, m, seed=m + 1)
+    d2, idx, w = ops.three_nn(T(unk, dev), T(kn, dev), want_weight=True)
+    rd2, ridx = cpu.three_nn(unk, kn)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(d2.cpu().numpy(), rd2)                       # same rounded ops -> bit equal
+    if m >= 3:
+        assert np.array_equal(w.cpu().numpy(), cpu.three_weights(rd2))
+
+
+def test_three_nn_ties_keep_earlier_index(dev, cpu):
+    from pointrcnn_amd import ops
+    kn = np.tile(unit_cloud(1, 50, seed=9), (1, 3, 1))                 # every known point three times
+    unk = unit_cloud(1, 200, seed=10)
+    _, idx = ops.three_nn(T(unk, dev), T(kn, dev))
+    assert np.array_equal(idx.cpu().numpy(), cpu.three_nn(unk, kn)[1])
+
+
+# ------------------------------------------------------------------ gather / group / interpolate (+ grads)
+def test_gather_group_interp_forward_exact(dev, cpu):
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(0)
+    B, C, N, M, ns = 2, 19, 700, 130, 12
+    feat = r.normal(size=(B, C, N)).astype(np.float32)
+    idx = r.integers(0, N, (B, M)).astype(np.int32)
+    gidx = r.integers(0, N, (B, M, ns)).astype(np.int32)
+    assert np.array_equal(ops.gather(T(feat, dev), T(idx, dev)).cpu().numpy(), cpu.gather(feat, idx))
+    assert np.array_equal(ops.group(T(feat, dev), T(gidx, dev)).cpu().numpy(), cpu.group(feat, gidx))
+    cl = np.ascontiguousarray(feat.transpose(0, 2, 1))
+    assert np.array_equal(ops.gather_rows(T(cl, dev), T(idx, dev)).cpu().numpy(),
+                          cpu.gather(feat, idx).transpose(0, 2, 1))
+    i3 = r.integers(0, N, (B, M, 3)).astype(np.int32)
+    w3 = r.random((B, M, 3)).astype(np.float32)
+    got = ops.three_interpolate(T(feat, dev), T(i3, dev), T(w3, dev)).cpu().numpy()
+    assert np.array_equal(got, cpu.three_interp(feat, i3, w3))        # same op order, no FMA -> bit equal
+
+
+def test_gather_group_interp_backward(dev, cpu):
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(1)
+    B, C, N, M, ns = 2, 7, 300, 90, 6
+    idx = r.integers(0, N, (B, M)).astype(np.int32)
+    gidx = r.integers(0, N, (B, M, ns)).astype(np.int32)
+    go = r.normal(size=(B, C, M)).astype(np.float32)
+    ggo = r.normal(size=(B, C, M, ns)).astype(np.float32)
+    np.testing.assert_allclose(ops.gather_grad(T(go, dev), T(idx, dev), N).cpu().numpy(), cpu.gather_grad(go, idx, N),
+                               atol=1e-5)
+    np.testing.assert_allclose(ops.group_grad(T(ggo, dev), T(gidx, dev), N).cpu().numpy(),
+                               cpu.group_grad(ggo, gidx, N), atol=1e-5)
+    i3 = r.integers(0, N, (B, M, 3)).astype(np.int32)
+    w3 = r.random((B, M, 3)).astype(np.float32)
+    np.testing.assert_allclose(ops.three_interpolate_grad(T(go, dev), T(i3, dev), T(w3, dev), N).cpu().numpy(),
+                               cpu.three_interp_grad(go, i3, w3, N), atol=1e-5)
+
+
+def test_autograd_functions_backward(dev, cpu):
+    """the drop-in autograd Functions route gradients through the HIP backward kernels"""
+    import pointrcnn_amd
+    pointrcnn_amd.install()
+    from pointnet2_lib.pointnet2 import pointnet2_utils as pu
+    r = np.random.default_rng(2)
+    feat = torch.tensor(r.normal(size=(2, 5, 100)).astype(np.float32), device=dev, requires_grad=True)
+    gidx = T(r.integers(0, 100, (2, 30, 4)).astype(np.int32), dev)
+    out = pu.grouping_operation(feat, gidx)
+    out.sum().backward()
+    want = cpu.group_grad(np.ones((2, 5, 30, 4), np.float32), gidx.cpu().numpy(), 100)
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), want, atol=1e-5)
+
+
+def test_op_argument_errors(dev):
+    from pointrcnn_amd import ops, _cabi
+    with pytest.raises(RuntimeError):
+        ops.furthest_point_sample(torch.zeros(1, 10, 3), 4)                       # CPU tensor: no fallback
+    with pytest.raises(_cabi.PointOpsError):
+        ops.furthest_point_sample(torch.zeros(1, 10, 3, device=dev), 11)          # npoint > N

@@ -1,0 +1,173 @@
+"""GPU parity: roipool3d and iou3d through the C ABI vs the CPU oracle (canonical trig, bit-exact),
+vs golden fixtures generated from the reference's own code (tests/golden/make_golden.py), and through
+the drop-in `roipool3d_cuda` / `iou3d_cuda` modules."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLDEN, enlarge, kitti_cloud, rand_bev, rand_boxes3d
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ------------------------------------------------------------------ roipool3d
+@pytest.mark.parametrize("B,N,M,C,S", [(2, 4096, 40, 16, 64), (1, 16384, 100, 130, 512), (2, 1000, 7, 0, 32),
+                                       (1, 333, 5, 3, 600), (3, 257, 9, 5, 16)])
+def test_roipool3d_matches_oracle(dev, cpu, B, N, M, C, S):
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(N + M)
+    xyz = kitti_cloud(B, N, seed=N)
+    boxes = np.stack([enlarge(rand_boxes3d(xyz[b], M, seed=b + 1), 1.0) for b in range(B)])
+    boxes[:, -1, 0] += 500.0                                  # one box far away from every point: empty
+    feat = r.normal(size=(B, N, C)).astype(np.float32)
+    want, wempty = cpu.roipool3d(xyz, boxes, feat, S, trig_mode=1)
+    got, gempty = ops.roipool3d(T(xyz, dev), T(boxes, dev), T(feat, dev), S)
+    assert np.array_equal(gempty.cpu().numpy(), wempty) and wempty[:, -1].all()
+    assert np.array_equal(got.cpu().numpy(), want)            # gathered copies: bit equal
+
+
+def test_roipool3d_dense_box_truncates_at_S(dev, cpu):
+    """more in-box points than S: the FIRST S in index order are kept (roipool3d.cpp:150-160)"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(0)
+    N, S = 5000, 128
+    xyz = (r.random((1, N, 3)).astype(np.float32) - 0.5) * np.array([3.0, 1.0, 3.0], np.float32)
+    box = np.array([[[0, 0.8, 0, 1.6, 4.0, 4.0, 0.3]]], np.float32)
+    feat = np.arange(N, dtype=np.float32).reshape(1, N, 1)
+    want, _ = cpu.roipool3d(xyz, box, feat, S)
+    got, _ = ops.roipool3d(T(xyz, dev), T(box, dev), T(feat, dev), S)
+    assert np.array_equal(got.cpu().numpy(), want)
+    ids = got.cpu().numpy()[0, 0, :, 3]
+    assert (np.diff(ids) > 0).all()                           # strictly ascending point indices, no wrap
+
+
+def test_roipool3d_golden_from_reference(dev):
+    """fixture produced by the reference's own roipool3d.cpp CPU code (oracle/_ref)"""
+    from pointrcnn_amd import ops
+    g = np.load(os.path.join(GOLDEN, "roipool3d_ref.npz"))
+    got, gempty = ops.roipool3d(T(g["xyz"], dev), T(g["boxes"], dev), T(g["feat"], dev), int(g["S"]))
+    got = got.cpu().numpy()
+    assert np.array_equal(gempty.cpu().numpy()[0], g["empty"].astype(np.int32))
+    assert np.array_equal(got[0, :, :, :3], g["pooled_pts"]) and np.array_equal(got[0, :, :, 3:], g["pooled_feat"])
+
+
+def test_roipool3d_dropin_module(dev, cpu):
+    """roipool3d_cuda.{forward, pts_in_boxes3d_cpu, roipool3d_cpu} with the reference's calling convention
+    (roipool3d_utils.py:21-26, 40-41, 65-68)"""
+    import roipool3d_cuda
+    r = np.random.default_rng(4)
+    N, M, C, S = 3000, 12, 6, 48
+    xyz = kitti_cloud(1, N, seed=77)
+    boxes = enlarge(rand_boxes3d(xyz[0], M, seed=5), 1.0)[None]
+    feat = r.normal(size=(1, N, C)).astype(np.float32)
+    pooled = torch.cuda.FloatTensor(torch.Size((1, M, S, 3 + C))).zero_()
+    empty = torch.cuda.IntTensor(torch.Size((1, M))).zero_()
+    assert roipool3d_cuda.forward(T(xyz, dev), T(boxes, dev), T(feat, dev), pooled, empty) == 1
+    want, wempty = cpu.roipool3d(xyz, boxes, feat, S)
+    assert np.array_equal(pooled.cpu().numpy(), want) and np.array_equal(empty.cpu().numpy(), wempty)
+    flags = torch.LongTensor(torch.Size((M, N)))
+    roipool3d_cuda.pts_in_boxes3d_cpu(flags, torch.from_numpy(xyz[0]), torch.from_numpy(boxes[0]))
+    assert np.array_equal(flags.numpy(), cpu.pts_in_boxes3d(xyz[0], boxes[0]))
+    pp = torch.zeros(M, S, 3); pf = torch.zeros(M, S, C); pe = torch.zeros(M, dtype=torch.int64)
+    roipool3d_cuda.roipool3d_cpu(torch.from_numpy(xyz[0]), torch.from_numpy(boxes[0]), torch.from_numpy(feat[0]), pp, pf, pe)
+    assert np.array_equal(pp.numpy(), want[0, :, :, :3]) and np.array_equal(pf.numpy(), want[0, :, :, 3:])
+    assert np.array_equal(pe.numpy(), wempty[0])
+    with pytest.raises(RuntimeError):
+        roipool3d_cuda.forward(torch.from_numpy(xyz), T(boxes, dev), T(feat, dev), pooled, empty)   # CPU input
+
+
+# ------------------------------------------------------------------ iou3d
+@pytest.mark.parametrize("na,nb,spread", [(300, 200, 6.0), (17, 33, 2.0), (1, 1, 1.0), (64, 65, 3.0)])
+def test_overlap_and_iou_match_oracle_bitexact(dev, cpu, na, nb, spread):
+    from pointrcnn_amd import ops
+    a, b = rand_bev(na, spread, seed=na), rand_bev(nb, spread, seed=nb + 100)
+    assert np.array_equal(ops.boxes_overlap_bev(T(a, dev), T(b, dev)).cpu().numpy(), cpu.boxes_overlap_bev(a, b, 1))
+    assert np.array_equal(ops.boxes_iou_bev(T(a, dev), T(b, dev)).cpu().numpy(), cpu.boxes_iou_bev(a, b, 1))
+
+
+def test_overlap_degenerate_pairs(dev, cpu):
+    """identical boxes, shared edges, containment, axis-aligned (angle 0, pi/2): the clipping corner cases"""
+    from pointrcnn_amd import ops
+    base = np.array([[0, 0, 2, 4, 0.0], [0, 0, 2, 4, 0.0], [2, 0, 4, 4, 0.0], [0.5, 1, 1.5, 3, 0.0],
+                     [0, 0, 2, 4, np.pi / 2], [0, 0, 2, 4, 0.7], [0, 0, 2, 4, 0.7], [10, 10, 12, 14, 0.1],
+                     [0, 0, 2, 4, np.pi], [0, 0, 2, 4, -0.7]], np.float32)
+    got = ops.boxes_iou_bev(T(base, dev), T(base, dev)).cpu().numpy()
+    assert np.array_equal(got, cpu.boxes_iou_bev(base, base, 1))
+    np.testing.assert_allclose(np.diag(got), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["rotated", "normal"])
+@pytest.mark.parametrize("N,thr", [(1500, 0.1), (1500, 0.5), (1500, 0.8), (65, 0.3), (64, 0.3), (1, 0.5), (130, 0.0)])
+def test_nms_keep_matches_oracle(dev, cpu, kind, N, thr):
+    from pointrcnn_amd import ops
+    boxes = rand_bev(N, 8.0, seed=N)
+    keep, num = ops.nms_sorted(T(boxes, dev), thr, rotated=(kind == "rotated"))
+    got = keep[: int(num.item())].cpu().numpy()
+    assert np.array_equal(got, cpu.nms(boxes, thr, kind, 1))
+
+
+def test_nms_empty_and_duplicates(dev, cpu):
+    from pointrcnn_amd import ops
+    keep, num = ops.nms_sorted(torch.zeros((0, 5), device=dev), 0.5)
+    assert int(num.item()) == 0
+    dup = np.repeat(rand_bev(40, 5.0, seed=2), 3, axis=0)            # every box three times: duplicates suppressed
+    for kind in ("rotated", "normal"):
+        keep, num = ops.nms_sorted(T(dup, dev), 0.7, rotated=(kind == "rotated"))
+        got = keep[: int(num.item())].cpu().numpy()
+        assert np.array_equal(got, cpu.nms(dup, 0.7, kind, 1))
+        assert (got % 3 == 0).all()
+
+
+def test_nms_rpn_scale_normal(dev, cpu):
+    """the default RPN path: axis-aligned NMS on 6300 score-sorted proposals, thr 0.8 (default.yaml:61,165)"""
+    from pointrcnn_amd import ops
+    boxes = rand_bev(6300, 30.0, seed=63)
+    keep, num = ops.nms_sorted(T(boxes, dev), 0.8, rotated=False)
+    got = keep[: int(num.item())].cpu().numpy()
+    assert np.array_equal(got, cpu.nms(boxes, 0.8, "normal", 1))
+
+
+def test_iou3d_golden_from_reference(dev):
+    """fixtures produced by the reference's own iou3d sources run on the host (oracle/_ref): NMS keep sets
+    must be identical; overlap areas agree to 1e-5 (device trig differs from glibc's by ULPs)"""
+    from pointrcnn_amd import ops
+    g = np.load(os.path.join(GOLDEN, "iou3d_ref.npz"))
+    ov = ops.boxes_overlap_bev(T(g["a"], dev), T(g["b"], dev)).cpu().numpy()
+    np.testing.assert_allclose(ov, g["overlap"], atol=1e-5, rtol=0)
+    iou = ops.boxes_iou_bev(T(g["a"], dev), T(g["b"], dev)).cpu().numpy()
+    np.testing.assert_allclose(iou, g["iou"], atol=1e-5, rtol=0)
+    for kind in ("rotated", "normal"):
+        for thr in (0.1, 0.5, 0.8):
+            keep, num = ops.nms_sorted(T(g["nms_boxes"], dev), thr, rotated=(kind == "rotated"))
+            assert np.array_equal(keep[: int(num.item())].cpu().numpy(), g["keep_%s_%s" % (kind, thr)])
+
+
+def test_iou3d_dropin_module(dev, cpu):
+    """iou3d_cuda.* with the reference's calling convention (iou3d_utils.py:14-16,32-33,64-70)"""
+    import iou3d_cuda
+    boxes = rand_bev(500, 6.0, seed=11)
+    scores = np.random.default_rng(3).random(500).astype(np.float32)
+    tb, ts = T(boxes, dev), T(scores, dev)
+    ans = torch.cuda.FloatTensor(torch.Size((500, 500))).zero_()
+    assert iou3d_cuda.boxes_iou_bev_gpu(tb.contiguous(), tb.contiguous(), ans) == 1
+    assert np.array_equal(ans.cpu().numpy(), cpu.boxes_iou_bev(boxes, boxes, 1))
+    ans.zero_()
+    iou3d_cuda.boxes_overlap_bev_gpu(tb, tb, ans)
+    assert np.array_equal(ans.cpu().numpy(), cpu.boxes_overlap_bev(boxes, boxes, 1))
+    # iou3d_utils.nms_gpu, verbatim calling sequence
+    order = ts.sort(0, descending=True)[1]
+    sb = tb[order].contiguous()
+    for fn, kind in ((iou3d_cuda.nms_gpu, "rotated"), (iou3d_cuda.nms_normal_gpu, "normal")):
+        keep = torch.LongTensor(sb.size(0))
+        num_out = fn(sb, keep, 0.4)
+        picked = order[keep[:num_out].cuda()].contiguous().cpu().numpy()
+        want = order.cpu().numpy()[cpu.nms(sb.cpu().numpy(), 0.4, kind, 1)]
+        assert np.array_equal(picked, want)
+    with pytest.raises(RuntimeError):
+        iou3d_cuda.nms_gpu(torch.from_numpy(boxes), torch.LongTensor(500), 0.4)      # CPU boxes rejected
