@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- RPN inference throughput of the MI355X point-ops hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path -- the full RPN inference graph (PointNet++ MSG backbone: 4 SA + 4 FP
+levels, + cls/reg heads; lib/net/rpn.py:68-82 via pointrcnn_amd/rpn.py) -- over one batch of synthetic
+16 384-point clouds already resident in HBM.  Frames shard across ranks (one process per GPU, weak scaling:
+`--batch` frames per GPU); inference needs no collective, so the only distributed traffic is the barrier
+and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline     -- for the dominant kernel (the fused per-point MLP layer, fp32 MFMA): algorithmic FLOPs per
+                  launch / its average launch duration, measured with HIP events on the launch stream in an
+                  instrumented pass of the same steps; peak = 157.3 TFLOP/s dense fp32 MFMA.
+  cpu_baseline -- the CPU oracle restatement of the SAME graph (oracle/rpn_cpu.py, kind "port", 1 thread)
+                  timed on a bounded sample (one frame) on this box's host cores, rank 0 at N=1 only.
+  kernels      -- per-op-family GPU time of one step (ms) from the same event pass.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32-input MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (BASELINE metric: bs32)")
+    ap.add_argument("--npoints", type=int, default=16384)
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the step from a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class EventProfiler:
+    """Wraps the ctypes library: every prcnn_* launch is bracketed by HIP events recorded on the stream the
+    kernel is launched on (torch's current stream).  Used only in the instrumented pass, never in the timed one."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self.records = []          # (name, start, end, flops)
+
+    @staticmethod
+    def _flops(name, a):
+        if name == "prcnn_mlp_rows":
+            return 2.0 * a[2] * a[3] * a[6]
+        if name == "prcnn_mlp_group":
+            return 2.0 * (a[5] * a[7] * a[8]) * (a[9] + 3) * a[12]
+        if name == "prcnn_mlp_interp":
+            return 2.0 * (a[6] * a[7]) * (a[9] + a[10]) * a[13]
+        return 0.0
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("prcnn_") or name in ("prcnn_last_error", "prcnn_abi_version", "prcnn_wpack_floats",
+                                                      "prcnn_nms_workspace_bytes"):
+            return fn
+
+        def wrapped(*args):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = fn(*args)
+            e.record()
+            self.records.append((name, s, e, self._flops(name, args)))
+            return rc
+        return wrapped
+
+    def summary(self):
+        torch.cuda.synchronize()
+        fam = {}
+        for name, s, e, fl in self.records:
+            key = "mlp" if name.startswith("prcnn_mlp_") else name[len("prcnn_"):]
+            d = fam.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0})
+            d["ms"] += s.elapsed_time(e)
+            d["launches"] += 1
+            d["flops"] += fl
+        return fam
+
+
+def cpu_baseline(model, clouds_cpu, gpu_out):
+    """the oracle port of the same graph on one frame (bounded sample), single thread"""
+    import oracle
+    from oracle import rpn_cpu
+    cpu = oracle.cpu()
+    spec = rpn_cpu.extract_rpn_weights(model)
+    timings = {}
+    nframes = min(3, clouds_cpu.shape[0])
+    t0 = time.perf_counter()
+    outs = [rpn_cpu.rpn_forward_frame(cpu, clouds_cpu[f].numpy(), spec, timings) for f in range(nframes)]
+    dt = time.perf_counter() - t0
+    out = outs[0]
+    err = {}
+    for k in ("rpn_cls", "rpn_reg"):
+        ref = out[k]
+        got = gpu_out[k][0].float().cpu().numpy()
+        err[k] = float(abs(got - ref).max() / max(1.0, abs(ref).max()))
+    return {"value": round(nframes / dt, 5), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames (16384 pts each) of the same RPN graph through oracle/rpn_cpu.py, %.1f s" % (nframes, dt),
+            "host_cores_available": os.cpu_count(),
+            "breakdown_s": {k: round(v, 2) for k, v in sorted(timings.items())},
+            "gpu_vs_oracle_rel_err_frame0": err}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP kernels are the only implementation of the hot path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from pointrcnn_amd import _cabi, rpn
+    _cabi.lib()
+    torch.manual_seed(1234)
+    model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
+    clouds_cpu = rpn.synthetic_clouds(args.batch, args.npoints, seed0=100 + rank * args.batch)
+    clouds = clouds_cpu.to(dev)
+    batch = {"pts_input": clouds}
+
+    def step():
+        with torch.no_grad():
+            return model(batch)
+
+    for _ in range(max(1, args.warmup)):        # packs weights, fills the caching allocator
+        out = step()
+    torch.cuda.synchronize()
+
+    graph = None
+    if args.graph != "off":
+        try:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(g):
+                gout = step()
+            g.replay()
+            torch.cuda.synchronize()
+            for k in ("rpn_cls", "rpn_reg"):                 # the replayed graph must reproduce the eager result
+                assert torch.equal(gout[k], out[k]), "graph replay differs from eager (%s)" % k
+            graph, out = g, gout
+        except Exception as e:  # noqa: BLE001
+            if args.graph == "on":
+                raise
+            print("[bench] hipGraph capture unavailable (%s); timing eager launches" % str(e).split("\n")[0],
+                  file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    run = graph.replay if graph is not None else step
+    for _ in range(args.warmup):
+        run()
+
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames = args.batch * world * args.steps
+    line = {
+        "metric": "KITTI frames/sec, RPN inference end-to-end (16384 pts/frame, bs%d per GPU)" % args.batch,
+        "value": round(frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Full RPN PointNet++ backbone (4 SA-MSG + 4 FP) + cls/reg heads, tools/cfgs/default.yaml, "
+                               "%d pts/frame, batch %d per GPU, random-init weights, eval-mode BN" % (args.npoints, args.batch),
+                   "frames_per_gpu": args.batch, "npoints": args.npoints, "parallelism": "frames sharded, dp%d" % world,
+                   "launch": "hipGraph replay" if graph is not None else "eager"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        prof = EventProfiler(_cabi._lib)
+        real = _cabi._lib
+        _cabi._lib = prof
+        try:
+            nprof = min(3, args.steps)
+            for _ in range(nprof):
+                step()
+            fam = prof.summary()
+        finally:
+            _cabi._lib = real
+        mlp = fam.get("mlp", {"ms": 0.0, "launches": 1, "flops": 0.0})
+        achieved = mlp["flops"] / (mlp["ms"] * 1e-3) / 1e12 if mlp["ms"] > 0 else 0.0
+        line["roofline"] = {"kernel": "mlp_layer_kernel (fused gather/interp + fp32 MFMA + bias/ReLU/max-pool)",
+                            "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                            "launches_per_step": mlp["launches"] // nprof,
+                            "avg_launch_us": round(1e3 * mlp["ms"] / max(1, mlp["launches"]), 2),
+                            "flops_per_step": mlp["flops"] / nprof}
+        line["kernels"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "launches_per_step": v["launches"] // nprof}
+                           for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(model, clouds_cpu, out)
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""CPU restatement of ONE frame of the RPN inference graph, built only from oracle ops -- TEST INFRASTRUCTURE.
+
+Follows lib/net/pointnet2_msg.py:56-70 (4 SA-MSG levels, 4 FP levels) and lib/net/rpn.py:68-82 (heads) with the
+PointNet++ module semantics of SURVEY.md Appendix A.4-A.6.  Used by bench.py's `cpu_baseline` leg (timed on the
+host cores beside the GPU number) and by tests/ (end-to-end parity of the fused HIP graph).  Weights come in
+as folded (conv+eval-BN) numpy matrices in torch layout, so this file has no torch dependency.
+"""
+import time
+
+import numpy as np
+
+
+def extract_rpn_weights(model):
+    """model: pointrcnn_amd.rpn.RPN (or the reference's RPN on the drop-in modules) -> plain numpy spec."""
+    import pointnet2_lib.pointnet2.pytorch_utils as pt_utils
+
+    def fold(layer):
+        conv, bn, act = layer._parts()
+        w, b = pt_utils._fold_bn(conv, bn)
+        return (w.cpu().numpy(), None if b is None else b.cpu().numpy(), act is not None)
+
+    spec = {"sa": [], "fp": [], "cls": [], "reg": []}
+    for sa in model.backbone_net.SA_modules:
+        scales = []
+        for g, mlp in zip(sa.groupers, sa.mlps):
+            scales.append({"radius": g.radius, "nsample": g.nsample, "layers": [fold(l) for l in mlp.layers()]})
+        spec["sa"].append({"npoint": sa.npoint, "scales": scales})
+    for fp in model.backbone_net.FP_modules:
+        spec["fp"].append([fold(l) for l in fp.mlp.layers()])
+    for name, seq in (("cls", model.rpn_cls_layer), ("reg", model.rpn_reg_layer)):
+        for m in seq:
+            if hasattr(m, "_parts"):
+                spec[name].append(fold(m))
+    return spec
+
+
+def _mlp(cpu, rows, layers):
+    for w, b, relu in layers:
+        rows = cpu.linear_rows(rows, w, b, relu)
+    return rows
+
+
+def rpn_forward_frame(cpu, xyz, spec, timings=None):
+    """xyz (N,3) f32 -> dict(rpn_cls (N,1), rpn_reg (N,R), backbone_features (N,128)); single-threaded."""
+    t = timings if timings is not None else {}
+
+    def tick(name, t0):
+        t[name] = t.get(name, 0.0) + time.perf_counter() - t0
+
+    l_xyz = [np.ascontiguousarray(xyz, dtype=np.float32)]
+    l_feat = [None]                                        # channels-last (n, C)
+    for level in spec["sa"]:
+        p = l_xyz[-1]
+        t0 = time.perf_counter()
+        fidx = cpu.fps(p[None], level["npoint"])[0]
+        tick("fps", t0)
+        new_xyz = p[fidx]
+        outs = []
+        for sc in level["scales"]:
+            t0 = time.perf_counter()
+            idx = cpu.ball_query(sc["radius"], sc["nsample"], p[None], new_xyz[None])
+            tick("ball_query", t0)
+            t0 = time.perf_counter()
+            gx = cpu.group(p.T[None], idx) - new_xyz.T[None, :, :, None]                  # (1,3,M,ns)
+            g = gx if l_feat[-1] is None else np.concatenate([gx, cpu.group(l_feat[-1].T[None], idx)], 1)
+            rows = np.ascontiguousarray(g[0].transpose(1, 2, 0).reshape(-1, g.shape[1]))
+            tick("group", t0)
+            t0 = time.perf_counter()
+            rows = _mlp(cpu, rows, sc["layers"])
+            outs.append(rows.reshape(level["npoint"], sc["nsample"], -1).max(1))
+            tick("mlp", t0)
+        l_xyz.append(new_xyz)
+        l_feat.append(np.concatenate(outs, 1))
+    for i in range(-1, -(len(spec["fp"]) + 1), -1):
+        unknown, known = l_xyz[i - 1], l_xyz[i]
+        t0 = time.perf_counter()
+        d2, idx3 = cpu.three_nn(unknown[None], known[None])
+        w3 = cpu.three_weights(d2)
+        tick("three_nn", t0)
+        t0 = time.perf_counter()
+        interp = cpu.three_interp(l_feat[i].T[None], idx3, w3)[0].T                        # (n, C2)
+        rows = interp if l_feat[i - 1] is None else np.concatenate([interp, l_feat[i - 1]], 1)
+        tick("interp", t0)
+        t0 = time.perf_counter()
+        l_feat[i - 1] = _mlp(cpu, np.ascontiguousarray(rows), spec["fp"][i])
+        tick("mlp", t0)
+    feats = l_feat[0]
+    t0 = time.perf_counter()
+    out = {"backbone_features": feats, "rpn_cls": _mlp(cpu, feats, spec["cls"]), "rpn_reg": _mlp(cpu, feats, spec["reg"])}
+    tick("mlp", t0)
+    return out
