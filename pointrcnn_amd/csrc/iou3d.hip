@@ -216,14 +216,16 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
         unsigned long long diag = row < N ? mask[(size_t)row * W + blk] : 0ULL;
         unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
         unsigned long long cur = remv[blk];
-        cur = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cur >> 32)) << 32) |
-              (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)cur);
+        // readfirstlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high one
+        cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur >> 32)) << 32) |
+              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur);
         const int nrows = min(64, N - blk * 64);
         unsigned long long kept = 0ULL;
         for (int t = 0; t < nrows; t++) {                // serial inside the block, registers only
             if (!((cur >> t) & 1ULL)) {
                 kept |= 1ULL << t;
-                unsigned lo = __builtin_amdgcn_readlane(dlo, t), hi = __builtin_amdgcn_readlane(dhi, t);
+                unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, t);
+                unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, t);
                 cur |= ((unsigned long long)hi << 32) | lo;
             }
         }

@@ -118,13 +118,14 @@ __global__ __launch_bounds__(NB_THREADS) void three_nn_kernel(const float* __res
         dist2[o] = b1; dist2[o + 1] = b2; dist2[o + 2] = b3;
         idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
         if (weight) {
-            // PointnetFPModule: w = 1/(dist+1e-8), normalised; sqrt and divide are
-            // correctly rounded on gfx950 under hipcc defaults, as in the oracle.
-            float r0 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(b1), 1e-8f));
-            float r1 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(b2), 1e-8f));
-            float r2 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(b3), 1e-8f));
-            float s = __fadd_rn(__fadd_rn(r0, r1), r2);
-            weight[o] = __fdiv_rn(r0, s); weight[o + 1] = __fdiv_rn(r1, s); weight[o + 2] = __fdiv_rn(r2, s);
+            // PointnetFPModule: w = 1/(dist+1e-8), normalised
+            // sqrtf and '/' are IEEE correctly rounded here (-fhip-fp32-correctly-rounded-divide-sqrt, set
+            // explicitly in build.py); the __fsqrt_rn/__fdiv_rn intrinsics are NOT (they map to native ops).
+            float r0 = 1.0f / (sqrtf(b1) + 1e-8f);
+            float r1 = 1.0f / (sqrtf(b2) + 1e-8f);
+            float r2 = 1.0f / (sqrtf(b3) + 1e-8f);
+            float s = (r0 + r1) + r2;
+            weight[o] = r0 / s; weight[o + 1] = r1 / s; weight[o + 2] = r2 / s;
         }
     }
 }
