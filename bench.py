@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (BASELINE metric: bs32)")
     ap.add_argument("--npoints", type=int, default=16384)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the step from a hipGraph")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="batches in flight per GPU: step k runs on HIP stream k %% streams, so one batch's FPS "
+                         "(1 workgroup per frame = 32 of 256 CUs) overlaps another batch's MLP / neighbour kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -136,52 +139,64 @@ def main():
     _cabi.lib()
     torch.manual_seed(1234)
     model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
+    nstreams = max(1, args.streams)
     clouds_cpu = rpn.synthetic_clouds(args.batch, args.npoints, seed0=100 + rank * args.batch)
-    clouds = clouds_cpu.to(dev)
-    batch = {"pts_input": clouds}
+    batches = [{"pts_input": clouds_cpu.to(dev)}]
+    for s_ in range(1, nstreams):          # every in-flight slot owns its (resident) input batch
+        batches.append({"pts_input": rpn.synthetic_clouds(args.batch, args.npoints,
+                                                          seed0=100 + (world * s_ + rank) * args.batch).to(dev)})
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
 
-    def step():
+    def step(slot=0):
         with torch.no_grad():
-            return model(batch)
+            return model(batches[slot])
 
     for _ in range(max(1, args.warmup)):        # packs weights, fills the caching allocator
-        out = step()
+        out = step(0)
     torch.cuda.synchronize()
 
-    graph = None
+    graphs = None
     if args.graph != "off":
         try:
-            g = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.cuda.graph(g):
-                gout = step()
-            g.replay()
+            graphs, gouts = [], []
+            for slot in range(nstreams):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(streams[slot]):
+                    step(slot)
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, stream=streams[slot]):
+                    gouts.append(step(slot))
+                graphs.append(g)
+            graphs[0].replay()
             torch.cuda.synchronize()
             for k in ("rpn_cls", "rpn_reg"):                 # the replayed graph must reproduce the eager result
-                assert torch.equal(gout[k], out[k]), "graph replay differs from eager (%s)" % k
-            graph, out = g, gout
+                assert torch.equal(gouts[0][k], out[k]), "graph replay differs from eager (%s)" % k
+            out = gouts[0]
         except Exception as e:  # noqa: BLE001
             if args.graph == "on":
                 raise
             print("[bench] hipGraph capture unavailable (%s); timing eager launches" % str(e).split("\n")[0],
                   file=sys.stderr)
-            graph = None
+            graphs = None
             torch.cuda.synchronize()
 
-    run = graph.replay if graph is not None else step
-    for _ in range(args.warmup):
-        run()
+    def run(k):
+        slot = k % nstreams
+        with torch.cuda.stream(streams[slot]):
+            if graphs is not None:
+                graphs[slot].replay()
+            else:
+                step(slot)
+
+    for k in range(args.warmup):
+        run(k)
 
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
+    for k in range(args.steps):
+        run(k)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -190,6 +205,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    graph = graphs
 
     frames = args.batch * world * args.steps
     line = {
@@ -200,7 +216,7 @@ def main():
         "config": {"workload": "Full RPN PointNet++ backbone (4 SA-MSG + 4 FP) + cls/reg heads, tools/cfgs/default.yaml, "
                                "%d pts/frame, batch %d per GPU, random-init weights, eval-mode BN" % (args.npoints, args.batch),
                    "frames_per_gpu": args.batch, "npoints": args.npoints, "parallelism": "frames sharded, dp%d" % world,
-                   "launch": "hipGraph replay" if graph is not None else "eager"},
+                   "launch": "hipGraph replay" if graph is not None else "eager", "streams": nstreams},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -210,7 +226,7 @@ def main():
         try:
             nprof = min(3, args.steps)
             for _ in range(nprof):
-                step()
+                step(0)
             fam = prof.summary()
         finally:
             _cabi._lib = real

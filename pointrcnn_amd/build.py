@@ -20,6 +20,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fh
          "-Wall", "-Wno-unused-function"]
 
 
+# per-file extra flags.  fps.hip: finite-math-only lets fminf/fmaxf lower to bare v_min_f32/v_max_f32 (no NaN
+# canonicalisation); it permits no reassociation or contraction, so results are unchanged for finite inputs.
+# no-slp-vectorize: packed v_pk_*_f32 have no throughput advantage on gfx950 and cost operand-shuffle movs.
+EXTRA_FLAGS = {"fps.hip": ["-ffinite-math-only", "-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -44,7 +50,7 @@ def build(force=False, verbose=True):
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
-        procs.append((src, obj, subprocess.Popen([HIPCC] + FLAGS + ["-c", src, "-o", obj],
+        procs.append((src, obj, subprocess.Popen([HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj],
                                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     objs = []
     for src, obj, p in procs:

@@ -5,19 +5,48 @@
 // individually rounded fp32 ops, arg-max ties -> LOWEST point index.
 //
 // Design (latency-bound op: npoint dependent iterations): one workgroup per frame, the frame's points
-// and running min-distances live in VGPRs (PPT points per lane: x,y,z,t = 4*PPT registers) so an
-// iteration touches no memory except one 32-byte LDS slot per wave.  Per iteration:
-//   lane-local min-update + arg-max over PPT points   (VALU, ILP = PPT)
-//   wave arg-max: DPP max of the float bits, then DPP min of the candidate indices (12 VALU)
-//   the winning lane's coordinates are pulled out with v_readlane (uniform register index)
-//   wave partials (val, idx, x, y, z) -> LDS slot[iter&1][wave]; ONE s_barrier; every wave re-reduces
-//   the <=16 partials redundantly inside one DPP row.  Slots are double-buffered by iteration parity,
-//   which is what makes a single barrier per iteration sufficient.
+// and running min-distances live in VGPRs so an iteration touches no memory except one 32-byte LDS slot per
+// wave.  Point ownership is LANE-MAJOR (lane t of the block owns points t*PPT .. t*PPT+PPT-1), so "lowest
+// point index among the maxima" == lowest wave, then lowest lane, then lowest register slot -- which lets
+// the arg-max tie-break run on the scalar unit (ballot + find-first-set) instead of a second cross-lane
+// reduction.  Per iteration:
+//   lane-local min-update + running max over PPT points      (10 VALU per point, ILP = PPT)
+//   wave max of the float bits: 6 DPP steps (v_max_i32_dpp)   -> wmax in an SGPR
+//   owner lane  = ffs(ballot(lane max == wmax))               (SALU)
+//   owner slot  = first i with ballot(t[i] == wmax) bit set at the owner lane (PPT v_cmp + SALU)
+//   owner's coordinates via uniform register index + v_readlane
+//   wave partials (val, idx, x, y, z) -> LDS slot[iter&1][wave]; ONE s_barrier; every wave re-reduces the
+//   <=16 partials redundantly (4 DPP steps + ballot).  Slots are double-buffered by iteration parity, which
+//   is what makes a single barrier per iteration sufficient.
 // Single-wave configurations (N <= 1024) skip LDS and the barrier entirely.
 #include "common.h"
 
 template <int PPT> struct fvec_t { typedef float type __attribute__((ext_vector_type(PPT))); };
 template <> struct fvec_t<1> { typedef float type __attribute__((ext_vector_type(2))); };  // avoid 1-wide vectors
+
+// v = max(v, v shifted by the DPP pattern) in ONE VALU op.  Lanes whose DPP source is invalid (or whose row
+// is masked off) keep v.  The leading s_nop covers the VALU-write -> DPP-read hazard hipcc cannot see
+// inside an asm statement.
+#define FPS_DPP_MAX(v, ctrl) asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl : "+v"(v))
+
+__device__ __forceinline__ int wave_max_i32_fused(int v) {
+    FPS_DPP_MAX(v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    FPS_DPP_MAX(v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    FPS_DPP_MAX(v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    FPS_DPP_MAX(v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    FPS_DPP_MAX(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    FPS_DPP_MAX(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1");
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int row0_max_i32_fused(int v) {          // first 16 lanes only, result from lane 15
+    FPS_DPP_MAX(v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    FPS_DPP_MAX(v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    FPS_DPP_MAX(v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    FPS_DPP_MAX(v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    asm volatile("s_nop 1");
+    return __builtin_amdgcn_readlane(v, 15);
+}
 
 template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict__ xyz, int N, int npoint,
@@ -36,33 +65,35 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict_
     fvec px, py, pz, pt;
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
-        int k = i * BLOCK + tid;
+        int k = tid * PPT + i;            // lane-major ownership
         bool ok = k < N;
         px[i] = ok ? p[k * 3 + 0] : 0.f;
         py[i] = ok ? p[k * 3 + 1] : 0.f;
         pz[i] = ok ? p[k * 3 + 2] : 0.f;
-        pt[i] = ok ? 1e10f : -1.0f;      // padding lanes can never win the (signed) arg-max
+        pt[i] = ok ? 1e10f : -1.0f;      // padding can never win the (signed) arg-max
     }
     if (tid == 0 && npoint > 0) out[0] = 0;
     float x0 = p[0], y0 = p[1], z0 = p[2];
 
     for (int j = 1; j < npoint; j++) {
         float best = -2.0f;
-        int bi = 0;
 #pragma unroll
         for (int i = 0; i < PPT; i++) {
             float d = sqdist3(px[i], py[i], pz[i], x0, y0, z0);
-            float t = d < pt[i] ? d : pt[i];
+            float t = __builtin_fminf(pt[i], d);
             pt[i] = t;
-            if (t > best) { best = t; bi = i; }     // strict '>' keeps the lowest k of this lane
+            best = __builtin_fmaxf(best, t);
         }
-        // wave arg-max with lowest-index tie break
-        int vb = __float_as_int(best);              // best >= 0 or -1/-2: signed int order == float order
-        int wmax = wave_max_i32(vb);
-        int cand = (vb == wmax) ? (bi * BLOCK + tid) : 0x7fffffff;
-        int widx = wave_min_i32(cand);
-        int istar = __builtin_amdgcn_readfirstlane(widx / BLOCK);   // register slot of the winner (uniform)
-        int owner = widx & 63;                                       // its lane (BLOCK % 64 == 0)
+        // wave arg-max, ties -> lowest point index == lowest lane, then lowest slot
+        const int wmax = wave_max_i32_fused(__float_as_int(best));       // >= 0, or -1/-2: int order == float order
+        const float wmaxf = __int_as_float(wmax);
+        const int owner = __builtin_ctzll(__ballot(best == wmaxf));      // lowest lane holding the maximum
+        int istar = PPT - 1;
+#pragma unroll
+        for (int i = PPT - 2; i >= 0; i--)                               // lowest matching slot of that lane
+            if ((__ballot(pt[i] == wmaxf) >> owner) & 1ULL) istar = i;
+        istar = __builtin_amdgcn_readfirstlane(istar);
+        const int widx = (wave * 64 + owner) * PPT + istar;
         float sx = px[istar], sy = py[istar], sz = pz[istar];
         float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), owner));
         float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), owner));
@@ -73,7 +104,7 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict_
         } else {
             float* s = slot[j & 1][wave];
             if (lane == 0) {
-                s[0] = __int_as_float(wmax); s[1] = __int_as_float(widx);
+                s[0] = wmaxf; s[1] = __int_as_float(widx);
                 s[2] = wx; s[3] = wy; s[4] = wz;
             }
             __syncthreads();
@@ -81,10 +112,9 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict_
             int v = lane < NW ? __float_as_int(r[0]) : (int)0x80000000;
             int id = __float_as_int(r[1]);
             float rx = r[2], ry = r[3], rz = r[4];
-            int gmax = row0_max_i32(v);
-            int c2 = (v == gmax) ? id : 0x7fffffff;
-            gidx = row0_min_i32(c2);
-            int wwin = (gidx % BLOCK) >> 6;          // wave that owns the winner (uniform)
+            const int gmax = row0_max_i32_fused(v);
+            const int wwin = __builtin_ctzll(__ballot(v == gmax));       // lowest wave holding the global maximum
+            gidx = __builtin_amdgcn_readlane(id, wwin);
             x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx), wwin));
             y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry), wwin));
             z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rz), wwin));

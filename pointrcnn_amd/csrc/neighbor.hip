@@ -4,7 +4,7 @@
 // SURVEY Appendix A.3 / A.5 and oracle prcnn_cpu_ball_query / prcnn_cpu_three_nn.
 //
 // Both are brute-force scans (compulsory HBM traffic is tiny: N*12 B per frame; the work is VALU):
-// a workgroup owns 256 query points (one per lane) of one frame and streams the frame's candidate
+// a workgroup owns 64 (ball query) or 256 (three_nn) query points (one per lane) of one frame and streams the frame's candidate
 // points through LDS in coalesced chunks, expanded to float4 so that the inner loop is ONE
 // ds_read_b128 broadcast (all lanes read the same address: conflict-free) per candidate.  Scanning
 // candidates in ascending index order makes the "first nsample hits in index order" contract fall
@@ -12,28 +12,32 @@
 // same centroids: ball_query2 evaluates both in the same pass (half the scans).
 #include "common.h"
 
-#define NB_THREADS 256
-#define NB_CHUNK 2048      // candidates staged per LDS chunk: 2048 * 16 B = 32 KB
+#define BQ_THREADS 64       // ball query: ONE wave per workgroup -> wave-local staging, 4x more workgroups than 256-thread
+                            // blocks (the op only has B*M threads in total), no cross-wave barrier in the scan
+#define NN_THREADS 256      // three_nn has n >= 4x more query points: 256-thread blocks share each staged chunk
+#define NB_CHUNK 1024       // candidates staged per LDS chunk: 1024 * 16 B = 16 KB
 
+template <int THREADS>
 __device__ __forceinline__ void stage_chunk(const float* __restrict__ p, int c0, int N, float4* spts, int tid) {
     // p: frame base (N,3).  Coalesced dword loads of the flat xyz stream, expanded to float4 in LDS.
+    // Slots past the end of the frame are filled with +inf so the scan loops need no bounds test.
     int cnt = min(NB_CHUNK, N - c0);
     const float* src = p + (size_t)c0 * 3;
     float* s = reinterpret_cast<float*>(spts);
-    for (int i = tid; i < cnt * 3; i += NB_THREADS) {
+    for (int i = tid; i < NB_CHUNK * 3; i += THREADS) {
         int pt = i / 3, c = i - pt * 3;
-        s[pt * 4 + c] = src[i];
+        s[pt * 4 + c] = pt < cnt ? src[i] : INFINITY;
     }
 }
 
 template <bool DUAL>
-__global__ __launch_bounds__(NB_THREADS) void ball_query_kernel(const float* __restrict__ xyz,
+__global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float* __restrict__ xyz,
                                                                 const float* __restrict__ new_xyz, int N, int M,
                                                                 float r2a, int nsa, int32_t* __restrict__ idxa,
                                                                 float r2b, int nsb, int32_t* __restrict__ idxb) {
     __shared__ float4 spts[NB_CHUNK];
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int m = blockIdx.x * NB_THREADS + tid;
+    const int m = blockIdx.x * BQ_THREADS + tid;
     const bool valid = m < M;
     const float* __restrict__ p = xyz + (size_t)b * N * 3;
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -48,25 +52,35 @@ __global__ __launch_bounds__(NB_THREADS) void ball_query_kernel(const float* __r
     bool done = !valid;
 
     for (int c0 = 0; c0 < N; c0 += NB_CHUNK) {
+        if (__all(done)) break;                    // single-wave workgroup: the whole block is finished
         __syncthreads();
-        stage_chunk(p, c0, N, spts, tid);
+        stage_chunk<BQ_THREADS>(p, c0, N, spts, tid);
         __syncthreads();
-        const int cnt = min(NB_CHUNK, N - c0);
-        if (__all(done)) continue;                 // this wave is finished; still helps staging
         if (!done) {
-#pragma unroll 4
-            for (int i = 0; i < cnt; i++) {
-                float4 c = spts[i];
-                float d2 = sqdist3(qx, qy, qz, c.x, c.y, c.z);
-                if (d2 < r2max) {
-                    int k = c0 + i;
-                    if (d2 < r2a && cnta < nsa) {
-                        if (cnta == 0) firsta = k;
-                        oa[cnta++] = k;
-                    }
-                    if (DUAL && d2 < r2b && cntb < nsb) {
-                        if (cntb == 0) firstb = k;
-                        ob[cntb++] = k;
+            for (int i0 = 0; i0 < NB_CHUNK; i0 += 8) {
+                // 8 independent distance evaluations, ONE test for "any of them inside the larger ball"
+                float d2[8];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    float4 c = spts[i0 + u];
+                    d2[u] = sqdist3(qx, qy, qz, c.x, c.y, c.z);     // padded slots give +inf
+                    any |= d2[u] < r2max;
+                }
+                if (any) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (d2[u] < r2max) {
+                            int k = c0 + i0 + u;
+                            if (d2[u] < r2a && cnta < nsa) {
+                                if (cnta == 0) firsta = k;
+                                oa[cnta++] = k;
+                            }
+                            if (DUAL && d2[u] < r2b && cntb < nsb) {
+                                if (cntb == 0) firstb = k;
+                                ob[cntb++] = k;
+                            }
+                        }
                     }
                     if (cnta >= nsa && (!DUAL || cntb >= nsb)) { done = true; break; }
                 }
@@ -80,13 +94,13 @@ __global__ __launch_bounds__(NB_THREADS) void ball_query_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(NB_THREADS) void three_nn_kernel(const float* __restrict__ unknown,
+__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float* __restrict__ unknown,
                                                               const float* __restrict__ known, int n, int m,
                                                               float* __restrict__ dist2, int32_t* __restrict__ idx,
                                                               float* __restrict__ weight) {
     __shared__ float4 spts[NB_CHUNK];
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int i = blockIdx.x * NB_THREADS + tid;
+    const int i = blockIdx.x * NN_THREADS + tid;
     const bool valid = i < n;
     const float* __restrict__ p = known + (size_t)b * m * 3;
     float ux = 0.f, uy = 0.f, uz = 0.f;
@@ -98,18 +112,28 @@ __global__ __launch_bounds__(NB_THREADS) void three_nn_kernel(const float* __res
     int i1 = 0, i2 = 0, i3 = 0;
     for (int c0 = 0; c0 < m; c0 += NB_CHUNK) {
         __syncthreads();
-        stage_chunk(p, c0, m, spts, tid);
+        stage_chunk<NN_THREADS>(p, c0, m, spts, tid);
         __syncthreads();
-        const int cnt = min(NB_CHUNK, m - c0);
-#pragma unroll 4
-        for (int j = 0; j < cnt; j++) {
-            float4 c = spts[j];
-            float d = sqdist3(ux, uy, uz, c.x, c.y, c.z);
-            if (d < b3) {                       // rare after warm-up: keeps the common path to one compare
-                int k = c0 + j;
-                if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
-                else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
-                else { b3 = d; i3 = k; }
+        for (int j0 = 0; j0 < NB_CHUNK; j0 += 8) {
+            float d[8];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                float4 c = spts[j0 + u];
+                d[u] = sqdist3(ux, uy, uz, c.x, c.y, c.z);           // padded slots give +inf: never < b3
+                any |= d[u] < b3;
+            }
+            if (any) {                              // rare after warm-up
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    float dd = d[u];
+                    if (dd < b3) {
+                        int k = c0 + j0 + u;
+                        if (dd < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = dd; i1 = k; }
+                        else if (dd < b2) { b3 = b2; i3 = i2; b2 = dd; i2 = k; }
+                        else { b3 = dd; i3 = k; }
+                    }
+                }
             }
         }
     }
@@ -136,13 +160,13 @@ static int ball_query_impl(const float* xyz, const float* new_xyz, int B, int N,
     PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && nsa > 0 && (!dual || nsb > 0),
                   "prcnn_ball_query: bad shape B=%d N=%d M=%d nsample=%d/%d", B, N, M, nsa, nsb);
     if (B == 0 || M == 0) return PRCNN_OK;
-    dim3 grid(prcnn_divup(M, NB_THREADS), B);
+    dim3 grid(prcnn_divup(M, BQ_THREADS), B);
     float r2a = ra * ra, r2b = rb * rb;        // fp32 product, as the oracle
     if (dual)
-        hipLaunchKernelGGL(ball_query_kernel<true>, grid, dim3(NB_THREADS), 0, s, xyz, new_xyz, N, M, r2a, nsa, ia, r2b,
+        hipLaunchKernelGGL(ball_query_kernel<true>, grid, dim3(BQ_THREADS), 0, s, xyz, new_xyz, N, M, r2a, nsa, ia, r2b,
                            nsb, ib);
     else
-        hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(NB_THREADS), 0, s, xyz, new_xyz, N, M, r2a, nsa, ia,
+        hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(BQ_THREADS), 0, s, xyz, new_xyz, N, M, r2a, nsa, ia,
                            0.f, 0, (int32_t*)nullptr);
     PRCNN_LAUNCH_CHECK("prcnn_ball_query");
     return PRCNN_OK;
@@ -165,7 +189,7 @@ PRCNN_API int prcnn_three_nn(const float* unknown, const float* known, int B, in
     PRCNN_REQUIRE(unknown && known && dist2 && idx, "prcnn_three_nn: null pointer");
     PRCNN_REQUIRE(B >= 0 && n >= 0 && m > 0, "prcnn_three_nn: bad shape B=%d n=%d m=%d", B, n, m);
     if (B == 0 || n == 0) return PRCNN_OK;
-    hipLaunchKernelGGL(three_nn_kernel, dim3(prcnn_divup(n, NB_THREADS), B), dim3(NB_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(three_nn_kernel, dim3(prcnn_divup(n, NN_THREADS), B), dim3(NN_THREADS), 0, (hipStream_t)stream,
                        unknown, known, n, m, dist2, idx, weight);
     PRCNN_LAUNCH_CHECK("prcnn_three_nn");
     return PRCNN_OK;

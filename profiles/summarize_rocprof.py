@@ -10,15 +10,15 @@ import sys
 
 def rows_from_db(path):
     c = sqlite3.connect(path)
-    return [(r[0], r[1], r[2] / 1e3, r[3] / 1e3, r[4]) for r in
+    return [(r[0], r[1], r[2], r[3], r[4]) for r in   # rocpd top_kernels durations are in microseconds
             c.execute("select name,total_calls,total_duration,average,percentage from top_kernels")]
 
 
 def rows_from_csv(path):
     out = []
     for r in csv.DictReader(open(path)):
-        out.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6 * 1e3 / 1e3,
-                    float(r["AverageNs"]) / 1e3 / 1e3 * 1e3 / 1e3, float(r["Percentage"])))
+        out.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3,
+                    float(r["Percentage"])))
     return out
 
 
