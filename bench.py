@@ -66,6 +66,16 @@ class EventProfiler:
             return 2.0 * (a[5] * a[7] * a[8]) * (a[9] + 3) * a[12]
         if name == "prcnn_mlp_interp":
             return 2.0 * (a[6] * a[7]) * (a[9] + a[10]) * a[13]
+
+        def chain(rows, k0, nout):                 # sum of K_l * N_l over the stack, true (unpadded) widths
+            widths = [k0] + list(nout)
+            return 2.0 * rows * sum(x * y for x, y in zip(widths[:-1], widths[1:]))
+        if name == "prcnn_mlp_chain_rows":
+            return chain(a[2], a[3], a[7])
+        if name == "prcnn_mlp_chain_group":
+            return chain(a[5] * a[7] * a[8], a[9] + 3, a[13])
+        if name == "prcnn_mlp_chain_interp":
+            return chain(a[6] * a[7], a[9] + a[10], a[14])
         return 0.0
 
     def __getattr__(self, name):
@@ -232,7 +242,7 @@ def main():
             _cabi._lib = real
         mlp = fam.get("mlp", {"ms": 0.0, "launches": 1, "flops": 0.0})
         achieved = mlp["flops"] / (mlp["ms"] * 1e-3) / 1e12 if mlp["ms"] > 0 else 0.0
-        line["roofline"] = {"kernel": "mlp_layer_kernel (fused gather/interp + fp32 MFMA + bias/ReLU/max-pool)",
+        line["roofline"] = {"kernel": "mlp_chain_kernel + mlp_layer_kernel (fused gather/interp + fp32 MFMA + bias/ReLU/max-pool)",
                             "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                             "launches_per_step": mlp["launches"] // nprof,

@@ -134,6 +134,28 @@ int prcnn_mlp_interp(const float* known_cl, int ld_known, const int32_t* idx3, c
                      int ld_skip, int B, int n, int m, int C2, int C1, const float* wpack, const float* bias,
                      int Nout, int relu, float* out, int ld_out, int col_off, prcnn_stream_t stream);
 
+/* Register-resident layer CHAIN: up to 3 consecutive layers (a whole SharedMLP) in ONE kernel; one wave owns 32
+ * rows and carries them through every layer inside the register file (the MFMA accumulator layout of layer l is
+ * the B-operand layout of layer l+1), so intermediate activations touch neither LDS nor HBM and a gathered /
+ * interpolated input row is built once.  Same arithmetic as the per-layer calls (fp32 MFMA, fp32 accumulate).
+ * wpack[l], bias[l], nout[l], relu[l] are HOST arrays of length nlayers; every bias[l] (device, may be NULL) must
+ * hold 32*ceil(nout[l]/32) floats (zero padded).  Limits: nout[l] <= 128; pool_ns in {0,16,32} (group variant:
+ * pool_ns == nsample or 0).  Only a fixed set of width combinations is instantiated: ask
+ * prcnn_mlp_chain_supported first, or handle PRCNN_EUNSUPPORTED by issuing the per-layer calls.
+ * mode: 0 = rows, 1 = group, 2 = interp. */
+int prcnn_mlp_chain_supported(int mode, int nlayers, const int* nout, int pool_ns);
+int prcnn_mlp_chain_rows(const float* in, int ld_in, int64_t rows, int K, int nlayers, const float* const* wpack,
+                         const float* const* bias, const int* nout, const int* relu, float* out, int ld_out,
+                         int col_off, int pool_ns, prcnn_stream_t stream);
+int prcnn_mlp_chain_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl,
+                          int ld_feat, int B, int N, int M, int nsample, int C, int nlayers,
+                          const float* const* wpack, const float* const* bias, const int* nout, const int* relu,
+                          float* out, int ld_out, int col_off, int pool_ns, prcnn_stream_t stream);
+int prcnn_mlp_chain_interp(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3,
+                           const float* skip_cl, int ld_skip, int B, int n, int m, int C2, int C1, int nlayers,
+                           const float* const* wpack, const float* const* bias, const int* nout, const int* relu,
+                           float* out, int ld_out, int col_off, prcnn_stream_t stream);
+
 /* out[r, col_off + c] = max over ns consecutive rows of in (generic nsample fallback for pooling) */
 int prcnn_maxpool_rows(const float* in, int ld_in, int64_t rows_out, int ns, int C, float* out, int ld_out,
                        int col_off, prcnn_stream_t stream);

@@ -66,6 +66,8 @@ template <> struct Raw<MODE_PLAIN> { float4 a; };
 template <> struct Raw<MODE_GROUP> { float4 a; };
 template <> struct Raw<MODE_INTERP> { float4 a, b, c; };
 
+__host__ __device__ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // ---- per-row metadata (computed once per thread for its 4 rows) -------------------------------
@@ -317,6 +319,184 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
     }
 }
 
+// =====================================================================================================
+// Register-resident layer CHAIN (whole SharedMLP in one kernel, one wave = 32 rows, no LDS, no barriers).
+//
+// The layer is computed transposed: out^T[n][row] = sum_k W[n][k] * act^T[k][row], i.e. the MFMA A operand is
+// the packed weight (lane (h,i) -> W[32*ob+i][8*kb+4*h+s], exactly the prcnn_pack_weight image) and the B
+// operand is the activation of the lane's own row (lane (h,j) -> act[row j][8*kb+4*h+s]).  The 32x32 MFMA
+// returns D[i][j] with lane (h,j) holding i = (r&3) + 8*(r>>2) + 4*h in register r = 4*q+s, i.e. channel
+// 32*ob + 8*q + 4*h + s of row j -- which IS the B operand element (k-block 4*ob+q, step s) of the next
+// layer.  So accumulators feed the next layer's MFMAs directly: the chain never leaves the register file.
+// Bias+ReLU are applied in place; the max-pool over nsample rows is a DPP max over the 16-lane rows of the
+// row (= lane) axis.  Intermediate activations never touch LDS or HBM, and an interpolated / gathered input
+// row is built exactly once (the per-layer kernel rebuilds it for every 64-column tile).
+// Limits: every layer width <= 128 (4 blocks of 32), pool_ns in {0,16,32}; wider layers use mlp_layer_kernel.
+// =====================================================================================================
+struct ChainParams {
+    MlpParams a;               // prologue description + layer 0 (wpack/bias/K/KB/Nout/relu) + output/pool
+    const float* wpack1; const float* bias1; int KB1, N1, relu1;
+    const float* wpack2; const float* bias2; int KB2, N2, relu2;
+    int nlayers;
+};
+
+#define CH_DPP_FMAX(v, ctrl) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
+
+__device__ __forceinline__ float4 ldw(const float* __restrict__ wpack, int KB, int ob, int kb, int lane) {
+    return ld4(wpack + (((long)ob * KB + kb) * 64 + lane) * 4);
+}
+
+// bias (padded to 32*NB by the host) + optional ReLU, in the D-register layout
+template <int NB>
+__device__ __forceinline__ void bias_act(f32x16 (&acc)[NB], const float* __restrict__ bias, int relu, int h) {
+#pragma unroll
+    for (int ob = 0; ob < NB; ob++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float4 b = bias ? ld4(bias + ob * 32 + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float v0 = acc[ob][4 * q + 0] + b.x, v1 = acc[ob][4 * q + 1] + b.y;
+            float v2 = acc[ob][4 * q + 2] + b.z, v3 = acc[ob][4 * q + 3] + b.w;
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            acc[ob][4 * q + 0] = v0; acc[ob][4 * q + 1] = v1; acc[ob][4 * q + 2] = v2; acc[ob][4 * q + 3] = v3;
+        }
+}
+
+// next layer from register-resident activations: out[ob] += W[ob, kb] * in[kb/4][4*(kb%4)+s]
+template <int NBI, int NBO>
+__device__ __forceinline__ void chain_layer(const f32x16 (&in)[NBI], f32x16 (&out)[NBO],
+                                            const float* __restrict__ wpack, int KB, int lane) {
+#pragma unroll
+    for (int ob = 0; ob < NBO; ob++) out[ob] = (f32x16){0};
+#pragma unroll
+    for (int kb = 0; kb < NBI * 4; kb++) {
+        if (kb < KB) {                      // uniform: K of this layer = true width of the previous one
+#pragma unroll
+            for (int ob = 0; ob < NBO; ob++) {
+                float4 w = ldw(wpack, KB, ob, kb, lane);
+                out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, in[kb / 4][4 * (kb % 4) + 0], out[ob], 0, 0, 0);
+                out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, in[kb / 4][4 * (kb % 4) + 1], out[ob], 0, 0, 0);
+                out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, in[kb / 4][4 * (kb % 4) + 2], out[ob], 0, 0, 0);
+                out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, in[kb / 4][4 * (kb % 4) + 3], out[ob], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// epilogue of the last layer: (activated) acc -> out, plain store or max over nsample rows (= lanes)
+template <int NB>
+__device__ __forceinline__ void chain_store(const ChainParams& C, f32x16 (&acc)[NB], int Nlast, long row, bool valid,
+                                            int lane, int h) {
+    const MlpParams& P = C.a;
+    const bool vec = ((P.ld_out | P.col_off) % 4 == 0) && aligned16(P.out);
+    if (P.pool_ns == 0) {
+        if (!valid) return;
+        float* o = P.out + row * P.ld_out + P.col_off;
+#pragma unroll
+        for (int ob = 0; ob < NB; ob++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int c = ob * 32 + 8 * q + 4 * h;
+                if (c >= Nlast) continue;
+                if (vec && c + 4 <= Nlast) {
+                    *reinterpret_cast<float4*>(o + c) = make_float4(acc[ob][4 * q], acc[ob][4 * q + 1], acc[ob][4 * q + 2], acc[ob][4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+                        if (c + s < Nlast) o[c + s] = acc[ob][4 * q + s];
+                }
+            }
+        return;
+    }
+    // max over the 16-lane DPP rows of the row axis (lanes 0-15 / 16-31 of each half are 16 consecutive rows);
+    // ReLU'd values are >= 0 and rows past the end hold 0 contributions only in groups that are not stored
+    const int j = lane & 31;
+    const bool writer = P.pool_ns == 16 ? ((j & 15) == 15) : (j == 31);
+    const long group = P.pool_ns == 16 ? (row / 16) : (row / 32);
+    const long groups = P.rows / P.pool_ns;
+    float* o = P.out + group * P.ld_out + P.col_off;
+#pragma unroll
+    for (int ob = 0; ob < NB; ob++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float v[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                float x = acc[ob][4 * q + s];
+                CH_DPP_FMAX(x, "row_shr:1 row_mask:0xf bank_mask:0xf");
+                CH_DPP_FMAX(x, "row_shr:2 row_mask:0xf bank_mask:0xf");
+                CH_DPP_FMAX(x, "row_shr:4 row_mask:0xf bank_mask:0xf");
+                CH_DPP_FMAX(x, "row_shr:8 row_mask:0xf bank_mask:0xf");
+                if (P.pool_ns == 32) CH_DPP_FMAX(x, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+                asm volatile("s_nop 1");
+                v[s] = x;
+            }
+            int c = ob * 32 + 8 * q + 4 * h;
+            if (writer && valid && group < groups && c < Nlast) {
+                if (vec && c + 4 <= Nlast) *reinterpret_cast<float4*>(o + c) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+                        if (c + s < Nlast) o[c + s] = v[s];
+                }
+            }
+        }
+}
+
+template <int MODE, int NB0, int NB1, int NB2>
+__global__ __launch_bounds__(256) void mlp_chain_kernel(const ChainParams C) {
+    const MlpParams& P = C.a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const long row = ((long)blockIdx.x * 4 + wave) * 32 + j;
+    RowMeta<MODE> meta;
+    make_meta<MODE>(P, row, meta);
+
+    // ---- layer 0: the B operand is the gathered / interpolated / plain input row, streamed over K ----
+    f32x16 a0[NB0];
+#pragma unroll
+    for (int ob = 0; ob < NB0; ob++) a0[ob] = (f32x16){0};
+    {
+        Raw<MODE> cur, nxt;
+        fetch<MODE>(P, meta, 4 * h, cur);
+        float4 wc[NB0], wn[NB0];
+#pragma unroll
+        for (int ob = 0; ob < NB0; ob++) wc[ob] = ldw(P.wpack, P.KB, ob, 0, lane);
+        for (int kb = 0; kb < P.KB; kb++) {
+            const bool more = kb + 1 < P.KB;
+            if (more) {
+                fetch<MODE>(P, meta, 8 * (kb + 1) + 4 * h, nxt);
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) wn[ob] = ldw(P.wpack, P.KB, ob, kb + 1, lane);
+            }
+            float4 b = finish<MODE>(P, meta, 8 * kb + 4 * h, cur);
+#pragma unroll
+            for (int ob = 0; ob < NB0; ob++) {
+                a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[ob].x, b.x, a0[ob], 0, 0, 0);
+                a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[ob].y, b.y, a0[ob], 0, 0, 0);
+                a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[ob].z, b.z, a0[ob], 0, 0, 0);
+                a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[ob].w, b.w, a0[ob], 0, 0, 0);
+            }
+            if (more) {
+                cur = nxt;
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) wc[ob] = wn[ob];
+            }
+        }
+    }
+    bias_act<NB0>(a0, P.bias, P.relu, h);
+    if (NB1 == 0) { chain_store<NB0>(C, a0, P.Nout, row, meta.valid, lane, h); return; }
+
+    f32x16 a1[NB1 ? NB1 : 1];
+    chain_layer<NB0, (NB1 ? NB1 : 1)>(a0, a1, C.wpack1, C.KB1, lane);
+    bias_act<(NB1 ? NB1 : 1)>(a1, C.bias1, C.relu1, h);
+    if (NB2 == 0) { chain_store<(NB1 ? NB1 : 1)>(C, a1, C.N1, row, meta.valid, lane, h); return; }
+
+    f32x16 a2[NB2 ? NB2 : 1];
+    chain_layer<(NB1 ? NB1 : 1), (NB2 ? NB2 : 1)>(a1, a2, C.wpack2, C.KB2, lane);
+    bias_act<(NB2 ? NB2 : 1)>(a2, C.bias2, C.relu2, h);
+    chain_store<(NB2 ? NB2 : 1)>(C, a2, C.N2, row, meta.valid, lane, h);
+}
+
 __global__ void pack_weight_kernel(const float* __restrict__ w, int Nout, int K, int k_rot, int KB, int NB,
                                    float* __restrict__ wpack) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,7 +525,6 @@ __global__ void maxpool_rows_kernel(const float* __restrict__ in, int ld_in, lon
     out[r * ld_out + col_off + c] = m;
 }
 
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     PRCNN_REQUIRE(P.wpack && P.out, "prcnn_mlp: null weight/output pointer");
@@ -440,4 +619,120 @@ PRCNN_API int prcnn_maxpool_rows(const float* in, int ld_in, int64_t rows_out, i
                        ld_in, (long)rows_out, ns, C, out, ld_out, col_off);
     PRCNN_LAUNCH_CHECK("prcnn_maxpool_rows");
     return PRCNN_OK;
+}
+
+// ---- chain launcher -----------------------------------------------------------------------------
+template <int MODE, int NB0, int NB1, int NB2>
+static void launch_chain(const ChainParams& C, hipStream_t s) {
+    dim3 grid(prcnn_divup(C.a.rows, 128));
+    hipLaunchKernelGGL((mlp_chain_kernel<MODE, NB0, NB1, NB2>), grid, dim3(256), 0, s, C);
+}
+
+static int nb32(int n) { return (n + 31) / 32; }
+
+static bool chain_instance_exists(int mode, int n0, int n1, int n2) {
+    struct { int m, a, b, c; } T[] = {{MODE_GROUP, 1, 1, 1}, {MODE_GROUP, 1, 1, 2}, {MODE_GROUP, 2, 2, 4}, {MODE_GROUP, 2, 3, 4},
+                                      {MODE_INTERP, 4, 4, 0}, {MODE_PLAIN, 4, 4, 0}, {MODE_PLAIN, 4, 1, 0}, {MODE_PLAIN, 4, 3, 0}};
+    for (auto& t : T)
+        if (t.m == mode && t.a == n0 && t.b == n1 && t.c == n2) return true;
+    return false;
+}
+
+PRCNN_API int prcnn_mlp_chain_supported(int mode, int nlayers, const int* nout, int pool_ns) {
+    if (!nout || nlayers < 1 || nlayers > 3) return 0;
+    if (!(pool_ns == 0 || pool_ns == 16 || pool_ns == 32)) return 0;
+    for (int l = 0; l < nlayers; l++)
+        if (nout[l] <= 0 || nout[l] > 128) return 0;
+    return chain_instance_exists(mode, nb32(nout[0]), nlayers > 1 ? nb32(nout[1]) : 0, nlayers > 2 ? nb32(nout[2]) : 0) ? 1 : 0;
+}
+
+// returns PRCNN_EUNSUPPORTED when no instance matches
+static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
+    MlpParams& P = C.a;
+    P.KB = (P.K + 7) / 8;
+    P.NB = nb32(P.Nout);
+    const int n0 = nb32(P.Nout), n1 = C.nlayers > 1 ? nb32(C.N1) : 0, n2 = C.nlayers > 2 ? nb32(C.N2) : 0;
+    if (C.nlayers > 1) C.KB1 = (P.Nout + 7) / 8;
+    if (C.nlayers > 2) C.KB2 = (C.N1 + 7) / 8;
+    if (P.rows == 0) return PRCNN_OK;
+#define CHAIN_CASE(M, A, B, CC) if (mode == M && n0 == A && n1 == B && n2 == CC) { launch_chain<M, A, B, CC>(C, s); PRCNN_LAUNCH_CHECK("prcnn_mlp_chain"); return PRCNN_OK; }
+    CHAIN_CASE(MODE_GROUP, 1, 1, 1)
+    CHAIN_CASE(MODE_GROUP, 1, 1, 2)
+    CHAIN_CASE(MODE_GROUP, 2, 2, 4)
+    CHAIN_CASE(MODE_GROUP, 2, 3, 4)
+    CHAIN_CASE(MODE_INTERP, 4, 4, 0)
+    CHAIN_CASE(MODE_PLAIN, 4, 4, 0)
+    CHAIN_CASE(MODE_PLAIN, 4, 1, 0)
+    CHAIN_CASE(MODE_PLAIN, 4, 3, 0)
+#undef CHAIN_CASE
+    return prcnn_fail(PRCNN_EUNSUPPORTED, "prcnn_mlp_chain: no register-chain instance for mode %d widths (%d,%d,%d)/32", mode, n0, n1, n2);
+}
+
+static int fill_chain(ChainParams& C, int nlayers, const float* const* wpack, const float* const* bias, const int* nout,
+                      const int* relu, float* out, int ld_out, int col_off, int pool_ns) {
+    PRCNN_REQUIRE(nlayers >= 1 && nlayers <= 3, "prcnn_mlp_chain: nlayers=%d (1..3)", nlayers);
+    PRCNN_REQUIRE(wpack && bias && nout && relu && out, "prcnn_mlp_chain: null pointer");
+    for (int l = 0; l < nlayers; l++) {
+        PRCNN_REQUIRE(wpack[l] && aligned16(wpack[l]), "prcnn_mlp_chain: layer %d wpack null/unaligned", l);
+        PRCNN_REQUIRE(bias[l] == nullptr || aligned16(bias[l]), "prcnn_mlp_chain: layer %d bias must be 16-byte aligned and padded to a multiple of 32", l);
+        PRCNN_REQUIRE(nout[l] > 0 && nout[l] <= 128, "prcnn_mlp_chain: layer %d width %d (1..128)", l, nout[l]);
+    }
+    PRCNN_REQUIRE(pool_ns == 0 || pool_ns == 16 || pool_ns == 32, "prcnn_mlp_chain: pool_ns=%d (0/16/32)", pool_ns);
+    PRCNN_REQUIRE(ld_out >= col_off + nout[nlayers - 1], "prcnn_mlp_chain: ld_out too small");
+    C.nlayers = nlayers;
+    C.a.wpack = wpack[0]; C.a.bias = bias[0]; C.a.Nout = nout[0]; C.a.relu = relu[0];
+    if (nlayers > 1) { C.wpack1 = wpack[1]; C.bias1 = bias[1]; C.N1 = nout[1]; C.relu1 = relu[1]; }
+    if (nlayers > 2) { C.wpack2 = wpack[2]; C.bias2 = bias[2]; C.N2 = nout[2]; C.relu2 = relu[2]; }
+    C.a.out = out; C.a.ld_out = ld_out; C.a.col_off = col_off; C.a.pool_ns = pool_ns;
+    return PRCNN_OK;
+}
+
+PRCNN_API int prcnn_mlp_chain_rows(const float* in, int ld_in, int64_t rows, int K, int nlayers,
+                                   const float* const* wpack, const float* const* bias, const int* nout,
+                                   const int* relu, float* out, int ld_out, int col_off, int pool_ns,
+                                   prcnn_stream_t stream) {
+    PRCNN_REQUIRE(in && ld_in >= K && K > 0 && rows >= 0, "prcnn_mlp_chain_rows: bad input");
+    ChainParams C = {};
+    int rc = fill_chain(C, nlayers, wpack, bias, nout, relu, out, ld_out, col_off, pool_ns);
+    if (rc) return rc;
+    PRCNN_REQUIRE(pool_ns == 0 || rows % pool_ns == 0, "prcnn_mlp_chain_rows: rows not a multiple of pool_ns");
+    C.a.rows = rows; C.a.K = K; C.a.in = in; C.a.ld_in = ld_in;
+    C.a.vec_a = aligned16(in) && (ld_in % 4 == 0);
+    return dispatch_chain(MODE_PLAIN, C, (hipStream_t)stream);
+}
+
+PRCNN_API int prcnn_mlp_chain_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl,
+                                    int ld_feat, int B, int N, int M, int nsample, int C_, int nlayers,
+                                    const float* const* wpack, const float* const* bias, const int* nout,
+                                    const int* relu, float* out, int ld_out, int col_off, int pool_ns,
+                                    prcnn_stream_t stream) {
+    PRCNN_REQUIRE(xyz && idx && (C_ == 0 || feat_cl), "prcnn_mlp_chain_group: null pointer");
+    PRCNN_REQUIRE(B >= 0 && N > 0 && M > 0 && nsample > 0 && C_ >= 0 && (C_ == 0 || ld_feat >= C_), "prcnn_mlp_chain_group: bad shape");
+    ChainParams C = {};
+    int rc = fill_chain(C, nlayers, wpack, bias, nout, relu, out, ld_out, col_off, pool_ns);
+    if (rc) return rc;
+    PRCNN_REQUIRE(pool_ns == 0 || pool_ns == nsample, "prcnn_mlp_chain_group: pool_ns must equal nsample");
+    C.a.rows = (long)B * M * nsample; C.a.K = C_ + 3;
+    C.a.xyz = xyz; C.a.new_xyz = new_xyz; C.a.idx = idx; C.a.feat = feat_cl; C.a.ld_feat = ld_feat;
+    C.a.N = N; C.a.M = M; C.a.ns = nsample; C.a.C = C_;
+    C.a.vec_a = C_ > 0 && aligned16(feat_cl) && (ld_feat % 4 == 0);
+    return dispatch_chain(MODE_GROUP, C, (hipStream_t)stream);
+}
+
+PRCNN_API int prcnn_mlp_chain_interp(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3,
+                                     const float* skip_cl, int ld_skip, int B, int n, int m, int C2, int C1,
+                                     int nlayers, const float* const* wpack, const float* const* bias,
+                                     const int* nout, const int* relu, float* out, int ld_out, int col_off,
+                                     prcnn_stream_t stream) {
+    PRCNN_REQUIRE(known_cl && idx3 && w3 && (C1 == 0 || skip_cl), "prcnn_mlp_chain_interp: null pointer");
+    PRCNN_REQUIRE(B >= 0 && n > 0 && m > 0 && C2 > 0 && C1 >= 0 && ld_known >= C2 && (C1 == 0 || ld_skip >= C1), "prcnn_mlp_chain_interp: bad shape");
+    ChainParams C = {};
+    int rc = fill_chain(C, nlayers, wpack, bias, nout, relu, out, ld_out, col_off, 0);
+    if (rc) return rc;
+    C.a.rows = (long)B * n; C.a.K = C2 + C1;
+    C.a.known = known_cl; C.a.idx3 = idx3; C.a.w3 = w3; C.a.skip = skip_cl; C.a.ld_known = ld_known; C.a.ld_skip = ld_skip;
+    C.a.n = n; C.a.m = m; C.a.C2 = C2; C.a.C1 = C1;
+    C.a.vec_a = aligned16(known_cl) && (ld_known % 4 == 0);
+    C.a.vec_b = C1 > 0 && aligned16(skip_cl) && (ld_skip % 4 == 0) && (C2 % 4 == 0);
+    return dispatch_chain(MODE_INTERP, C, (hipStream_t)stream);
 }

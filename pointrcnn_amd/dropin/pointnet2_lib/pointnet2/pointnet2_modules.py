@@ -113,6 +113,11 @@ class _PointnetSAModuleBase(nn.Module):
             fused_pool = ns in _POOL_FUSED
             dst = (out_cl.view(B * M, -1), col)
             ctr = None if group_all else new_xyz
+            if fused_pool and ns in (16, 32) and ops.chain_supported(1, layers, ns):
+                # whole SharedMLP + max-pool in one register-resident kernel
+                ops.mlp_chain_group(xyz, ctr, idxs[i], feat_cl, layers, out=dst, pool_ns=ns)
+                col += c_outs[i]
+                continue
             if len(layers) == 1:
                 x = ops.mlp_group(xyz, ctr, idxs[i], feat_cl, layers[0], out=dst if fused_pool else None,
                                   pool_ns=ns if fused_pool else 0)
@@ -189,6 +194,9 @@ class PointnetFPModule(nn.Module):
         known_cl = _channels_last(known_feats)
         skip_cl = _channels_last(unknow_feats)
         layers = [m.packed() for m in self.mlp.layers()]
-        x = ops.mlp_interp(known_cl, idx3, w3, skip_cl, layers[0])
-        x = _run_mlp_tail(x, layers, 1, None, 0)
+        if ops.chain_supported(2, layers, 0):
+            x = ops.mlp_chain_interp(known_cl, idx3, w3, skip_cl, layers)
+        else:
+            x = ops.mlp_interp(known_cl, idx3, w3, skip_cl, layers[0])
+            x = _run_mlp_tail(x, layers, 1, None, 0)
         return x.view(B, n, -1).transpose(1, 2)

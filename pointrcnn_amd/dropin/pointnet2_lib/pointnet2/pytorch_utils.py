@@ -46,6 +46,45 @@ def _rows_view(x_cl):
     return x_cl
 
 
+def run_conv_stack(mods, x):
+    """Fused inference of consecutive 1x1 conv(+BN+ReLU) layers `mods` (all `fusable()`), x = (B,C,L) or (B,C,H,W).
+    One register-chain kernel for the whole stack when an instance exists, else one kernel per layer.
+    Returns a (B,C_out,...) VIEW of a channels-last buffer."""
+    nd = x.dim()
+    perm = (0, 2, 1) if nd == 3 else (0, 2, 3, 1)
+    x_cl = _rows_view(x.permute(*perm))
+    layers = [m.packed() for m in mods]
+    if len(layers) > 1 and ops.chain_supported(0, layers, 0):
+        y = ops.mlp_chain_rows(x_cl, layers)
+    else:
+        y = x_cl
+        for lin in layers:
+            y = ops.mlp_rows(y, lin)
+    y = y.view(*x_cl.shape[:-1], y.shape[-1])
+    return y.permute(0, 2, 1) if nd == 3 else y.permute(0, 3, 1, 2)
+
+
+def _inference_input(x):
+    return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
+
+
+def fused_sequential(seq, x):
+    """Run an nn.Sequential of pt_utils conv layers (+ eval-mode Dropout) -- e.g. the RPN heads, lib/net/rpn.py:20-46
+    -- through run_conv_stack when every member allows it; otherwise exactly seq(x)."""
+    mods = []
+    for m in seq:
+        if isinstance(m, nn.Dropout):
+            if m.training:
+                return seq(x)
+            continue
+        if not (isinstance(m, _ConvBase) and m.fusable()):
+            return seq(x)
+        mods.append(m)
+    if not mods or not _inference_input(x):
+        return seq(x)
+    return run_conv_stack(mods, x)
+
+
 class _BNBase(nn.Sequential):
     def __init__(self, in_size, batch_norm=None, name=""):
         super().__init__()
@@ -140,13 +179,7 @@ class _ConvBase(nn.Sequential):
     def forward(self, x):
         if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or not self.fusable():
             return super().forward(x)
-        # (B,C,L) or (B,C,H,W) -> channels-last rows; zero-copy when x is a transposed channels-last view
-        nd = x.dim()
-        perm = (0, 2, 1) if nd == 3 else (0, 2, 3, 1)
-        x_cl = _rows_view(x.permute(*perm))
-        y = ops.mlp_rows(x_cl, self.packed())
-        y = y.view(*x_cl.shape[:-1], y.shape[-1])
-        return y.permute(0, 2, 1) if nd == 3 else y.permute(0, 3, 1, 2)
+        return run_conv_stack([self], x)
 
 
 class Conv1d(_ConvBase):
@@ -183,6 +216,11 @@ class SharedMLP(nn.Sequential):
 
     def fusable(self):
         return all(isinstance(m, _ConvBase) and m.fusable() for m in self.children())
+
+    def forward(self, x):
+        if _inference_input(x) and self.fusable():
+            return run_conv_stack(self.layers(), x)
+        return super().forward(x)
 
 
 class FC(nn.Sequential):

@@ -4,6 +4,8 @@ PyTorch is used for device memory and streams only; every computation below is o
 libprcnn_pointops.so on torch's CURRENT stream (so it composes with torch.cuda.graphs and side streams).
 Shapes and argument meaning mirror the reference op surface (see each function's citation).
 """
+import ctypes
+
 import torch
 
 from . import _cabi
@@ -165,7 +167,91 @@ class PackedLinear:
         self.wpack = torch.empty((L.prcnn_wpack_floats(self.nout, self.k),), dtype=_F32, device=weight.device)
         _cabi.check(L.prcnn_pack_weight(_p(weight), self.nout, self.k, k_rot, _p(self.wpack), _stream()),
                     "prcnn_pack_weight")
-        self.bias = None if bias is None else _chk(bias.contiguous(), "bias", ndim=1)
+        # bias is kept zero-padded to a multiple of 32 entries (the chain kernel reads whole 32-channel blocks)
+        self.bias = None
+        if bias is not None:
+            _chk(bias.contiguous(), "bias", ndim=1)
+            self.bias = torch.zeros(((self.nout + 31) // 32 * 32,), dtype=_F32, device=weight.device)
+            self.bias[: self.nout] = bias
+
+
+_MODE_ROWS, _MODE_GROUP, _MODE_INTERP = 0, 1, 2
+_chain_ok = {}
+
+
+def chain_supported(mode, layers, pool_ns=0):
+    """True when the register-resident chain kernel has an instance for this stack of PackedLinear layers."""
+    key = (mode, tuple(l.nout for l in layers), pool_ns)
+    hit = _chain_ok.get(key)
+    if hit is None:
+        arr = (ctypes.c_int * len(layers))(*[l.nout for l in layers])
+        hit = bool(_cabi.lib().prcnn_mlp_chain_supported(mode, len(layers), arr, pool_ns)) if 1 <= len(layers) <= 3 else False
+        _chain_ok[key] = hit
+    return hit
+
+
+class _ChainArgs:
+    """host arrays (wpack*, bias*, nout, relu) describing a stack of PackedLinear layers"""
+
+    def __init__(self, layers):
+        n = len(layers)
+        self.n = n
+        self.wpack = (ctypes.c_void_p * n)(*[l.wpack.data_ptr() for l in layers])
+        self.bias = (ctypes.c_void_p * n)(*[(l.bias.data_ptr() if l.bias is not None else None) for l in layers])
+        self.nout = (ctypes.c_int * n)(*[l.nout for l in layers])
+        self.relu = (ctypes.c_int * n)(*[int(l.relu) for l in layers])
+
+
+def _chain_args(layers):
+    key = tuple(id(l) for l in layers)
+    hit = getattr(layers[0], "_chain_cache", None)
+    if hit is None or hit[0] != key:
+        hit = (key, _ChainArgs(layers))
+        layers[0]._chain_cache = hit
+    return hit[1]
+
+
+def mlp_chain_rows(x, layers, out=None, pool_ns=0):
+    """whole stack on channels-last rows in one kernel (see mlp_rows for the layout contract)"""
+    if x.stride(-1) != 1:
+        raise RuntimeError("mlp_chain_rows: last dim must be contiguous")
+    K = x.shape[-1]
+    rows = x.numel() // K
+    ld_in = x.stride(-2) if x.dim() > 1 else K
+    rows_out = rows // pool_ns if pool_ns else rows
+    buf, ld_out, col_off = _out_buf(out, rows_out, layers[-1], x.device)
+    a = _chain_args(layers)
+    _cabi.check(_cabi.lib().prcnn_mlp_chain_rows(_p(x), ld_in, rows, K, a.n, a.wpack, a.bias, a.nout, a.relu, _p(buf),
+                                                 ld_out, col_off, pool_ns, _stream()), "prcnn_mlp_chain_rows")
+    return buf
+
+
+def mlp_chain_group(xyz, new_xyz, idx, feat_cl, layers, out=None, pool_ns=0):
+    B, N, _ = xyz.shape
+    _, M, ns = idx.shape
+    C = 0 if feat_cl is None else feat_cl.shape[-1]
+    ld_feat = 0 if feat_cl is None else feat_cl.stride(-2)
+    rows = B * M * ns
+    rows_out = rows // pool_ns if pool_ns else rows
+    buf, ld_out, col_off = _out_buf(out, rows_out, layers[-1], xyz.device)
+    a = _chain_args(layers)
+    _cabi.check(_cabi.lib().prcnn_mlp_chain_group(_p(xyz), _p(new_xyz), _p(idx), _p(feat_cl), ld_feat, B, N, M, ns, C, a.n,
+                                                  a.wpack, a.bias, a.nout, a.relu, _p(buf), ld_out, col_off, pool_ns,
+                                                  _stream()), "prcnn_mlp_chain_group")
+    return buf
+
+
+def mlp_chain_interp(known_cl, idx3, w3, skip_cl, layers, out=None):
+    B, m, C2 = known_cl.shape
+    n = idx3.shape[1]
+    C1 = 0 if skip_cl is None else skip_cl.shape[-1]
+    ld_skip = 0 if skip_cl is None else skip_cl.stride(-2)
+    buf, ld_out, col_off = _out_buf(out, B * n, layers[-1], known_cl.device)
+    a = _chain_args(layers)
+    _cabi.check(_cabi.lib().prcnn_mlp_chain_interp(_p(known_cl), known_cl.stride(-2), _p(idx3), _p(w3), _p(skip_cl), ld_skip,
+                                                   B, n, m, C2, C1, a.n, a.wpack, a.bias, a.nout, a.relu, _p(buf), ld_out,
+                                                   col_off, _stream()), "prcnn_mlp_chain_interp")
+    return buf
 
 
 def _out_buf(out, rows, lin, device):

@@ -117,8 +117,11 @@ class RPN(nn.Module):
     def forward(self, input_data):
         pts_input = input_data["pts_input"]
         backbone_xyz, backbone_features = self.backbone_net(pts_input)                     # (B,N,3), (B,C,N)
-        rpn_cls = self.rpn_cls_layer(backbone_features).transpose(1, 2).contiguous()      # (B,N,1)
-        rpn_reg = self.rpn_reg_layer(backbone_features).transpose(1, 2).contiguous()      # (B,N,reg)
+        # fused_sequential == self.rpn_*_layer(x) (it falls back to exactly that), but runs conv+bn+relu -> conv as
+        # one register-chain kernel at inference; the reference's own rpn.py calls the Sequential directly and gets
+        # one fused kernel per layer instead
+        rpn_cls = pt_utils.fused_sequential(self.rpn_cls_layer, backbone_features).transpose(1, 2).contiguous()  # (B,N,1)
+        rpn_reg = pt_utils.fused_sequential(self.rpn_reg_layer, backbone_features).transpose(1, 2).contiguous()  # (B,N,reg)
         return {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": backbone_xyz,
                 "backbone_features": backbone_features}
 

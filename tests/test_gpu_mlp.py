@@ -135,3 +135,79 @@ def test_mlp_interp_matches_oracle(dev, cpu, C2, C1, Nout):
     got = ops.mlp_interp(T(kf.transpose(0, 2, 1), dev), T(idx3, dev), T(w3, dev),
                          None if sf is None else T(sf.transpose(0, 2, 1), dev), lin(dev, w, b, True))
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=mlp_tol(want), rtol=0)
+
+
+# ------------------------------------------------------------------ register-resident layer chains
+def _stack(r, dims, scale=0.25):
+    ws = [(r.normal(size=(dims[i + 1], dims[i])) * scale).astype(np.float32) for i in range(len(dims) - 1)]
+    bs = [r.normal(size=(dims[i + 1],)).astype(np.float32) * 0.2 for i in range(len(dims) - 1)]
+    return ws, bs
+
+
+@pytest.mark.parametrize("C,widths,ns", [(0, (16, 16, 32), 16), (0, (32, 32, 64), 32), (96, (64, 64, 128), 16),
+                                         (96, (64, 96, 128), 32)])
+def test_chain_group_equals_oracle_and_per_layer(dev, cpu, C, widths, ns):
+    """the four RPN SA1/SA2 stacks (default.yaml:41-44) as ONE kernel: vs the oracle and vs the per-layer kernels"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(C + ns)
+    B, N, M = 2, 700, 45                               # rows = 2*45*ns: not a multiple of the 128-row workgroup
+    xyz = unit_cloud(B, N, seed=ns)
+    new_xyz = xyz[:, :M].copy()
+    idx = cpu.ball_query(0.3, ns, xyz, new_xyz)
+    feat = r.normal(size=(B, C, N)).astype(np.float32) if C else None
+    ws, bs = _stack(r, (C + 3,) + widths)
+    gx = cpu.group(xyz.transpose(0, 2, 1), idx) - new_xyz.transpose(0, 2, 1)[..., None]
+    g = gx if feat is None else np.concatenate([gx, cpu.group(feat, idx)], 1)
+    rows = g.transpose(0, 2, 3, 1).reshape(-1, C + 3)
+    for w, b in zip(ws, bs):
+        rows = cpu.linear_rows(rows, w, b, True)
+    want = rows.reshape(B * M, ns, -1).max(1)
+    layers = [lin(dev, ws[0], bs[0], True, k_rot=3 if C else 0)] + [lin(dev, w, b, True) for w, b in zip(ws[1:], bs[1:])]
+    assert ops.chain_supported(1, layers, ns)
+    feat_cl = None if feat is None else T(feat.transpose(0, 2, 1), dev)
+    out = torch.full((B * M, widths[-1] + 8), -3.0, device=dev)
+    ops.mlp_chain_group(T(xyz, dev), T(new_xyz, dev), T(idx, dev), feat_cl, layers, out=(out, 4), pool_ns=ns)
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got[:, 4:4 + widths[-1]], want, atol=mlp_tol(want), rtol=0)
+    assert (got[:, :4] == -3.0).all() and (got[:, 4 + widths[-1]:] == -3.0).all()
+    x = ops.mlp_group(T(xyz, dev), T(new_xyz, dev), T(idx, dev), feat_cl, layers[0])
+    x = ops.mlp_rows(x, layers[1])
+    x = ops.mlp_rows(x, layers[2], pool_ns=ns).cpu().numpy()
+    np.testing.assert_allclose(got[:, 4:4 + widths[-1]], x, atol=mlp_tol(want), rtol=0)
+
+
+def test_chain_interp_and_rows_equal_oracle(dev, cpu):
+    """FP0 stack (256 -> 128 -> 128, no skip) and the two RPN head stacks (128 -> 128 -> {1, 76})"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(11)
+    B, n, m, C2 = 2, 301, 90, 256
+    unk, kn = unit_cloud(B, n, seed=1), unit_cloud(B, m, seed=2)
+    d2, idx3 = cpu.three_nn(unk, kn)
+    w3 = cpu.three_weights(d2)
+    kf = r.normal(size=(B, C2, m)).astype(np.float32)
+    ws, bs = _stack(r, (C2, 128, 128), 0.1)
+    rows = cpu.three_interp(kf, idx3, w3).transpose(0, 2, 1).reshape(-1, C2)
+    want = cpu.linear_rows(cpu.linear_rows(rows, ws[0], bs[0], True), ws[1], bs[1], True)
+    layers = [lin(dev, w, b, True) for w, b in zip(ws, bs)]
+    assert ops.chain_supported(2, layers, 0)
+    got = ops.mlp_chain_interp(T(kf.transpose(0, 2, 1), dev), T(idx3, dev), T(w3, dev), None, layers).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=mlp_tol(want), rtol=0)
+    feats = want                                            # (602,128) rows feed the heads
+    for nout in (1, 76, 128):
+        hw, hb = _stack(r, (128, 128, nout), 0.1)
+        ref = cpu.linear_rows(cpu.linear_rows(feats, hw[0], hb[0], True), hw[1], hb[1], False)
+        hl = [lin(dev, hw[0], hb[0], True), lin(dev, hw[1], hb[1], False)]
+        assert ops.chain_supported(0, hl, 0)
+        out = ops.mlp_chain_rows(T(feats, dev), hl).cpu().numpy()
+        assert out.shape == (602, nout)
+        np.testing.assert_allclose(out, ref, atol=mlp_tol(ref), rtol=0)
+
+
+def test_chain_unsupported_shapes_are_reported_not_guessed(dev):
+    from pointrcnn_amd import ops, _cabi
+    r = np.random.default_rng(0)
+    ws, bs = _stack(r, (20, 256, 64))
+    layers = [lin(dev, w, b, True) for w, b in zip(ws, bs)]
+    assert not ops.chain_supported(0, layers, 0)            # 256 > 128
+    with pytest.raises(_cabi.PointOpsError):
+        ops.mlp_chain_rows(torch.zeros(64, 20, device=dev), layers)
