@@ -21,6 +21,7 @@
 // Single-wave configurations (N <= 1024) skip LDS and the barrier entirely.
 #include "common.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int PPT> struct fvec_t { typedef float type __attribute__((ext_vector_type(PPT))); };
 template <> struct fvec_t<1> { typedef float type __attribute__((ext_vector_type(2))); };  // avoid 1-wide vectors
 
@@ -77,12 +78,25 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict_
 
     for (int j = 1; j < npoint; j++) {
         float best = -2.0f;
+        if (PPT >= 2) {
+            // packed fp32: plain v_add/v_mul_f32 issue at ~3.6 cycles per wave64 op on CDNA4, v_pk_* at the full
+            // rate.  Same individually rounded operations per component (no FMA), two points per instruction.
+            const f32x2 qx = {x0, x0}, qy = {y0, y0}, qz = {z0, z0};
 #pragma unroll
-        for (int i = 0; i < PPT; i++) {
-            float d = sqdist3(px[i], py[i], pz[i], x0, y0, z0);
-            float t = __builtin_fminf(pt[i], d);
-            pt[i] = t;
-            best = __builtin_fmaxf(best, t);
+            for (int i = 0; i + 1 < PPT; i += 2) {
+                f32x2 dx = (f32x2){px[i], px[i + 1]} - qx;
+                f32x2 dy = (f32x2){py[i], py[i + 1]} - qy;
+                f32x2 dz = (f32x2){pz[i], pz[i + 1]} - qz;
+                f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                float t0 = __builtin_fminf(pt[i], d.x), t1 = __builtin_fminf(pt[i + 1], d.y);
+                pt[i] = t0; pt[i + 1] = t1;
+                best = __builtin_fmaxf(best, __builtin_fmaxf(t0, t1));
+            }
+        } else {
+            float d = sqdist3(px[0], py[0], pz[0], x0, y0, z0);
+            float t = __builtin_fminf(pt[0], d);
+            pt[0] = t;
+            best = t;
         }
         // wave arg-max, ties -> lowest point index == lowest lane, then lowest slot
         const int wmax = wave_max_i32_fused(__float_as_int(best));       // >= 0, or -1/-2: int order == float order

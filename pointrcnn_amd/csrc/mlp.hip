@@ -320,7 +320,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
 }
 
 // =====================================================================================================
-// Register-resident layer CHAIN (whole SharedMLP in one kernel, one wave = 32 rows, no LDS, no barriers).
+// Register-resident layer CHAIN (whole SharedMLP in one kernel, one wave = 32 rows, activations never in LDS/HBM).
 //
 // The layer is computed transposed: out^T[n][row] = sum_k W[n][k] * act^T[k][row], i.e. the MFMA A operand is
 // the packed weight (lane (h,i) -> W[32*ob+i][8*kb+4*h+s], exactly the prcnn_pack_weight image) and the B
@@ -361,23 +361,71 @@ __device__ __forceinline__ void bias_act(f32x16 (&acc)[NB], const float* __restr
         }
 }
 
-// next layer from register-resident activations: out[ob] += W[ob, kb] * in[kb/4][4*(kb%4)+s]
+// ---- weight staging: the 4 waves of a workgroup walk the same (layer, k-block) sequence, so each packed weight
+// tile (1 KB = one (ob,kb) MFMA A-operand for 64 lanes) is fetched from L2 ONCE per workgroup into LDS and read by
+// all waves with conflict-free ds_read_b128 (lane-linear image).  A stage = G k-blocks x NB output blocks
+// (<= 16 tiles = 16 KB), double buffered: one s_barrier per stage (~64 MFMAs per wave).
+#define CH_WAVES 4
+#define CH_STAGE_TILES 16
+template <int NB> struct ChStage { static constexpr int G = CH_STAGE_TILES / NB; static constexpr int TPW = (G * NB + CH_WAVES - 1) / CH_WAVES; };
+
+template <int NB>
+__device__ __forceinline__ void stage_load(const float* __restrict__ wpack, int KB, int st, int wave, int lane, float4 (&r)[4]) {
+    constexpr int G = ChStage<NB>::G;
+#pragma unroll
+    for (int u = 0; u < ChStage<NB>::TPW; u++) {
+        int tt = wave + CH_WAVES * u, kbl = tt / NB, ob = tt - kbl * NB, kb = st * G + kbl;
+        r[u] = (tt < G * NB && kb < KB) ? ldw(wpack, KB, ob, kb, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int NB>
+__device__ __forceinline__ void stage_store(float* ws, int wave, int lane, const float4 (&r)[4]) {
+#pragma unroll
+    for (int u = 0; u < ChStage<NB>::TPW; u++) {
+        int tt = wave + CH_WAVES * u;
+        if (tt < ChStage<NB>::G * NB) *reinterpret_cast<float4*>(ws + (tt * 64 + lane) * 4) = r[u];
+    }
+}
+__device__ __forceinline__ float4 lds_w(const float* ws, int tile, int lane) {
+    return *reinterpret_cast<const float4*>(ws + (tile * 64 + lane) * 4);
+}
+
+// next layer from register-resident activations: out[ob] += W[ob, kb] * in[kb/4][4*(kb%4)+s].
+// Fully unrolled (register indices must be compile-time); every branch below is workgroup-uniform.
 template <int NBI, int NBO>
-__device__ __forceinline__ void chain_layer(const f32x16 (&in)[NBI], f32x16 (&out)[NBO],
-                                            const float* __restrict__ wpack, int KB, int lane) {
+__device__ __forceinline__ void chain_layer(const f32x16 (&in)[NBI], f32x16 (&out)[NBO], const float* __restrict__ wpack,
+                                            int KB, float (*Ws)[CH_STAGE_TILES * 256], int wave, int lane) {
+    constexpr int G = ChStage<NBO>::G;
+    constexpr int NST = (NBI * 4 + G - 1) / G;
 #pragma unroll
     for (int ob = 0; ob < NBO; ob++) out[ob] = (f32x16){0};
+    float4 wr[4];
+    stage_load<NBO>(wpack, KB, 0, wave, lane, wr);
+    stage_store<NBO>(Ws[0], wave, lane, wr);
+    __syncthreads();
 #pragma unroll
-    for (int kb = 0; kb < NBI * 4; kb++) {
-        if (kb < KB) {                      // uniform: K of this layer = true width of the previous one
+    for (int st = 0; st < NST; st++) {
+        if (st * G < KB) {
+            const bool more = (st + 1) * G < KB;
+            if (more) stage_load<NBO>(wpack, KB, st + 1, wave, lane, wr);
+            const float* ws = Ws[st & 1];
 #pragma unroll
-            for (int ob = 0; ob < NBO; ob++) {
-                float4 w = ldw(wpack, KB, ob, kb, lane);
-                out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, in[kb / 4][4 * (kb % 4) + 0], out[ob], 0, 0, 0);
-                out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, in[kb / 4][4 * (kb % 4) + 1], out[ob], 0, 0, 0);
-                out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, in[kb / 4][4 * (kb % 4) + 2], out[ob], 0, 0, 0);
-                out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, in[kb / 4][4 * (kb % 4) + 3], out[ob], 0, 0, 0);
+            for (int kbl = 0; kbl < G; kbl++) {
+                const int kb = st * G + kbl;
+                if (kb < NBI * 4 && kb < KB) {
+#pragma unroll
+                    for (int ob = 0; ob < NBO; ob++) {
+                        float4 w = lds_w(ws, kbl * NBO + ob, lane);
+                        const int pb = kb < NBI * 4 ? kb / 4 : 0, q = kb % 4;
+                        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, in[pb][4 * q + 0], out[ob], 0, 0, 0);
+                        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, in[pb][4 * q + 1], out[ob], 0, 0, 0);
+                        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, in[pb][4 * q + 2], out[ob], 0, 0, 0);
+                        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, in[pb][4 * q + 3], out[ob], 0, 0, 0);
+                    }
+                }
             }
+            if (more) stage_store<NBO>(Ws[(st + 1) & 1], wave, lane, wr);
+            __syncthreads();
         }
     }
 }
@@ -451,48 +499,55 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(const ChainParams C) {
     RowMeta<MODE> meta;
     make_meta<MODE>(P, row, meta);
 
+    __shared__ __attribute__((aligned(16))) float Ws[2][CH_STAGE_TILES * 256];
+
     // ---- layer 0: the B operand is the gathered / interpolated / plain input row, streamed over K ----
     f32x16 a0[NB0];
 #pragma unroll
     for (int ob = 0; ob < NB0; ob++) a0[ob] = (f32x16){0};
     {
+        constexpr int G = ChStage<NB0>::G;
+        const int nst = (P.KB + G - 1) / G;
+        float4 wr[4];
+        stage_load<NB0>(P.wpack, P.KB, 0, wave, lane, wr);
         Raw<MODE> cur, nxt;
         fetch<MODE>(P, meta, 4 * h, cur);
-        float4 wc[NB0], wn[NB0];
+        stage_store<NB0>(Ws[0], wave, lane, wr);
+        __syncthreads();
+        for (int st = 0; st < nst; st++) {
+            const bool more_st = st + 1 < nst;
+            if (more_st) stage_load<NB0>(P.wpack, P.KB, st + 1, wave, lane, wr);
+            const float* ws = Ws[st & 1];
+            for (int kbl = 0; kbl < G; kbl++) {
+                const int kb = st * G + kbl;
+                if (kb >= P.KB) break;
+                const bool more = kb + 1 < P.KB;
+                if (more) fetch<MODE>(P, meta, 8 * (kb + 1) + 4 * h, nxt);
+                float4 b = finish<MODE>(P, meta, 8 * kb + 4 * h, cur);
 #pragma unroll
-        for (int ob = 0; ob < NB0; ob++) wc[ob] = ldw(P.wpack, P.KB, ob, 0, lane);
-        for (int kb = 0; kb < P.KB; kb++) {
-            const bool more = kb + 1 < P.KB;
-            if (more) {
-                fetch<MODE>(P, meta, 8 * (kb + 1) + 4 * h, nxt);
-#pragma unroll
-                for (int ob = 0; ob < NB0; ob++) wn[ob] = ldw(P.wpack, P.KB, ob, kb + 1, lane);
+                for (int ob = 0; ob < NB0; ob++) {
+                    float4 w = lds_w(ws, kbl * NB0 + ob, lane);
+                    a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, b.x, a0[ob], 0, 0, 0);
+                    a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, b.y, a0[ob], 0, 0, 0);
+                    a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, b.z, a0[ob], 0, 0, 0);
+                    a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, b.w, a0[ob], 0, 0, 0);
+                }
+                if (more) cur = nxt;
             }
-            float4 b = finish<MODE>(P, meta, 8 * kb + 4 * h, cur);
-#pragma unroll
-            for (int ob = 0; ob < NB0; ob++) {
-                a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[ob].x, b.x, a0[ob], 0, 0, 0);
-                a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[ob].y, b.y, a0[ob], 0, 0, 0);
-                a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[ob].z, b.z, a0[ob], 0, 0, 0);
-                a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[ob].w, b.w, a0[ob], 0, 0, 0);
-            }
-            if (more) {
-                cur = nxt;
-#pragma unroll
-                for (int ob = 0; ob < NB0; ob++) wc[ob] = wn[ob];
-            }
+            if (more_st) stage_store<NB0>(Ws[(st + 1) & 1], wave, lane, wr);
+            __syncthreads();
         }
     }
     bias_act<NB0>(a0, P.bias, P.relu, h);
     if (NB1 == 0) { chain_store<NB0>(C, a0, P.Nout, row, meta.valid, lane, h); return; }
 
     f32x16 a1[NB1 ? NB1 : 1];
-    chain_layer<NB0, (NB1 ? NB1 : 1)>(a0, a1, C.wpack1, C.KB1, lane);
+    chain_layer<NB0, (NB1 ? NB1 : 1)>(a0, a1, C.wpack1, C.KB1, Ws, wave, lane);
     bias_act<(NB1 ? NB1 : 1)>(a1, C.bias1, C.relu1, h);
     if (NB2 == 0) { chain_store<(NB1 ? NB1 : 1)>(C, a1, C.N1, row, meta.valid, lane, h); return; }
 
     f32x16 a2[NB2 ? NB2 : 1];
-    chain_layer<(NB1 ? NB1 : 1), (NB2 ? NB2 : 1)>(a1, a2, C.wpack2, C.KB2, lane);
+    chain_layer<(NB1 ? NB1 : 1), (NB2 ? NB2 : 1)>(a1, a2, C.wpack2, C.KB2, Ws, wave, lane);
     bias_act<(NB2 ? NB2 : 1)>(a2, C.bias2, C.relu2, h);
     chain_store<(NB2 ? NB2 : 1)>(C, a2, C.N2, row, meta.valid, lane, h);
 }

@@ -15,19 +15,32 @@
 #define BQ_THREADS 64       // ball query: ONE wave per workgroup -> wave-local staging, 4x more workgroups than 256-thread
                             // blocks (the op only has B*M threads in total), no cross-wave barrier in the scan
 #define NN_THREADS 256      // three_nn has n >= 4x more query points: 256-thread blocks share each staged chunk
-#define NB_CHUNK 1024       // candidates staged per LDS chunk: 1024 * 16 B = 16 KB
+#define NB_CHUNK 1024       // candidates staged per LDS chunk: 512 pairs * 32 B = 16 KB
+
+// On CDNA4 only PACKED fp32 VALU ops (v_pk_add/mul_f32) run at the full 64 lanes x 2 rate; plain v_add/v_mul_f32
+// measured ~3.6 cycles per wave64 instruction.  Candidates are therefore staged as PAIRS -- LDS record of pair p =
+// {x0,x1,y0,y1 | z0,z1,-,-} (two ds_read_b128 broadcasts) -- and every distance evaluation below is a float2
+// expression the compiler lowers to v_pk_*: same individually rounded operations per component, half the VALU issue.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int THREADS>
-__device__ __forceinline__ void stage_chunk(const float* __restrict__ p, int c0, int N, float4* spts, int tid) {
-    // p: frame base (N,3).  Coalesced dword loads of the flat xyz stream, expanded to float4 in LDS.
-    // Slots past the end of the frame are filled with +inf so the scan loops need no bounds test.
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ p, int c0, int N, float* s, int tid) {
+    // p: frame base (N,3).  Coalesced dword loads of the flat xyz stream.  Point i of the chunk goes to pair i>>1,
+    // slot i&1.  Slots past the end of the frame are filled with +inf so the scan loops need no bounds test.
     int cnt = min(NB_CHUNK, N - c0);
     const float* src = p + (size_t)c0 * 3;
-    float* s = reinterpret_cast<float*>(spts);
     for (int i = tid; i < NB_CHUNK * 3; i += THREADS) {
         int pt = i / 3, c = i - pt * 3;
-        s[pt * 4 + c] = pt < cnt ? src[i] : INFINITY;
+        s[(pt >> 1) * 8 + c * 2 + (pt & 1)] = pt < cnt ? src[i] : INFINITY;
     }
+}
+
+// squared distances of the query to the two candidates of pair record `rec` (canonical arithmetic per component)
+__device__ __forceinline__ f32x2 pair_sqdist(const float* rec, f32x2 qx, f32x2 qy, f32x2 qz) {
+    float4 a = *reinterpret_cast<const float4*>(rec);          // x0 x1 y0 y1
+    f32x2 z = *reinterpret_cast<const f32x2*>(rec + 4);        // z0 z1
+    f32x2 dx = qx - (f32x2){a.x, a.y}, dy = qy - (f32x2){a.z, a.w}, dz = qz - z;
+    return (dx * dx + dy * dy) + dz * dz;                       // -ffp-contract=off: no FMA, left to right
 }
 
 template <bool DUAL>
@@ -35,7 +48,7 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float* __r
                                                                 const float* __restrict__ new_xyz, int N, int M,
                                                                 float r2a, int nsa, int32_t* __restrict__ idxa,
                                                                 float r2b, int nsb, int32_t* __restrict__ idxb) {
-    __shared__ float4 spts[NB_CHUNK];
+    __shared__ __attribute__((aligned(16))) float spts[NB_CHUNK * 4];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int m = blockIdx.x * BQ_THREADS + tid;
     const bool valid = m < M;
@@ -45,6 +58,7 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float* __r
         const float* q = new_xyz + ((size_t)b * M + m) * 3;
         qx = q[0]; qy = q[1]; qz = q[2];
     }
+    const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
     int32_t* oa = idxa + ((size_t)b * M + (valid ? m : 0)) * nsa;
     int32_t* ob = DUAL ? idxb + ((size_t)b * M + (valid ? m : 0)) * nsb : nullptr;
     int cnta = 0, cntb = 0, firsta = 0, firstb = 0;
@@ -58,25 +72,25 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float* __r
         __syncthreads();
         if (!done) {
             for (int i0 = 0; i0 < NB_CHUNK; i0 += 8) {
-                // 8 independent distance evaluations, ONE test for "any of them inside the larger ball"
-                float d2[8];
+                // 8 candidates = 4 packed pairs, ONE test for "any of them inside the larger ball"
+                f32x2 d2[4];
                 bool any = false;
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    float4 c = spts[i0 + u];
-                    d2[u] = sqdist3(qx, qy, qz, c.x, c.y, c.z);     // padded slots give +inf
-                    any |= d2[u] < r2max;
+                for (int u = 0; u < 4; u++) {
+                    d2[u] = pair_sqdist(spts + (i0 / 2 + u) * 8, qx2, qy2, qz2);     // padded slots give +inf
+                    any |= (d2[u].x < r2max) | (d2[u].y < r2max);
                 }
                 if (any) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        if (d2[u] < r2max) {
+                        float d = (u & 1) ? d2[u >> 1].y : d2[u >> 1].x;
+                        if (d < r2max) {
                             int k = c0 + i0 + u;
-                            if (d2[u] < r2a && cnta < nsa) {
+                            if (d < r2a && cnta < nsa) {
                                 if (cnta == 0) firsta = k;
                                 oa[cnta++] = k;
                             }
-                            if (DUAL && d2[u] < r2b && cntb < nsb) {
+                            if (DUAL && d < r2b && cntb < nsb) {
                                 if (cntb == 0) firstb = k;
                                 ob[cntb++] = k;
                             }
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float* __res
                                                               const float* __restrict__ known, int n, int m,
                                                               float* __restrict__ dist2, int32_t* __restrict__ idx,
                                                               float* __restrict__ weight) {
-    __shared__ float4 spts[NB_CHUNK];
+    __shared__ __attribute__((aligned(16))) float spts[NB_CHUNK * 4];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int i = blockIdx.x * NN_THREADS + tid;
     const bool valid = i < n;
@@ -108,6 +122,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float* __res
         const float* u = unknown + ((size_t)b * n + i) * 3;
         ux = u[0]; uy = u[1]; uz = u[2];
     }
+    const f32x2 ux2 = {ux, ux}, uy2 = {uy, uy}, uz2 = {uz, uz};
     float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
     int i1 = 0, i2 = 0, i3 = 0;
     for (int c0 = 0; c0 < m; c0 += NB_CHUNK) {
@@ -115,18 +130,17 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float* __res
         stage_chunk<NN_THREADS>(p, c0, m, spts, tid);
         __syncthreads();
         for (int j0 = 0; j0 < NB_CHUNK; j0 += 8) {
-            float d[8];
+            f32x2 d[4];
             bool any = false;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                float4 c = spts[j0 + u];
-                d[u] = sqdist3(ux, uy, uz, c.x, c.y, c.z);           // padded slots give +inf: never < b3
-                any |= d[u] < b3;
+            for (int u = 0; u < 4; u++) {
+                d[u] = pair_sqdist(spts + (j0 / 2 + u) * 8, ux2, uy2, uz2);          // padded slots: +inf, never < b3
+                any |= (d[u].x < b3) | (d[u].y < b3);
             }
             if (any) {                              // rare after warm-up
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    float dd = d[u];
+                    float dd = (u & 1) ? d[u >> 1].y : d[u >> 1].x;
                     if (dd < b3) {
                         int k = c0 + j0 + u;
                         if (dd < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = dd; i1 = k; }
