@@ -7,8 +7,8 @@
 // lib/net/rcnn_net.py:23-41.  The grouped tensor never exists here: rows of the GEMM A operand are
 // gathered (or 3-NN-interpolated) from channels-last features straight into LDS.
 //
-// GEMM view: out[rows x Nout] = A[rows x K] * W^T[K x Nout].  Workgroup tile 128 rows x 64 cols, 4 waves
-// as 2(M) x 2(N); each wave owns 64 rows x 32 cols = two v_mfma_f32_32x32x2_f32 accumulators (exact fp32
+// GEMM view: out[rows x Nout] = A[rows x K] * W^T[K x Nout].  Workgroup tile 128 rows x 64 (or 128) cols, 4 waves
+// as 2(M) x 2(N); each wave owns 64 rows x 32 (or 64) cols = two (four) v_mfma_f32_32x32x2_f32 accumulators (exact fp32
 // products, fp32 accumulation: the result is an fp32 FMA chain, no reduced precision anywhere).
 // K is walked in chunks of 32 (four 8-wide k-blocks).  Inside a k-block the MFMA step s pairs
 // k = 8*kb + s (lanes 0-31) with k = 8*kb + 4 + s (lanes 32-63): a lane's four A values for the block
@@ -195,17 +195,20 @@ template <> __device__ __forceinline__ float4 finish<MODE_INTERP>(const MlpParam
     return o;
 }
 
-template <int MODE>
+// WNB = 32-column blocks per wave: 1 -> workgroup tile 128x64 (narrow layers), 2 -> 128x128 (wide layers: twice
+// the MFMAs per LDS operand read, and a gathered / interpolated A tile is rebuilt for half as many column tiles).
+template <int MODE, int WNB>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams P) {
+    constexpr int QN = 2 * WNB;                          // n-blocks per workgroup
     __shared__ __attribute__((aligned(16))) float As[2][MLP_BM * MLP_ALD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][2 * 4 * 256];
+    __shared__ __attribute__((aligned(16))) float Bs[2][QN * 4 * 256];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, j = lane & 31;
     const long row0 = (long)blockIdx.x * MLP_BM;
-    const int nb0 = blockIdx.y * 2;
+    const int nb0 = blockIdx.y * QN;
     const int nchunks = (P.KB + 3) >> 2;
 
     // fill-phase assignment: thread -> float4 column c4 of rows r0 + 32*u
@@ -215,13 +218,13 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
     for (int u = 0; u < 4; u++) make_meta<MODE>(P, row0 + r0 + 32 * u, meta[u]);
 
     Raw<MODE> ra[4];
-    float4 rb[2];
+    float4 rb[QN];
     auto load_chunk = [&](int c) {
         const int k = c * MLP_BK + c4 * 4;
 #pragma unroll
         for (int u = 0; u < 4; u++) fetch<MODE>(P, meta[u], k, ra[u]);
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < QN; u++) {
             int f = tid + 256 * u;                 // float4 index inside the [q][kbl][64] image
             int q = f >> 8, rr = f & 255, kbl = rr >> 6, o4 = rr & 63;
             int nb = nb0 + q, kb = c * 4 + kbl;
@@ -237,11 +240,15 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
             *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * u) * MLP_ALD + c4 * 4]) = v;
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) *reinterpret_cast<float4*>(&Bs[buf][(tid + 256 * u) * 4]) = rb[u];
+        for (int u = 0; u < QN; u++) *reinterpret_cast<float4*>(&Bs[buf][(tid + 256 * u) * 4]) = rb[u];
     };
 
-    f32x16 acc0 = {0}, acc1 = {0};
-    const bool n_active = (nb0 + wn) < P.NB;
+    f32x16 acc[2][WNB];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int n = 0; n < WNB; n++) acc[r][n] = (f32x16){0};
+    const bool n_active = (nb0 + wn * WNB) < P.NB;      // at least this wave's first column block exists
 
     load_chunk(0);
     store_chunk(0, 0);
@@ -252,19 +259,30 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
         if (n_active) {
             const int nkb = min(4, P.KB - c * 4);
             const float* a_base = &As[buf][(wm * 64 + j) * MLP_ALD + 4 * h];
-            const float* b_base = &Bs[buf][wn * 1024 + lane * 4];
+            const float* b_base = &Bs[buf][wn * WNB * 1024 + lane * 4];
             for (int kbl = 0; kbl < nkb; kbl++) {
-                float4 a0 = *reinterpret_cast<const float4*>(a_base + kbl * 8);
-                float4 a1 = *reinterpret_cast<const float4*>(a_base + 32 * MLP_ALD + kbl * 8);
-                float4 bq = *reinterpret_cast<const float4*>(b_base + kbl * 256);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bq.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bq.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bq.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bq.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bq.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bq.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bq.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bq.w, acc1, 0, 0, 0);
+                float4 a[2], bq[WNB];
+                a[0] = *reinterpret_cast<const float4*>(a_base + kbl * 8);
+                a[1] = *reinterpret_cast<const float4*>(a_base + 32 * MLP_ALD + kbl * 8);
+#pragma unroll
+                for (int n = 0; n < WNB; n++) bq[n] = *reinterpret_cast<const float4*>(b_base + n * 1024 + kbl * 256);
+                // k-step outermost: consecutive MFMAs hit different accumulators (no dependent-accumulator stall)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, bq[n].x, acc[r][n], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].y, bq[n].y, acc[r][n], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].z, bq[n].z, acc[r][n], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].w, bq[n].w, acc[r][n], 0, 0, 0);
             }
         }
         if (c + 1 < nchunks) store_chunk(c + 1, buf ^ 1);
@@ -273,47 +291,54 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
 
     // ---- epilogue -------------------------------------------------------------------------------
     if (!n_active) return;
-    const int n = (nb0 + wn) * 32 + j;
-    const bool n_ok = n < P.Nout;
-    const float bias = (P.bias && n_ok) ? P.bias[n] : 0.f;
     const long wrow0 = row0 + wm * 64;
-    if (P.pool_ns == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
-            long g0 = wrow0 + rin, g1 = wrow0 + 32 + rin;
-            float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
-            if (P.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            if (n_ok && g0 < P.rows) P.out[g0 * P.ld_out + P.col_off + n] = v0;
-            if (n_ok && g1 < P.rows) P.out[g1 * P.ld_out + P.col_off + n] = v1;
-        }
-    } else {
-        // max over nsample consecutive rows.  max commutes with the (monotone) bias add and ReLU, so
-        // they are applied once per pooled value: bit-identical to pooling the activated rows.
-        float lo0 = acc0[0], hi0 = acc0[8], lo1 = acc1[0], hi1 = acc1[8];
+    for (int nn = 0; nn < WNB; nn++) {
+        const int nb = nb0 + wn * WNB + nn;
+        if (nb >= P.NB) break;
+        const int n = nb * 32 + j;
+        const bool n_ok = n < P.Nout;
+        const float bias = (P.bias && n_ok) ? P.bias[n] : 0.f;
+        const f32x16& acc0 = acc[0][nn];
+        const f32x16& acc1 = acc[1][nn];
+        if (P.pool_ns == 0) {
 #pragma unroll
-        for (int r = 1; r < 8; r++) {
-            lo0 = fmaxf(lo0, acc0[r]); hi0 = fmaxf(hi0, acc0[8 + r]);
-            lo1 = fmaxf(lo1, acc1[r]); hi1 = fmaxf(hi1, acc1[8 + r]);
-        }
-        lo0 = fmaxf(lo0, __shfl_xor(lo0, 32)); hi0 = fmaxf(hi0, __shfl_xor(hi0, 32));
-        lo1 = fmaxf(lo1, __shfl_xor(lo1, 32)); hi1 = fmaxf(hi1, __shfl_xor(hi1, 32));
-        const long groups = P.rows / P.pool_ns;
-        float v[4]; long g[4]; int cnt;
-        if (P.pool_ns == 16) {
-            long g0 = wrow0 / 16;
-            v[0] = lo0; v[1] = hi0; v[2] = lo1; v[3] = hi1; g[0] = g0; g[1] = g0 + 1; g[2] = g0 + 2; g[3] = g0 + 3; cnt = 4;
-        } else if (P.pool_ns == 32) {
-            long g0 = wrow0 / 32;
-            v[0] = fmaxf(lo0, hi0); v[1] = fmaxf(lo1, hi1); g[0] = g0; g[1] = g0 + 1; cnt = 2;
+            for (int r = 0; r < 16; r++) {
+                int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                long g0 = wrow0 + rin, g1 = wrow0 + 32 + rin;
+                float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
+                if (P.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                if (n_ok && g0 < P.rows) P.out[g0 * P.ld_out + P.col_off + n] = v0;
+                if (n_ok && g1 < P.rows) P.out[g1 * P.ld_out + P.col_off + n] = v1;
+            }
         } else {
-            v[0] = fmaxf(fmaxf(lo0, hi0), fmaxf(lo1, hi1)); g[0] = wrow0 / 64; cnt = 1;
-        }
-        if (h == 0 && n_ok) {
-            for (int t = 0; t < cnt; t++) {
-                float o = v[t] + bias;
-                if (P.relu) o = fmaxf(o, 0.f);
-                if (g[t] < groups) P.out[g[t] * P.ld_out + P.col_off + n] = o;
+            // max over nsample consecutive rows.  max commutes with the (monotone) bias add and ReLU, so
+            // they are applied once per pooled value: bit-identical to pooling the activated rows.
+            float lo0 = acc0[0], hi0 = acc0[8], lo1 = acc1[0], hi1 = acc1[8];
+#pragma unroll
+            for (int r = 1; r < 8; r++) {
+                lo0 = fmaxf(lo0, acc0[r]); hi0 = fmaxf(hi0, acc0[8 + r]);
+                lo1 = fmaxf(lo1, acc1[r]); hi1 = fmaxf(hi1, acc1[8 + r]);
+            }
+            lo0 = fmaxf(lo0, __shfl_xor(lo0, 32)); hi0 = fmaxf(hi0, __shfl_xor(hi0, 32));
+            lo1 = fmaxf(lo1, __shfl_xor(lo1, 32)); hi1 = fmaxf(hi1, __shfl_xor(hi1, 32));
+            const long groups = P.rows / P.pool_ns;
+            float v[4]; long g[4]; int cnt;
+            if (P.pool_ns == 16) {
+                long g0 = wrow0 / 16;
+                v[0] = lo0; v[1] = hi0; v[2] = lo1; v[3] = hi1; g[0] = g0; g[1] = g0 + 1; g[2] = g0 + 2; g[3] = g0 + 3; cnt = 4;
+            } else if (P.pool_ns == 32) {
+                long g0 = wrow0 / 32;
+                v[0] = fmaxf(lo0, hi0); v[1] = fmaxf(lo1, hi1); g[0] = g0; g[1] = g0 + 1; cnt = 2;
+            } else {
+                v[0] = fmaxf(fmaxf(lo0, hi0), fmaxf(lo1, hi1)); g[0] = wrow0 / 64; cnt = 1;
+            }
+            if (h == 0 && n_ok) {
+                for (int t = 0; t < cnt; t++) {
+                    float o = v[t] + bias;
+                    if (P.relu) o = fmaxf(o, 0.f);
+                    if (g[t] < groups) P.out[g[t] * P.ld_out + P.col_off + n] = o;
+                }
             }
         }
     }
@@ -413,15 +438,19 @@ __device__ __forceinline__ void chain_layer(const f32x16 (&in)[NBI], f32x16 (&ou
             for (int kbl = 0; kbl < G; kbl++) {
                 const int kb = st * G + kbl;
                 if (kb < NBI * 4 && kb < KB) {
+                    const int pb = kb < NBI * 4 ? kb / 4 : 0, q = kb % 4;
+                    float4 w[NBO];
 #pragma unroll
-                    for (int ob = 0; ob < NBO; ob++) {
-                        float4 w = lds_w(ws, kbl * NBO + ob, lane);
-                        const int pb = kb < NBI * 4 ? kb / 4 : 0, q = kb % 4;
-                        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, in[pb][4 * q + 0], out[ob], 0, 0, 0);
-                        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, in[pb][4 * q + 1], out[ob], 0, 0, 0);
-                        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, in[pb][4 * q + 2], out[ob], 0, 0, 0);
-                        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, in[pb][4 * q + 3], out[ob], 0, 0, 0);
-                    }
+                    for (int ob = 0; ob < NBO; ob++) w[ob] = lds_w(ws, kbl * NBO + ob, lane);
+                    // k-step outermost: consecutive MFMAs hit different accumulators
+#pragma unroll
+                    for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].x, in[pb][4 * q + 0], out[ob], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].y, in[pb][4 * q + 1], out[ob], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].z, in[pb][4 * q + 2], out[ob], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].w, in[pb][4 * q + 3], out[ob], 0, 0, 0);
                 }
             }
             if (more) stage_store<NBO>(Ws[(st + 1) & 1], wave, lane, wr);
@@ -524,14 +553,17 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(const ChainParams C) {
                 const bool more = kb + 1 < P.KB;
                 if (more) fetch<MODE>(P, meta, 8 * (kb + 1) + 4 * h, nxt);
                 float4 b = finish<MODE>(P, meta, 8 * kb + 4 * h, cur);
+                float4 w[NB0];
 #pragma unroll
-                for (int ob = 0; ob < NB0; ob++) {
-                    float4 w = lds_w(ws, kbl * NB0 + ob, lane);
-                    a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, b.x, a0[ob], 0, 0, 0);
-                    a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, b.y, a0[ob], 0, 0, 0);
-                    a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, b.z, a0[ob], 0, 0, 0);
-                    a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, b.w, a0[ob], 0, 0, 0);
-                }
+                for (int ob = 0; ob < NB0; ob++) w[ob] = lds_w(ws, kbl * NB0 + ob, lane);
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].x, b.x, a0[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].y, b.y, a0[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].z, b.z, a0[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].w, b.w, a0[ob], 0, 0, 0);
                 if (more) cur = nxt;
             }
             if (more_st) stage_store<NB0>(Ws[(st + 1) & 1], wave, lane, wr);
@@ -591,10 +623,17 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     if (P.rows == 0) return PRCNN_OK;
     P.KB = (P.K + 7) / 8;
     P.NB = (P.Nout + 31) / 32;
-    dim3 grid(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, 2));
-    if (mode == MODE_PLAIN) hipLaunchKernelGGL(mlp_layer_kernel<MODE_PLAIN>, grid, dim3(MLP_THREADS), 0, s, P);
-    else if (mode == MODE_GROUP) hipLaunchKernelGGL(mlp_layer_kernel<MODE_GROUP>, grid, dim3(MLP_THREADS), 0, s, P);
-    else hipLaunchKernelGGL(mlp_layer_kernel<MODE_INTERP>, grid, dim3(MLP_THREADS), 0, s, P);
+    const bool wide = P.NB >= 4;                    // >= 97 output channels: 128x128 workgroup tile
+    dim3 grid(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, wide ? 4 : 2));
+#define MLP_LAUNCH(M)                                                                                         \
+    do {                                                                                                      \
+        if (wide) hipLaunchKernelGGL((mlp_layer_kernel<M, 2>), grid, dim3(MLP_THREADS), 0, s, P);             \
+        else hipLaunchKernelGGL((mlp_layer_kernel<M, 1>), grid, dim3(MLP_THREADS), 0, s, P);                  \
+    } while (0)
+    if (mode == MODE_PLAIN) MLP_LAUNCH(MODE_PLAIN);
+    else if (mode == MODE_GROUP) MLP_LAUNCH(MODE_GROUP);
+    else MLP_LAUNCH(MODE_INTERP);
+#undef MLP_LAUNCH
     PRCNN_LAUNCH_CHECK("prcnn_mlp");
     return PRCNN_OK;
 }
