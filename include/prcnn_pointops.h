@@ -186,9 +186,11 @@ int prcnn_boxes_iou_bev(const float* boxes_a, int Na, const float* boxes_b, int 
 size_t prcnn_nms_workspace_bytes(int N);
 /* Greedy NMS over boxes ALREADY sorted by descending score (iou3d_utils.py:64-66): box i suppresses
  * j>i iff iou(i,j) > thresh.  Entirely on the device: keep (N) i64 receives the kept positions in
- * ascending order, num_keep (1) i32 their count.  No host synchronisation. */
-int prcnn_nms(const float* boxes, int N, float thresh, int kind, int64_t* keep, int32_t* num_keep, void* workspace,
-              size_t workspace_bytes, prcnn_stream_t stream);
+ * ascending order, num_keep (1) i32 their count.  No host synchronisation.
+ * max_keep: 0 = full sweep (reference semantics); > 0 = stop once that many boxes are kept -- the leading
+ * max_keep entries are identical to the full result (what lib/rpn/proposal_layer.py:112 consumes). */
+int prcnn_nms(const float* boxes, int N, float thresh, int kind, int max_keep, int64_t* keep, int32_t* num_keep,
+              void* workspace, size_t workspace_bytes, prcnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ SIGNATURES = {
     "prcnn_boxes_overlap_bev": (_I, [_P, _I, _P, _I, _P, _P]),
     "prcnn_boxes_iou_bev": (_I, [_P, _I, _P, _I, _P, _P]),
     "prcnn_nms_workspace_bytes": (_Z, [_I]),
-    "prcnn_nms": (_I, [_P, _I, _F, _I, _P, _P, _P, _Z, _P]),
+    "prcnn_nms": (_I, [_P, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
 }
 
 _lib = None

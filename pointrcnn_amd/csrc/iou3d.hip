@@ -203,48 +203,67 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     if (row < N) mask[(size_t)row * W + col_blk] = bits;
 }
 
-// ---- NMS: greedy sweep on the device (iou3d.cpp:100-119), one wave per problem -------------------
-__global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int N, int W,
-                                                       int64_t* __restrict__ keep, int32_t* __restrict__ num_keep) {
-    extern __shared__ unsigned long long remv[];         // W words: bit set = suppressed
-    const int lane = threadIdx.x;
-    for (int w = lane; w < W; w += 64) remv[w] = 0ULL;
+// ---- NMS: greedy sweep on the device (iou3d.cpp:100-119), one 256-thread workgroup per problem ------
+// Per 64-box block: wave 0 resolves the block serially on the scalar unit (diag word per lane, v_readlane);
+// then all 4 waves fold the kept rows into the suppression words of later blocks, one word per thread with 16
+// independent loads in flight (the fold is latency-bound: a dependent load per kept row is what made the first
+// version slow).  max_keep > 0 ends the sweep as soon as enough boxes are kept.
+#define SWEEP_THREADS 256
+__global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int N, int W,
+                                                                  int max_keep, int64_t* __restrict__ keep,
+                                                                  int32_t* __restrict__ num_keep) {
+    extern __shared__ unsigned long long remv[];         // W words: bit set = suppressed; then 2 words of exchange
+    unsigned long long* xchg = remv + W;                 // [0] = kept bits of the current block, [1] = running count
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int w = tid; w < W; w += SWEEP_THREADS) remv[w] = 0ULL;
+    if (tid == 0) xchg[1] = 0ULL;
     __syncthreads();
-    int num = 0;
     for (int blk = 0; blk < W; blk++) {
-        const int row = blk * 64 + lane;
-        unsigned long long diag = row < N ? mask[(size_t)row * W + blk] : 0ULL;
-        unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-        unsigned long long cur = remv[blk];
-        // readfirstlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high one
-        cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur >> 32)) << 32) |
-              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur);
-        const int nrows = min(64, N - blk * 64);
-        unsigned long long kept = 0ULL;
-        for (int t = 0; t < nrows; t++) {                // serial inside the block, registers only
-            if (!((cur >> t) & 1ULL)) {
-                kept |= 1ULL << t;
-                unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, t);
-                unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, t);
-                cur |= ((unsigned long long)hi << 32) | lo;
+        if (wave == 0) {
+            const int row = blk * 64 + lane;
+            unsigned long long diag = row < N ? mask[(size_t)row * W + blk] : 0ULL;
+            unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            unsigned long long cur = remv[blk];
+            // readfirstlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high one
+            cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur >> 32)) << 32) |
+                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur);
+            int num = (int)xchg[1];
+            num = __builtin_amdgcn_readfirstlane(num);
+            const int nrows = min(64, N - blk * 64);
+            unsigned long long kept = 0ULL;
+            for (int t = 0; t < nrows; t++) {            // serial inside the block, registers only
+                if (!((cur >> t) & 1ULL)) {
+                    kept |= 1ULL << t;
+                    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, t);
+                    unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, t);
+                    cur |= ((unsigned long long)hi << 32) | lo;
+                }
             }
+            if ((kept >> lane) & 1ULL) keep[num + __popcll(kept & ((1ULL << lane) - 1ULL))] = row;
+            if (lane == 0) { xchg[0] = kept; xchg[1] = (unsigned long long)(num + __popcll(kept)); }
         }
-        if ((kept >> lane) & 1ULL) keep[num + __popcll(kept & ((1ULL << lane) - 1ULL))] = row;
-        num += __popcll(kept);
+        __syncthreads();
+        const unsigned long long kept = xchg[0];
+        const int num = (int)xchg[1];
+        if (max_keep > 0 && num >= max_keep) break;       // uniform: every thread reads the same LDS word
         // fold the kept rows of this block into the suppression words of later blocks
-        for (int w = blk + 1 + lane; w < W; w += 64) {
+        for (int w = blk + 1 + tid; w < W; w += SWEEP_THREADS) {
             unsigned long long acc = remv[w];
-            unsigned long long kk = kept;
-            while (kk) {
-                int t = __ffsll((long long)kk) - 1;
-                kk &= kk - 1ULL;
-                acc |= mask[(size_t)(blk * 64 + t) * W + w];
+            const unsigned long long* col = mask + (size_t)blk * 64 * W + w;
+#pragma unroll 1
+            for (int t0 = 0; t0 < 64; t0 += 16) {
+                unsigned long long part[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++)               // 16 independent loads; `kept` is uniform
+                    part[u] = ((kept >> (t0 + u)) & 1ULL) ? col[(size_t)(t0 + u) * W] : 0ULL;
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc |= part[u];
             }
             remv[w] = acc;
         }
         __syncthreads();
     }
-    if (lane == 0) *num_keep = num;
+    if (tid == 0) *num_keep = (max_keep > 0 && (int)xchg[1] > max_keep) ? max_keep : (int)xchg[1];
 }
 
 static int pair_matrix(const char* op, bool iou, const float* a, int na, const float* b, int nb, float* out, hipStream_t s) {
@@ -273,10 +292,10 @@ PRCNN_API size_t prcnn_nms_workspace_bytes(int N) {
     return (size_t)N * W * sizeof(unsigned long long);
 }
 
-PRCNN_API int prcnn_nms(const float* boxes, int N, float thresh, int kind, int64_t* keep, int32_t* num_keep,
+PRCNN_API int prcnn_nms(const float* boxes, int N, float thresh, int kind, int max_keep, int64_t* keep, int32_t* num_keep,
                         void* workspace, size_t workspace_bytes, prcnn_stream_t stream) {
     PRCNN_REQUIRE(num_keep, "prcnn_nms: null num_keep");
-    PRCNN_REQUIRE(N >= 0, "prcnn_nms: bad N=%d", N);
+    PRCNN_REQUIRE(N >= 0 && max_keep >= 0, "prcnn_nms: bad N=%d max_keep=%d", N, max_keep);
     PRCNN_REQUIRE(kind == PRCNN_NMS_ROTATED || kind == PRCNN_NMS_NORMAL, "prcnn_nms: bad kind %d", kind);
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) {
@@ -295,7 +314,7 @@ PRCNN_API int prcnn_nms(const float* boxes, int N, float thresh, int kind, int64
     else
         hipLaunchKernelGGL(nms_mask_kernel<PRCNN_NMS_NORMAL>, grid, dim3(64), 0, s, boxes, N, thresh, W, mask);
     PRCNN_LAUNCH_CHECK("prcnn_nms(mask)");
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), (size_t)W * 8, s, mask, N, W, keep, num_keep);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(SWEEP_THREADS), (size_t)(W + 2) * 8, s, mask, N, W, max_keep, keep, num_keep);
     PRCNN_LAUNCH_CHECK("prcnn_nms(sweep)");
     return PRCNN_OK;
 }

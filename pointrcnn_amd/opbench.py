@@ -1,0 +1,122 @@
+"""Per-operator roofline report on one MI355X:  python -m pointrcnn_amd.opbench [--quick]
+
+For every operator on the hot path, at the shapes of tools/cfgs/default.yaml (per-GPU batch 32, 16 384 pts) and the
+BASELINE config-5 dense case (65 536 pts, 512 RoIs, batch 8), prints one JSON line with the average launch duration
+(HIP events on the launch stream, 20 iterations after 3 warm-ups) and
+    gather-class ops (gather / group / three_interpolate / roipool3d): algorithmic bytes (idx + read + write)
+        -> achieved GB/s vs 8 TB/s HBM3E (6.3 TB/s measured copy ceiling);
+    search ops (fps / ball_query / three_nn / nms): distance (pair) evaluations per second;
+    fused MLP: algorithmic FLOP/s vs 157.3 TFLOP/s dense fp32 MFMA.
+Algorithmic work per unit follows SURVEY.md 8(d).
+"""
+import argparse
+import json
+
+import torch
+
+from . import ops, rpn
+
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TF = 157.3
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def emit(name, shape, sec, **kw):
+    d = {"op": name, "shape": shape, "avg_launch_us": round(sec * 1e6, 1)}
+    if "bytes" in kw:
+        gbs = kw["bytes"] / sec / 1e9
+        d.update(bound="hbm", algorithmic_MB=round(kw["bytes"] / 1e6, 1), achieved_GBps=round(gbs, 1),
+                 frac_of_8TBps=round(gbs / HBM_PEAK_GBS, 3))
+    if "pairs" in kw:
+        d.update(bound="valu", pair_evals=kw["pairs"], achieved_Gpairs_per_s=round(kw["pairs"] / sec / 1e9, 1))
+    if "flops" in kw:
+        tf = kw["flops"] / sec / 1e12
+        d.update(bound="mfma", achieved_TFLOPs=round(tf, 2), frac_of_peak=round(tf / MFMA_F32_PEAK_TF, 3))
+    print(json.dumps(d), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B = 8 if args.quick else 32
+    N = 16384
+    xyz = rpn.synthetic_clouds(B, N, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+
+    # ---- search ops
+    emit("fps", "B%d %d->4096" % (B, N), timeit(lambda: ops.furthest_point_sample(xyz, 4096), 5, 1), pairs=B * N * 4096)
+    new_xyz = ops.gather_rows(xyz, ops.furthest_point_sample(xyz, 4096))
+    emit("ball_query2", "B%d N%d M4096 r(.1,.5) ns(16,32)" % (B, N),
+         timeit(lambda: ops.ball_query2(0.1, 16, 0.5, 32, xyz, new_xyz)), pairs=B * N * 4096)
+    emit("three_nn", "B%d n%d m4096" % (B, N), timeit(lambda: ops.three_nn(xyz, new_xyz)), pairs=B * N * 4096)
+
+    # ---- gather-class ops in the op-surface (B,C,N) layout
+    feat = torch.randn(B, 96, 4096, device=dev)
+    xyz1 = new_xyz
+    nx2 = ops.gather_rows(xyz1, ops.furthest_point_sample(xyz1, 1024))
+    idx = ops.ball_query(1.0, 32, xyz1, nx2)
+    emit("grouping_operation", "B%d C96 N4096 M1024 ns32" % B, timeit(lambda: ops.group(feat, idx)),
+         bytes=B * (1024 * 32 * 4 + 2 * 96 * 1024 * 32 * 4))
+    fidx = ops.furthest_point_sample(xyz1, 1024)
+    emit("gather_operation", "B%d C96 N4096 M1024" % B, timeit(lambda: ops.gather(feat, fidx)),
+         bytes=B * (1024 * 4 + 2 * 96 * 1024 * 4))
+    d2, i3, w3 = ops.three_nn(xyz, xyz1, want_weight=True)
+    kf = torch.randn(B, 256, 4096, device=dev)
+    emit("three_interpolate", "B%d C256 m4096 n%d" % (B, N), timeit(lambda: ops.three_interpolate(kf, i3, w3)),
+         bytes=B * (N * 24 + 3 * 256 * N * 4 + 256 * N * 4))
+
+    # ---- roipool3d: config 3 (M=100, C=130, S=512) and config 5 dense (65536 pts, 512 RoIs, batch 8)
+    def rois_for(x, M, seed):
+        gg = torch.Generator().manual_seed(seed)
+        pick = torch.randint(0, x.shape[1], (x.shape[0], M), generator=gg).to(dev)
+        ctr = torch.gather(x, 1, pick.unsqueeze(-1).expand(-1, -1, 3))
+        sz = torch.tensor([1.6 + 2, 1.7 + 2, 4.0 + 2], device=dev).expand(x.shape[0], M, 3)
+        ry = (torch.rand(x.shape[0], M, 1, generator=gg).to(dev) - 0.5) * 6.28
+        return torch.cat([ctr[..., 0:1], ctr[..., 1:2] + 1.8, ctr[..., 2:3], sz, ry], 2).contiguous()
+
+    pf = torch.randn(B, N, 130, device=dev)
+    rois = rois_for(xyz, 100, 1)
+    emit("roipool3d", "B%d N%d M100 C130 S512 (config 3)" % (B, N), timeit(lambda: ops.roipool3d(xyz, rois, pf, 512)),
+         bytes=B * 2 * 100 * 512 * 133 * 4)
+    if not args.quick:
+        Bd, Nd, Md = 8, 65536, 512
+        xd = rpn.synthetic_clouds(Bd, Nd, seed0=500, device=dev)
+        pfd = torch.randn(Bd, Nd, 130, device=dev)
+        rd = rois_for(xd, Md, 2)
+        emit("roipool3d", "B%d N%d M%d C130 S512 (config 5 dense)" % (Bd, Nd, Md),
+             timeit(lambda: ops.roipool3d(xd, rd, pfd, 512), 5, 1), bytes=Bd * 2 * Md * 512 * 133 * 4)
+        del xd, pfd, rd
+
+    # ---- NMS (default RPN path: normal, 6300 boxes, thr 0.8) and rotated
+    c = torch.rand(6300, 2, generator=g) * torch.tensor([80.0, 70.0])
+    s = torch.rand(6300, 2, generator=g) * torch.tensor([0.5, 1.5]) + torch.tensor([0.8, 1.7])
+    bev = torch.cat([c - s, c + s, (torch.rand(6300, 1, generator=g) - 0.5) * 6.28], 1).to(dev)
+    emit("nms_normal", "N6300 thr0.8", timeit(lambda: ops.nms_sorted(bev, 0.8, rotated=False)), pairs=6300 * 6299 // 2)
+    emit("nms_rotated", "N6300 thr0.8", timeit(lambda: ops.nms_sorted(bev, 0.8, rotated=True), 5, 1), pairs=6300 * 6299 // 2)
+
+    # ---- fused MLP: the whole RPN graph's MLP FLOPs are reported by bench.py; here two representative stacks
+    model = rpn.randomize_bn_stats(rpn.RPN()).to(dev).eval()
+    sa2 = model.backbone_net.SA_modules[1]
+    f1 = torch.randn(B, 96, 4096, device=dev)
+    with torch.no_grad():
+        sec = timeit(lambda: sa2(xyz1, f1))
+    macs = 1024 * (16 * (99 * 64 + 64 * 64 + 64 * 128) + 32 * (99 * 64 + 64 * 96 + 96 * 128))
+    emit("SA2 module (fps+ball_query+fused MLP chains)", "B%d 4096->1024" % B, sec, flops=2.0 * B * macs)
+
+
+if __name__ == "__main__":
+    main()

@@ -72,7 +72,7 @@ def gather_rows(in_cl, idx):
     B, N, C = in_cl.shape
     M = idx.shape[1]
     out = torch.empty((B, M, C), dtype=_F32, device=in_cl.device)
-    _cabi.check(_cabi.lib().prcnn_gather_rows(_p(in_cl), in_cl.stride(-2), _p(idx), B, N, M, C, _p(out), _stream()),
+    _cabi.check(_cabi.lib().prcnn_gather_rows(_p(in_cl), _row_stride(in_cl), _p(idx), B, N, M, C, _p(out), _stream()),
                 "prcnn_gather_rows")
     return out
 
@@ -217,7 +217,7 @@ def mlp_chain_rows(x, layers, out=None, pool_ns=0):
         raise RuntimeError("mlp_chain_rows: last dim must be contiguous")
     K = x.shape[-1]
     rows = x.numel() // K
-    ld_in = x.stride(-2) if x.dim() > 1 else K
+    ld_in = _row_stride(x)
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, layers[-1], x.device)
     a = _chain_args(layers)
@@ -230,7 +230,7 @@ def mlp_chain_group(xyz, new_xyz, idx, feat_cl, layers, out=None, pool_ns=0):
     B, N, _ = xyz.shape
     _, M, ns = idx.shape
     C = 0 if feat_cl is None else feat_cl.shape[-1]
-    ld_feat = 0 if feat_cl is None else feat_cl.stride(-2)
+    ld_feat = 0 if feat_cl is None else _row_stride(feat_cl)
     rows = B * M * ns
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, layers[-1], xyz.device)
@@ -245,20 +245,29 @@ def mlp_chain_interp(known_cl, idx3, w3, skip_cl, layers, out=None):
     B, m, C2 = known_cl.shape
     n = idx3.shape[1]
     C1 = 0 if skip_cl is None else skip_cl.shape[-1]
-    ld_skip = 0 if skip_cl is None else skip_cl.stride(-2)
+    ld_skip = 0 if skip_cl is None else _row_stride(skip_cl)
     buf, ld_out, col_off = _out_buf(out, B * n, layers[-1], known_cl.device)
     a = _chain_args(layers)
-    _cabi.check(_cabi.lib().prcnn_mlp_chain_interp(_p(known_cl), known_cl.stride(-2), _p(idx3), _p(w3), _p(skip_cl), ld_skip,
+    _cabi.check(_cabi.lib().prcnn_mlp_chain_interp(_p(known_cl), _row_stride(known_cl), _p(idx3), _p(w3), _p(skip_cl), ld_skip,
                                                    B, n, m, C2, C1, a.n, a.wpack, a.bias, a.nout, a.relu, _p(buf), ld_out,
                                                    col_off, _stream()), "prcnn_mlp_chain_interp")
     return buf
+
+
+def _row_stride(x):
+    """row stride (in elements) of a channels-last rows view (..., K): the stride of the innermost leading dim of
+    size > 1 (size-1 dims carry arbitrary strides); the caller guarantees uniform striding (pt_utils._rows_view)."""
+    for size, stride in zip(reversed(x.shape[:-1]), reversed(x.stride()[:-1])):
+        if size != 1:
+            return stride
+    return x.shape[-1]
 
 
 def _out_buf(out, rows, lin, device):
     if out is None:
         return torch.empty((rows, lin.nout), dtype=_F32, device=device), lin.nout, 0
     buf, col_off = out
-    return buf, buf.stride(-2), col_off
+    return buf, _row_stride(buf), col_off
 
 
 def mlp_rows(x, lin, out=None, pool_ns=0):
@@ -268,7 +277,7 @@ def mlp_rows(x, lin, out=None, pool_ns=0):
         raise RuntimeError("mlp_rows: last dim must be contiguous")
     K = x.shape[-1]
     rows = x.numel() // K
-    ld_in = x.stride(-2) if x.dim() > 1 else K
+    ld_in = _row_stride(x)
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, lin, x.device)
     _cabi.check(_cabi.lib().prcnn_mlp_rows(_p(x), ld_in, rows, K, _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu),
@@ -282,7 +291,7 @@ def mlp_group(xyz, new_xyz, idx, feat_cl, lin, out=None, pool_ns=0):
     B, N, _ = xyz.shape
     _, M, ns = idx.shape
     C = 0 if feat_cl is None else feat_cl.shape[-1]
-    ld_feat = 0 if feat_cl is None else feat_cl.stride(-2)
+    ld_feat = 0 if feat_cl is None else _row_stride(feat_cl)
     rows = B * M * ns
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, lin, xyz.device)
@@ -298,9 +307,9 @@ def mlp_interp(known_cl, idx3, w3, skip_cl, lin, out=None):
     B, m, C2 = known_cl.shape
     n = idx3.shape[1]
     C1 = 0 if skip_cl is None else skip_cl.shape[-1]
-    ld_skip = 0 if skip_cl is None else skip_cl.stride(-2)
+    ld_skip = 0 if skip_cl is None else _row_stride(skip_cl)
     buf, ld_out, col_off = _out_buf(out, B * n, lin, known_cl.device)
-    _cabi.check(_cabi.lib().prcnn_mlp_interp(_p(known_cl), known_cl.stride(-2), _p(idx3), _p(w3), _p(skip_cl), ld_skip,
+    _cabi.check(_cabi.lib().prcnn_mlp_interp(_p(known_cl), _row_stride(known_cl), _p(idx3), _p(w3), _p(skip_cl), ld_skip,
                                              B, n, m, C2, C1, _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu),
                                              _p(buf), ld_out, col_off, _stream()), "prcnn_mlp_interp")
     return buf
@@ -364,9 +373,11 @@ def boxes_iou_bev(boxes_a, boxes_b, out=None):
     return out
 
 
-def nms_sorted(boxes_sorted, thresh, rotated=True):
+def nms_sorted(boxes_sorted, thresh, rotated=True, max_keep=0):
     """Greedy NMS over boxes already sorted by descending score, fully on device.
-    -> keep (N) int64 (first num entries valid), num (1) int32.  No host sync."""
+    -> keep (N) int64 (first num entries valid), num (1) int32.  No host sync.
+    max_keep > 0 stops the sweep once that many boxes are kept (the proposal layer only uses the first
+    RPN_POST_NMS_TOP_N of them, lib/rpn/proposal_layer.py:112): same leading entries, a fraction of the work."""
     _chk(boxes_sorted, "boxes", ndim=2)
     N = boxes_sorted.shape[0]
     L = _cabi.lib()
@@ -374,6 +385,6 @@ def nms_sorted(boxes_sorted, thresh, rotated=True):
     num = torch.empty((1,), dtype=_INT, device=boxes_sorted.device)
     wsb = L.prcnn_nms_workspace_bytes(N)
     ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=boxes_sorted.device)
-    _cabi.check(L.prcnn_nms(_p(boxes_sorted), N, float(thresh), 0 if rotated else 1, _p(keep), _p(num), _p(ws), wsb,
-                            _stream()), "prcnn_nms")
+    _cabi.check(L.prcnn_nms(_p(boxes_sorted), N, float(thresh), 0 if rotated else 1, int(max_keep), _p(keep), _p(num),
+                            _p(ws), wsb, _stream()), "prcnn_nms")
     return keep, num

@@ -55,8 +55,8 @@ def test_argument_errors_return_codes_not_exit():
     assert lib.prcnn_fps(dummy, 1, 20000, 4, None, dummy, None) == -1         # large N needs tmp
     assert lib.prcnn_mlp_rows(dummy, 8, 128, 8, dummy, None, 16, 1, dummy, 16, 0, 20, None) == -1   # pool_ns=20
     assert b"pool_ns" in lib.prcnn_last_error()
-    assert lib.prcnn_nms(dummy, 10, 0.5, 7, dummy, dummy, dummy, 1 << 20, None) == -1               # bad kind
-    assert lib.prcnn_nms(dummy, 100, 0.5, 0, dummy, dummy, dummy, 8, None) == -1                     # workspace too small
+    assert lib.prcnn_nms(dummy, 10, 0.5, 7, 0, dummy, dummy, dummy, 1 << 20, None) == -1            # bad kind
+    assert lib.prcnn_nms(dummy, 100, 0.5, 0, 0, dummy, dummy, dummy, 8, None) == -1                  # workspace too small
     with pytest.raises(_cabi.PointOpsError):
         _cabi.check(-1, "x")
 

@@ -151,3 +151,73 @@ def test_full_rpn_fused_equals_composed(dev):
     for k in ("backbone_features", "rpn_cls", "rpn_reg"):
         a, b = out_f[k].cpu().numpy(), out_c[k].detach().cpu().numpy()
         np.testing.assert_allclose(a, b, atol=5e-4 * max(1.0, float(np.abs(b).max())), rtol=0)
+
+
+def _synthetic_rois(xyz, M, seed):
+    """(B,M,7) car-sized boxes centred on random points of each frame (stand-in for the proposal layer)"""
+    g = torch.Generator().manual_seed(seed)
+    B, N, _ = xyz.shape
+    pick = torch.randint(0, N, (B, M), generator=g)
+    ctr = torch.gather(xyz.cpu(), 1, pick.unsqueeze(-1).expand(-1, -1, 3))
+    h = torch.rand(B, M, 1, generator=g) * 0.4 + 1.4
+    w = torch.rand(B, M, 1, generator=g) * 0.3 + 1.5
+    l = torch.rand(B, M, 1, generator=g) * 1.0 + 3.5
+    ry = (torch.rand(B, M, 1, generator=g) - 0.5) * 6.28
+    return torch.cat([ctr[..., 0:1], ctr[..., 1:2] + h / 2, ctr[..., 2:3], h, w, l, ry], 2)
+
+
+def test_rcnn_stage_fused_equals_composed_and_roipool_oracle(dev, cpu):
+    """BASELINE config 3 shape of the second stage (rcnn_net.py:115-190): roipool3d (M=20 RoIs x 512 pts x 133 ch)
+    -> canonical transform -> SharedMLPs -> SA(npoint 128, ns 64) -> SA(32, 64) -> GroupAll -> heads, then the final
+    rotated NMS (eval_rcnn.py:618-619, thr 0.1).  Pooled points vs the oracle exactly; fused vs composed path."""
+    from pointrcnn_amd import rcnn
+    torch.manual_seed(5)
+    B, N, M = 2, 16384, 20
+    xyz = T(kitti_cloud(B, N, seed=300), dev)
+    rois = _synthetic_rois(xyz, M, seed=6).to(dev)
+    data = {"rpn_xyz": xyz, "rpn_features": torch.randn(B, N, 128, device=dev), "seg_mask": (torch.rand(B, N, device=dev) > 0.5).float(),
+            "pts_depth": torch.norm(xyz, p=2, dim=2), "roi_boxes3d": rois}
+    net = rcnn.RCNNNet().to(dev).eval()
+    with torch.no_grad():
+        out_f = net(data)
+    # roipool3d inside the stage == oracle on the same enlarged boxes and features
+    feat = torch.cat([data["seg_mask"].unsqueeze(2), (data["pts_depth"] / 70.0 - 0.5).unsqueeze(2), data["rpn_features"]], 2)
+    with torch.no_grad():
+        pooled, empty = rcnn.roipool3d_gpu(xyz, feat, rois, 1.0, 512)
+    want, wempty = cpu.roipool3d(xyz.cpu().numpy(), rcnn.enlarge_box3d(rois.view(-1, 7), 1.0).view(B, M, 7).cpu().numpy(),
+                                 feat.cpu().numpy(), 512)
+    assert np.array_equal(pooled.cpu().numpy(), want) and np.array_equal(empty.cpu().numpy(), wempty)
+    assert out_f["rcnn_cls"].shape == (B * M, 1) and out_f["rcnn_reg"].shape == (B * M, 46)   # rcnn_net.py:184-185
+    with torch.enable_grad():
+        data_c = dict(data, rpn_features=data["rpn_features"].clone().requires_grad_(True))
+        out_c = net(data_c)
+    for k in ("rcnn_cls", "rcnn_reg"):
+        a, b = out_f[k].cpu().numpy(), out_c[k].detach().cpu().numpy()
+        np.testing.assert_allclose(a, b, atol=5e-4 * max(1.0, float(np.abs(b).max())), rtol=0)
+    # final rotated NMS per frame on the RoIs with the stage's scores
+    for b in range(B):
+        bev = rcnn.boxes3d_to_bev_torch(rois[b])
+        scores = out_f["rcnn_cls"].view(B, M)[b]
+        keep = rcnn.nms_gpu(bev, scores, 0.1).cpu().numpy()
+        order = torch.sort(scores, descending=True)[1].cpu().numpy()
+        want_keep = order[cpu.nms(bev[torch.from_numpy(order).to(dev)].cpu().numpy(), 0.1, "rotated", 1)]
+        assert np.array_equal(keep, want_keep)
+
+
+def test_rpn_backward_composed_path(dev):
+    """config 4 building block: one training-style step of an SA+FP pair through the HIP backward kernels
+    (group / gather / three_interpolate grads) -- gradients reach every parameter and are finite"""
+    from pointnet2_lib.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
+    torch.manual_seed(6)
+    sa = PointnetSAModuleMSG(npoint=128, radii=[0.2, 0.4], nsamples=[16, 32], mlps=[[8, 16, 32], [8, 16, 32]],
+                             use_xyz=True, bn=True).to(dev).train()
+    fp = PointnetFPModule(mlp=[64 + 8, 32, 16]).to(dev).train()
+    xyz = T(unit_cloud(4, 1024, seed=9), dev)
+    feat = torch.randn(4, 8, 1024, device=dev, requires_grad=True)
+    new_xyz, f1 = sa(xyz, feat)
+    out = fp(xyz, new_xyz, feat, f1)
+    assert out.shape == (4, 16, 1024)
+    out.square().mean().backward()
+    params = list(sa.parameters()) + list(fp.parameters())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    assert feat.grad is not None and torch.isfinite(feat.grad).all() and float(feat.grad.abs().sum()) > 0

@@ -171,3 +171,17 @@ def test_iou3d_dropin_module(dev, cpu):
         assert np.array_equal(picked, want)
     with pytest.raises(RuntimeError):
         iou3d_cuda.nms_gpu(torch.from_numpy(boxes), torch.LongTensor(500), 0.4)      # CPU boxes rejected
+
+
+def test_nms_max_keep_prefix(dev, cpu):
+    """max_keep stops the sweep early: the kept list is the exact prefix of the full result (what
+    proposal_layer.py:112 `keep_idx[:post_top_n]` consumes), for both kinds and across block boundaries"""
+    from pointrcnn_amd import ops
+    boxes = rand_bev(3000, 12.0, seed=77)
+    for kind in ("rotated", "normal"):
+        full = cpu.nms(boxes, 0.5, kind, 1)
+        for mk in (1, 30, 70, 200, 512):
+            keep, num = ops.nms_sorted(T(boxes, dev), 0.5, rotated=(kind == "rotated"), max_keep=mk)
+            n = int(num.item())
+            assert n == min(mk, len(full))
+            assert np.array_equal(keep[:n].cpu().numpy(), full[:n])
