@@ -37,12 +37,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32-input MFMA peak (/opt/ski
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (BASELINE metric: bs32)")
     ap.add_argument("--npoints", type=int, default=16384)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the step from a hipGraph")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: step k runs on HIP stream k %% streams, so one batch's FPS "
                          "(1 workgroup per frame = 32 of 256 CUs) overlaps another batch's MLP / neighbour kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -250,6 +250,20 @@ def main():
                             "flops_per_step": mlp["flops"] / nprof}
         line["kernels"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "launches_per_step": v["launches"] // nprof}
                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+        # HBM bytes per launch of the same kernel family from the PMC passes committed under profiles/ (rocprofv3
+        # --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied there); null when absent.
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and args.batch == 32 and args.npoints == 16384:
+            try:
+                line["roofline"]["traffic"] = json.load(open(tpath))["per_step_bs32"]["mlp"]["hbm_bytes_per_launch_corrected"]
+                line["roofline"]["traffic_unit"] = "bytes/launch (PMC, profiles/r01_hbm_traffic.json)"
+            except (KeyError, ValueError):
+                pass
+        if "fps" in fam:      # the longest single kernel is latency/VALU-bound, neither HBM nor MFMA: report its rate
+            evals = args.batch * sum(n * m for n, m in zip([args.npoints] + rpn.RPNConfig.SA_NPOINTS[:-1], rpn.RPNConfig.SA_NPOINTS))
+            line["fps_kernel"] = {"ms_per_step": round(fam["fps"]["ms"] / nprof, 3), "distance_evals_per_step": evals,
+                                  "Gevals_per_s": round(evals / (fam["fps"]["ms"] / nprof * 1e-3) / 1e9, 1),
+                                  "note": "serial chain, 1 workgroup/frame (32 of 256 CUs); hidden by --streams"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(model, clouds_cpu, out)
