@@ -9,9 +9,8 @@
 // One workgroup per (frame, box).  Each of the 4 waves scans a contiguous quarter of the frame's points;
 // a wave-wide __ballot + prefix popcount compacts its hits in index order into its own LDS list (no
 // barrier inside the scan).  The four lists are concatenated in wave order == index order, truncated at
-// S.  The gather then writes the box's S x (3+C) output block with one wave per row: reads are
-// contiguous within a point's feature row, writes are fully coalesced.  Nothing but the inputs and the
-// output touches HBM.
+// S.  The gather then writes the box's contiguous S x (3+C) output block as one flat, fully coalesced stream
+// (reads are contiguous within a point's feature row).  Nothing but the inputs and the output touches HBM.
 #include "common.h"
 
 #define RP_THREADS 256
@@ -59,14 +58,25 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(const float* __re
     const int per_wave = (((N + RP_WAVES - 1) / RP_WAVES) + 63) & ~63;
     const int k_begin = wave * per_wave, k_end = min(N, k_begin + per_wave);
     int cnt = 0;                               // wave-uniform
-    for (int k0 = k_begin; k0 < k_end && cnt < S; k0 += 64) {
-        int k = k0 + lane;
-        bool in = false;
-        if (k < k_end) in = pt_in_box(box, p[k * 3], p[k * 3 + 1], p[k * 3 + 2]);
-        unsigned long long mask = __ballot(in);
-        int pos = cnt + __popcll(mask & ((1ULL << lane) - 1ULL));
-        if (in && pos < S) mylist[pos] = k;
-        cnt += __popcll(mask);
+    for (int k0 = k_begin; k0 < k_end && cnt < S; k0 += 256) {
+        // 4 x 64 points per trip: the 12 loads are independent (the scan is load-latency bound), the four
+        // ballots are consumed in index order
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int k = k0 + u * 64 + lane;
+            float x = 0.f, y = 0.f, z = 0.f;
+            bool ok = k < k_end;
+            if (ok) { x = p[k * 3]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
+            in[u] = ok && pt_in_box(box, x, y, z);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            unsigned long long mask = __ballot(in[u]);
+            int pos = cnt + __popcll(mask & ((1ULL << lane) - 1ULL));
+            if (in[u] && pos < S) mylist[pos] = k0 + u * 64 + lane;
+            cnt += __popcll(mask);
+        }
     }
     if (lane == 0) wcnt[wave] = min(cnt, S);
     __syncthreads();
@@ -88,12 +98,24 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(const float* __re
         for (size_t e = tid; e < (size_t)S * W; e += RP_THREADS) o[e] = 0.f;
         return;
     }
+    // Flattened copy of the box's contiguous S x W output block: thread t handles elements t, t+256, ...; every
+    // store instruction writes 64 consecutive floats (a row of 3+C = 133 floats does not divide into wave-sized
+    // pieces, so a row-per-wave mapping would leave the third pass almost empty).  (row, col) of the element is
+    // tracked incrementally -- no integer division in the loop.
+    // wrap-duplicate once in the index list (slot k >= cnt copies slot k % cnt, roipool3d.cpp:176-191) so the copy
+    // loop needs no modulo; reads touch only slots < total, writes only slots >= total
+    for (int s2 = total + tid; s2 < S; s2 += RP_THREADS) sel[s2] = sel[s2 % total];
+    __syncthreads();
     const float* __restrict__ f = feat + (size_t)b * N * C;
-    for (int s = wave; s < S; s += RP_WAVES) {
-        int k = sel[s < total ? s : s % total];
-        float* row = o + (size_t)s * W;
-        const float* src = f + (size_t)k * C;
-        for (int c = lane; c < W; c += 64) row[c] = c < 3 ? p[k * 3 + c] : src[c - 3];
+    const int total_e = S * W;
+    const int qstep = RP_THREADS / W, rstep = RP_THREADS - qstep * W;
+    int srow = tid / W, scol = tid - srow * W;
+#pragma unroll 4
+    for (int e = tid; e < total_e; e += RP_THREADS) {
+        int k = sel[srow];
+        o[e] = scol < 3 ? p[k * 3 + scol] : f[(size_t)k * C + (scol - 3)];
+        srow += qstep; scol += rstep;
+        if (scol >= W) { scol -= W; srow++; }
     }
 }
 
