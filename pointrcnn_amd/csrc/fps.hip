@@ -179,10 +179,10 @@ static void launch_fps(const float* xyz, int B, int N, int npoint, int32_t* idx,
 }
 
 PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, int32_t* idx, prcnn_stream_t stream) {
-    PRCNN_REQUIRE(xyz && idx, "prcnn_fps: null pointer");
     PRCNN_REQUIRE(B >= 0 && N > 0 && npoint >= 0, "prcnn_fps: bad shape B=%d N=%d npoint=%d", B, N, npoint);
     PRCNN_REQUIRE(npoint <= N, "prcnn_fps: npoint %d > N %d", npoint, N);
-    if (B == 0 || npoint == 0) return PRCNN_OK;
+    if (B == 0 || npoint == 0) return PRCNN_OK;          // empty problem: pointers may legitimately be null
+    PRCNN_REQUIRE(xyz && idx, "prcnn_fps: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (N <= 64) launch_fps<64, 1>(xyz, B, N, npoint, idx, s);
     else if (N <= 128) launch_fps<64, 2>(xyz, B, N, npoint, idx, s);

@@ -90,8 +90,9 @@ __global__ __launch_bounds__(G_THREADS) void gather_rows_kernel(const float* __r
 }
 
 static int check_bcn(const char* op, const void* a, const void* b, const void* c, int B, int C, int N, long J) {
-    if (!a || !b || !c) return prcnn_fail(PRCNN_EINVAL, "%s: null pointer", op);
     if (B < 0 || C < 0 || N <= 0 || J < 0) return prcnn_fail(PRCNN_EINVAL, "%s: bad shape B=%d C=%d N=%d J=%ld", op, B, C, N, J);
+    if (B == 0 || C == 0 || J == 0) return PRCNN_OK;      // empty problem: pointers may legitimately be null
+    if (!a || !b || !c) return prcnn_fail(PRCNN_EINVAL, "%s: null pointer", op);
     return PRCNN_OK;
 }
 
@@ -143,9 +144,9 @@ PRCNN_API int prcnn_group_grad(const float* grad_out, const int32_t* idx, int B,
 
 PRCNN_API int prcnn_three_interp(const float* feat, const int32_t* idx, const float* weight, int B, int C, int m, int n,
                                  float* out, prcnn_stream_t stream) {
-    PRCNN_REQUIRE(feat && idx && weight && out, "prcnn_three_interp: null pointer");
     PRCNN_REQUIRE(B >= 0 && C >= 0 && m > 0 && n >= 0, "prcnn_three_interp: bad shape B=%d C=%d m=%d n=%d", B, C, m, n);
     if (B == 0 || C == 0 || n == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(feat && idx && weight && out, "prcnn_three_interp: null pointer");
     hipLaunchKernelGGL(three_interp_kernel, dim3(prcnn_divup(n, G_THREADS), B), dim3(G_THREADS), 0, (hipStream_t)stream,
                        feat, idx, weight, C, m, n, out);
     PRCNN_LAUNCH_CHECK("prcnn_three_interp");
@@ -154,9 +155,9 @@ PRCNN_API int prcnn_three_interp(const float* feat, const int32_t* idx, const fl
 
 PRCNN_API int prcnn_three_interp_grad(const float* grad_out, const int32_t* idx, const float* weight, int B, int C,
                                       int n, int m, float* grad_feat, prcnn_stream_t stream) {
-    PRCNN_REQUIRE(grad_out && idx && weight && grad_feat, "prcnn_three_interp_grad: null pointer");
     PRCNN_REQUIRE(B >= 0 && C >= 0 && m > 0 && n >= 0, "prcnn_three_interp_grad: bad shape");
     if (B == 0 || C == 0 || n == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(grad_out && idx && weight && grad_feat, "prcnn_three_interp_grad: null pointer");
     hipLaunchKernelGGL(three_interp_grad_kernel, dim3(prcnn_divup(n, G_THREADS), B), dim3(G_THREADS), 0,
                        (hipStream_t)stream, grad_out, idx, weight, C, n, m, grad_feat);
     PRCNN_LAUNCH_CHECK("prcnn_three_interp_grad");
@@ -165,9 +166,9 @@ PRCNN_API int prcnn_three_interp_grad(const float* grad_out, const int32_t* idx,
 
 PRCNN_API int prcnn_gather_rows(const float* in_cl, int ld_in, const int32_t* idx, int B, int N, int M, int C,
                                 float* out, prcnn_stream_t stream) {
-    PRCNN_REQUIRE(in_cl && idx && out, "prcnn_gather_rows: null pointer");
     PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && C > 0 && ld_in >= C, "prcnn_gather_rows: bad shape");
     if (B == 0 || M == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(in_cl && idx && out, "prcnn_gather_rows: null pointer");
     hipLaunchKernelGGL(gather_rows_kernel, dim3(prcnn_divup((long)M * C, G_THREADS), B), dim3(G_THREADS), 0,
                        (hipStream_t)stream, in_cl, ld_in, idx, N, M, C, out);
     PRCNN_LAUNCH_CHECK("prcnn_gather_rows");

@@ -267,9 +267,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const unsigned
 }
 
 static int pair_matrix(const char* op, bool iou, const float* a, int na, const float* b, int nb, float* out, hipStream_t s) {
-    if (!a || !b || !out) return prcnn_fail(PRCNN_EINVAL, "%s: null pointer", op);
     if (na < 0 || nb < 0) return prcnn_fail(PRCNN_EINVAL, "%s: bad shape", op);
     if (na == 0 || nb == 0) return PRCNN_OK;
+    if (!a || !b || !out) return prcnn_fail(PRCNN_EINVAL, "%s: null pointer", op);
     dim3 grid(prcnn_divup(nb, 16), prcnn_divup(na, 16));
     if (iou) hipLaunchKernelGGL(pair_matrix_kernel<true>, grid, dim3(256), 0, s, a, na, b, nb, out);
     else hipLaunchKernelGGL(pair_matrix_kernel<false>, grid, dim3(256), 0, s, a, na, b, nb, out);

@@ -170,10 +170,10 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float* __res
 
 static int ball_query_impl(const float* xyz, const float* new_xyz, int B, int N, int M, float ra, int nsa, int32_t* ia,
                            float rb, int nsb, int32_t* ib, bool dual, hipStream_t s) {
-    PRCNN_REQUIRE(xyz && new_xyz && ia && (!dual || ib), "prcnn_ball_query: null pointer");
     PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && nsa > 0 && (!dual || nsb > 0),
                   "prcnn_ball_query: bad shape B=%d N=%d M=%d nsample=%d/%d", B, N, M, nsa, nsb);
     if (B == 0 || M == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(xyz && new_xyz && ia && (!dual || ib), "prcnn_ball_query: null pointer");
     dim3 grid(prcnn_divup(M, BQ_THREADS), B);
     float r2a = ra * ra, r2b = rb * rb;        // fp32 product, as the oracle
     if (dual)
@@ -200,9 +200,9 @@ PRCNN_API int prcnn_ball_query2(const float* xyz, const float* new_xyz, int B, i
 
 PRCNN_API int prcnn_three_nn(const float* unknown, const float* known, int B, int n, int m, float* dist2, int32_t* idx,
                              float* weight, prcnn_stream_t stream) {
-    PRCNN_REQUIRE(unknown && known && dist2 && idx, "prcnn_three_nn: null pointer");
     PRCNN_REQUIRE(B >= 0 && n >= 0 && m > 0, "prcnn_three_nn: bad shape B=%d n=%d m=%d", B, n, m);
     if (B == 0 || n == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(unknown && known && dist2 && idx, "prcnn_three_nn: null pointer");
     hipLaunchKernelGGL(three_nn_kernel, dim3(prcnn_divup(n, NN_THREADS), B), dim3(NN_THREADS), 0, (hipStream_t)stream,
                        unknown, known, n, m, dist2, idx, weight);
     PRCNN_LAUNCH_CHECK("prcnn_three_nn");

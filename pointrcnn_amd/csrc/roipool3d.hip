@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) void pts_in_boxes3d_kernel(const float* __rest
 
 PRCNN_API int prcnn_roipool3d(const float* xyz, const float* boxes3d, const float* feat, int B, int N, int M, int C,
                               int S, float* pooled, int32_t* empty, prcnn_stream_t stream) {
-    PRCNN_REQUIRE(xyz && boxes3d && pooled && empty && (C == 0 || feat), "prcnn_roipool3d: null pointer");
     PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && C >= 0 && S > 0, "prcnn_roipool3d: bad shape B=%d N=%d M=%d C=%d S=%d", B, N, M, C, S);
+    if (B == 0 || M == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(xyz && boxes3d && pooled && empty && (C == 0 || feat), "prcnn_roipool3d: null pointer");
     size_t lds_bytes = (size_t)(RP_WAVES + 1) * S * sizeof(int32_t);
     PRCNN_REQUIRE(lds_bytes <= 60 * 1024, "prcnn_roipool3d: sampled_pt_num %d too large for the LDS index lists", S);
     if (B == 0 || M == 0) return PRCNN_OK;
@@ -146,9 +147,9 @@ PRCNN_API int prcnn_roipool3d(const float* xyz, const float* boxes3d, const floa
 
 PRCNN_API int prcnn_pts_in_boxes3d(const float* pts, const float* boxes3d, int N, int M, int32_t* flags,
                                    prcnn_stream_t stream) {
-    PRCNN_REQUIRE(pts && boxes3d && flags, "prcnn_pts_in_boxes3d: null pointer");
     PRCNN_REQUIRE(N >= 0 && M >= 0, "prcnn_pts_in_boxes3d: bad shape");
     if (N == 0 || M == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(pts && boxes3d && flags, "prcnn_pts_in_boxes3d: null pointer");
     hipLaunchKernelGGL(pts_in_boxes3d_kernel, dim3(prcnn_divup(N, 256), M), dim3(256), 0, (hipStream_t)stream, pts,
                        boxes3d, N, M, flags);
     PRCNN_LAUNCH_CHECK("prcnn_pts_in_boxes3d");

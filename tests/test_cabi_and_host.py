@@ -48,6 +48,7 @@ def test_argument_errors_return_codes_not_exit():
     from pointrcnn_amd import _cabi
     lib = _cabi.lib()
     assert lib.prcnn_fps(None, 1, 16, 4, None, None, None) == -1
+    assert lib.prcnn_fps(None, 0, 16, 4, None, None, None) == 0              # empty problem: nothing to do, no pointer needed
     assert b"null" in lib.prcnn_last_error()
     dummy = ctypes.c_void_p(16)
     assert lib.prcnn_fps(dummy, 1, 16, 32, None, dummy, None) == -1           # npoint > N
