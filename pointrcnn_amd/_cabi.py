@@ -65,14 +65,15 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if not os.path.exists(path) or (os.path.exists(_build.HIPCC) and _build._stale()):
+    if not os.path.exists(path):
+        # Build only when the library is MISSING (never silently on a stale check: under torchrun every rank gets
+        # here at once).  `python -m pointrcnn_amd.build` / __graft_entry__.build() is the explicit rebuild.
         try:
             _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001
-            if not os.path.exists(path):
-                raise PointOpsError(
-                    "libprcnn_pointops.so is missing and could not be built (%s). The HIP extension is "
-                    "mandatory: there is no CPU fallback. Run `python -m pointrcnn_amd.build`." % e)
+            raise PointOpsError(
+                "libprcnn_pointops.so is missing and could not be built (%s). The HIP extension is "
+                "mandatory: there is no CPU fallback. Run `python -m pointrcnn_amd.build`." % e)
     try:
         handle = ctypes.CDLL(path)
     except OSError as e:

@@ -6,6 +6,7 @@ hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the
 so a GPU box never needs to compile.  Flags: -ffp-contract=off is part of the arithmetic contract
 (include/prcnn_pointops.h): no implicit FMA anywhere, explicit MFMA/fma only where written.
 """
+import fcntl
 import glob
 import os
 import subprocess
@@ -39,28 +40,36 @@ def _stale():
 
 
 def build(force=False, verbose=True):
-    """Compile every .hip translation unit (in parallel) and link the shared library."""
+    """Compile every .hip translation unit (in parallel) and link the shared library.  Serialised across processes
+    by a lock file; the .so is linked to a temporary name and renamed into place, so a concurrent loader never sees
+    a half-written library."""
     if not force and not _stale():
         return LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s and %s is missing or stale" % (HIPCC, LIB))
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
-    os.makedirs(objdir, exist_ok=True)
-    procs = []
-    for src in sources():
-        obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
-        procs.append((src, obj, subprocess.Popen([HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj],
-                                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    objs = []
-    for src, obj, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
-        if verbose and out.strip():
-            print(out.decode())
-        objs.append(obj)
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():          # another process built it while we waited
+            return LIB
+        objdir = os.path.join(LIBDIR, "obj")
+        os.makedirs(objdir, exist_ok=True)
+        procs = []
+        for src in sources():
+            obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
+            procs.append((src, obj, subprocess.Popen([HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj],
+                                                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs = []
+        for src, obj, p in procs:
+            out, _ = p.communicate()
+            if p.returncode != 0:
+                raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
+            if verbose and out.strip():
+                print(out.decode())
+            objs.append(obj)
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs, check=True)
+        os.replace(tmp, LIB)
     if verbose:
         print("built", LIB)
     return LIB
