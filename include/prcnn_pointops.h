@@ -123,16 +123,35 @@ int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, const float*
 
 /* A row (b,m,s) = [ feat_cl[b, idx[b,m,s], 0:C],  xyz[b, idx[b,m,s]] - new_xyz[b,m] ]  (K = C+3;
  * C may be 0 with feat_cl NULL).  new_xyz NULL => GroupAll semantics (no centroid subtraction).
- * rows = B*M*nsample. */
+ * rows = B*M*nsample.
+ * HOISTED FIRST LAYER (act_wx, act_bias non-NULL; both NULL = the classic form above): grouping is a linear gather
+ * and the first conv of a SharedMLP is linear, so W.[feat[idx]; dxyz] = (W_f.feat)[idx] + W_x.dxyz.  The caller
+ * computes Z = W_f.feat once per SOURCE point (N rows instead of M*nsample) with prcnn_mlp_rows and passes it as
+ * feat_cl (C = width of that first layer, C % 4 == 0); act_wx is (C,3) row-major = the dxyz columns of the first
+ * layer's weight, act_bias (C, padded to x4) its bias.  The A row is then relu(Z[idx] + act_wx.dxyz + act_bias),
+ * K = C, and wpack/bias describe the SECOND layer.  Same result up to fp32 reassociation. */
 int prcnn_mlp_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl, int ld_feat,
-                    int B, int N, int M, int nsample, int C, const float* wpack, const float* bias, int Nout,
-                    int relu, float* out, int ld_out, int col_off, int pool_ns, prcnn_stream_t stream);
+                    int B, int N, int M, int nsample, int C, const float* act_wx, const float* act_bias,
+                    const float* wpack, const float* bias, int Nout, int relu, float* out, int ld_out, int col_off,
+                    int pool_ns, prcnn_stream_t stream);
 
 /* A row (b,i) = [ sum_j w3[b,i,j] * known_cl[b, idx3[b,i,j], 0:C2],  skip_cl[b,i,0:C1] ]  (K = C2+C1;
- * C1 may be 0 with skip_cl NULL).  rows = B*n. */
+ * C1 may be 0 with skip_cl NULL).  rows = B*n.
+ * HOISTED FIRST LAYER (act_bias non-NULL, requires C1 == 0): interpolation is linear, so W.interp(x) = interp(W.x).
+ * The caller computes Y = W.known once per KNOWN point (m rows instead of n) and passes it as known_cl (C2 = width
+ * of that layer); the A row is relu(interp(Y) + act_bias) and wpack/bias describe the second layer. */
 int prcnn_mlp_interp(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3, const float* skip_cl,
-                     int ld_skip, int B, int n, int m, int C2, int C1, const float* wpack, const float* bias,
-                     int Nout, int relu, float* out, int ld_out, int col_off, prcnn_stream_t stream);
+                     int ld_skip, int B, int n, int m, int C2, int C1, const float* act_bias, const float* wpack,
+                     const float* bias, int Nout, int relu, float* out, int ld_out, int col_off,
+                     prcnn_stream_t stream);
+
+/* Hoisted FP first layer WITH skip features: out[row,n] = act( sum_k in[row,k]*W_b[n,k] + bias[n]
+ *                                                             + sum_j w3[row,j] * y_cl[b*m + idx3[row,j], n] )
+ * where `in` are the skip features (K = C1), W_b the skip columns of the first layer's weight and
+ * y_cl = W_a.known (B*m rows, ld_y floats apart) the interpolated part computed per known point.  rows = B*n. */
+int prcnn_mlp_rows_addinterp(const float* in, int ld_in, int K, const float* wpack, const float* bias, int Nout,
+                             int relu, const float* y_cl, int ld_y, const int32_t* idx3, const float* w3, int B, int n,
+                             int m, float* out, int ld_out, int col_off, prcnn_stream_t stream);
 
 /* Register-resident layer CHAIN: up to 3 consecutive layers (a whole SharedMLP) in ONE kernel; one wave owns 32
  * rows and carries them through every layer inside the register file (the MFMA accumulator layout of layer l is
@@ -142,18 +161,20 @@ int prcnn_mlp_interp(const float* known_cl, int ld_known, const int32_t* idx3, c
  * hold 32*ceil(nout[l]/32) floats (zero padded).  Limits: nout[l] <= 128; pool_ns in {0,16,32} (group variant:
  * pool_ns == nsample or 0).  Only a fixed set of width combinations is instantiated: ask
  * prcnn_mlp_chain_supported first, or handle PRCNN_EUNSUPPORTED by issuing the per-layer calls.
- * mode: 0 = rows, 1 = group, 2 = interp. */
+ * mode: 0 = rows, 1 = group, 2 = interp.  act_wx / act_bias: hoisted first layer, as for prcnn_mlp_group /
+ * prcnn_mlp_interp (the chain then starts at the second layer). */
 int prcnn_mlp_chain_supported(int mode, int nlayers, const int* nout, int pool_ns);
 int prcnn_mlp_chain_rows(const float* in, int ld_in, int64_t rows, int K, int nlayers, const float* const* wpack,
                          const float* const* bias, const int* nout, const int* relu, float* out, int ld_out,
                          int col_off, int pool_ns, prcnn_stream_t stream);
 int prcnn_mlp_chain_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl,
-                          int ld_feat, int B, int N, int M, int nsample, int C, int nlayers,
+                          int ld_feat, int B, int N, int M, int nsample, int C, const float* act_wx,
+                          const float* act_bias, int nlayers,
                           const float* const* wpack, const float* const* bias, const int* nout, const int* relu,
                           float* out, int ld_out, int col_off, int pool_ns, prcnn_stream_t stream);
 int prcnn_mlp_chain_interp(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3,
-                           const float* skip_cl, int ld_skip, int B, int n, int m, int C2, int C1, int nlayers,
-                           const float* const* wpack, const float* const* bias, const int* nout, const int* relu,
+                           const float* skip_cl, int ld_skip, int B, int n, int m, int C2, int C1,
+                           const float* act_bias, int nlayers, const float* const* wpack, const float* const* bias, const int* nout, const int* relu,
                            float* out, int ld_out, int col_off, prcnn_stream_t stream);
 
 /* out[r, col_off + c] = max over ns consecutive rows of in (generic nsample fallback for pooling) */

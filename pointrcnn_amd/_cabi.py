@@ -33,12 +33,13 @@ SIGNATURES = {
     "prcnn_wpack_floats": (_Z, [_I, _I]),
     "prcnn_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
     "prcnn_mlp_rows": (_I, [_P, _I, _L, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
-    "prcnn_mlp_group": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
-    "prcnn_mlp_interp": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P]),
+    "prcnn_mlp_group": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
+    "prcnn_mlp_interp": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P]),
+    "prcnn_mlp_rows_addinterp": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
     "prcnn_mlp_chain_supported": (_I, [_I, _I, _P, _I]),
     "prcnn_mlp_chain_rows": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "prcnn_mlp_chain_group": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "prcnn_mlp_chain_interp": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "prcnn_mlp_chain_group": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "prcnn_mlp_chain_interp": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "prcnn_maxpool_rows": (_I, [_P, _I, _L, _I, _I, _P, _I, _I, _P]),
     "prcnn_roipool3d": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "prcnn_pts_in_boxes3d": (_I, [_P, _P, _I, _I, _P, _P]),

@@ -54,6 +54,16 @@ struct MlpParams {
     const float* skip;
     int ld_known, ld_skip, n, m, C2, C1;
     int vec_a, vec_b;     // 16-byte vector loads legal for source a (feat/known/in) / source b (skip)
+    // ---- first-layer hoisting (the first conv of a SharedMLP is linear, gathers are linear: they commute) ----
+    // act = 1 (MODE_GROUP): the gathered source is Z = W_f . feat (pre-computed per SOURCE point); the A row is
+    //        relu(Z[idx] + act_wx . dxyz + act_bias), K = C (no appended dxyz columns)
+    // act = 2 (MODE_INTERP, C1 = 0): the interpolated source is Y = W . known; the A row is relu(interp(Y) + act_bias)
+    int act;
+    const float* act_wx;     // (K,3) row-major: the dxyz columns of the original first-layer weight
+    const float* act_bias;   // (K), padded to a multiple of 4
+    // epilogue add (MODE_PLAIN, no pooling): out += sum_j w3[row,j] * addY[b*m + idx3[row,j], n]  (before ReLU)
+    const float* addY;
+    int ldY;
 };
 
 template <int MODE> struct RowMeta;
@@ -131,6 +141,7 @@ template <> __device__ __forceinline__ float4 finish<MODE_PLAIN>(const MlpParams
 
 __device__ __forceinline__ float group_elem(const MlpParams& P, const RowMeta<MODE_GROUP>& r, int kk) {
     if (kk < P.C) return P.feat[r.off + kk];
+    if (P.act) return 0.f;                       // hoisted mode: K == C, nothing appended
     int t = kk - P.C;
     return t == 0 ? r.dx : (t == 1 ? r.dy : (t == 2 ? r.dz : 0.f));
 }
@@ -143,8 +154,24 @@ template <> __device__ __forceinline__ void fetch<MODE_GROUP>(const MlpParams& P
     v.a.z = group_elem(P, r, k + 2);
     v.a.w = group_elem(P, r, k + 3);
 }
-template <> __device__ __forceinline__ float4 finish<MODE_GROUP>(const MlpParams&, const RowMeta<MODE_GROUP>&, int, const Raw<MODE_GROUP>& v) {
-    return v.a;
+// relu(z + wx . d + b) for 4 consecutive channels k..k+3 (act_wx rows are 3 floats, act_bias padded to x4)
+__device__ __forceinline__ float4 act_group4(const MlpParams& P, float4 z, int k, float dx, float dy, float dz) {
+    const float4 w0 = ld4(P.act_wx + (long)k * 3), w1 = ld4(P.act_wx + (long)k * 3 + 4), w2 = ld4(P.act_wx + (long)k * 3 + 8);
+    const float4 b = ld4(P.act_bias + k);
+    float4 o;
+    o.x = fmaxf(z.x + (w0.x * dx + w0.y * dy + w0.z * dz) + b.x, 0.f);
+    o.y = fmaxf(z.y + (w0.w * dx + w1.x * dy + w1.y * dz) + b.y, 0.f);
+    o.z = fmaxf(z.z + (w1.z * dx + w1.w * dy + w2.x * dz) + b.z, 0.f);
+    o.w = fmaxf(z.w + (w2.y * dx + w2.z * dy + w2.w * dz) + b.w, 0.f);
+    return o;
+}
+template <> __device__ __forceinline__ float4 finish<MODE_GROUP>(const MlpParams& P, const RowMeta<MODE_GROUP>& r, int k, const Raw<MODE_GROUP>& v) {
+    if (!P.act || !r.valid || k >= P.K) return v.a;
+    float4 o = act_group4(P, v.a, k, r.dx, r.dy, r.dz);
+    if (k + 1 >= P.K) o.y = 0.f;                  // keep the zero padding beyond K
+    if (k + 2 >= P.K) o.z = 0.f;
+    if (k + 3 >= P.K) o.w = 0.f;
+    return o;
 }
 
 __device__ __forceinline__ float interp1(float w0, float f0, float w1, float f1, float w2, float f2) {
@@ -192,7 +219,23 @@ template <> __device__ __forceinline__ float4 finish<MODE_INTERP>(const MlpParam
     o.y = (k + 1 < P.C2) ? interp1(r.w0, v.a.y, r.w1, v.b.y, r.w2, v.c.y) : v.a.y;
     o.z = (k + 2 < P.C2) ? interp1(r.w0, v.a.z, r.w1, v.b.z, r.w2, v.c.z) : v.a.z;
     o.w = (k + 3 < P.C2) ? interp1(r.w0, v.a.w, r.w1, v.b.w, r.w2, v.c.w) : v.a.w;
+    if (P.act && r.valid) {                       // hoisted mode (C1 == 0): relu(interp(Y) + b), zero padding kept
+        const float4 b = ld4(P.act_bias + k);
+        o.x = fmaxf(o.x + b.x, 0.f);
+        o.y = (k + 1 < P.C2) ? fmaxf(o.y + b.y, 0.f) : 0.f;
+        o.z = (k + 2 < P.C2) ? fmaxf(o.z + b.z, 0.f) : 0.f;
+        o.w = (k + 3 < P.C2) ? fmaxf(o.w + b.w, 0.f) : 0.f;
+    }
     return o;
+}
+
+// sum_j w3[row,j] * addY[(b*m + idx3[row,j]) * ldY + n]: the interpolated pre-activation of the hoisted FP first layer
+__device__ __forceinline__ float interp_gather(const MlpParams& P, long row, int n) {
+    const int b = (int)(row / P.n);
+    const int32_t* id = P.idx3 + row * 3;
+    const float* w = P.w3 + row * 3;
+    const float* y = P.addY + (long)b * P.m * P.ldY + n;
+    return (w[0] * y[(long)id[0] * P.ldY] + w[1] * y[(long)id[1] * P.ldY]) + w[2] * y[(long)id[2] * P.ldY];
 }
 
 // WNB = 32-column blocks per wave: 1 -> workgroup tile 128x64 (narrow layers), 2 -> 128x128 (wide layers: twice
@@ -307,6 +350,10 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
                 int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
                 long g0 = wrow0 + rin, g1 = wrow0 + 32 + rin;
                 float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
+                if (P.addY && n_ok) {             // hoisted FP first layer: + sum_j w_j * Y[idx_j, n]
+                    if (g0 < P.rows) v0 += interp_gather(P, g0, n);
+                    if (g1 < P.rows) v1 += interp_gather(P, g1, n);
+                }
                 if (P.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
                 if (n_ok && g0 < P.rows) P.out[g0 * P.ld_out + P.col_off + n] = v0;
                 if (n_ok && g1 < P.rows) P.out[g1 * P.ld_out + P.col_off + n] = v1;
@@ -667,10 +714,36 @@ PRCNN_API int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, co
     return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
 }
 
+// act_wx / act_bias non-null: hoisted first layer -- feat_cl is Z = W_f . feat per source point (C = width of that
+// layer), the A row is relu(Z[idx] + act_wx . dxyz + act_bias) and K = C.
+static int set_group_act(MlpParams& P, const float* act_wx, const float* act_bias, int C) {
+    if (!act_wx && !act_bias) return PRCNN_OK;
+    PRCNN_REQUIRE(act_wx && act_bias && C > 0, "prcnn_mlp_group: act_wx and act_bias must both be given (C > 0)");
+    PRCNN_REQUIRE(aligned16(act_wx) && aligned16(act_bias) && C % 4 == 0,
+                  "prcnn_mlp_group: hoisted mode needs 16-byte aligned act_wx/act_bias and C %% 4 == 0 (C=%d)", C);
+    P.act = 1; P.act_wx = act_wx; P.act_bias = act_bias; P.K = C;
+    return PRCNN_OK;
+}
+
+PRCNN_API int prcnn_mlp_rows_addinterp(const float* in, int ld_in, int K, const float* wpack, const float* bias, int Nout,
+                                       int relu, const float* y_cl, int ld_y, const int32_t* idx3, const float* w3, int B,
+                                       int n, int m, float* out, int ld_out, int col_off, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(in && y_cl && idx3 && w3, "prcnn_mlp_rows_addinterp: null pointer");
+    PRCNN_REQUIRE(B >= 0 && n > 0 && m > 0 && ld_in >= K && ld_y >= Nout && ld_out >= col_off + Nout,
+                  "prcnn_mlp_rows_addinterp: bad shape B=%d n=%d m=%d K=%d Nout=%d", B, n, m, K, Nout);
+    MlpParams P = {};
+    P.rows = (long)B * n; P.K = K; P.wpack = wpack; P.bias = bias; P.Nout = Nout; P.relu = relu;
+    P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.pool_ns = 0;
+    P.in = in; P.ld_in = ld_in;
+    P.vec_a = aligned16(in) && (ld_in % 4 == 0);
+    P.addY = y_cl; P.ldY = ld_y; P.idx3 = idx3; P.w3 = w3; P.n = n; P.m = m;
+    return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
+}
+
 PRCNN_API int prcnn_mlp_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl,
-                              int ld_feat, int B, int N, int M, int nsample, int C, const float* wpack,
-                              const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, int pool_ns,
-                              prcnn_stream_t stream) {
+                              int ld_feat, int B, int N, int M, int nsample, int C, const float* act_wx,
+                              const float* act_bias, const float* wpack, const float* bias, int Nout, int relu,
+                              float* out, int ld_out, int col_off, int pool_ns, prcnn_stream_t stream) {
     PRCNN_REQUIRE(xyz && idx, "prcnn_mlp_group: null pointer");
     PRCNN_REQUIRE(C == 0 || feat_cl, "prcnn_mlp_group: C=%d but feat_cl is null", C);
     PRCNN_REQUIRE(B >= 0 && N > 0 && M > 0 && nsample > 0 && C >= 0 && (C == 0 || ld_feat >= C),
@@ -682,13 +755,25 @@ PRCNN_API int prcnn_mlp_group(const float* xyz, const float* new_xyz, const int3
     P.xyz = xyz; P.new_xyz = new_xyz; P.idx = idx; P.feat = feat_cl; P.ld_feat = ld_feat;
     P.N = N; P.M = M; P.ns = nsample; P.C = C;
     P.vec_a = C > 0 && aligned16(feat_cl) && (ld_feat % 4 == 0);
+    int rc = set_group_act(P, act_wx, act_bias, C);
+    if (rc) return rc;
     return launch_mlp(MODE_GROUP, P, (hipStream_t)stream);
+}
+
+// act_bias non-null (requires C1 == 0): hoisted first layer -- known_cl is Y = W . known per known point, the A row
+// is relu(interp(Y) + act_bias).
+static int set_interp_act(MlpParams& P, const float* act_bias, int C2, int C1) {
+    if (!act_bias) return PRCNN_OK;
+    PRCNN_REQUIRE(C1 == 0 && aligned16(act_bias) && C2 % 4 == 0,
+                  "prcnn_mlp_interp: hoisted mode needs C1 == 0, aligned act_bias and C2 %% 4 == 0 (C2=%d C1=%d)", C2, C1);
+    P.act = 2; P.act_bias = act_bias;
+    return PRCNN_OK;
 }
 
 PRCNN_API int prcnn_mlp_interp(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3,
                                const float* skip_cl, int ld_skip, int B, int n, int m, int C2, int C1,
-                               const float* wpack, const float* bias, int Nout, int relu, float* out, int ld_out,
-                               int col_off, prcnn_stream_t stream) {
+                               const float* act_bias, const float* wpack, const float* bias, int Nout, int relu,
+                               float* out, int ld_out, int col_off, prcnn_stream_t stream) {
     PRCNN_REQUIRE(known_cl && idx3 && w3, "prcnn_mlp_interp: null pointer");
     PRCNN_REQUIRE(C1 == 0 || skip_cl, "prcnn_mlp_interp: C1=%d but skip_cl is null", C1);
     PRCNN_REQUIRE(B >= 0 && n > 0 && m > 0 && C2 > 0 && C1 >= 0 && ld_known >= C2 && (C1 == 0 || ld_skip >= C1),
@@ -701,6 +786,8 @@ PRCNN_API int prcnn_mlp_interp(const float* known_cl, int ld_known, const int32_
     P.n = n; P.m = m; P.C2 = C2; P.C1 = C1;
     P.vec_a = aligned16(known_cl) && (ld_known % 4 == 0);
     P.vec_b = C1 > 0 && aligned16(skip_cl) && (ld_skip % 4 == 0) && (C2 % 4 == 0);
+    int rc = set_interp_act(P, act_bias, C2, C1);
+    if (rc) return rc;
     return launch_mlp(MODE_INTERP, P, (hipStream_t)stream);
 }
 
@@ -726,7 +813,9 @@ static int nb32(int n) { return (n + 31) / 32; }
 
 static bool chain_instance_exists(int mode, int n0, int n1, int n2) {
     struct { int m, a, b, c; } T[] = {{MODE_GROUP, 1, 1, 1}, {MODE_GROUP, 1, 1, 2}, {MODE_GROUP, 2, 2, 4}, {MODE_GROUP, 2, 3, 4},
-                                      {MODE_INTERP, 4, 4, 0}, {MODE_PLAIN, 4, 4, 0}, {MODE_PLAIN, 4, 1, 0}, {MODE_PLAIN, 4, 3, 0}};
+                                      {MODE_GROUP, 2, 4, 0}, {MODE_GROUP, 3, 4, 0},          // hoisted SA2 stacks
+                                      {MODE_INTERP, 4, 4, 0}, {MODE_INTERP, 4, 0, 0},        // FP0 / hoisted FP0
+                                      {MODE_PLAIN, 4, 4, 0}, {MODE_PLAIN, 4, 1, 0}, {MODE_PLAIN, 4, 3, 0}};
     for (auto& t : T)
         if (t.m == mode && t.a == n0 && t.b == n1 && t.c == n2) return true;
     return false;
@@ -754,7 +843,10 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
     CHAIN_CASE(MODE_GROUP, 1, 1, 2)
     CHAIN_CASE(MODE_GROUP, 2, 2, 4)
     CHAIN_CASE(MODE_GROUP, 2, 3, 4)
+    CHAIN_CASE(MODE_GROUP, 2, 4, 0)
+    CHAIN_CASE(MODE_GROUP, 3, 4, 0)
     CHAIN_CASE(MODE_INTERP, 4, 4, 0)
+    CHAIN_CASE(MODE_INTERP, 4, 0, 0)
     CHAIN_CASE(MODE_PLAIN, 4, 4, 0)
     CHAIN_CASE(MODE_PLAIN, 4, 1, 0)
     CHAIN_CASE(MODE_PLAIN, 4, 3, 0)
@@ -796,7 +888,8 @@ PRCNN_API int prcnn_mlp_chain_rows(const float* in, int ld_in, int64_t rows, int
 }
 
 PRCNN_API int prcnn_mlp_chain_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl,
-                                    int ld_feat, int B, int N, int M, int nsample, int C_, int nlayers,
+                                    int ld_feat, int B, int N, int M, int nsample, int C_, const float* act_wx,
+                                    const float* act_bias, int nlayers,
                                     const float* const* wpack, const float* const* bias, const int* nout,
                                     const int* relu, float* out, int ld_out, int col_off, int pool_ns,
                                     prcnn_stream_t stream) {
@@ -810,12 +903,14 @@ PRCNN_API int prcnn_mlp_chain_group(const float* xyz, const float* new_xyz, cons
     C.a.xyz = xyz; C.a.new_xyz = new_xyz; C.a.idx = idx; C.a.feat = feat_cl; C.a.ld_feat = ld_feat;
     C.a.N = N; C.a.M = M; C.a.ns = nsample; C.a.C = C_;
     C.a.vec_a = C_ > 0 && aligned16(feat_cl) && (ld_feat % 4 == 0);
+    rc = set_group_act(C.a, act_wx, act_bias, C_);
+    if (rc) return rc;
     return dispatch_chain(MODE_GROUP, C, (hipStream_t)stream);
 }
 
 PRCNN_API int prcnn_mlp_chain_interp(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3,
                                      const float* skip_cl, int ld_skip, int B, int n, int m, int C2, int C1,
-                                     int nlayers, const float* const* wpack, const float* const* bias,
+                                     const float* act_bias, int nlayers, const float* const* wpack, const float* const* bias,
                                      const int* nout, const int* relu, float* out, int ld_out, int col_off,
                                      prcnn_stream_t stream) {
     PRCNN_REQUIRE(known_cl && idx3 && w3 && (C1 == 0 || skip_cl), "prcnn_mlp_chain_interp: null pointer");
@@ -828,5 +923,7 @@ PRCNN_API int prcnn_mlp_chain_interp(const float* known_cl, int ld_known, const 
     C.a.n = n; C.a.m = m; C.a.C2 = C2; C.a.C1 = C1;
     C.a.vec_a = aligned16(known_cl) && (ld_known % 4 == 0);
     C.a.vec_b = C1 > 0 && aligned16(skip_cl) && (ld_skip % 4 == 0) && (C2 % 4 == 0);
+    rc = set_interp_act(C.a, act_bias, C2, C1);
+    if (rc) return rc;
     return dispatch_chain(MODE_INTERP, C, (hipStream_t)stream);
 }

@@ -20,6 +20,8 @@ from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
 
 _POOL_FUSED = (16, 32, 64)
+# exact-algebra optimisation of the fused inference path (see _forward_fused); switchable for A/B tests
+HOIST_FIRST_LAYER = True
 
 
 def _channels_last(features):
@@ -103,26 +105,48 @@ class _PointnetSAModuleBase(nn.Module):
             else:                                   # GroupAll: one group holding every point, no centring
                 idxs[i] = torch.arange(N, dtype=torch.int32, device=xyz.device).view(1, 1, N).expand(B, 1, N).contiguous()
 
+        # First-layer hoisting: the first conv of every scale is linear and grouping is a linear gather, so
+        # W.[dxyz; feat[idx]] = W_x.dxyz + (W_f.feat)[idx].  Z = W_f.feat is computed ONCE per source point for all
+        # scales in a single GEMM (N rows instead of M*nsample rows: 4-8x fewer), the grouped rows then enter the
+        # second layer as relu(Z[idx] + W_x.dxyz + b).  Same result up to fp32 reassociation.
+        hoist = None
+        if feat_cl is not None and HOIST_FIRST_LAYER:
+            parts = [mlp.layers()[0].hoisted_group() if len(mlp.layers()) >= 2 else None for mlp in self.mlps]
+            if all(p is not None for p in parts):
+                key = tuple(id(p[0]) for p in parts)
+                if getattr(self, "_prcnn_zlin", (None, None))[0] != key:
+                    self._prcnn_zlin = (key, ops.PackedLinear(torch.cat([p[0] for p in parts], 0).contiguous(), None, relu=False))
+                z_all = ops.mlp_rows(feat_cl, self._prcnn_zlin[1]).view(B, N, -1)
+                hoist, zoff = [], 0
+                for p in parts:
+                    hoist.append((z_all[..., zoff:zoff + p[0].shape[0]], (p[1], p[2])))
+                    zoff += p[0].shape[0]
+
         col = 0
         for i, (g, mlp) in enumerate(zip(self.groupers, self.mlps)):
             group_all = not isinstance(g, pointnet2_utils.QueryAndGroup)
             ns = idxs[i].shape[2]
             mods = mlp.layers()
-            # torch's grouped channel order is [dxyz(3), feat(C)]; the kernel's A row is [feat(C), dxyz(3)]
-            layers = [mods[0].packed(k_rot=3 if feat_cl is not None else 0)] + [m.packed() for m in mods[1:]]
             fused_pool = ns in _POOL_FUSED
             dst = (out_cl.view(B * M, -1), col)
             ctr = None if group_all else new_xyz
+            if hoist is not None:
+                src, act = hoist[i]
+                layers = [m.packed() for m in mods[1:]]
+            else:
+                src, act = feat_cl, None
+                # torch's grouped channel order is [dxyz(3), feat(C)]; the kernel's A row is [feat(C), dxyz(3)]
+                layers = [mods[0].packed(k_rot=3 if feat_cl is not None else 0)] + [m.packed() for m in mods[1:]]
             if fused_pool and ns in (16, 32) and ops.chain_supported(1, layers, ns):
-                # whole SharedMLP + max-pool in one register-resident kernel
-                ops.mlp_chain_group(xyz, ctr, idxs[i], feat_cl, layers, out=dst, pool_ns=ns)
+                # whole (remaining) SharedMLP + max-pool in one register-resident kernel
+                ops.mlp_chain_group(xyz, ctr, idxs[i], src, layers, out=dst, pool_ns=ns, act=act)
                 col += c_outs[i]
                 continue
             if len(layers) == 1:
-                x = ops.mlp_group(xyz, ctr, idxs[i], feat_cl, layers[0], out=dst if fused_pool else None,
-                                  pool_ns=ns if fused_pool else 0)
+                x = ops.mlp_group(xyz, ctr, idxs[i], src, layers[0], out=dst if fused_pool else None,
+                                  pool_ns=ns if fused_pool else 0, act=act)
             else:
-                x = ops.mlp_group(xyz, ctr, idxs[i], feat_cl, layers[0])
+                x = ops.mlp_group(xyz, ctr, idxs[i], src, layers[0], act=act)
                 x = _run_mlp_tail(x, layers, 1, dst if fused_pool else None, ns if fused_pool else 0)
             if not fused_pool:
                 ops.maxpool_rows(x, ns, out=dst)
@@ -193,7 +217,25 @@ class PointnetFPModule(nn.Module):
         _, idx3, w3 = ops.three_nn(unknown, known, want_weight=True)
         known_cl = _channels_last(known_feats)
         skip_cl = _channels_last(unknow_feats)
-        layers = [m.packed() for m in self.mlp.layers()]
+        mods = self.mlp.layers()
+        # First-layer hoisting: interpolation is linear, so W.[interp(x); skip] = interp(W_a.x) + W_b.skip.  W_a.x is
+        # computed per KNOWN point (m rows instead of n: 4x fewer); the interpolated rows are added in the epilogue of
+        # the skip GEMM, or (no skip features) enter the second layer as relu(interp(Y) + b).
+        parts = mods[0].hoisted_interp(known_cl.shape[-1]) if HOIST_FIRST_LAYER else None
+        if parts is not None and (skip_cl is not None or len(mods) >= 2):
+            lin_a, lin_b, bias0 = parts
+            y = ops.mlp_rows(known_cl, lin_a).view(B, known_cl.shape[1], -1)
+            rest = [m.packed() for m in mods[1:]]
+            if skip_cl is not None:
+                x = ops.mlp_rows_addinterp(skip_cl, lin_b, y, idx3, w3)
+                x = _run_mlp_tail(x, rest, 0, None, 0) if rest else x
+            elif ops.chain_supported(2, rest, 0):
+                x = ops.mlp_chain_interp(y, idx3, w3, None, rest, act_bias=bias0)
+            else:
+                x = ops.mlp_interp(y, idx3, w3, None, rest[0], act_bias=bias0)
+                x = _run_mlp_tail(x, rest, 1, None, 0)
+            return x.view(B, n, -1).transpose(1, 2)
+        layers = [m.packed() for m in mods]
         if ops.chain_supported(2, layers, 0):
             x = ops.mlp_chain_interp(known_cl, idx3, w3, skip_cl, layers)
         else:

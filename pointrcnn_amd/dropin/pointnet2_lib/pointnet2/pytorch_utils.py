@@ -176,6 +176,55 @@ class _ConvBase(nn.Sequential):
         self._prcnn_cache[k_rot] = (key, lin)
         return lin
 
+    def _folded(self):
+        """(w (Nout,K), b (Nout) or None, has_relu, cache key) of conv + eval-BN"""
+        conv, bn, act = self._parts()
+        tensors = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
+        if bn is not None:
+            tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        w, b = _fold_bn(conv, bn)
+        return w, b, act is not None, key
+
+    def _cached(self, tag, build):
+        conv, bn, _ = self._parts()
+        tensors = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
+        if bn is not None:
+            tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        hit = self._prcnn_cache.get(tag)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        val = build()
+        self._prcnn_cache[tag] = (key, val)
+        return val
+
+    def hoisted_group(self):
+        """First layer of an SA stack, split for hoisting: W = [W_x (dxyz, 3 cols) | W_f (features)] in torch's grouped
+        channel order.  -> (w_f (N0,C) tensor, act_wx (N0,3), act_bias (N0)) or None when not applicable."""
+        def build():
+            w, b, relu, _ = self._folded()
+            n0, k = w.shape
+            if not relu or k <= 3 or n0 % 4 or (k - 3) % 4:
+                return None
+            bias = b if b is not None else torch.zeros(n0, device=w.device)
+            return (w[:, 3:].contiguous(), w[:, :3].contiguous(), bias.contiguous())
+        return self._cached("hoist_group", build)
+
+    def hoisted_interp(self, c2):
+        """First layer of an FP stack, split for hoisting: W = [W_a (interpolated, c2 cols) | W_b (skip)].
+        -> (lin_a: PackedLinear(W_a, no bias, no act), lin_b: PackedLinear(W_b, bias, relu) or None, bias (N0)) or None"""
+        def build():
+            w, b, relu, _ = self._folded()
+            n0, k = w.shape
+            if not relu or n0 % 4 or c2 % 4 or c2 > k:
+                return None
+            bias = (b if b is not None else torch.zeros(n0, device=w.device)).contiguous()
+            lin_a = ops.PackedLinear(w[:, :c2].contiguous(), None, relu=False)
+            lin_b = ops.PackedLinear(w[:, c2:].contiguous(), bias, relu=True) if k > c2 else None
+            return (lin_a, lin_b, bias)
+        return self._cached(("hoist_interp", c2), build)
+
     def forward(self, x):
         if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or not self.fusable():
             return super().forward(x)

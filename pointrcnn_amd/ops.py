@@ -226,7 +226,7 @@ def mlp_chain_rows(x, layers, out=None, pool_ns=0):
     return buf
 
 
-def mlp_chain_group(xyz, new_xyz, idx, feat_cl, layers, out=None, pool_ns=0):
+def mlp_chain_group(xyz, new_xyz, idx, feat_cl, layers, out=None, pool_ns=0, act=None):
     B, N, _ = xyz.shape
     _, M, ns = idx.shape
     C = 0 if feat_cl is None else feat_cl.shape[-1]
@@ -235,13 +235,14 @@ def mlp_chain_group(xyz, new_xyz, idx, feat_cl, layers, out=None, pool_ns=0):
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, layers[-1], xyz.device)
     a = _chain_args(layers)
-    _cabi.check(_cabi.lib().prcnn_mlp_chain_group(_p(xyz), _p(new_xyz), _p(idx), _p(feat_cl), ld_feat, B, N, M, ns, C, a.n,
+    awx, ab = (None, None) if act is None else act
+    _cabi.check(_cabi.lib().prcnn_mlp_chain_group(_p(xyz), _p(new_xyz), _p(idx), _p(feat_cl), ld_feat, B, N, M, ns, C, _p(awx), _p(ab), a.n,
                                                   a.wpack, a.bias, a.nout, a.relu, _p(buf), ld_out, col_off, pool_ns,
                                                   _stream()), "prcnn_mlp_chain_group")
     return buf
 
 
-def mlp_chain_interp(known_cl, idx3, w3, skip_cl, layers, out=None):
+def mlp_chain_interp(known_cl, idx3, w3, skip_cl, layers, out=None, act_bias=None):
     B, m, C2 = known_cl.shape
     n = idx3.shape[1]
     C1 = 0 if skip_cl is None else skip_cl.shape[-1]
@@ -249,8 +250,8 @@ def mlp_chain_interp(known_cl, idx3, w3, skip_cl, layers, out=None):
     buf, ld_out, col_off = _out_buf(out, B * n, layers[-1], known_cl.device)
     a = _chain_args(layers)
     _cabi.check(_cabi.lib().prcnn_mlp_chain_interp(_p(known_cl), _row_stride(known_cl), _p(idx3), _p(w3), _p(skip_cl), ld_skip,
-                                                   B, n, m, C2, C1, a.n, a.wpack, a.bias, a.nout, a.relu, _p(buf), ld_out,
-                                                   col_off, _stream()), "prcnn_mlp_chain_interp")
+                                                   B, n, m, C2, C1, _p(act_bias), a.n, a.wpack, a.bias, a.nout, a.relu, _p(buf),
+                                                   ld_out, col_off, _stream()), "prcnn_mlp_chain_interp")
     return buf
 
 
@@ -285,9 +286,11 @@ def mlp_rows(x, lin, out=None, pool_ns=0):
     return buf
 
 
-def mlp_group(xyz, new_xyz, idx, feat_cl, lin, out=None, pool_ns=0):
+def mlp_group(xyz, new_xyz, idx, feat_cl, lin, out=None, pool_ns=0, act=None):
     """First SA layer fused with ball-query grouping.  xyz (B,N,3), new_xyz (B,M,3) or None (GroupAll),
-    idx (B,M,ns) i32, feat_cl (B,N,C) channels-last or None -> (B*M*ns[/pool_ns], Nout)."""
+    idx (B,M,ns) i32, feat_cl (B,N,C) channels-last or None -> (B*M*ns[/pool_ns], Nout).
+    act = (act_wx (C,3), act_bias (C)) selects the HOISTED form: feat_cl is Z = W_f.feat per source point and `lin` is
+    the SECOND layer (see include/prcnn_pointops.h)."""
     B, N, _ = xyz.shape
     _, M, ns = idx.shape
     C = 0 if feat_cl is None else feat_cl.shape[-1]
@@ -295,23 +298,38 @@ def mlp_group(xyz, new_xyz, idx, feat_cl, lin, out=None, pool_ns=0):
     rows = B * M * ns
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, lin, xyz.device)
-    _cabi.check(_cabi.lib().prcnn_mlp_group(_p(xyz), _p(new_xyz), _p(idx), _p(feat_cl), ld_feat, B, N, M, ns, C,
+    awx, ab = (None, None) if act is None else act
+    _cabi.check(_cabi.lib().prcnn_mlp_group(_p(xyz), _p(new_xyz), _p(idx), _p(feat_cl), ld_feat, B, N, M, ns, C, _p(awx), _p(ab),
                                             _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu), _p(buf), ld_out,
                                             col_off, pool_ns, _stream()), "prcnn_mlp_group")
     return buf
 
 
-def mlp_interp(known_cl, idx3, w3, skip_cl, lin, out=None):
+def mlp_interp(known_cl, idx3, w3, skip_cl, lin, out=None, act_bias=None):
     """First FP layer fused with three_interpolate + skip concat.  known_cl (B,m,C2), idx3/w3 (B,n,3),
-    skip_cl (B,n,C1) or None -> (B*n, Nout)."""
+    skip_cl (B,n,C1) or None -> (B*n, Nout).  act_bias (C2) selects the HOISTED form (skip_cl must be None): known_cl
+    is Y = W.known per known point, the row is relu(interp(Y) + act_bias) and `lin` is the second layer."""
     B, m, C2 = known_cl.shape
     n = idx3.shape[1]
     C1 = 0 if skip_cl is None else skip_cl.shape[-1]
     ld_skip = 0 if skip_cl is None else _row_stride(skip_cl)
     buf, ld_out, col_off = _out_buf(out, B * n, lin, known_cl.device)
     _cabi.check(_cabi.lib().prcnn_mlp_interp(_p(known_cl), _row_stride(known_cl), _p(idx3), _p(w3), _p(skip_cl), ld_skip,
-                                             B, n, m, C2, C1, _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu),
-                                             _p(buf), ld_out, col_off, _stream()), "prcnn_mlp_interp")
+                                             B, n, m, C2, C1, _p(act_bias), _p(lin.wpack), _p(lin.bias), lin.nout,
+                                             int(lin.relu), _p(buf), ld_out, col_off, _stream()), "prcnn_mlp_interp")
+    return buf
+
+
+def mlp_rows_addinterp(skip_cl, lin_b, y_cl, idx3, w3, out=None):
+    """Hoisted FP first layer with skip features: act(skip . W_b^T + bias + interp(y_cl)); skip_cl (B,n,C1),
+    y_cl (B,m,Nout) = W_a.known, idx3/w3 (B,n,3) -> (B*n, Nout)."""
+    B, n, C1 = skip_cl.shape
+    m = y_cl.shape[1]
+    buf, ld_out, col_off = _out_buf(out, B * n, lin_b, skip_cl.device)
+    _cabi.check(_cabi.lib().prcnn_mlp_rows_addinterp(_p(skip_cl), _row_stride(skip_cl), C1, _p(lin_b.wpack), _p(lin_b.bias),
+                                                     lin_b.nout, int(lin_b.relu), _p(y_cl), _row_stride(y_cl), _p(idx3),
+                                                     _p(w3), B, n, m, _p(buf), ld_out, col_off, _stream()),
+                "prcnn_mlp_rows_addinterp")
     return buf
 
 

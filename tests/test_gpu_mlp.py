@@ -211,3 +211,70 @@ def test_chain_unsupported_shapes_are_reported_not_guessed(dev):
     assert not ops.chain_supported(0, layers, 0)            # 256 > 128
     with pytest.raises(_cabi.PointOpsError):
         ops.mlp_chain_rows(torch.zeros(64, 20, device=dev), layers)
+
+
+# ------------------------------------------------------------------ first-layer hoisting (exact algebra, fewer FLOPs)
+@pytest.mark.parametrize("chain", [False, True])
+def test_hoisted_group_equals_unhoisted_oracle(dev, cpu, chain):
+    """W.[dxyz; feat[idx]] computed as relu((W_f.feat)[idx] + W_x.dxyz + b): compared against the oracle's plain
+    group -> layer -> layer -> max-pool on the ORIGINAL weights (SA2 widths 99 -> 64 -> 96 -> 128, nsample 32)"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(21)
+    B, N, M, ns, C = 2, 900, 40, 32, 96
+    widths = (64, 96, 128) if chain else (64, 160, 72)      # (3,4,0)/32 has a chain instance; 160 forces the tiled path
+    xyz = unit_cloud(B, N, seed=4)
+    new_xyz = xyz[:, :M].copy()
+    idx = cpu.ball_query(0.3, ns, xyz, new_xyz)
+    feat = r.normal(size=(B, C, N)).astype(np.float32)
+    ws, bs = _stack(r, (C + 3,) + widths, 0.15)
+    gx = cpu.group(xyz.transpose(0, 2, 1), idx) - new_xyz.transpose(0, 2, 1)[..., None]
+    rows = np.concatenate([gx, cpu.group(feat, idx)], 1).transpose(0, 2, 3, 1).reshape(-1, C + 3)
+    for w, b in zip(ws, bs):
+        rows = cpu.linear_rows(rows, w, b, True)
+    want = rows.reshape(B * M, ns, -1).max(1)
+    # hoisted: Z per source point, second/third layers on activated gathered rows
+    feat_cl = T(feat.transpose(0, 2, 1), dev)
+    z = ops.mlp_rows(feat_cl, lin(dev, ws[0][:, 3:].copy(), None, False)).view(B, N, -1)
+    act = (T(ws[0][:, :3].copy(), dev), T(bs[0], dev))
+    rest = [lin(dev, w, b, True) for w, b in zip(ws[1:], bs[1:])]
+    if chain:
+        assert ops.chain_supported(1, rest, ns)
+        got = ops.mlp_chain_group(T(xyz, dev), T(new_xyz, dev), T(idx, dev), z, rest, pool_ns=ns, act=act)
+    else:
+        x = ops.mlp_group(T(xyz, dev), T(new_xyz, dev), T(idx, dev), z, rest[0], act=act)
+        got = ops.mlp_rows(x, rest[1], pool_ns=ns)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=mlp_tol(want), rtol=0)
+
+
+def test_hoisted_interp_equals_unhoisted_oracle(dev, cpu):
+    """W.[interp(x); skip] computed as interp(W_a.x) + W_b.skip (epilogue add), and the no-skip form
+    relu(interp(Y) + b) feeding the second layer (tiled and chain), vs the oracle's plain interpolate -> layers"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(22)
+    B, n, m, C2, C1 = 2, 500, 130, 256, 96
+    unk, kn = unit_cloud(B, n, seed=5), unit_cloud(B, m, seed=6)
+    d2, idx3 = cpu.three_nn(unk, kn)
+    w3 = cpu.three_weights(d2)
+    kf = r.normal(size=(B, C2, m)).astype(np.float32)
+    sf = r.normal(size=(B, C1, n)).astype(np.float32)
+    interp = cpu.three_interp(kf, idx3, w3)
+    # with skip: 352 -> 256 -> 256 (FP1 shape class)
+    ws, bs = _stack(r, (C2 + C1, 256, 256), 0.08)
+    rows = np.concatenate([interp, sf], 1).transpose(0, 2, 1).reshape(-1, C2 + C1)
+    want = cpu.linear_rows(cpu.linear_rows(rows, ws[0], bs[0], True), ws[1], bs[1], True)
+    y = ops.mlp_rows(T(kf.transpose(0, 2, 1), dev), lin(dev, ws[0][:, :C2].copy(), None, False)).view(B, m, -1)
+    x = ops.mlp_rows_addinterp(T(sf.transpose(0, 2, 1), dev), lin(dev, ws[0][:, C2:].copy(), bs[0], True), y, T(idx3, dev), T(w3, dev))
+    got = ops.mlp_rows(x, lin(dev, ws[1], bs[1], True)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=mlp_tol(want), rtol=0)
+    # without skip: 256 -> 128 -> 128 (FP0): chain (4,0,0) and tiled
+    ws, bs = _stack(r, (C2, 128, 128), 0.08)
+    rows = interp.transpose(0, 2, 1).reshape(-1, C2)
+    want = cpu.linear_rows(cpu.linear_rows(rows, ws[0], bs[0], True), ws[1], bs[1], True)
+    y = ops.mlp_rows(T(kf.transpose(0, 2, 1), dev), lin(dev, ws[0], None, False)).view(B, m, -1)
+    l1 = lin(dev, ws[1], bs[1], True)
+    b0 = T(bs[0], dev)
+    assert ops.chain_supported(2, [l1], 0)
+    got_c = ops.mlp_chain_interp(y, T(idx3, dev), T(w3, dev), None, [l1], act_bias=b0).cpu().numpy()
+    got_t = ops.mlp_interp(y, T(idx3, dev), T(w3, dev), None, l1, act_bias=b0).cpu().numpy()
+    np.testing.assert_allclose(got_c, want, atol=mlp_tol(want), rtol=0)
+    np.testing.assert_allclose(got_t, want, atol=mlp_tol(want), rtol=0)
