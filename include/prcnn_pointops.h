@@ -52,8 +52,11 @@ const char* prcnn_last_error(void);
  * ------------------------------------------------------------------------------------------- */
 
 /* furthest_point_sampling_wrapper(B,N,npoint,xyz,temp,idx): xyz (B,N,3) -> idx (B,npoint) i32.
- * Start index 0, ties -> lowest point index.  `tmp` (B,N) f32 scratch is only needed when
- * N > 16384 (HBM-resident variant); may be NULL otherwise. */
+ * Start index 0, ties -> lowest point index.  `tmp` (B,N) 4-byte scratch (upstream's `temp` argument):
+ *   N > 16384           required: HBM-resident running min-distances;
+ *   2048 < N <= 16384   optional: when given, selects the spatially pruned kernel (Morton pre-sort into `tmp`, exact
+ *                       bounding-box skip; bit-identical results); NULL = the register-resident kernel;
+ *   N <= 2048           ignored. */
 int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, int32_t* idx, prcnn_stream_t stream);
 
 /* gather_points_wrapper(B,C,N,npoint,feat,idx,out): out[b,c,m] = feat[b,c,idx[b,m]] */

@@ -5,6 +5,7 @@ libprcnn_pointops.so on torch's CURRENT stream (so it composes with torch.cuda.g
 Shapes and argument meaning mirror the reference op surface (see each function's citation).
 """
 import ctypes
+import os
 
 import torch
 
@@ -12,6 +13,9 @@ from . import _cabi
 
 _INT = torch.int32
 _F32 = torch.float32
+# Opt-in: the spatially pruned FPS kernel (Morton pre-sort + exact bounding-box skip) for 2048 < N <= 16384.  Bit-identical
+# results; faster for a single batch in flight, slightly slower when several batches share the GPU (see csrc/fps.hip).
+FPS_PRUNED = os.environ.get("PRCNN_FPS_PRUNED", "0") == "1"
 
 
 def _stream():
@@ -42,7 +46,9 @@ def furthest_point_sample(xyz, npoint):
     _chk(xyz, "xyz", ndim=3)
     B, N, _ = xyz.shape
     idx = torch.empty((B, npoint), dtype=_INT, device=xyz.device)
-    tmp = torch.empty((B, N), dtype=_F32, device=xyz.device) if N > 16384 else None
+    # (B,N) 4-byte scratch: Morton-order permutation of the spatially pruned kernel (2048 < N <= 16384), or the
+    # HBM-resident min-distance array (N > 16384); the small-N kernels need none
+    tmp = torch.empty((B, N), dtype=_F32, device=xyz.device) if (N > 16384 or (N > 2048 and FPS_PRUNED)) else None
     L = _cabi.lib()
     _cabi.check(L.prcnn_fps(_p(xyz), B, N, npoint, _p(tmp), _p(idx), _stream()), "prcnn_fps")
     return idx

@@ -170,3 +170,26 @@ def test_op_argument_errors(dev):
         ops.furthest_point_sample(torch.zeros(1, 10, 3), 4)                       # CPU tensor: no fallback
     with pytest.raises(_cabi.PointOpsError):
         ops.furthest_point_sample(torch.zeros(1, 10, 3, device=dev), 11)          # npoint > N
+
+
+@pytest.mark.parametrize("B,N,npoint", [(2, 16384, 2048), (2, 4096, 1024), (1, 8192, 700), (2, 5000, 333), (1, 2049, 64)])
+def test_fps_pruned_variant_is_bit_identical(dev, cpu, B, N, npoint):
+    """the opt-in spatially pruned kernel (Morton pre-sort + exact bounding-box skip, csrc/fps.hip) returns exactly the
+    oracle's indices, on distinct points, duplicated points (original-index tie-break) and lattices"""
+    from pointrcnn_amd import ops
+    old = ops.FPS_PRUNED
+    ops.FPS_PRUNED = True
+    try:
+        clouds = [kitti_cloud(B, N, seed=N)]
+        dup = clouds[0].copy()
+        dup[:, N // 2:] = dup[:, : N - N // 2]                      # every point of the first half twice
+        clouds.append(dup)
+        g = np.stack(np.meshgrid(np.arange(32), np.arange(8), np.arange(32), indexing="ij"), -1).reshape(1, -1, 3)
+        clouds.append(np.tile(g.astype(np.float32)[:, :N], (B, 1, 1)) if g.shape[1] >= N else None)
+        for xyz in clouds:
+            if xyz is None:
+                continue
+            got = ops.furthest_point_sample(T(xyz, dev), npoint).cpu().numpy()
+            assert np.array_equal(got, cpu.fps(xyz, npoint))
+    finally:
+        ops.FPS_PRUNED = old
