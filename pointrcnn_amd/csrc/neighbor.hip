@@ -65,11 +65,34 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float* __r
     const float r2max = DUAL ? fmaxf(r2a, r2b) : r2a;
     bool done = !valid;
 
+    // The chunk for iteration c+1 is fetched into registers while chunk c is scanned: with one wave per workgroup
+    // nothing else would hide the global-load latency of the staging.
+    constexpr int PER_LANE = NB_CHUNK * 3 / BQ_THREADS;       // 48 floats of the flat xyz stream per lane per chunk
+    float pre[PER_LANE];
+    auto fetch_chunk = [&](int c0) {
+        const int cnt3 = min(NB_CHUNK, N - c0) * 3;
+        const float* src = p + (size_t)c0 * 3;
+#pragma unroll
+        for (int u = 0; u < PER_LANE; u++) {
+            int i = tid + u * BQ_THREADS;
+            pre[u] = i < cnt3 ? src[i] : INFINITY;          // slots past the frame end: +inf, never a hit
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int u = 0; u < PER_LANE; u++) {
+            int i = tid + u * BQ_THREADS;
+            int pt = i / 3, c = i - pt * 3;
+            spts[(pt >> 1) * 8 + c * 2 + (pt & 1)] = pre[u];
+        }
+    };
+    fetch_chunk(0);
     for (int c0 = 0; c0 < N; c0 += NB_CHUNK) {
         if (__all(done)) break;                    // single-wave workgroup: the whole block is finished
         __syncthreads();
-        stage_chunk<BQ_THREADS>(p, c0, N, spts, tid);
+        store_chunk();
         __syncthreads();
+        if (c0 + NB_CHUNK < N) fetch_chunk(c0 + NB_CHUNK);
         if (!done) {
             for (int i0 = 0; i0 < NB_CHUNK; i0 += 8) {
                 // 8 candidates = 4 packed pairs, ONE test for "any of them inside the larger ball"
