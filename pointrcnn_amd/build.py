@@ -15,7 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libprcnn_pointops.so")
+# PRCNN_POINTOPS_LIB selects an alternative build of the library (A/B comparisons on one box)
+LIB = os.environ.get("PRCNN_POINTOPS_LIB") or os.path.join(LIBDIR, "libprcnn_pointops.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]

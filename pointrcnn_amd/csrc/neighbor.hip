@@ -23,18 +23,7 @@
 // expression the compiler lowers to v_pk_*: same individually rounded operations per component, half the VALU issue.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int THREADS>
-__device__ __forceinline__ void stage_chunk(const float* __restrict__ p, int c0, int N, float* s, int tid) {
-    // p: frame base (N,3).  Coalesced dword loads of the flat xyz stream.  Point i of the chunk goes to pair i>>1,
-    // slot i&1.  Slots past the end of the frame are filled with +inf so the scan loops need no bounds test.
-    int cnt = min(NB_CHUNK, N - c0);
-    const float* src = p + (size_t)c0 * 3;
-    for (int i = tid; i < NB_CHUNK * 3; i += THREADS) {
-        int pt = i / 3, c = i - pt * 3;
-        s[(pt >> 1) * 8 + c * 2 + (pt & 1)] = pt < cnt ? src[i] : INFINITY;
-    }
-}
-
+// LDS record of candidate pair p: floats [8p .. 8p+7] = {x0,x1,y0,y1,z0,z1,-,-}; point i of a chunk goes to pair i>>1, slot i&1.
 // squared distances of the query to the two candidates of pair record `rec` (canonical arithmetic per component)
 __device__ __forceinline__ f32x2 pair_sqdist(const float* rec, f32x2 qx, f32x2 qy, f32x2 qz) {
     float4 a = *reinterpret_cast<const float4*>(rec);          // x0 x1 y0 y1
@@ -148,10 +137,29 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float* __res
     const f32x2 ux2 = {ux, ux}, uy2 = {uy, uy}, uz2 = {uz, uz};
     float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
     int i1 = 0, i2 = 0, i3 = 0;
+    // next chunk prefetched into registers while the current one is scanned (hides the staging latency)
+    constexpr int PER_LANE = NB_CHUNK * 3 / NN_THREADS;       // 12 floats of the flat xyz stream per lane per chunk
+    float pre[PER_LANE];
+    auto fetch_chunk = [&](int c0) {
+        const int cnt3 = min(NB_CHUNK, m - c0) * 3;
+        const float* src = p + (size_t)c0 * 3;
+#pragma unroll
+        for (int u = 0; u < PER_LANE; u++) {
+            int e = tid + u * NN_THREADS;
+            pre[u] = e < cnt3 ? src[e] : INFINITY;          // slots past the end: +inf, never < b3
+        }
+    };
+    fetch_chunk(0);
     for (int c0 = 0; c0 < m; c0 += NB_CHUNK) {
         __syncthreads();
-        stage_chunk<NN_THREADS>(p, c0, m, spts, tid);
+#pragma unroll
+        for (int u = 0; u < PER_LANE; u++) {
+            int e = tid + u * NN_THREADS;
+            int pt = e / 3, c = e - pt * 3;
+            spts[(pt >> 1) * 8 + c * 2 + (pt & 1)] = pre[u];
+        }
         __syncthreads();
+        if (c0 + NB_CHUNK < m) fetch_chunk(c0 + NB_CHUNK);
         for (int j0 = 0; j0 < NB_CHUNK; j0 += 8) {
             f32x2 d[4];
             bool any = false;
