@@ -216,6 +216,47 @@ size_t prcnn_nms_workspace_bytes(int N);
 int prcnn_nms(const float* boxes, int N, float thresh, int kind, int max_keep, int64_t* keep, int32_t* num_keep,
               void* workspace, size_t workspace_bytes, prcnn_stream_t stream);
 
+/* ======================================================================================================
+ * Proposal stage: batched, sync-free replacements for the per-frame Python loop
+ * between the RPN heads and roipool3d.  Oracle twins: prcnn_cpu_decode_bbox_target / _proposal_layer / _nms_batched.
+ * ====================================================================================================== */
+
+/* lib/utils/bbox_transform.py:24-121  decode_bbox_target(roi_box3d, pred_reg, loc_scope, loc_bin_size, num_head_bin,
+ * anchor_size, get_xz_fine, get_y_by_bin, loc_y_scope, loc_y_bin_size, get_ry_fine) -- same argument meaning.
+ *   roi (N, roi_cols) device: roi_cols 3 = xyz points (RPN stage, proposal_layer.py:23), 7 = RoI boxes (eval_rcnn.py:509,
+ *   rotated back by roi ry).  pred_reg (N, C) device; C must equal the channel count the flags imply (the reference
+ *   asserts, :106) else PRCNN_EINVAL.  anchor_size_host: 3 floats h,w,l in HOST memory (cfg.CLS_MEAN_SIZE[0]).
+ *   Scalars are doubles because the reference computes them in Python floats before they meet a tensor.
+ *   y_to_bottom != 0 also applies proposal_layer.py:32 (y += h/2).  out (N, 7) device [x,y,z,h,w,l,ry]. */
+int prcnn_decode_bbox_target(const float* roi, int roi_cols, const float* pred_reg, long N, int C, double loc_scope,
+                             double loc_bin_size, int num_head_bin, const float* anchor_size_host, int get_xz_fine,
+                             int get_y_by_bin, double loc_y_scope, double loc_y_bin_size, int get_ry_fine, int y_to_bottom,
+                             float* out, prcnn_stream_t stream);
+
+/* workspace for prcnn_proposal_layer: pre_max = max(pre1, pre2), post_max = max(post1, post2) */
+size_t prcnn_proposal_workspace_bytes(int B, int pre_max, int post_max);
+/* lib/rpn/proposal_layer.py:35-141 on decoded boxes3d (B, N, 7) and raw scores (B, N), whole batch, no host sync:
+ * per frame order rows by descending score (NaN first, ties by ascending row -- torch.sort leaves tie order open),
+ *   use_range != 0 (distance_based_proposal :58-117): area 1 = rows with r0 < z <= r1, area 2 = r1 < z <= r2; keep the
+ *       first pre1 / pre2 of each; an empty area 2 borrows ranks [pre1, pre1+pre2) of area 1 (:91-98);
+ *   use_range == 0 (score_based_proposal :119-141): one list, first pre1 rows (pre2 = post2 = 0);
+ * greedy NMS (nms_kind, nms_thresh) on the BEV boxes (kitti_utils.py:134-147) of each list, first post1 / post2 survivors,
+ * concatenated into out_boxes (B, post1+post2, 7) / out_scores (B, post1+post2), zero padded (:38-39).
+ * out_count (B) i32, optional: rows filled per frame.  An empty area contributes nothing (the reference asserts, :90).
+ * N <= 16384 (PRCNN_EUNSUPPORTED above: the sort is LDS-resident). */
+int prcnn_proposal_layer(const float* scores, const float* boxes3d, int B, int N, int use_range, float r0, float r1, float r2,
+                         int pre1, int pre2, int post1, int post2, float nms_thresh, int nms_kind, float* out_boxes,
+                         float* out_scores, int32_t* out_count, void* workspace, size_t workspace_bytes, prcnn_stream_t stream);
+
+size_t prcnn_nms_batched_workspace_bytes(int B, int M);
+/* Final detection select (tools/eval_rcnn.py:600-614) for the whole batch: per frame, rows with valid[b,i] != 0
+ * (valid NULL = all), ordered by descending score, greedy NMS on their BEV boxes; unlike iou3d_cuda.nms_gpu the boxes need
+ * NOT be pre-sorted.  keep (B, max_keep) i32: row indices in kept order, -1 padded; num_keep (B) i32.
+ * max_keep 0 = M.  PRCNN_EUNSUPPORTED when max_keep boxes do not fit the LDS kept list (~1900 rotated): use prcnn_nms. */
+int prcnn_nms_batched(const float* boxes3d, const float* scores, const uint8_t* valid, int B, int M, float thresh, int kind,
+                      int max_keep, int32_t* keep, int32_t* num_keep, void* workspace, size_t workspace_bytes,
+                      prcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,7 @@ class _Cpu:
         build()
         self.lib = ctypes.CDLL(os.path.join(_HERE, "libprcnn_oracle.so"))
         self.lib.prcnn_cpu_nms.restype = ctypes.c_int
+        self.lib.prcnn_cpu_decode_bbox_target.restype = ctypes.c_int
 
     # ---- PointNet++ ops ----
     def fps(self, xyz, npoint):
@@ -190,6 +191,52 @@ class _Cpu:
         self.lib.prcnn_cpu_nms_mask(_p(boxes, _F), N, ctypes.c_float(thresh), 0 if kind == "rotated" else 1,
                                     trig_mode, _p(mask, _U))
         return mask
+
+    # ---- proposal stage ----
+    def decode_bbox_target(self, roi, reg, loc_scope, loc_bin_size, num_head_bin, anchor_size, get_xz_fine=True,
+                           get_y_by_bin=False, loc_y_scope=0.5, loc_y_bin_size=0.25, get_ry_fine=False,
+                           y_to_bottom=False, trig_mode=1):
+        roi, reg, anchor = _f32(roi), _f32(reg), _f32(anchor_size)
+        out = np.zeros((reg.shape[0], 7), np.float32)
+        rc = self.lib.prcnn_cpu_decode_bbox_target(
+            _p(roi, _F), roi.shape[1], _p(reg, _F), reg.shape[0], reg.shape[1], ctypes.c_double(loc_scope),
+            ctypes.c_double(loc_bin_size), int(num_head_bin), _p(anchor, _F), int(get_xz_fine), int(get_y_by_bin),
+            ctypes.c_double(loc_y_scope), ctypes.c_double(loc_y_bin_size), int(get_ry_fine), int(y_to_bottom), trig_mode,
+            _p(out, _F))
+        if rc:
+            raise ValueError("decode_bbox_target: channel layout does not match C=%d" % reg.shape[1])
+        return out
+
+    def argsort_desc(self, scores):
+        scores = _f32(scores)
+        order = np.zeros(scores.shape, np.int32)
+        self.lib.prcnn_cpu_argsort_desc(_p(scores, _F), scores.shape[0], _p(order, _I))
+        return order
+
+    def proposal_layer(self, scores, boxes3d, pre, post, thresh, kind="normal", ranges=(0.0, 40.0, 80.0), trig_mode=1):
+        """pre / post = (n_area1, n_area2); ranges=None -> score_based_proposal"""
+        scores, boxes3d = _f32(scores), _f32(boxes3d)
+        B, N = scores.shape
+        tot = post[0] + post[1]
+        ob, osc, cnt = np.zeros((B, tot, 7), np.float32), np.zeros((B, tot), np.float32), np.zeros((B,), np.int32)
+        r = ranges if ranges is not None else (0.0, 0.0, 0.0)
+        self.lib.prcnn_cpu_proposal_layer(_p(scores, _F), _p(boxes3d, _F), B, N, int(ranges is not None),
+                                          ctypes.c_float(r[0]), ctypes.c_float(r[1]), ctypes.c_float(r[2]), pre[0], pre[1],
+                                          post[0], post[1], ctypes.c_float(thresh), 0 if kind == "rotated" else 1, trig_mode,
+                                          _p(ob, _F), _p(osc, _F), _p(cnt, _I))
+        return ob, osc, cnt
+
+    def nms_batched(self, boxes3d, scores, valid, thresh, kind="rotated", max_keep=0, trig_mode=1):
+        boxes3d, scores = _f32(boxes3d), _f32(scores)
+        B, M = scores.shape
+        mk = M if max_keep <= 0 or max_keep > M else max_keep
+        keep, num = np.zeros((B, mk), np.int32), np.zeros((B,), np.int32)
+        v = None if valid is None else np.ascontiguousarray(valid, dtype=np.uint8)
+        self.lib.prcnn_cpu_nms_batched(_p(boxes3d, _F), _p(scores, _F),
+                                       None if v is None else v.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), B, M,
+                                       ctypes.c_float(thresh), 0 if kind == "rotated" else 1, trig_mode, mk,
+                                       _p(keep, _I), _p(num, _I))
+        return keep, num
 
 
 class _Ref:

@@ -525,3 +525,207 @@ PRCNN_EXPORT void prcnn_cpu_nms_mask(const float* boxes, int N, float thresh, in
             mask[(size_t)i * cbn + cb] = t;
         }
 }
+
+/* ======================================================================================================
+ * Proposal stage: bin-based box decode + distance-split top-k + NMS + top-k.
+ *   PINNED -- golden fixtures under tests/golden/proposal_ref.npz are produced by the reference's own
+ *   lib/utils/bbox_transform.py and lib/rpn/proposal_layer.py imported on CPU (tests/golden/make_golden.py),
+ *   with the compiled-extension calls inside iou3d_utils.nms_* routed to oracle/_ref.
+ * ====================================================================================================== */
+
+static inline int argmax_first(const float* v, int n) {       /* torch.argmax: first maximal value; NaN is maximal */
+    int best = 0;
+    for (int i = 1; i < n; i++) {
+        if (v[best] != v[best]) break;                        /* NaN already found: it is the first maximum */
+        if (v[i] > v[best] || v[i] != v[i]) best = i;
+    }
+    return best;
+}
+
+static inline float remainder_f32(float a, float b) {         /* torch.remainder (ATen BinaryOpsKernel: fmod + sign fix) */
+    float m = fmodf(a, b);
+    if (m != 0.0f && ((b < 0.0f) != (m < 0.0f))) m += b;
+    return m;
+}
+
+/* lib/utils/bbox_transform.py:24-121 decode_bbox_target.  Every torch tensor op is one individually rounded
+ * fp32 operation; Python-side scalars are computed in double and rounded to fp32 when they meet a tensor.
+ *   roi: (N, roi_cols) with roi_cols 3 (xyz: RPN stage, proposal_layer.py:23) or 7 (RoI boxes: eval_rcnn.py:509)
+ *   y_to_bottom: also apply proposal_layer.py:32  (y += h / 2)
+ * returns 0, or -1 when C does not match the layout implied by the flags (the reference asserts, :106). */
+PRCNN_EXPORT int prcnn_cpu_decode_bbox_target(const float* roi, int roi_cols, const float* reg, int N, int C,
+                                              double loc_scope, double loc_bin_size, int num_head_bin, const float* anchor,
+                                              int get_xz_fine, int get_y_by_bin, double loc_y_scope, double loc_y_bin_size,
+                                              int get_ry_fine, int y_to_bottom, int trig_mode, float* out) {
+    const int nb = (int)(loc_scope / loc_bin_size) * 2;       /* :42 */
+    const int nyb = (int)(loc_y_scope / loc_y_bin_size) * 2;  /* :43 */
+    int off = nb * 2;
+    const int x_res_l = nb * 2, z_res_l = nb * 3;
+    if (get_xz_fine) off = nb * 4;
+    int y_bin_l = 0, y_res_l = 0, y_off = 0;
+    if (get_y_by_bin) { y_bin_l = off; y_res_l = off + nyb; off += 2 * nyb; } else { y_off = off; off += 1; }
+    const int ry_bin_l = off, ry_res_l = off + num_head_bin, size_l = off + 2 * num_head_bin;
+    if (size_l + 3 != C || (roi_cols != 3 && roi_cols != 7)) return -1;
+    const float lbs = (float)loc_bin_size, half_lbs = (float)(loc_bin_size / 2), scope = (float)loc_scope;
+    const float lybs = (float)loc_y_bin_size, half_lybs = (float)(loc_y_bin_size / 2), yscope = (float)loc_y_scope;
+    const double PI = 3.141592653589793;
+    for (int i = 0; i < N; i++) {
+        const float* r = reg + (size_t)i * C;
+        const float* b = roi + (size_t)i * roi_cols;
+        int xb = argmax_first(r, nb), zb = argmax_first(r + nb, nb);
+        float px = ((float)xb * lbs + half_lbs) - scope;     /* :53-54 */
+        float pz = ((float)zb * lbs + half_lbs) - scope;
+        if (get_xz_fine) {                                    /* :56-67 */
+            px = px + r[x_res_l + xb] * lbs;
+            pz = pz + r[z_res_l + zb] * lbs;
+        }
+        float py;
+        if (get_y_by_bin) {                                   /* :70-79 */
+            int yb = argmax_first(r + y_bin_l, nyb);
+            float y_res = r[y_res_l + yb] * lybs;
+            py = (((float)yb * lybs + half_lybs) - yscope) + y_res;
+            py = py + b[1];
+        } else {
+            py = b[1] + r[y_off];                             /* :84 */
+        }
+        int rb = argmax_first(r + ry_bin_l, num_head_bin);
+        float rn = r[ry_res_l + rb], ry;
+        if (get_ry_fine) {                                    /* :92-96 */
+            double apc = (PI / 2) / num_head_bin;
+            float ry_res = rn * (float)(apc / 2);
+            ry = ((((float)rb * (float)apc) + (float)(apc / 2)) + ry_res) - (float)(PI / 4);
+        } else {                                              /* :97-103 */
+            double apc = (2 * PI) / num_head_bin;
+            float ry_res = rn * (float)(apc / 2);
+            ry = remainder_f32((float)rb * (float)apc + ry_res, (float)(2 * PI));
+            if (ry > (float)PI) ry = ry - (float)(2 * PI);
+        }
+        float h = r[size_l] * anchor[0] + anchor[0];          /* :109-110 */
+        float w = r[size_l + 1] * anchor[1] + anchor[1];
+        float l = r[size_l + 2] * anchor[2] + anchor[2];
+        if (roi_cols == 7) {                                  /* :116-119 -> rotate_pc_along_y_torch(box, -roi_ry) :5-21 */
+            float ang = -b[6], ca, sa;
+            if (trig_mode == 0) { ca = cosf(ang); sa = sinf(ang); }
+            else { ca = (float)cos((double)ang); sa = (float)sin((double)ang); }
+            float nx = px * ca + pz * (-sa);
+            float nz = px * sa + pz * ca;
+            px = nx; pz = nz;
+            ry = ry + b[6];
+        }
+        px = px + b[0];                                       /* :120 */
+        pz = pz + b[2];
+        if (y_to_bottom) py = py + h / 2;                     /* proposal_layer.py:32 */
+        float* o = out + (size_t)i * 7;
+        o[0] = px; o[1] = py; o[2] = pz; o[3] = h; o[4] = w; o[5] = l; o[6] = ry;
+    }
+    return 0;
+}
+
+/* descending-score order, canonical total order: NaN first (torch.sort treats NaN as the largest value),
+ * -0.0 == +0.0, ties by ascending index (torch.sort's tie order is unspecified unless stable=True). */
+typedef struct { float s; int32_t i; } sort_rec;
+static int sort_rec_cmp(const void* pa, const void* pb) {
+    const sort_rec *a = (const sort_rec*)pa, *b = (const sort_rec*)pb;
+    int an = a->s != a->s, bn = b->s != b->s;
+    if (an != bn) return an ? -1 : 1;
+    if (!an) { if (a->s > b->s) return -1; if (a->s < b->s) return 1; }
+    return a->i < b->i ? -1 : (a->i > b->i ? 1 : 0);
+}
+PRCNN_EXPORT void prcnn_cpu_argsort_desc(const float* scores, int N, int32_t* order) {
+    sort_rec* r = (sort_rec*)malloc(sizeof(sort_rec) * (size_t)(N > 0 ? N : 1));
+    for (int i = 0; i < N; i++) { r[i].s = scores[i]; r[i].i = i; }
+    qsort(r, (size_t)N, sizeof(sort_rec), sort_rec_cmp);
+    for (int i = 0; i < N; i++) order[i] = r[i].i;
+    free(r);
+}
+
+static void box3d_to_bev(const float* b, float* v) {          /* kitti_utils.py:134-147 */
+    float half_l = b[5] / 2, half_w = b[4] / 2;
+    v[0] = b[0] - half_l; v[1] = b[2] - half_w; v[2] = b[0] + half_l; v[3] = b[2] + half_w; v[4] = b[6];
+}
+
+/* greedy NMS over a candidate list (already in descending-score order), stopping after max_keep survivors:
+ * identical keep set to prcnn_cpu_nms(...)[:max_keep] (a box is only ever tested against KEPT earlier boxes). */
+static int nms_list(const float* boxes3d, const int32_t* cand, int n, float thresh, int kind, int trig_mode, int max_keep,
+                    int32_t* kept) {
+    float* kb = (float*)malloc(sizeof(float) * 5 * (size_t)(max_keep > 0 ? max_keep : 1));
+    int nk = 0;
+    for (int c = 0; c < n && nk < max_keep; c++) {
+        float v[5];
+        box3d_to_bev(boxes3d + (size_t)cand[c] * 7, v);
+        int dead = 0;
+        for (int k = 0; k < nk && !dead; k++) {
+            float iou = kind == 0 ? iou_bev(kb + k * 5, v, trig_mode) : iou_normal(kb + k * 5, v);
+            dead = iou > thresh;
+        }
+        if (!dead) { memcpy(kb + nk * 5, v, sizeof(v)); kept[nk++] = cand[c]; }
+    }
+    free(kb);
+    return nk;
+}
+
+/* lib/rpn/proposal_layer.py:35-119 on already-decoded boxes (B,N,7) and raw scores (B,N).
+ *   use_range=1: distance_based_proposal :58-117 -- area 1 = (r0, r1], area 2 = (r1, r2]; area 2 empty -> ranks
+ *                [pre1, pre1+pre2) of area 1 (:91-98).  (The reference ASSERTS when area 1 is empty, :90; here an
+ *                empty area simply contributes no proposals.)
+ *   use_range=0: score_based_proposal :119-141 (pre2 = post2 = 0, always rotated NMS in the reference).
+ * out_boxes (B, post1+post2, 7) / out_scores (B, post1+post2) are zero padded (:38-39); out_count (B) = rows filled. */
+PRCNN_EXPORT void prcnn_cpu_proposal_layer(const float* scores, const float* boxes3d, int B, int N, int use_range, float r0,
+                                           float r1, float r2, int pre1, int pre2, int post1, int post2, float thresh,
+                                           int kind, int trig_mode, float* out_boxes, float* out_scores, int32_t* out_count) {
+    const int post = post1 + post2;
+    int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    int32_t* a1 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    int32_t* a2 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    int32_t* kept = (int32_t*)malloc(sizeof(int32_t) * (size_t)(post > 0 ? post : 1));
+    memset(out_boxes, 0, sizeof(float) * 7 * (size_t)B * post);
+    memset(out_scores, 0, sizeof(float) * (size_t)B * post);
+    for (int b = 0; b < B; b++) {
+        const float* sc = scores + (size_t)b * N;
+        const float* bx = boxes3d + (size_t)b * N * 7;
+        prcnn_cpu_argsort_desc(sc, N, order);                 /* :35 */
+        int n1 = 0, n2 = 0;
+        for (int k = 0; k < N; k++) {
+            float d = bx[(size_t)order[k] * 7 + 2];           /* :78 dist = z of the score-ordered proposals */
+            if (!use_range) { a1[n1++] = order[k]; continue; }
+            if (d > r0 && d <= r1) a1[n1++] = order[k];       /* :79,82 */
+            if (d > r1 && d <= r2) a2[n2++] = order[k];
+        }
+        int tot = 0;
+        for (int seg = 0; seg < 2; seg++) {
+            const int32_t* cand; int n, pre = seg ? pre2 : pre1, postk = seg ? post2 : post1;
+            if (seg == 0) { cand = a1; n = n1 < pre ? n1 : pre; }                     /* :90-91 */
+            else if (!use_range) { cand = a2; n = 0; }
+            else if (n2 != 0) { cand = a2; n = n2 < pre ? n2 : pre; }
+            else { int s = n1 < pre1 ? n1 : pre1; cand = a1 + s; n = n1 - s < pre ? n1 - s : pre; }   /* :97-98 */
+            int nk = nms_list(bx, cand, n, thresh, kind, trig_mode, postk, kept);     /* :101-110 */
+            for (int k = 0; k < nk; k++, tot++) {
+                memcpy(out_boxes + ((size_t)b * post + tot) * 7, bx + (size_t)kept[k] * 7, sizeof(float) * 7);
+                out_scores[(size_t)b * post + tot] = sc[kept[k]];
+            }
+        }
+        if (out_count) out_count[b] = tot;
+    }
+    free(order); free(a1); free(a2); free(kept);
+}
+
+/* Final detection select (tools/eval_rcnn.py:600-614), per frame: rows with valid != 0 (the caller's
+ * norm_score > SCORE_THRESH test), ordered by descending raw score, greedy NMS on their BEV boxes.
+ * keep (B, M): indices into the frame's M rows in kept order, -1 padded; num_keep (B). */
+PRCNN_EXPORT void prcnn_cpu_nms_batched(const float* boxes3d, const float* scores, const uint8_t* valid, int B, int M,
+                                        float thresh, int kind, int trig_mode, int max_keep, int32_t* keep, int32_t* num_keep) {
+    if (max_keep <= 0 || max_keep > M) max_keep = M;
+    int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)(M > 0 ? M : 1));
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (size_t)(M > 0 ? M : 1));
+    for (int b = 0; b < B; b++) {
+        prcnn_cpu_argsort_desc(scores + (size_t)b * M, M, order);
+        int n = 0;
+        for (int k = 0; k < M; k++)
+            if (!valid || valid[(size_t)b * M + order[k]]) cand[n++] = order[k];
+        int32_t* kp = keep + (size_t)b * max_keep;
+        int nk = nms_list(boxes3d + (size_t)b * M * 7, cand, n, thresh, kind, trig_mode, max_keep, kp);
+        for (int k = nk; k < max_keep; k++) kp[k] = -1;
+        num_keep[b] = nk;
+    }
+    free(order); free(cand);
+}

@@ -14,6 +14,7 @@ _I = ctypes.c_int
 _F = ctypes.c_float
 _L = ctypes.c_int64
 _Z = ctypes.c_size_t
+_D = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/prcnn_pointops.h one for one
 SIGNATURES = {
@@ -47,6 +48,11 @@ SIGNATURES = {
     "prcnn_boxes_iou_bev": (_I, [_P, _I, _P, _I, _P, _P]),
     "prcnn_nms_workspace_bytes": (_Z, [_I]),
     "prcnn_nms": (_I, [_P, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
+    "prcnn_decode_bbox_target": (_I, [_P, _I, _P, ctypes.c_long, _I, _D, _D, _I, _P, _I, _I, _D, _D, _I, _I, _P, _P]),
+    "prcnn_proposal_workspace_bytes": (_Z, [_I, _I, _I]),
+    "prcnn_proposal_layer": (_I, [_P, _P, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _Z, _P]),
+    "prcnn_nms_batched_workspace_bytes": (_Z, [_I, _I]),
+    "prcnn_nms_batched": (_I, [_P, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
 }
 
 _lib = None

@@ -14,142 +14,7 @@
 //     iou3d_kernel.cu:258), and the greedy sweep runs ON THE DEVICE (one wave per problem, suppression
 //     bitmap in LDS) instead of a synchronous D2H copy of the N x N/64 mask plus a host loop
 //     (iou3d.cpp:86-116): no host synchronisation anywhere.
-#include "common.h"
-
-struct Pt { float x, y; };
-struct RBox {
-    float x1, y1, x2, y2;   // raw extents
-    float cx, cy;           // centre
-    float c, s;             // cos(angle), sin(angle)
-    Pt p[5];                // rotated corners, p[4] == p[0]
-};
-
-__device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
-
-__device__ __forceinline__ Pt rotate_around_center(float cx, float cy, float c, float s, float px, float py) {
-    float dx = sub(px, cx), dy = sub(py, cy);                                   // iou3d_kernel.cu:98-102
-    Pt r;
-    r.x = add(add(mul(dx, c), mul(dy, s)), cx);
-    r.y = add(add(mul(-dx, s), mul(dy, c)), cy);
-    return r;
-}
-
-__device__ void make_rbox(const float* __restrict__ b, RBox& r) {
-    r.x1 = b[0]; r.y1 = b[1]; r.x2 = b[2]; r.y2 = b[3];
-    r.cx = add(r.x1, r.x2) / 2; r.cy = add(r.y1, r.y2) / 2;
-    r.c = (float)cos((double)b[4]);
-    r.s = (float)sin((double)b[4]);
-    r.p[0] = rotate_around_center(r.cx, r.cy, r.c, r.s, r.x1, r.y1);
-    r.p[1] = rotate_around_center(r.cx, r.cy, r.c, r.s, r.x2, r.y1);
-    r.p[2] = rotate_around_center(r.cx, r.cy, r.c, r.s, r.x2, r.y2);
-    r.p[3] = rotate_around_center(r.cx, r.cy, r.c, r.s, r.x1, r.y2);
-    r.p[4] = r.p[0];
-}
-
-__device__ __forceinline__ float cross3(Pt p1, Pt p2, Pt p0) {                  // iou3d_kernel.cu:38-40
-    return sub(mul(sub(p1.x, p0.x), sub(p2.y, p0.y)), mul(sub(p2.x, p0.x), sub(p1.y, p0.y)));
-}
-
-__device__ __forceinline__ bool check_rect_cross(Pt p1, Pt p2, Pt q1, Pt q2) {  // iou3d_kernel.cu:42-48
-    return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
-           fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
-}
-
-// iou3d_kernel.cu:50-65 with (cos(-a), sin(-a)) = (c, -s)
-__device__ __forceinline__ bool check_in_box2d(const RBox& box, Pt p) {
-    const float MARGIN = 1e-5f;
-    float dx = sub(p.x, box.cx), dy = sub(p.y, box.cy);
-    float sn = -box.s;
-    float rot_x = add(add(mul(dx, box.c), mul(dy, sn)), box.cx);
-    float rot_y = add(add(mul(-dx, sn), mul(dy, box.c)), box.cy);
-    return rot_x > sub(box.x1, MARGIN) && rot_x < add(box.x2, MARGIN) && rot_y > sub(box.y1, MARGIN) &&
-           rot_y < add(box.y2, MARGIN);
-}
-
-// iou3d_kernel.cu:67-96
-__device__ __forceinline__ bool seg_intersection(Pt p1, Pt p0, Pt q1, Pt q0, Pt& ans) {
-    const float EPS = 1e-8f;
-    if (!check_rect_cross(p0, p1, q0, q1)) return false;
-    float s1 = cross3(q0, p1, p0), s2 = cross3(p1, q1, p0), s3 = cross3(p0, q1, q0), s4 = cross3(q1, p1, q0);
-    if (!(mul(s1, s2) > 0 && mul(s3, s4) > 0)) return false;
-    float s5 = cross3(q1, p1, p0);
-    if (fabsf(sub(s5, s1)) > EPS) {
-        float den = sub(s5, s1);
-        ans.x = sub(mul(s5, q0.x), mul(s1, q1.x)) / den;
-        ans.y = sub(mul(s5, q0.y), mul(s1, q1.y)) / den;
-    } else {
-        float a0 = sub(p0.y, p1.y), b0 = sub(p1.x, p0.x), c0 = sub(mul(p0.x, p1.y), mul(p1.x, p0.y));
-        float a1 = sub(q0.y, q1.y), b1 = sub(q1.x, q0.x), c1 = sub(mul(q0.x, q1.y), mul(q1.x, q0.y));
-        float D = sub(mul(a0, b1), mul(a1, b0));
-        ans.x = sub(mul(b0, c1), mul(b1, c0)) / D;
-        ans.y = sub(mul(a1, c0), mul(a0, c1)) / D;
-    }
-    return true;
-}
-
-// canonical ordering key: strictly increasing in atan2(dy,dx) over (-pi, pi]; IEEE +,-,/ only
-__device__ __forceinline__ float angle_key(float dx, float dy) {
-    float s = add(fabsf(dx), fabsf(dy));
-    if (!(s > 0.0f)) return 0.0f;
-    float t = dy / s;
-    if (dx >= 0.0f) return t;
-    return dy >= 0.0f ? sub(2.0f, t) : sub(-2.0f, t);
-}
-
-// iou3d_kernel.cu:108-212
-__device__ float box_overlap(const RBox& A, const RBox& B) {
-    Pt cp[24];
-    float key[24];
-    float pcx = 0.f, pcy = 0.f;
-    int cnt = 0;
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            Pt ans;
-            if (seg_intersection(A.p[i + 1], A.p[i], B.p[j + 1], B.p[j], ans)) {
-                pcx = add(pcx, ans.x); pcy = add(pcy, ans.y);
-                cp[cnt++] = ans;
-            }
-        }
-    for (int k = 0; k < 4; k++) {
-        if (check_in_box2d(A, B.p[k])) { pcx = add(pcx, B.p[k].x); pcy = add(pcy, B.p[k].y); cp[cnt++] = B.p[k]; }
-        if (check_in_box2d(B, A.p[k])) { pcx = add(pcx, A.p[k].x); pcy = add(pcy, A.p[k].y); cp[cnt++] = A.p[k]; }
-    }
-    if (cnt == 0) return 0.0f;
-    pcx = pcx / (float)cnt; pcy = pcy / (float)cnt;
-    for (int i = 0; i < cnt; i++) key[i] = angle_key(sub(cp[i].x, pcx), sub(cp[i].y, pcy));
-    for (int j = 0; j < cnt - 1; j++)                                            // iou3d_kernel.cu:188-196
-        for (int i = 0; i < cnt - j - 1; i++)
-            if (key[i] > key[i + 1]) {
-                Pt t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
-                float tk = key[i]; key[i] = key[i + 1]; key[i + 1] = tk;
-            }
-    float area = 0.f;
-    for (int k = 0; k < cnt - 1; k++) {                                          // iou3d_kernel.cu:206-211
-        float ux = sub(cp[k].x, cp[0].x), uy = sub(cp[k].y, cp[0].y);
-        float vx = sub(cp[k + 1].x, cp[0].x), vy = sub(cp[k + 1].y, cp[0].y);
-        area = add(area, sub(mul(ux, vy), mul(uy, vx)));
-    }
-    return fabsf(area) / 2.0f;
-}
-
-__device__ __forceinline__ float iou_bev(const RBox& a, const RBox& b) {         // iou3d_kernel.cu:214-221
-    float sa = mul(sub(a.x2, a.x1), sub(a.y2, a.y1));
-    float sb = mul(sub(b.x2, b.x1), sub(b.y2, b.y1));
-    float ov = box_overlap(a, b);
-    return ov / fmaxf(sub(add(sa, sb), ov), 1e-8f);
-}
-
-__device__ __forceinline__ float iou_normal(const float* a, const float* b) {    // iou3d_kernel.cu:295-303
-    float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
-    float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
-    float width = fmaxf(sub(right, left), 0.f), height = fmaxf(sub(bottom, top), 0.f);
-    float interS = mul(width, height);
-    float Sa = mul(sub(a[2], a[0]), sub(a[3], a[1]));
-    float Sb = mul(sub(b[2], b[0]), sub(b[3], b[1]));
-    return interS / fmaxf(sub(add(Sa, Sb), interS), 1e-8f);
-}
+#include "iou3d_geom.h"
 
 // ---- pairwise matrices: 16x16 pair tile per workgroup, boxes prepared once in LDS ---------------
 template <bool IOU>

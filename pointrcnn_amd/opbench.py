@@ -108,6 +108,29 @@ def main():
     emit("nms_normal", "N6300 thr0.8", timeit(lambda: ops.nms_sorted(bev, 0.8, rotated=False)), pairs=6300 * 6299 // 2)
     emit("nms_rotated", "N6300 thr0.8", timeit(lambda: ops.nms_sorted(bev, 0.8, rotated=True), 5, 1), pairs=6300 * 6299 // 2)
 
+    # ---- proposal stage, whole batch per call: decode 76 regression channels -> boxes, then
+    # score sort + distance split + NMS + top-k.  Scene: 40 % of the points vote for one of 24 cars (tight clusters
+    # of overlapping high-score boxes), the rest is clutter -- the regime where NMS has to reject most candidates.
+    reg = torch.randn(B * N, 76, device=dev)
+    anchor = (1.52563191462, 1.62856739989, 3.88311640418)
+    emit("decode_bbox_target", "B%d N%d C76" % (B, N),
+         timeit(lambda: ops.decode_bbox_target(xyz.view(-1, 3), reg, 3.0, 0.5, 12, anchor, y_to_bottom=True)),
+         bytes=B * N * (76 + 3 + 7) * 4)
+    gg = torch.Generator().manual_seed(3)
+    nfg = int(N * 0.4)
+    obj = torch.rand(B, 24, 7, generator=gg) * torch.tensor([70., .4, 62., .3, .3, 1., 6.28]) + torch.tensor([-35., .8, 4., 1.4, 1.5, 3.4, -3.14])
+    own = torch.randint(0, 24, (B, nfg), generator=gg)
+    fgb = torch.gather(obj, 1, own.unsqueeze(-1).expand(-1, -1, 7)) + torch.randn(B, nfg, 7, generator=gg) * torch.tensor([.08, .03, .12, .03, .03, .06, .03])
+    bgb = torch.rand(B, N - nfg, 7, generator=gg) * torch.tensor([80., 4., 70., 1., .8, 2., 6.28]) + torch.tensor([-40., -1., .2, 1., 1.2, 3., -3.14])
+    boxes3d = torch.cat([fgb, bgb], 1).to(dev).contiguous()
+    scores = torch.cat([torch.randn(B, nfg, generator=gg) + 2.5, torch.randn(B, N - nfg, generator=gg) - 3.0], 1).to(dev)
+    for rot in (False, True):
+        emit("proposal_layer(%s nms 0.8, 6300/2700 -> 70/30)" % ("rotated" if rot else "normal"), "B%d N%d" % (B, N),
+             timeit(lambda: ops.proposal_layer(scores, boxes3d, (6300, 2700), (70, 30), 0.8, rotated=rot)), pairs=B * N)
+    rb = boxes3d[:, :100].contiguous()
+    rs = scores[:, :100].contiguous()
+    emit("nms_batched(rotated 0.1)", "B%d M100" % B, timeit(lambda: ops.nms_batched(rb, rs, None, 0.1, True)), pairs=B * 100)
+
     # ---- fused MLP: the whole RPN graph's MLP FLOPs are reported by bench.py; here two representative stacks
     model = rpn.randomize_bn_stats(rpn.RPN()).to(dev).eval()
     sa2 = model.backbone_net.SA_modules[1]

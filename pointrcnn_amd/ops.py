@@ -412,3 +412,73 @@ def nms_sorted(boxes_sorted, thresh, rotated=True, max_keep=0):
     _cabi.check(L.prcnn_nms(_p(boxes_sorted), N, float(thresh), 0 if rotated else 1, int(max_keep), _p(keep), _p(num),
                             _p(ws), wsb, _stream()), "prcnn_nms")
     return keep, num
+
+
+# ---------------------------------------------------------------------------------------------------------
+# proposal stage
+# ---------------------------------------------------------------------------------------------------------
+def decode_bbox_target(roi, pred_reg, loc_scope, loc_bin_size, num_head_bin, anchor_size, get_xz_fine=True,
+                       get_y_by_bin=False, loc_y_scope=0.5, loc_y_bin_size=0.25, get_ry_fine=False, y_to_bottom=False):
+    """lib/utils/bbox_transform.py:24-121 as one kernel.  roi (N,3|7), pred_reg (N,C) -> (N,7).
+    anchor_size: 3 host floats (h, w, l)."""
+    _chk(roi, "roi", ndim=2)
+    _chk(pred_reg, "pred_reg", ndim=2)
+    if roi.shape[0] != pred_reg.shape[0]:
+        raise ValueError("decode_bbox_target: %d rois vs %d regression rows" % (roi.shape[0], pred_reg.shape[0]))
+    N, C = pred_reg.shape
+    out = torch.empty((N, 7), dtype=torch.float32, device=pred_reg.device)
+    anchor = (ctypes.c_float * 3)(*[float(a) for a in anchor_size])
+    _cabi.check(_cabi.lib().prcnn_decode_bbox_target(
+        _p(roi), roi.shape[1], _p(pred_reg), N, C, float(loc_scope), float(loc_bin_size), int(num_head_bin),
+        ctypes.cast(anchor, ctypes.c_void_p), int(bool(get_xz_fine)), int(bool(get_y_by_bin)), float(loc_y_scope),
+        float(loc_y_bin_size), int(bool(get_ry_fine)), int(bool(y_to_bottom)), _p(out), _stream()), "prcnn_decode_bbox_target")
+    return out
+
+
+def proposal_layer(scores, boxes3d, pre, post, nms_thresh, rotated=False, ranges=(0.0, 40.0, 80.0)):
+    """lib/rpn/proposal_layer.py:35-141 for the whole batch, no host sync.
+    scores (B,N) raw, boxes3d (B,N,7) decoded; pre/post = (area 1, area 2) top-n; ranges=None -> score based.
+    -> rois (B, post[0]+post[1], 7), roi_scores (B, post[0]+post[1]) zero padded, count (B) int32."""
+    _chk(scores, "scores", ndim=2)
+    _chk(boxes3d, "boxes3d", ndim=3)
+    B, N = scores.shape
+    if tuple(boxes3d.shape) != (B, N, 7):
+        raise ValueError("proposal_layer: boxes3d must be (%d, %d, 7), got %s" % (B, N, tuple(boxes3d.shape)))
+    L = _cabi.lib()
+    tot = int(post[0]) + int(post[1])
+    dev = scores.device
+    rois = torch.empty((B, tot, 7), dtype=torch.float32, device=dev)
+    roi_scores = torch.empty((B, tot), dtype=torch.float32, device=dev)
+    count = torch.empty((B,), dtype=_INT, device=dev)
+    wsb = L.prcnn_proposal_workspace_bytes(B, max(pre), max(post))
+    ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=dev)
+    r = ranges if ranges is not None else (0.0, 0.0, 0.0)
+    _cabi.check(L.prcnn_proposal_layer(_p(scores), _p(boxes3d), B, N, int(ranges is not None), float(r[0]), float(r[1]),
+                                       float(r[2]), int(pre[0]), int(pre[1]), int(post[0]), int(post[1]), float(nms_thresh),
+                                       0 if rotated else 1, _p(rois), _p(roi_scores), _p(count), _p(ws), wsb, _stream()),
+                "prcnn_proposal_layer")
+    return rois, roi_scores, count
+
+
+def nms_batched(boxes3d, scores, valid=None, thresh=0.1, rotated=True, max_keep=0):
+    """tools/eval_rcnn.py:600-614 for the whole batch: per frame select valid rows, order by score, greedy NMS.
+    boxes3d (B,M,7), scores (B,M), valid (B,M) bool/uint8 or None -> keep (B,max_keep) int32 (-1 padded), num (B)."""
+    _chk(boxes3d, "boxes3d", ndim=3)
+    _chk(scores, "scores", ndim=2)
+    B, M = scores.shape
+    if tuple(boxes3d.shape) != (B, M, 7):
+        raise ValueError("nms_batched: boxes3d must be (%d, %d, 7), got %s" % (B, M, tuple(boxes3d.shape)))
+    if valid is not None:
+        if tuple(valid.shape) != (B, M) or not valid.is_cuda:
+            raise ValueError("nms_batched: valid must be a (%d, %d) device tensor" % (B, M))
+        valid = valid.to(torch.uint8).contiguous()
+    mk = M if max_keep <= 0 or max_keep > M else int(max_keep)
+    L = _cabi.lib()
+    dev = scores.device
+    keep = torch.empty((B, max(mk, 1)), dtype=_INT, device=dev)
+    num = torch.empty((B,), dtype=_INT, device=dev)
+    wsb = L.prcnn_nms_batched_workspace_bytes(B, M)
+    ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=dev)
+    _cabi.check(L.prcnn_nms_batched(_p(boxes3d), _p(scores), _p(valid) if valid is not None else None, B, M, float(thresh),
+                                    0 if rotated else 1, mk, _p(keep), _p(num), _p(ws), wsb, _stream()), "prcnn_nms_batched")
+    return keep[:, :mk], num

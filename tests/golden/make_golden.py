@@ -4,6 +4,9 @@
     iou3d_ref.npz, roipool3d_ref.npz -- outputs of the REFERENCE'S OWN native code (lib/utils/iou3d/src/*,
         lib/utils/roipool3d/src/* compiled for the host by oracle/build_ref.py -> oracle/_ref).  Needs
         /root/reference; the fixtures travel to the GPU box, the reference does not.
+    proposal_ref.npz -- outputs of the REFERENCE'S OWN Python proposal stage (lib/utils/bbox_transform.py
+        decode_bbox_target, lib/rpn/proposal_layer.py ProposalLayer) imported on CPU by ref_proposal.py, with the NMS
+        extension calls routed to oracle/_ref.  Inputs are regenerated from seeds (tests/util.py); their CRCs are stored.
     pointnet2_oracle.npz -- outputs of the CPU oracle (oracle/prcnn_oracle.c) for the PointNet++ ops, whose
         reference source is an empty git submodule (parity unpinned: these pin the ORACLE's behaviour across
         refactors, not the reference's).
@@ -19,7 +22,61 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 import oracle  # noqa: E402
-from util import enlarge, kitti_cloud, rand_bev, rand_boxes3d, unit_cloud  # noqa: E402
+from util import enlarge, kitti_cloud, rand_bev, rand_boxes3d, rpn_like_scene, unit_cloud  # noqa: E402
+
+
+def proposal_cases():
+    """name -> kwargs shared by make_golden.py and the tests (inputs are regenerated from these seeds)"""
+    return {
+        "test_normal": dict(B=2, N=16384, seed=1, mode="TEST", nms="normal", z_max=70.4, distance=True),
+        "test_rotate": dict(B=2, N=16384, seed=1, mode="TEST", nms="rotate", z_max=70.4, distance=True),
+        "train_normal": dict(B=1, N=16384, seed=2, mode="TRAIN", nms="normal", z_max=70.4, distance=True),
+        "near_only": dict(B=1, N=16384, seed=3, mode="TEST", nms="normal", z_max=38.0, distance=True),
+        "sparse": dict(B=2, N=2000, seed=4, mode="TEST", nms="rotate", z_max=70.4, distance=True),
+        "score_based": dict(B=1, N=4096, seed=5, mode="TEST", nms="rotate", z_max=70.4, distance=False),
+    }
+
+
+def crc(*arrays):
+    import zlib
+    c = 0
+    for a in arrays:
+        c = zlib.crc32(np.ascontiguousarray(a).tobytes(), c)
+    return np.uint32(c)
+
+
+def make_proposal_golden():
+    import torch
+    import ref_proposal
+    cfg, decode, make_pl, anchor = ref_proposal.load()
+    out = {}
+    for name, c in proposal_cases().items():
+        xyz, sc, reg = rpn_like_scene(c["B"], c["N"], seed=c["seed"], z_max=c["z_max"])
+        cfg.RPN.NMS_TYPE = c["nms"]
+        cfg.TEST.RPN_DISTANCE_BASED_PROPOSE = c["distance"]
+        rois, rs = make_pl(c["mode"])(torch.from_numpy(sc), torch.from_numpy(reg), torch.from_numpy(xyz))
+        out[name + "_rois"], out[name + "_scores"], out[name + "_crc"] = rois.numpy(), rs.numpy(), crc(xyz, sc, reg)
+        print(name, "filled", (rois.abs().sum(-1) > 0).sum(1).tolist())
+    cfg.TEST.RPN_DISTANCE_BASED_PROPOSE = True
+    # decode_bbox_target alone, the RPN layout (roi = xyz) and the RCNN layouts (roi = boxes, eval_rcnn.py:509-517)
+    xyz, sc, reg = rpn_like_scene(1, 4096, seed=6)
+    t = torch.from_numpy
+    out["dec_rpn"] = decode(t(xyz[0]), t(reg[0]), anchor_size=anchor(), loc_scope=3.0, loc_bin_size=0.5, num_head_bin=12,
+                            get_xz_fine=True, get_y_by_bin=False, get_ry_fine=False).numpy()
+    out["dec_rpn_coarse"] = decode(t(xyz[0]), t(np.ascontiguousarray(reg[0][:, 24:])), anchor_size=anchor(), loc_scope=3.0,
+                                   loc_bin_size=0.5, num_head_bin=12, get_xz_fine=False).numpy()
+    r = np.random.default_rng(7)
+    rois7 = rand_boxes3d(xyz[0], 512, seed=8)
+    reg46 = r.normal(0, 1, (512, 46)).astype(np.float32)
+    reg53 = r.normal(0, 1, (512, 53)).astype(np.float32)
+    out["dec_rois7"], out["dec_reg46"], out["dec_reg53"] = rois7, reg46, reg53
+    out["dec_rcnn"] = decode(t(rois7.copy()), t(reg46), anchor_size=anchor(), loc_scope=1.5, loc_bin_size=0.5, num_head_bin=9,
+                             get_xz_fine=True, get_y_by_bin=False, loc_y_scope=0.5, loc_y_bin_size=0.25, get_ry_fine=True).numpy()
+    out["dec_rcnn_ybin"] = decode(t(rois7.copy()), t(reg53), anchor_size=anchor(), loc_scope=1.5, loc_bin_size=0.5,
+                                  num_head_bin=9, get_xz_fine=True, get_y_by_bin=True, loc_y_scope=0.5, loc_y_bin_size=0.25,
+                                  get_ry_fine=True).numpy()
+    out["dec_crc"] = crc(xyz, reg)
+    np.savez_compressed(os.path.join(HERE, "proposal_ref.npz"), **out)
 
 
 def main():
@@ -52,6 +109,7 @@ def main():
     d2, i3 = cpu.three_nn(pts[:, :300], new_xyz)
     np.savez_compressed(os.path.join(HERE, "pointnet2_oracle.npz"), xyz=pts, fps_idx=fidx, ball_idx=bq,
                         nn_dist2=d2, nn_idx=i3, nn_w=cpu.three_weights(d2))
+    make_proposal_golden()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 

@@ -1,0 +1,146 @@
+"""Proposal stage on the GPU (decode_kernel / sort_split_kernel / greedy_nms_kernel / assemble_kernel) through the
+C ABI: bit-exact against the CPU oracle and the golden vectors made by the reference's own Python."""
+import numpy as np
+import pytest
+import torch
+
+from proposal_cases import case_inputs, golden, proposal_cases
+from rcnn_bev import bev
+from util import ANCHOR, rand_boxes3d, rpn_like_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("name", sorted(proposal_cases()))
+def test_proposal_layer_equals_golden_and_oracle(dev, cpu, name):
+    from pointrcnn_amd import ops
+    g = golden()
+    xyz, sc, reg, kw = case_inputs(name)
+    B, N = sc.shape
+    boxes = ops.decode_bbox_target(_t(xyz.reshape(-1, 3), dev), _t(reg.reshape(-1, 76), dev), 3.0, 0.5, 12, ANCHOR,
+                                   get_xz_fine=True, y_to_bottom=True).view(B, N, 7)
+    ob = cpu.decode_bbox_target(xyz.reshape(-1, 3), reg.reshape(-1, 76), 3.0, 0.5, 12, ANCHOR, get_xz_fine=True,
+                                y_to_bottom=True).reshape(B, N, 7)
+    assert np.array_equal(boxes.cpu().numpy(), ob)
+    rois, scores, cnt = ops.proposal_layer(_t(sc, dev), boxes, kw["pre"], kw["post"], kw["thresh"],
+                                           rotated=kw["kind"] == "rotated", ranges=kw["ranges"])
+    o_rois, o_scores, o_cnt = cpu.proposal_layer(sc, ob, kw["pre"], kw["post"], kw["thresh"], kw["kind"], kw["ranges"])
+    assert np.array_equal(cnt.cpu().numpy(), o_cnt)
+    assert np.array_equal(rois.cpu().numpy(), o_rois) and np.array_equal(scores.cpu().numpy(), o_scores)
+    assert np.array_equal(rois.cpu().numpy(), g[name + "_rois"]) and np.array_equal(scores.cpu().numpy(), g[name + "_scores"])
+
+
+def test_decode_variants_equal_oracle_and_golden(dev, cpu):
+    from pointrcnn_amd import ops
+    g = golden()
+    xyz, sc, reg = rpn_like_scene(1, 4096, seed=6)
+    out = ops.decode_bbox_target(_t(xyz[0], dev), _t(reg[0], dev), 3.0, 0.5, 12, ANCHOR, get_xz_fine=True)
+    assert np.array_equal(out.cpu().numpy(), g["dec_rpn"])
+    out = ops.decode_bbox_target(_t(xyz[0], dev), _t(reg[0][:, 24:], dev), 3.0, 0.5, 12, ANCHOR, get_xz_fine=False)
+    assert np.array_equal(out.cpu().numpy(), g["dec_rpn_coarse"])
+    for key, regk, ybin in (("dec_rcnn", "dec_reg46", False), ("dec_rcnn_ybin", "dec_reg53", True)):
+        out = ops.decode_bbox_target(_t(g["dec_rois7"], dev), _t(g[regk], dev), 1.5, 0.5, 9, ANCHOR, get_xz_fine=True,
+                                     get_y_by_bin=ybin, loc_y_scope=0.5, loc_y_bin_size=0.25, get_ry_fine=True).cpu().numpy()
+        o = cpu.decode_bbox_target(g["dec_rois7"], g[regk], 1.5, 0.5, 9, ANCHOR, get_xz_fine=True, get_y_by_bin=ybin,
+                                   loc_y_scope=0.5, loc_y_bin_size=0.25, get_ry_fine=True, trig_mode=1)
+        assert np.array_equal(out, o)                                   # canonical trig: bit-exact
+        np.testing.assert_allclose(out, g[key], rtol=0, atol=1e-5)      # reference Python (torch cos/sin + bmm)
+    # odd row counts, NaN / tie logits: first maximum wins, NaN is maximal (torch.argmax)
+    r = np.random.default_rng(3)
+    reg = r.integers(-2, 3, (777, 76)).astype(np.float32)              # many exact ties
+    reg[5, 3] = np.nan
+    reg[6, 20] = np.nan
+    pts = r.normal(size=(777, 3)).astype(np.float32)
+    out = ops.decode_bbox_target(_t(pts, dev), _t(reg, dev), 3.0, 0.5, 12, ANCHOR).cpu().numpy()
+    assert np.array_equal(out, cpu.decode_bbox_target(pts, reg, 3.0, 0.5, 12, ANCHOR), equal_nan=True)
+
+
+def test_decode_and_proposal_argument_errors(dev):
+    from pointrcnn_amd import ops
+    from pointrcnn_amd._cabi import PointOpsError
+    z = torch.zeros
+    with pytest.raises(PointOpsError):
+        ops.decode_bbox_target(z((4, 3), device=dev), z((4, 75), device=dev), 3.0, 0.5, 12, ANCHOR)
+    with pytest.raises(PointOpsError):
+        ops.decode_bbox_target(z((4, 5), device=dev), z((4, 76), device=dev), 3.0, 0.5, 12, ANCHOR)
+    with pytest.raises(PointOpsError):          # the LDS-resident sort holds 16384 rows
+        ops.proposal_layer(z((1, 20000), device=dev), z((1, 20000, 7), device=dev), (6300, 2700), (70, 30), 0.8)
+    with pytest.raises(RuntimeError):
+        ops.proposal_layer(z((1, 8)), z((1, 8, 7)), (6, 2), (2, 1), 0.8)          # CPU tensors: no CPU path
+    # empty problems are fine
+    rois, scores, cnt = ops.proposal_layer(z((2, 0), device=dev), z((2, 0, 7), device=dev), (6300, 2700), (70, 30), 0.8)
+    assert rois.shape == (2, 100, 7) and float(rois.abs().sum()) == 0 and cnt.tolist() == [0, 0]
+
+
+def test_score_ties_nan_and_small_frames(dev, cpu):
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(11)
+    for N in (1, 15, 16, 17, 100, 1000, 1025):
+        boxes = rand_boxes3d(np.stack([r.uniform(-30, 30, N), np.ones(N), r.uniform(1, 75, N)], 1), N, seed=N, jitter=0.3)[None]
+        sc = r.integers(-3, 4, (1, N)).astype(np.float32)              # heavy ties -> order by row index
+        if N > 20:
+            sc[0, 7] = np.nan
+            sc[0, 11] = -0.0
+        rois, scores, cnt = ops.proposal_layer(_t(sc, dev), _t(boxes, dev), (6300, 2700), (70, 30), 0.8, rotated=True)
+        o = cpu.proposal_layer(sc, boxes, (6300, 2700), (70, 30), 0.8, "rotated")
+        assert np.array_equal(rois.cpu().numpy(), o[0]) and np.array_equal(cnt.cpu().numpy(), o[2]), N
+        assert np.array_equal(scores.cpu().numpy(), o[1], equal_nan=True), N
+
+
+def test_nms_batched_equals_oracle_and_sorted_nms(dev, cpu):
+    """tools/eval_rcnn.py:600-614: score-threshold select + rotated NMS 0.1 on the refined boxes, whole batch at once"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(5)
+    B, M = 6, 100
+    ctr = np.stack([r.uniform(-10, 10, 30), np.ones(30), r.uniform(5, 30, 30)], 1)
+    boxes = np.stack([rand_boxes3d(ctr, M, seed=40 + b, jitter=0.4) for b in range(B)])
+    sc = r.normal(size=(B, M)).astype(np.float32)
+    valid = 1 / (1 + np.exp(-sc)) > 0.3
+    valid[3] = False                                                     # a frame with nothing above threshold
+    for kind, thr, v in (("rotated", 0.1, valid), ("normal", 0.5, None), ("rotated", 0.8, None)):
+        keep, num = ops.nms_batched(_t(boxes, dev), _t(sc, dev), None if v is None else _t(v, dev), thr, kind == "rotated")
+        ok, on = cpu.nms_batched(boxes, sc, v, thr, kind)
+        assert np.array_equal(num.cpu().numpy(), on) and np.array_equal(keep.cpu().numpy(), ok)
+        for b in range(B):                                               # same answer as the pre-sorted single-frame NMS
+            order = cpu.argsort_desc(sc[b])
+            sel = order if v is None else order[v[b][order]]
+            assert np.array_equal(sel[cpu.nms(bev(boxes[b][sel]), thr, kind)], ok[b, :on[b]])
+    keep, num = ops.nms_batched(_t(boxes, dev), _t(sc, dev), None, 0.1, True, max_keep=5)
+    ok, on = cpu.nms_batched(boxes, sc, None, 0.1, "rotated", 5)
+    assert keep.shape == (B, 5) and np.array_equal(keep.cpu().numpy(), ok) and np.array_equal(num.cpu().numpy(), on)
+
+
+def test_full_batch_properties(dev):
+    """BASELINE config 3 size (bs32 x 16384): per-frame results do not depend on the batch, survivors are ordered,
+    inside their distance area, mutually below the NMS threshold, and the padding is zero."""
+    from pointrcnn_amd import ops
+    xyz, sc, reg = rpn_like_scene(32, 16384, seed=9)
+    B, N = sc.shape
+    boxes = ops.decode_bbox_target(_t(xyz.reshape(-1, 3), dev), _t(reg.reshape(-1, 76), dev), 3.0, 0.5, 12, ANCHOR,
+                                   y_to_bottom=True).view(B, N, 7)
+    sct = _t(sc, dev)
+    for rotated in (False, True):
+        rois, scores, cnt = ops.proposal_layer(sct, boxes, (6300, 2700), (70, 30), 0.8, rotated=rotated)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(dev)
+        r2, s2, c2 = ops.proposal_layer(sct[perm].contiguous(), boxes[perm].contiguous(), (6300, 2700), (70, 30), 0.8, rotated=rotated)
+        assert torch.equal(r2, rois[perm]) and torch.equal(s2, scores[perm]) and torch.equal(c2, cnt[perm])
+        r1, s1, c1 = ops.proposal_layer(sct[5:6].contiguous(), boxes[5:6].contiguous(), (6300, 2700), (70, 30), 0.8, rotated=rotated)
+        assert torch.equal(r1[0], rois[5]) and torch.equal(s1[0], scores[5])
+        rois_c, scores_c, cnt_c = rois.cpu().numpy(), scores.cpu().numpy(), cnt.cpu().numpy()
+        for b in range(B):
+            n = cnt_c[b]
+            assert (rois_c[b, n:] == 0).all() and (scores_c[b, n:] == 0).all()
+            z = rois_c[b, :n, 2]
+            n1 = int((z <= 40).sum())
+            assert n1 <= 70 and n - n1 <= 30 and (z[:n1] > 0).all() and (z[n1:] > 40).all() and (z[n1:] <= 80).all()
+            assert (np.diff(scores_c[b, :n1]) <= 0).all() and (np.diff(scores_c[b, n1:n]) <= 0).all()
+        # survivors of one area are pairwise below the threshold
+        bv = torch.from_numpy(bev(rois_c[0, :cnt_c[0]])).to(dev)
+        n1 = int((rois_c[0, :cnt_c[0], 2] <= 40).sum())
+        if rotated:
+            iou = ops.boxes_iou_bev(bv[:n1].contiguous(), bv[:n1].contiguous()).cpu().numpy()
+            assert (np.triu(iou, 1) <= 0.8).all()

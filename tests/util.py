@@ -43,3 +43,57 @@ def enlarge(boxes, e):
 def mlp_tol(ref):
     """absolute tolerance for the fp32-MFMA MLP against the double-accumulated oracle (1e-5 relative to scale)"""
     return 1e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+ANCHOR = np.array([1.52563191462, 1.62856739989, 3.88311640418], np.float32)    # default.yaml:19 CLS_MEAN_SIZE
+
+
+def encode_rpn_reg(pts, boxes, rng, loc_scope=3.0, loc_bin_size=0.5, num_head_bin=12, noise=0.3, peak=6.0):
+    """Synthetic RPN regression rows (n, 76) whose bin-based decode (bbox_transform.py:24-121, LOC_XZ_FINE) lands on
+    `boxes` (n,7 with y = box centre): the inverse of the decode, bins get a `peak` logit over N(0, noise) clutter."""
+    n = pts.shape[0]
+    nb = int(loc_scope / loc_bin_size) * 2
+    reg = rng.normal(0, noise, (n, 4 * nb + 1 + 2 * num_head_bin + 3)).astype(np.float32)
+    rows = np.arange(n)
+    for col, axis in ((0, 0), (1, 2)):                       # x bins, z bins
+        d = np.clip(boxes[:, axis] - pts[:, axis], -loc_scope + 1e-3, loc_scope - 1e-3) + loc_scope
+        b = np.floor(d / loc_bin_size).astype(np.int64)
+        reg[rows, col * nb + b] += peak
+        reg[rows, (2 + col) * nb + b] = (d - (b * loc_bin_size + loc_bin_size / 2)) / loc_bin_size
+    reg[:, 4 * nb] = boxes[:, 1] - pts[:, 1]
+    apc = 2 * np.pi / num_head_bin
+    sh = (boxes[:, 6] + apc / 2) % (2 * np.pi)
+    hb = np.floor(sh / apc).astype(np.int64)
+    reg[rows, 4 * nb + 1 + hb] += peak
+    reg[rows, 4 * nb + 1 + num_head_bin + hb] = (sh - (hb * apc + apc / 2)) / (apc / 2)
+    reg[:, -3:] = (boxes[:, 3:6] - ANCHOR) / ANCHOR
+    return reg
+
+
+def rpn_like_scene(B, N, seed=0, nobj=24, fg_frac=0.4, z_max=70.4):
+    """What the RPN heads emit on a driving scene, synthetically: xyz (B,N,3), raw scores (B,N), reg (B,N,76).
+    fg_frac of the points sit on `nobj` cars and vote (with noise) for their car's box -> tight clusters of heavily
+    overlapping proposals with high scores, which is what makes the NMS do real work; the rest is background clutter."""
+    xyz = np.empty((B, N, 3), np.float32)
+    scores = np.empty((B, N), np.float32)
+    reg = np.empty((B, N, 76), np.float32)
+    for b in range(B):
+        r = np.random.default_rng(seed * 1000 + b)
+        nfg = int(N * fg_frac)
+        obj = np.stack([r.uniform(-35, 35, nobj), r.uniform(0.8, 1.2, nobj), r.uniform(4, z_max - 4, nobj),
+                        r.uniform(1.4, 1.7, nobj), r.uniform(1.5, 1.8, nobj), r.uniform(3.4, 4.4, nobj),
+                        r.uniform(-np.pi, np.pi, nobj)], 1)
+        own = r.integers(0, nobj, nfg)
+        pf = obj[own, :3] + r.normal(0, 1, (nfg, 3)) * np.array([0.8, 0.4, 1.2])
+        pb = np.stack([r.uniform(-40, 40, N - nfg), r.uniform(-1, 3, N - nfg), r.uniform(0.1, z_max, N - nfg)], 1)
+        tgt_f = obj[own] + r.normal(0, 1, (nfg, 7)) * np.array([0.08, 0.03, 0.12, 0.03, 0.03, 0.06, 0.03])
+        tgt_b = np.concatenate([pb + r.normal(0, 1.0, (N - nfg, 3)), r.uniform(1.0, 2.0, (N - nfg, 1)),
+                                r.uniform(1.2, 2.0, (N - nfg, 1)), r.uniform(3.0, 5.0, (N - nfg, 1)),
+                                r.uniform(-np.pi, np.pi, (N - nfg, 1))], 1)
+        pts = np.concatenate([pf, pb]).astype(np.float32)
+        tgt = np.concatenate([tgt_f, tgt_b])
+        perm = r.permutation(N)
+        xyz[b] = pts[perm]
+        reg[b] = encode_rpn_reg(pts.astype(np.float64), tgt, r)[perm]
+        scores[b] = np.concatenate([r.normal(2.5, 1.0, nfg), r.normal(-3.0, 1.0, N - nfg)]).astype(np.float32)[perm]
+    return xyz, scores, reg
