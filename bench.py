@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: step k runs on HIP stream k %% streams, so one batch's FPS "
                          "(1 workgroup per frame = 32 of 256 CUs) overlaps another batch's MLP / neighbour kernels")
+    ap.add_argument("--proposals", choices=["off", "normal", "rotate"], default="normal",
+                    help="also run the proposal layer (decode + sort + distance split + NMS + top-100, lib/rpn/proposal_layer.py) "
+                         "inside every step, as tools/eval_rcnn.py --eval_mode rpn does after the heads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -159,9 +162,17 @@ def main():
                                                           seed0=100 + (world * s_ + rank) * args.batch).to(dev)})
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
 
+    proposal_layer = None
+    if args.proposals != "off":
+        from pointrcnn_amd.proposal_layer import ProposalConfig, ProposalLayer
+        proposal_layer = ProposalLayer("TEST", cfg=type("Cfg", (ProposalConfig,), {"NMS_TYPE": args.proposals}))
+
     def step(slot=0):
         with torch.no_grad():
-            return model(batches[slot])
+            o = model(batches[slot])
+            if proposal_layer is not None:
+                o["rois"], o["roi_scores_raw"] = proposal_layer(o["rpn_cls"][:, :, 0], o["rpn_reg"], o["backbone_xyz"])
+            return o
 
     for _ in range(max(1, args.warmup)):        # packs weights, fills the caching allocator
         out = step(0)
@@ -228,7 +239,8 @@ def main():
         "config": {"workload": "Full RPN PointNet++ backbone (4 SA-MSG + 4 FP) + cls/reg heads, tools/cfgs/default.yaml, "
                                "%d pts/frame, batch %d per GPU, random-init weights, eval-mode BN" % (args.npoints, args.batch),
                    "frames_per_gpu": args.batch, "npoints": args.npoints, "parallelism": "frames sharded, dp%d" % world,
-                   "launch": "hipGraph replay" if graph is not None else "eager", "streams": nstreams},
+                   "launch": "hipGraph replay" if graph is not None else "eager", "streams": nstreams,
+                   "proposal_layer": args.proposals},
     }
 
     if rank == 0 and not args.no_roofline:

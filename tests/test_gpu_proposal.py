@@ -144,3 +144,34 @@ def test_full_batch_properties(dev):
         if rotated:
             iou = ops.boxes_iou_bev(bv[:n1].contiguous(), bv[:n1].contiguous()).cpu().numpy()
             assert (np.triu(iou, 1) <= 0.8).all()
+
+
+def test_point_rcnn_end_to_end_config3(dev, cpu):
+    """BASELINE config 3: RPN -> proposal layer -> roipool3d -> RCNN -> decode + rotated NMS, random-init weights.
+    The proposal / detection glue on the device must equal the oracle run on the same head outputs."""
+    from pointrcnn_amd.point_rcnn import PointRCNN
+    from pointrcnn_amd.rpn import randomize_bn_stats, synthetic_clouds
+    torch.manual_seed(0)
+    for nms_type in ("normal", "rotate"):
+        model = randomize_bn_stats(PointRCNN(mode="TEST")).to(dev).eval()
+        model.rpn.proposal_layer.cfg = type("Cfg", (model.rpn.proposal_layer.cfg,), {"NMS_TYPE": nms_type})
+        pts = synthetic_clouds(2, 16384, device=dev)
+        with torch.no_grad():
+            out = model({"pts_input": pts})
+            pred, raw, keep, num = model.detections(out, score_thresh=0.3)
+        assert out["rois"].shape == (2, 100, 7) and out["roi_scores_raw"].shape == (2, 100)
+        assert out["rcnn_cls"].shape == (200, 1) and out["rcnn_reg"].shape == (200, 46)
+        sc = out["rpn_cls"][:, :, 0].cpu().numpy()
+        reg = out["rpn_reg"].cpu().numpy()
+        xyz = out["backbone_xyz"].cpu().numpy()
+        boxes = cpu.decode_bbox_target(xyz.reshape(-1, 3), reg.reshape(-1, 76), 3.0, 0.5, 12, ANCHOR, y_to_bottom=True)
+        o_rois, o_scores, _ = cpu.proposal_layer(sc, boxes.reshape(2, -1, 7), (6300, 2700), (70, 30), 0.8,
+                                                 "rotated" if nms_type == "rotate" else "normal")
+        assert np.array_equal(out["rois"].cpu().numpy(), o_rois) and np.array_equal(out["roi_scores_raw"].cpu().numpy(), o_scores)
+        o_pred = cpu.decode_bbox_target(o_rois.reshape(-1, 7), out["rcnn_reg"].cpu().numpy(), 1.5, 0.5, 9, ANCHOR,
+                                        get_xz_fine=True, get_ry_fine=True).reshape(2, 100, 7)
+        assert np.array_equal(pred.cpu().numpy(), o_pred)
+        raw_c = raw.cpu().numpy()
+        valid = torch.sigmoid(raw).cpu().numpy() > 0.3
+        ok, on = cpu.nms_batched(o_pred, raw_c, valid, 0.1, "rotated")
+        assert np.array_equal(keep.cpu().numpy(), ok) and np.array_equal(num.cpu().numpy(), on)
