@@ -257,6 +257,20 @@ int prcnn_nms_batched(const float* boxes3d, const float* scores, const uint8_t* 
                       int max_keep, int32_t* keep, int32_t* num_keep, void* workspace, size_t workspace_bytes,
                       prcnn_stream_t stream);
 
+/* Fused RCNN input builder = lib/net/rcnn_net.py:127-154 in one pass:
+ *   cat([extra0, extra1, feat]) -> roipool3d (first <= S in-box points per RoI, wrap-duplicated, boxes = pool_boxes3d,
+ *   already enlarged by the caller) -> pooled xyz -= roi centre (:146-147) -> rotate_pc_along_y_torch(pooled xyz, roi ry)
+ *   (kitti_utils.py:45-63), without the (B,N,2+C) and (B,M,S,5+C) tensors and without the per-frame Python loop.
+ * rois (B,M,7) define the canonical frame; NULL keeps scene coordinates.  extra0 / extra1: per-point scalar channels
+ * (B,N) (seg_mask, normalised depth) or NULL.  feat: (B,N,C) rows with stride ld_feat.
+ * out_pts : B*M*S rows of stride ld_pts, columns [x',y',z',extra0,extra1];
+ * out_feat: B*M*S rows of stride ld_out, C columns written at this pointer (point it INTO a wider buffer to place the
+ *           features where the next layer wants them).  empty (B,M) i32.  An empty RoI yields zeros run through the
+ *           same transform (i.e. -centre rotated), exactly what the reference's in-place ops produce. */
+int prcnn_roipool3d_canonical(const float* xyz, const float* pool_boxes3d, const float* rois, const float* extra0,
+                              const float* extra1, const float* feat, int ld_feat, int B, int N, int M, int C, int S,
+                              float* out_pts, int ld_pts, float* out_feat, int ld_out, int32_t* empty, prcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,6 +163,14 @@ class _Cpu:
                                      _p(out, _F), _p(empty, _I))
         return out, empty
 
+    def canonical_transform(self, pooled, rois, trig_mode=1):
+        """rcnn_net.py:143-150 on a pooled (B,M,S,W) tensor (returns a transformed copy)"""
+        out = _f32(pooled).copy()
+        rois = _f32(rois)
+        B, M, S, W = out.shape
+        self.lib.prcnn_cpu_canonical_transform(_p(out, _F), _p(rois, _F), B, M, S, W, trig_mode)
+        return out
+
     # ---- iou3d ----
     def boxes_overlap_bev(self, a, b, trig_mode=1):
         a, b = _f32(a), _f32(b)

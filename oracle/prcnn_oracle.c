@@ -729,3 +729,24 @@ PRCNN_EXPORT void prcnn_cpu_nms_batched(const float* boxes3d, const float* score
     }
     free(order); free(cand);
 }
+
+/* Canonical transformation of pooled RoI points, in place on a pooled tensor (B, M, S, W) whose first 3 columns are
+ * xyz (lib/net/rcnn_net.py:143-150): xyz -= roi centre (raw roi x,y,z), then kitti_utils.py:45-63
+ * rotate_pc_along_y_torch(xyz, roi ry): [x', z'] = [x, z] . R^T with R = [[cos, -sin], [sin, cos]].
+ * PINNED against the reference's own Python (tests/golden/make_golden.py: canonical_ref) to 1e-5: torch's cos/sin and
+ * bmm are not bit-specified; trig_mode 0 = cosf/sinf, 1 = canonical (double trig rounded once), products and sums
+ * individually rounded. */
+PRCNN_EXPORT void prcnn_cpu_canonical_transform(float* pooled, const float* rois, int B, int M, int S, int W, int trig_mode) {
+    for (size_t r = 0; r < (size_t)B * M; r++) {
+        const float* roi = rois + r * 7;
+        float ca, sa;
+        box_trig(roi[6], trig_mode, &ca, &sa);
+        for (int s = 0; s < S; s++) {
+            float* p = pooled + (r * S + s) * W;
+            float x = p[0] - roi[0], y = p[1] - roi[1], z = p[2] - roi[2];
+            float nx = x * ca + z * (-sa);
+            float nz = x * sa + z * ca;
+            p[0] = nx; p[1] = y; p[2] = nz;
+        }
+    }
+}

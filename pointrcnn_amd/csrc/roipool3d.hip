@@ -119,6 +119,115 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(const float* __re
     }
 }
 
+// ---- fused RCNN input builder (lib/net/rcnn_net.py:127-154) -------------------------------
+// The reference concatenates [seg_mask, depth, rpn_features] into a (B,N,130) tensor, pools it into (B,M,S,133),
+// subtracts the RoI centre in place and rotates each frame's RoIs in a Python loop (kitti_utils.py:45-63), after which
+// rcnn_net.py slices the pooled tensor apart again ([:, :, 0:5] -> xyz_up_layer, [:, :, 5:] -> cat -> merge_down_layer).
+// This kernel is the same point selection as roipool3d_kernel, but it reads the per-point channels where they already
+// are, applies the canonical transform while gathering, and writes the two consumers' operands directly:
+//   out_pts  rows [x', y', z', extra0, extra1] (stride ld_pts)             -> xyz_up_layer / the SA modules' xyz
+//   out_feat rows of C features at any (stride, column) of a wider buffer  -> the second half of merge_down_layer's input
+struct CanonParams {
+    const float* xyz;        // (B, N, 3)
+    const float* pool_boxes; // (B, M, 7) boxes used for the point-in-box test (already enlarged by the caller)
+    const float* rois;       // (B, M, 7) boxes defining the canonical frame, or NULL: keep scene coordinates
+    const float* extra[2];   // per-point scalar channels (B, N), NULL-terminated
+    const float* feat;       // (B, N, C) rows, stride ld_feat
+    float* out_pts;          // (B*M*S) rows, stride ld_pts, 3 + n_extra columns written
+    float* out_feat;         // (B*M*S) rows, stride ld_out, C columns written from column 0 of this pointer
+    int32_t* empty;          // (B, M)
+    int N, M, C, S, n_extra, ld_feat, ld_pts, ld_out;
+};
+
+__global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(CanonParams P) {
+    extern __shared__ int32_t lds[];          // RP_WAVES lists of S indices, then the merged list of S
+    __shared__ BoxConst sbox;
+    __shared__ float sroi[5];                 // centre x,y,z, cos(ry), sin(ry)
+    __shared__ int wcnt[RP_WAVES];
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = P.N, S = P.S, C = P.C;
+    if (tid == 0) sbox = make_box(P.pool_boxes + ((size_t)b * P.M + m) * 7);
+    if (tid == 64 && P.rois) {
+        const float* r = P.rois + ((size_t)b * P.M + m) * 7;
+        sroi[0] = r[0]; sroi[1] = r[1]; sroi[2] = r[2];
+        sroi[3] = (float)cos((double)r[6]); sroi[4] = (float)sin((double)r[6]);
+    }
+    __syncthreads();
+    const BoxConst box = sbox;
+    const float* __restrict__ p = P.xyz + (size_t)b * N * 3;
+    int32_t* mylist = lds + wave * S;
+    const int per_wave = (((N + RP_WAVES - 1) / RP_WAVES) + 63) & ~63;
+    const int k_begin = wave * per_wave, k_end = min(N, k_begin + per_wave);
+    int cnt = 0;
+    for (int k0 = k_begin; k0 < k_end && cnt < S; k0 += 256) {
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int k = k0 + u * 64 + lane;
+            float x = 0.f, y = 0.f, z = 0.f;
+            bool ok = k < k_end;
+            if (ok) { x = p[k * 3]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
+            in[u] = ok && pt_in_box(box, x, y, z);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            unsigned long long mask = __ballot(in[u]);
+            int pos = cnt + __popcll(mask & ((1ULL << lane) - 1ULL));
+            if (in[u] && pos < S) mylist[pos] = k0 + u * 64 + lane;
+            cnt += __popcll(mask);
+        }
+    }
+    if (lane == 0) wcnt[wave] = min(cnt, S);
+    __syncthreads();
+    int32_t* sel = lds + RP_WAVES * S;
+    int off = 0;
+    for (int w = 0; w < wave; w++) off += wcnt[w];
+    int total = 0;
+    for (int w = 0; w < RP_WAVES; w++) total += wcnt[w];
+    total = min(total, S);
+    for (int i = lane; i < wcnt[wave]; i += 64)
+        if (off + i < S) sel[off + i] = mylist[i];
+    __syncthreads();
+    if (tid == 0) P.empty[(size_t)b * P.M + m] = total == 0 ? 1 : 0;
+    for (int s2 = total + tid; s2 < S; s2 += RP_THREADS) sel[s2] = total ? sel[s2 % total] : -1;
+    __syncthreads();
+
+    // ---- xyz (+ canonical transform) and the scalar channels: one row per thread ----
+    const size_t row0 = ((size_t)b * P.M + m) * S;
+    const bool canon = P.rois != nullptr;
+    const float cx = sroi[0], cy = sroi[1], cz = sroi[2], ca = sroi[3], sa = sroi[4];
+    for (int s = tid; s < S; s += RP_THREADS) {
+        const int k = sel[s];
+        float x = 0.f, y = 0.f, z = 0.f;                      // an empty RoI pools zeros (roipool3d.cpp:165-170)
+        if (k >= 0) { x = p[k * 3]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
+        if (canon) {
+            x = __fsub_rn(x, cx); y = __fsub_rn(y, cy); z = __fsub_rn(z, cz);          // rcnn_net.py:146-147
+            const float nx = __fadd_rn(__fmul_rn(x, ca), __fmul_rn(z, -sa));             // kitti_utils.py:52-61
+            const float nz = __fadd_rn(__fmul_rn(x, sa), __fmul_rn(z, ca));
+            x = nx; z = nz;
+        }
+        float* o = P.out_pts + (row0 + s) * P.ld_pts;
+        o[0] = x; o[1] = y; o[2] = z;
+        for (int e = 0; e < P.n_extra; e++) o[3 + e] = k >= 0 ? P.extra[e][(size_t)b * N + k] : 0.f;
+    }
+    // ---- features: flat coalesced copy of S rows of C floats (row stride ld_out) ----
+    if (C > 0) {
+        const float* __restrict__ f = P.feat + (size_t)b * N * P.ld_feat;
+        float* __restrict__ of = P.out_feat + row0 * P.ld_out;
+        const int total_e = S * C;
+        const int qstep = RP_THREADS / C, rstep = RP_THREADS - qstep * C;
+        int srow = tid / C, scol = tid - srow * C;
+#pragma unroll 4
+        for (int e = tid; e < total_e; e += RP_THREADS) {
+            const int k = sel[srow];
+            of[(size_t)srow * P.ld_out + scol] = k >= 0 ? f[(size_t)k * P.ld_feat + scol] : 0.f;
+            srow += qstep; scol += rstep;
+            if (scol >= C) { scol -= C; srow++; }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pts_in_boxes3d_kernel(const float* __restrict__ pts,
                                                             const float* __restrict__ boxes3d, int N, int M,
                                                             int32_t* __restrict__ flags) {
@@ -153,5 +262,27 @@ PRCNN_API int prcnn_pts_in_boxes3d(const float* pts, const float* boxes3d, int N
     hipLaunchKernelGGL(pts_in_boxes3d_kernel, dim3(prcnn_divup(N, 256), M), dim3(256), 0, (hipStream_t)stream, pts,
                        boxes3d, N, M, flags);
     PRCNN_LAUNCH_CHECK("prcnn_pts_in_boxes3d");
+    return PRCNN_OK;
+}
+
+PRCNN_API int prcnn_roipool3d_canonical(const float* xyz, const float* pool_boxes3d, const float* rois, const float* extra0,
+                                        const float* extra1, const float* feat, int ld_feat, int B, int N, int M, int C, int S,
+                                        float* out_pts, int ld_pts, float* out_feat, int ld_out, int32_t* empty,
+                                        prcnn_stream_t stream) {
+    const char* op = "prcnn_roipool3d_canonical";
+    PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && C >= 0 && S > 0, "%s: bad shape B=%d N=%d M=%d C=%d S=%d", op, B, N, M, C, S);
+    if (B == 0 || M == 0) return PRCNN_OK;
+    const int n_extra = extra0 ? (extra1 ? 2 : 1) : 0;
+    PRCNN_REQUIRE(extra0 || !extra1, "%s: extra1 without extra0", op);
+    PRCNN_REQUIRE(xyz && pool_boxes3d && out_pts && empty && (C == 0 || (feat && out_feat)), "%s: null pointer", op);
+    PRCNN_REQUIRE(ld_pts >= 3 + n_extra && (C == 0 || (ld_feat >= C && ld_out >= C)), "%s: row strides smaller than the rows", op);
+    size_t lds_bytes = (size_t)(RP_WAVES + 1) * S * sizeof(int32_t);
+    PRCNN_REQUIRE(lds_bytes <= 60 * 1024, "%s: sampled_pt_num %d too large for the LDS index lists", op, S);
+    CanonParams P;
+    P.xyz = xyz; P.pool_boxes = pool_boxes3d; P.rois = rois; P.extra[0] = extra0; P.extra[1] = extra1; P.feat = feat;
+    P.out_pts = out_pts; P.out_feat = out_feat; P.empty = empty;
+    P.N = N; P.M = M; P.C = C; P.S = S; P.n_extra = n_extra; P.ld_feat = ld_feat; P.ld_pts = ld_pts; P.ld_out = ld_out;
+    hipLaunchKernelGGL(roipool3d_canonical_kernel, dim3(M, B), dim3(RP_THREADS), lds_bytes, (hipStream_t)stream, P);
+    PRCNN_LAUNCH_CHECK(op);
     return PRCNN_OK;
 }

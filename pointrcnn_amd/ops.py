@@ -367,6 +367,43 @@ def roipool3d(xyz, boxes3d_enlarged, pts_feature, sampled_pt_num):
     return pooled, empty
 
 
+def roipool3d_canonical(xyz, pool_boxes3d, rois, extras, feat_cl, sampled_pt_num, out_feat=None):
+    """Fused lib/net/rcnn_net.py:127-154: pool [extras..., feat] per RoI and move the pooled xyz into the RoI's
+    canonical frame, writing each consumer's operand directly.
+    xyz (B,N,3); pool_boxes3d (B,M,7) enlarged; rois (B,M,7) or None; extras: list of <= 2 (B,N) tensors;
+    feat_cl (B,N,C) channels-last rows (unit last stride).  out_feat = (buffer (B*M*S, W), col): write the C pooled
+    features at that column of a wider rows buffer (default: a fresh (B*M*S, C) tensor).
+    -> pts (B*M, S, 3+len(extras)), feat buffer, empty (B,M) i32"""
+    _chk(xyz, "xyz", ndim=3); _chk(pool_boxes3d, "pool_boxes3d", ndim=3)
+    B, N, _ = xyz.shape
+    if not (isinstance(feat_cl, torch.Tensor) and feat_cl.is_cuda and feat_cl.dtype == _F32 and feat_cl.dim() == 3
+            and feat_cl.stride(-1) == 1 and feat_cl.stride(0) == N * feat_cl.stride(1)):
+        raise RuntimeError("roipool3d_canonical: feat must be a (B,N,C) fp32 device tensor of uniformly strided rows")
+    M, C, S = pool_boxes3d.shape[1], feat_cl.shape[2], int(sampled_pt_num)
+    ex = [e.contiguous() for e in extras]
+    if len(ex) > 2:
+        raise ValueError("roipool3d_canonical: at most 2 scalar channels")
+    for e in ex:
+        _chk(e, "extra", ndim=2)
+    P = 3 + len(ex)
+    dev = xyz.device
+    pts = torch.empty((B * M, S, P), dtype=_F32, device=dev)
+    if out_feat is None:
+        fbuf, col = torch.empty((B * M * S, C), dtype=_F32, device=dev), 0
+    else:
+        fbuf, col = out_feat
+        if fbuf.dim() != 2 or fbuf.shape[0] != B * M * S or fbuf.stride(1) != 1 or col + C > fbuf.shape[1]:
+            raise ValueError("roipool3d_canonical: out_feat buffer must be (B*M*S, >= col + C) rows")
+    empty = torch.empty((B, M), dtype=_INT, device=dev)
+    if rois is not None:
+        _chk(rois, "rois", ndim=3)
+    _cabi.check(_cabi.lib().prcnn_roipool3d_canonical(
+        _p(xyz), _p(pool_boxes3d), _p(rois), _p(ex[0]) if ex else None, _p(ex[1]) if len(ex) > 1 else None, _p(feat_cl),
+        _row_stride(feat_cl), B, N, M, C, S, _p(pts), P, fbuf.data_ptr() + 4 * col, fbuf.stride(0), _p(empty), _stream()),
+        "prcnn_roipool3d_canonical")
+    return pts, fbuf, empty
+
+
 def pts_in_boxes3d(pts, boxes3d):
     """pts (N,3), boxes3d (M,7) -> flags (M,N) i32"""
     _chk(pts, "pts", ndim=2); _chk(boxes3d, "boxes3d", ndim=2)

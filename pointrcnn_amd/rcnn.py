@@ -141,7 +141,50 @@ class RCNNNet(nn.Module):
             pooled[k, :, :, 0:3] = rotate_pc_along_y_torch(pooled[k, :, :, 0:3], batch_rois[k, :, 6])
         return pooled.view(-1, pooled.shape[2], pooled.shape[3]), empty
 
+    def _fused_ok(self, input_data):
+        x = input_data["rpn_xyz"]
+        return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and not self.cfg.USE_INTENSITY \
+            and self.cfg.USE_MASK and self.xyz_up_layer.fusable() and self.merge_down_layer.fusable()
+
+    def _forward_fused(self, input_data):
+        """Inference fast path of rcnn_net.py:127-190.  One kernel builds the stage's inputs (prcnn_roipool3d_canonical:
+        per-point channels read where they are, canonical transform applied while gathering, pooled RPN features written
+        straight into the second half of merge_down_layer's input rows), so the (B,N,130) concat, the (B,M,512,133)
+        pooled tensor, the per-frame rotate loop and the (B*M,256,512) concat of the reference never exist."""
+        cfg = self.cfg
+        rpn_xyz, rois = input_data["rpn_xyz"].contiguous(), input_data["roi_boxes3d"].contiguous()
+        B, M = rois.shape[:2]
+        S = cfg.NUM_POINTS
+        extras = [input_data["seg_mask"]]
+        if cfg.USE_DEPTH:
+            extras.append(input_data["pts_depth"] / 70.0 - 0.5)
+        feat_cl = pt_utils._rows_view(input_data["rpn_features"])
+        c_up, C = cfg.XYZ_UP_LAYER[-1], feat_cl.shape[-1]
+        merged_in = torch.empty((B * M * S, c_up + C), dtype=torch.float32, device=rpn_xyz.device)
+        pool_boxes = enlarge_box3d(rois.view(-1, 7), cfg.POOL_EXTRA_WIDTH).view(B, M, 7)
+        pts, _, empty = ops.roipool3d_canonical(rpn_xyz, pool_boxes, rois, extras, feat_cl, S, out_feat=(merged_in, c_up))
+        up = [m.packed() for m in self.xyz_up_layer.layers()]
+        if len(up) > 1 and ops.chain_supported(0, up, 0):
+            ops.mlp_chain_rows(pts, up, out=(merged_in, 0))
+        else:
+            x = pts
+            for li, lin in enumerate(up):
+                x = ops.mlp_rows(x, lin, out=(merged_in, 0) if li == len(up) - 1 else None)
+        x = merged_in
+        for m in self.merge_down_layer.layers():
+            x = ops.mlp_rows(x, m.packed())
+        l_xyz, l_features = [pts[..., 0:3]], [x.view(B * M, S, -1).transpose(1, 2)]
+        for i in range(len(self.SA_modules)):
+            li_xyz, li_features = self.SA_modules[i](l_xyz[i], l_features[i])
+            l_xyz.append(li_xyz)
+            l_features.append(li_features)
+        rcnn_cls = pt_utils.fused_sequential(self.cls_layer, l_features[-1]).transpose(1, 2).contiguous().squeeze(1)
+        rcnn_reg = pt_utils.fused_sequential(self.reg_layer, l_features[-1]).transpose(1, 2).contiguous().squeeze(1)
+        return {"rcnn_cls": rcnn_cls, "rcnn_reg": rcnn_reg, "pooled_empty_flag": empty}
+
     def forward(self, input_data):
+        if self._fused_ok(input_data):
+            return self._forward_fused(input_data)
         pts_input, empty = self.pool_rois(input_data)
         xyz = pts_input[..., 0:3].contiguous()
         c = self.rcnn_input_channel

@@ -79,6 +79,26 @@ def make_proposal_golden():
     np.savez_compressed(os.path.join(HERE, "proposal_ref.npz"), **out)
 
 
+def make_canonical_golden(ref):
+    """rcnn_net.py:143-150 run with the reference's own kitti_utils.rotate_pc_along_y_torch on the reference's pooled tensor"""
+    import torch
+    import ref_proposal
+    ref_proposal.load()
+    import lib.utils.kitti_utils as kitti_utils
+    g = np.load(os.path.join(HERE, "roipool3d_ref.npz"))
+    xyz, boxes, feat, S = g["xyz"], g["boxes"], g["feat"], int(g["S"])
+    rois = boxes.copy()
+    rois[..., 3:6] -= 2.0                                # the un-enlarged RoIs (enlarge_box3d(rois, 1.0) == boxes)
+    rois[..., 1] -= 1.0
+    pooled, empty = ref.roipool3d_gpu(xyz, boxes, feat, S)
+    pf = torch.from_numpy(pooled.copy())
+    batch_rois = torch.from_numpy(rois)
+    pf[:, :, :, 0:3] -= batch_rois[:, :, 0:3].unsqueeze(dim=2)
+    for k in range(pf.shape[0]):
+        pf[k, :, :, 0:3] = kitti_utils.rotate_pc_along_y_torch(pf[k, :, :, 0:3], batch_rois[k, :, 6])
+    np.savez_compressed(os.path.join(HERE, "canonical_ref.npz"), rois=rois, pooled_canonical=pf.numpy(), empty=empty)
+
+
 def main():
     cpu, ref = oracle.cpu(), oracle.ref()
     if ref is None:
@@ -110,6 +130,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "pointnet2_oracle.npz"), xyz=pts, fps_idx=fidx, ball_idx=bq,
                         nn_dist2=d2, nn_idx=i3, nn_w=cpu.three_weights(d2))
     make_proposal_golden()
+    make_canonical_golden(ref)
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 

@@ -185,3 +185,35 @@ def test_nms_max_keep_prefix(dev, cpu):
             n = int(num.item())
             assert n == min(mk, len(full))
             assert np.array_equal(keep[:n].cpu().numpy(), full[:n])
+
+
+def test_roipool3d_canonical_equals_oracle_and_reference_python(dev, cpu):
+    """fused concat + roipool3d + canonical transform (rcnn_net.py:127-154) against the oracle
+    (bit-exact) and the reference's own Python ops run on the reference's pooled tensor (golden, 1e-5)."""
+    import os
+    from pointrcnn_amd import ops
+    from util import GOLDEN
+    g, r = np.load(os.path.join(GOLDEN, "canonical_ref.npz")), np.load(os.path.join(GOLDEN, "roipool3d_ref.npz"))
+    xyz, boxes, feat, S = r["xyz"], r["boxes"], r["feat"], int(r["S"])
+    B, N, C = feat.shape
+    M = boxes.shape[1]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # features as trailing channels of a wider buffer, outputs into a wider buffer: strides are honoured
+    wide = torch.zeros((B, N, C + 5), device=dev)
+    wide[..., 2:2 + C] = t(feat)
+    out_buf = torch.full((B * M * S, C + 7), -1.0, device=dev)
+    pts, fb, empty = ops.roipool3d_canonical(t(xyz), t(boxes), t(g["rois"]), [t(feat[..., 0]), t(feat[..., 1])],
+                                             wide[..., 2:2 + C], S, out_feat=(out_buf, 4))
+    want = cpu.canonical_transform(cpu.roipool3d(xyz, boxes, feat, S)[0], g["rois"])
+    assert np.array_equal(pts[..., 0:3].cpu().numpy().reshape(B, M, S, 3), want[..., 0:3])
+    assert np.array_equal(pts[..., 3:5].cpu().numpy().reshape(B, M, S, 2), want[..., 3:5])          # the two scalar channels
+    ob = out_buf.cpu().numpy()
+    assert np.array_equal(ob[:, 4:4 + C].reshape(B, M, S, C), want[..., 3:]) and (ob[:, :4] == -1).all() and (ob[:, 4 + C:] == -1).all()
+    assert np.array_equal(empty.cpu().numpy(), g["empty"])
+    np.testing.assert_allclose(pts[..., 0:3].cpu().numpy().reshape(B, M, S, 3), g["pooled_canonical"][..., 0:3], rtol=0, atol=1e-5)
+    assert empty.sum() >= 1                                                  # the fixture holds an empty RoI: -centre, rotated
+    # rois=None keeps scene coordinates == plain roipool3d
+    pts2, fb2, _ = ops.roipool3d_canonical(t(xyz), t(boxes), None, [], t(feat), S)
+    plain = cpu.roipool3d(xyz, boxes, feat, S)[0]
+    assert np.array_equal(pts2.cpu().numpy().reshape(B, M, S, 3), plain[..., :3])
+    assert np.array_equal(fb2.cpu().numpy().reshape(B, M, S, C), plain[..., 3:])
