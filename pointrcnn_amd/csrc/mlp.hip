@@ -631,6 +631,192 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(const ChainParams C) {
     chain_store<(NB2 ? NB2 : 1)>(C, a2, C.N2, row, meta.valid, lane, h);
 }
 
+// =====================================================================================================
+// FAST chain variant: the same computation as mlp_chain_kernel for the shapes that dominate the RPN graph (hoisted SA
+// stacks, the hoisted FP0 layer, the heads), written so that the layer-0 loop body is ONE straight-line block:
+//   * rows past the end are clamped to the last row (their results are simply not stored), every K is a multiple
+//     of the stage (host-checked), sources are 16-byte aligned: fetch / finish have no branches at all;
+//   * the activated-gather parameters (W_x, bias) sit in LDS;
+//   * the B operand of k-block kb+1 is produced (VALU) and the raw pieces of kb+2 are requested (VMEM) in the same
+//     block as the MFMAs of kb, so the scheduler runs them in the MFMA shadow instead of between MFMA bursts (the
+//     generic kernel's per-piece bounds checks split the loop into dozens of basic blocks and serialise the three);
+//   * the first weight stage of layer l+1 is requested while layer l computes.
+// Results are bit-identical to the generic kernel (same MFMA order, same activation arithmetic).
+// =====================================================================================================
+template <int NB> struct FStage { static constexpr int G = NB == 3 ? 4 : CH_STAGE_TILES / NB; static constexpr int TPW = (G * NB + CH_WAVES - 1) / CH_WAVES; };
+
+template <int NB>
+__device__ __forceinline__ void fstage_load(const float* __restrict__ wpack, int KB, int st, int wave, int lane, float4 (&r)[4]) {
+    constexpr int G = FStage<NB>::G;
+#pragma unroll
+    for (int u = 0; u < FStage<NB>::TPW; u++) {
+        const int tt = wave + CH_WAVES * u, kbl = tt / NB, ob = tt - kbl * NB;
+        if (tt < G * NB) r[u] = ldw(wpack, KB, ob, st * G + kbl, lane);            // compile-time condition after unrolling
+    }
+}
+template <int NB>
+__device__ __forceinline__ void fstage_store(float* ws, int wave, int lane, const float4 (&r)[4]) {
+#pragma unroll
+    for (int u = 0; u < FStage<NB>::TPW; u++) {
+        const int tt = wave + CH_WAVES * u;
+        if (tt < FStage<NB>::G * NB) *reinterpret_cast<float4*>(ws + (tt * 64 + lane) * 4) = r[u];
+    }
+}
+
+template <int MODE> __device__ __forceinline__ void fast_fetch(const MlpParams& P, const RowMeta<MODE>& r, int k, Raw<MODE>& v);
+template <> __device__ __forceinline__ void fast_fetch<MODE_PLAIN>(const MlpParams& P, const RowMeta<MODE_PLAIN>& r, int k, Raw<MODE_PLAIN>& v) {
+    v.a = ld4(P.in + r.off + k);
+}
+template <> __device__ __forceinline__ void fast_fetch<MODE_GROUP>(const MlpParams& P, const RowMeta<MODE_GROUP>& r, int k, Raw<MODE_GROUP>& v) {
+    v.a = ld4(P.feat + r.off + k);
+}
+template <> __device__ __forceinline__ void fast_fetch<MODE_INTERP>(const MlpParams& P, const RowMeta<MODE_INTERP>& r, int k, Raw<MODE_INTERP>& v) {
+    v.a = ld4(P.known + r.o0 + k); v.b = ld4(P.known + r.o1 + k); v.c = ld4(P.known + r.o2 + k);
+}
+// s_wx: act_wx (K,3) copied to LDS; s_b: act_bias (K)
+template <int MODE> __device__ __forceinline__ float4 fast_finish(const RowMeta<MODE>& r, int k, const Raw<MODE>& v, const float* s_wx, const float* s_b);
+template <> __device__ __forceinline__ float4 fast_finish<MODE_PLAIN>(const RowMeta<MODE_PLAIN>&, int, const Raw<MODE_PLAIN>& v, const float*, const float*) {
+    return v.a;
+}
+template <> __device__ __forceinline__ float4 fast_finish<MODE_GROUP>(const RowMeta<MODE_GROUP>& r, int k, const Raw<MODE_GROUP>& v, const float* s_wx, const float* s_b) {
+    const float4 w0 = ld4(s_wx + k * 3), w1 = ld4(s_wx + k * 3 + 4), w2 = ld4(s_wx + k * 3 + 8), b = ld4(s_b + k);
+    float4 o;                                        // same expression tree as act_group4
+    o.x = fmaxf(v.a.x + (w0.x * r.dx + w0.y * r.dy + w0.z * r.dz) + b.x, 0.f);
+    o.y = fmaxf(v.a.y + (w0.w * r.dx + w1.x * r.dy + w1.y * r.dz) + b.y, 0.f);
+    o.z = fmaxf(v.a.z + (w1.z * r.dx + w1.w * r.dy + w2.x * r.dz) + b.z, 0.f);
+    o.w = fmaxf(v.a.w + (w2.y * r.dx + w2.z * r.dy + w2.w * r.dz) + b.w, 0.f);
+    return o;
+}
+template <> __device__ __forceinline__ float4 fast_finish<MODE_INTERP>(const RowMeta<MODE_INTERP>& r, int k, const Raw<MODE_INTERP>& v, const float*, const float* s_b) {
+    const float4 b = ld4(s_b + k);
+    float4 o;
+    o.x = fmaxf(interp1(r.w0, v.a.x, r.w1, v.b.x, r.w2, v.c.x) + b.x, 0.f);
+    o.y = fmaxf(interp1(r.w0, v.a.y, r.w1, v.b.y, r.w2, v.c.y) + b.y, 0.f);
+    o.z = fmaxf(interp1(r.w0, v.a.z, r.w1, v.b.z, r.w2, v.c.z) + b.z, 0.f);
+    o.w = fmaxf(interp1(r.w0, v.a.w, r.w1, v.b.w, r.w2, v.c.w) + b.w, 0.f);
+    return o;
+}
+
+// layers >= 1 of the fast chain: KB == 4*NBI exactly (host-checked), first stage pre-loaded by the caller
+template <int NBI, int NBO, int NBN>
+__device__ __forceinline__ void fchain_layer(const f32x16 (&in)[NBI], f32x16 (&out)[NBO], const float* __restrict__ wpack,
+                                             float (*Ws)[CH_STAGE_TILES * 256], int wave, int lane, float4 (&wr)[4],
+                                             const float* __restrict__ wpack_next, float4 (&wnext)[4]) {
+    constexpr int G = FStage<NBO>::G, KB = NBI * 4;
+    static_assert(KB % G == 0, "stage size must divide the k-blocks");
+    constexpr int NST = KB / G;
+#pragma unroll
+    for (int ob = 0; ob < NBO; ob++) out[ob] = (f32x16){0};
+    fstage_store<NBO>(Ws[0], wave, lane, wr);
+    __syncthreads();
+    if (NBN > 0) fstage_load<(NBN > 0 ? NBN : 1)>(wpack_next, NBO * 4, 0, wave, lane, wnext);
+#pragma unroll
+    for (int st = 0; st < NST; st++) {
+        if (st + 1 < NST) fstage_load<NBO>(wpack, KB, st + 1, wave, lane, wr);
+        const float* ws = Ws[st & 1];
+#pragma unroll
+        for (int kbl = 0; kbl < G; kbl++) {
+            const int kb = st * G + kbl, pb = kb / 4, q = kb % 4;
+            float4 w[NBO];
+#pragma unroll
+            for (int ob = 0; ob < NBO; ob++) w[ob] = lds_w(ws, kbl * NBO + ob, lane);
+#pragma unroll
+            for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].x, in[pb][4 * q + 0], out[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].y, in[pb][4 * q + 1], out[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].z, in[pb][4 * q + 2], out[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].w, in[pb][4 * q + 3], out[ob], 0, 0, 0);
+        }
+        if (st + 1 < NST) fstage_store<NBO>(Ws[(st + 1) & 1], wave, lane, wr);
+        __syncthreads();
+    }
+}
+
+#define FAST_MAX_K 128
+template <int MODE, int NB0, int NB1, int NB2>
+__global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C) {
+    const MlpParams& P = C.a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const long row = ((long)blockIdx.x * 4 + wave) * 32 + j;
+    const bool valid = row < P.rows;
+    RowMeta<MODE> meta;
+    make_meta<MODE>(P, valid ? row : P.rows - 1, meta);
+
+    __shared__ __attribute__((aligned(16))) float Ws[2][CH_STAGE_TILES * 256];
+    __shared__ __attribute__((aligned(16))) float s_wx[(FAST_MAX_K + 16) * 3];
+    __shared__ __attribute__((aligned(16))) float s_b[FAST_MAX_K + 16];
+    if (MODE == MODE_GROUP)
+        for (int t = threadIdx.x; t < P.K * 3; t += 256) s_wx[t] = P.act_wx[t];
+    if (MODE != MODE_PLAIN)
+        for (int t = threadIdx.x; t < P.K; t += 256) s_b[t] = P.act_bias[t];
+
+    f32x16 a0[NB0];
+#pragma unroll
+    for (int ob = 0; ob < NB0; ob++) a0[ob] = (f32x16){0};
+    float4 w1s[4], w2s[4];
+    {
+        constexpr int G = FStage<NB0>::G;
+        const int nst = P.KB / G;                              // KB % G == 0 (host-checked)
+        const int klast = P.K - 8 + 4 * h;                     // last legal piece of this lane's k sub-range
+        float4 wr[4];
+        fstage_load<NB0>(P.wpack, P.KB, 0, wave, lane, wr);
+        // two pieces ahead: r1 = raw row piece of kb+1 (arrived), r2 = piece of kb+2 (requested in this block)
+        // (a deeper ring of 4 pieces measured no faster: the L2-resident sources answer within one k-block)
+        Raw<MODE> r0, r1;
+        fast_fetch<MODE>(P, meta, 4 * h, r0);
+        fast_fetch<MODE>(P, meta, min(8 + 4 * h, klast), r1);
+        fstage_store<NB0>(Ws[0], wave, lane, wr);
+        __syncthreads();                                       // Ws[0], s_wx, s_b visible
+        if (NB1 > 0) fstage_load<(NB1 ? NB1 : 1)>(C.wpack1, NB0 * 4, 0, wave, lane, w1s);
+        float4 bcur = fast_finish<MODE>(meta, 4 * h, r0, s_wx, s_b);
+        for (int st = 0; st < nst; st++) {
+            const bool more_st = st + 1 < nst;
+            if (more_st) fstage_load<NB0>(P.wpack, P.KB, st + 1, wave, lane, wr);
+            const float* ws = Ws[st & 1];
+#pragma unroll
+            for (int kbl = 0; kbl < G; kbl++) {
+                const int kb = st * G + kbl;
+                Raw<MODE> r2;
+                fast_fetch<MODE>(P, meta, min(8 * (kb + 2) + 4 * h, klast), r2);
+                float4 w[NB0];
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) w[ob] = lds_w(ws, kbl * NB0 + ob, lane);
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].x, bcur.x, a0[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].y, bcur.y, a0[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].z, bcur.z, a0[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].w, bcur.w, a0[ob], 0, 0, 0);
+                bcur = fast_finish<MODE>(meta, min(8 * (kb + 1) + 4 * h, klast), r1, s_wx, s_b);   // B operand of kb+1
+                r1 = r2;
+            }
+            if (more_st) fstage_store<NB0>(Ws[(st + 1) & 1], wave, lane, wr);
+            __syncthreads();
+        }
+    }
+    bias_act<NB0>(a0, P.bias, P.relu, h);
+    if constexpr (NB1 == 0) {
+        chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
+    } else {
+        f32x16 a1[NB1];
+        fchain_layer<NB0, NB1, NB2>(a0, a1, C.wpack1, Ws, wave, lane, w1s, C.wpack2, w2s);
+        bias_act<NB1>(a1, C.bias1, C.relu1, h);
+        if constexpr (NB2 == 0) {
+            chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
+        } else {
+            f32x16 a2[NB2];
+            fchain_layer<NB1, NB2, 0>(a1, a2, C.wpack2, Ws, wave, lane, w2s, nullptr, w1s);
+            bias_act<NB2>(a2, C.bias2, C.relu2, h);
+            chain_store<NB2>(C, a2, C.N2, row, valid, lane, h);
+        }
+    }
+}
+
 __global__ void pack_weight_kernel(const float* __restrict__ w, int Nout, int K, int k_rot, int KB, int NB,
                                    float* __restrict__ wpack) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -808,6 +994,26 @@ static void launch_chain(const ChainParams& C, hipStream_t s) {
     dim3 grid(prcnn_divup(C.a.rows, 128));
     hipLaunchKernelGGL((mlp_chain_kernel<MODE, NB0, NB1, NB2>), grid, dim3(256), 0, s, C);
 }
+template <int MODE, int NB0, int NB1, int NB2>
+static void launch_chain_fast(const ChainParams& C, hipStream_t s) {
+    dim3 grid(prcnn_divup(C.a.rows, 128));
+    hipLaunchKernelGGL((mlp_chain_fast_kernel<MODE, NB0, NB1, NB2>), grid, dim3(256), 0, s, C);
+}
+
+// the straight-line variant applies when nothing in the layer-0 loop needs a bounds check (see mlp_chain_fast_kernel)
+static bool chain_fast_ok(int mode, const ChainParams& C, int n0, int n1, int n2) {
+    const MlpParams& P = C.a;
+    if (P.K % 8 != 0 || P.K > FAST_MAX_K || P.K < 16 || !P.vec_a || P.addY) return false;
+    const int G0 = n0 == 3 ? 4 : CH_STAGE_TILES / n0;
+    if ((P.K / 8) % G0 != 0) return false;
+    if (n1 > 0 && P.Nout != n0 * 32) return false;                 // KB of layer 1 == 4 * NB0
+    if (n2 > 0 && C.N1 != n1 * 32) return false;
+    if (n1 > 0 && (n0 * 4) % (n1 == 3 ? 4 : CH_STAGE_TILES / n1) != 0) return false;
+    if (n2 > 0 && (n1 * 4) % (n2 == 3 ? 4 : CH_STAGE_TILES / n2) != 0) return false;
+    if (mode == MODE_GROUP) return P.act == 1 && P.K == P.C && P.act_wx && P.act_bias;
+    if (mode == MODE_INTERP) return P.act == 2 && P.C1 == 0 && P.K == P.C2 && P.act_bias;
+    return mode == MODE_PLAIN;
+}
 
 static int nb32(int n) { return (n + 31) / 32; }
 
@@ -838,6 +1044,16 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
     if (C.nlayers > 1) C.KB1 = (P.Nout + 7) / 8;
     if (C.nlayers > 2) C.KB2 = (C.N1 + 7) / 8;
     if (P.rows == 0) return PRCNN_OK;
+    if (chain_fast_ok(mode, C, n0, n1, n2)) {
+#define FAST_CASE(M, A, B, CC) if (mode == M && n0 == A && n1 == B && n2 == CC) { launch_chain_fast<M, A, B, CC>(C, s); PRCNN_LAUNCH_CHECK("prcnn_mlp_chain(fast)"); return PRCNN_OK; }
+        FAST_CASE(MODE_GROUP, 2, 4, 0)
+        FAST_CASE(MODE_GROUP, 3, 4, 0)
+        FAST_CASE(MODE_INTERP, 4, 0, 0)
+        FAST_CASE(MODE_PLAIN, 4, 1, 0)
+        FAST_CASE(MODE_PLAIN, 4, 3, 0)
+        FAST_CASE(MODE_PLAIN, 4, 4, 0)
+#undef FAST_CASE
+    }
 #define CHAIN_CASE(M, A, B, CC) if (mode == M && n0 == A && n1 == B && n2 == CC) { launch_chain<M, A, B, CC>(C, s); PRCNN_LAUNCH_CHECK("prcnn_mlp_chain"); return PRCNN_OK; }
     CHAIN_CASE(MODE_GROUP, 1, 1, 1)
     CHAIN_CASE(MODE_GROUP, 1, 1, 2)

@@ -1,0 +1,41 @@
+"""dev tool: per-launch table of the MLP kernels in one RPN step (HIP events per call): python tools/mlp_probe.py [rpn|rcnn]"""
+import sys
+import torch
+sys.path.insert(0, ".")
+import bench
+from pointrcnn_amd import _cabi, rpn
+
+which = sys.argv[1] if len(sys.argv) > 1 else "rpn"
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+_cabi.lib()
+if which == "rpn":
+    model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
+    data = {"pts_input": rpn.synthetic_clouds(32, 16384, device=dev)}
+    fn = lambda: model(data)
+else:
+    from pointrcnn_amd.point_rcnn import PointRCNN
+    model = rpn.randomize_bn_stats(PointRCNN(mode="TEST")).to(dev).eval()
+    data = {"pts_input": rpn.synthetic_clouds(32, 16384, device=dev)}
+    fn = lambda: model(data)
+with torch.no_grad():
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    prof = bench.EventProfiler(_cabi._lib)
+    real = _cabi._lib
+    _cabi._lib = prof
+    raw = []
+    orig_getattr = bench.EventProfiler.__getattr__
+    try:
+        fn()
+    finally:
+        _cabi._lib = real
+torch.cuda.synchronize()
+tot = 0.0
+for name, s, e, fl in prof.records:
+    ms = s.elapsed_time(e)
+    tot += ms
+    if name.startswith("prcnn_mlp") or ms > 0.05:
+        print("%-28s %8.1f us  %7.2f GFLOP  %6.1f TF/s" % (name[6:], ms * 1e3, fl / 1e9, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
+print("total %.2f ms" % tot)
