@@ -83,11 +83,43 @@ def gather_rows(in_cl, idx):
     return out
 
 
+# Frames with at least this many points are searched through a per-frame grid (csrc/grid.hip) instead of a full scan:
+# identical results, ~N/30 of the distance evaluations.  PRCNN_GRID_SEARCH=0 forces the scans (A/B, debugging).
+GRID_MIN_POINTS = 2048 if os.environ.get("PRCNN_GRID_SEARCH", "1") != "0" else 1 << 62
+
+
+class Grid:
+    """points of B frames binned into per-frame 64x64 x-z grids (prcnn_grid_build)"""
+
+    def __init__(self, xyz, min_cell=0.0):
+        _chk(xyz, "xyz", ndim=3)
+        self.B, self.N = xyz.shape[0], xyz.shape[1]
+        L = _cabi.lib()
+        nbytes = L.prcnn_grid_bytes(self.B, self.N)
+        self.buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=xyz.device)
+        _cabi.check(L.prcnn_grid_build(_p(xyz), self.B, self.N, float(min_cell), _p(self.buf), nbytes, _stream()), "prcnn_grid_build")
+
+
+def ball_query_grid(grid, new_xyz, radius_a, nsample_a, radius_b=0.0, nsample_b=0):
+    """== ball_query / ball_query2 on a Grid of the source points"""
+    _chk(new_xyz, "new_xyz", ndim=3)
+    B, M = new_xyz.shape[0], new_xyz.shape[1]
+    if B != grid.B:
+        raise ValueError("ball_query_grid: %d frames of centroids vs %d frames in the grid" % (B, grid.B))
+    ia = torch.empty((B, M, nsample_a), dtype=_INT, device=new_xyz.device)
+    ib = torch.empty((B, M, nsample_b), dtype=_INT, device=new_xyz.device) if nsample_b else None
+    _cabi.check(_cabi.lib().prcnn_ball_query2_grid(_p(grid.buf), _p(new_xyz), B, grid.N, M, float(radius_a), nsample_a, _p(ia),
+                                                   float(radius_b), nsample_b, _p(ib), _stream()), "prcnn_ball_query2_grid")
+    return (ia, ib) if nsample_b else ia
+
+
 def ball_query(radius, nsample, xyz, new_xyz):
     """xyz (B,N,3), new_xyz (B,M,3) -> idx (B,M,nsample) i32   [ball_query]"""
     _chk(xyz, "xyz", ndim=3); _chk(new_xyz, "new_xyz", ndim=3)
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
+    if N >= GRID_MIN_POINTS and B > 0 and M > 0:
+        return ball_query_grid(Grid(xyz, radius), new_xyz, radius, nsample)
     idx = torch.empty((B, M, nsample), dtype=_INT, device=xyz.device)
     _cabi.check(_cabi.lib().prcnn_ball_query(_p(xyz), _p(new_xyz), B, N, M, float(radius), nsample, _p(idx), _stream()),
                 "prcnn_ball_query")
@@ -99,6 +131,8 @@ def ball_query2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz):
     _chk(xyz, "xyz", ndim=3); _chk(new_xyz, "new_xyz", ndim=3)
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
+    if N >= GRID_MIN_POINTS and B > 0 and M > 0:
+        return ball_query_grid(Grid(xyz, max(radius_a, radius_b)), new_xyz, radius_a, nsample_a, radius_b, nsample_b)
     ia = torch.empty((B, M, nsample_a), dtype=_INT, device=xyz.device)
     ib = torch.empty((B, M, nsample_b), dtype=_INT, device=xyz.device)
     _cabi.check(_cabi.lib().prcnn_ball_query2(_p(xyz), _p(new_xyz), B, N, M, float(radius_a), nsample_a, _p(ia),
@@ -132,6 +166,11 @@ def three_nn(unknown, known, want_weight=False):
     d2 = torch.empty((B, n, 3), dtype=_F32, device=unknown.device)
     idx = torch.empty((B, n, 3), dtype=_INT, device=unknown.device)
     w = torch.empty((B, n, 3), dtype=_F32, device=unknown.device) if want_weight else None
+    if m >= GRID_MIN_POINTS and B > 0 and n > 0:
+        g = Grid(known, 0.0)
+        _cabi.check(_cabi.lib().prcnn_three_nn_grid(_p(g.buf), _p(unknown), B, n, m, _p(d2), _p(idx), _p(w), _stream()),
+                    "prcnn_three_nn_grid")
+        return (d2, idx, w) if want_weight else (d2, idx)
     _cabi.check(_cabi.lib().prcnn_three_nn(_p(unknown), _p(known), B, n, m, _p(d2), _p(idx), _p(w), _stream()),
                 "prcnn_three_nn")
     return (d2, idx, w) if want_weight else (d2, idx)
