@@ -147,9 +147,11 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict_
 // the wave skips its update and re-publishes its cached candidate.  Late in the sampling most waves skip (76 % of the
 // wave-updates on the benchmark clouds), and an updating wave has its SIMD's VALU to itself.
 // Results are bit-identical to the un-pruned kernel: ties are resolved on ORIGINAL point indices.
-// Measured (MI355X, bs32 x 16384 -> 4096): 5.9 -> 5.2 ms standalone (+6 % single-batch throughput), but ~3 % LOWER
-// throughput with 3 batches in flight (the lone updating wave per SIMD gets a smaller share of issue slots under
-// contention than four busy waves did), so the host layer enables it only on request (PRCNN_FPS_PRUNED=1).
+// Measured (MI355X, bs32 x 16384 -> 4096): 5.9 -> 5.2 ms standalone.  While the neighbour searches were full scans the
+// FPS chain hid behind them and this kernel was ~3 % slower with 3 batches in flight (the lone updating wave per SIMD
+// gets a smaller share of issue slots under contention); with the searches on the grid (grid.hip) the FPS chain is the
+// longest dependency of a batch and the shorter chain is worth +8 % RPN throughput, so the host layer uses it by
+// default (PRCNN_FPS_PRUNED=0 selects the plain kernel).
 // Selected by passing the (B,N) `tmp` buffer with 2048 < N <= 16384.
 // =====================================================================================================
 // finite stand-in for infinity (this file is built with -ffinite-math-only); FPS_BIG^2 * 3 still fits fp32
