@@ -333,6 +333,41 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
+    // Hoisted FP first layer (addY): every output element needs sum_j w_j * Y[idx_j, n].  Fetching that per accumulator
+    // element costs three 4-byte gathers per element; instead the workgroup builds the interpolated 128 x (64*WNB) tile
+    // once -- 16-byte loads, a row's 64 columns = 256 contiguous bytes per neighbour -- into the now idle operand
+    // buffers (As: 128 x 72 floats, Bs: 128 x 64) and the accumulators pick their elements up from LDS.
+    bool staged = false;
+    if (MODE == MODE_PLAIN && P.addY) {
+        staged = (P.Nout % 4 == 0) && (P.ldY % 4 == 0) && aligned16(P.addY);
+        if (staged) {
+#pragma unroll
+            for (int hf = 0; hf < WNB; hf++) {
+                float* T = hf == 0 ? &As[0][0] : &Bs[0][0];
+                const int ldt = hf == 0 ? 72 : 64;
+                const int ncol0 = (nb0 + hf * 2) * 32;
+                for (int f = tid; f < MLP_BM * 16; f += MLP_THREADS) {
+                    const int r = f >> 4, c = (f & 15) * 4, n = ncol0 + c;
+                    const long g = row0 + r;
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g < P.rows && n < P.Nout) {
+                        const int b = (int)(g / P.n);
+                        const int32_t* id = P.idx3 + g * 3;
+                        const float* w = P.w3 + g * 3;
+                        const float* y = P.addY + (long)b * P.m * P.ldY + n;
+                        const float4 y0 = ld4(y + (long)id[0] * P.ldY), y1 = ld4(y + (long)id[1] * P.ldY), y2 = ld4(y + (long)id[2] * P.ldY);
+                        const float w0 = w[0], w1 = w[1], w2 = w[2];
+                        o.x = (w0 * y0.x + w1 * y1.x) + w2 * y2.x;           // same expression as interp_gather
+                        o.y = (w0 * y0.y + w1 * y1.y) + w2 * y2.y;
+                        o.z = (w0 * y0.z + w1 * y1.z) + w2 * y2.z;
+                        o.w = (w0 * y0.w + w1 * y1.w) + w2 * y2.w;
+                    }
+                    *reinterpret_cast<float4*>(T + r * ldt + c) = o;
+                }
+            }
+            __syncthreads();
+        }
+    }
     if (!n_active) return;
     const long wrow0 = row0 + wm * 64;
 #pragma unroll
@@ -351,8 +386,16 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
                 long g0 = wrow0 + rin, g1 = wrow0 + 32 + rin;
                 float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
                 if (P.addY && n_ok) {             // hoisted FP first layer: + sum_j w_j * Y[idx_j, n]
-                    if (g0 < P.rows) v0 += interp_gather(P, g0, n);
-                    if (g1 < P.rows) v1 += interp_gather(P, g1, n);
+                    if (staged) {
+                        const int blk = wn * WNB + nn;
+                        const float* T = (blk >> 1) == 0 ? &As[0][0] : &Bs[0][0];
+                        const int ldt = (blk >> 1) == 0 ? 72 : 64, tc = (blk & 1) * 32 + j;
+                        v0 += T[(wm * 64 + rin) * ldt + tc];
+                        v1 += T[(wm * 64 + 32 + rin) * ldt + tc];
+                    } else {
+                        if (g0 < P.rows) v0 += interp_gather(P, g0, n);
+                        if (g1 < P.rows) v1 += interp_gather(P, g1, n);
+                    }
                 }
                 if (P.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
                 if (n_ok && g0 < P.rows) P.out[g0 * P.ld_out + P.col_off + n] = v0;
