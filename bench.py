@@ -85,8 +85,8 @@ class EventProfiler:
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
-        if not name.startswith("prcnn_") or name in ("prcnn_last_error", "prcnn_abi_version", "prcnn_wpack_floats",
-                                                      "prcnn_nms_workspace_bytes"):
+        if not name.startswith("prcnn_") or name.endswith("_bytes") or name in ("prcnn_last_error", "prcnn_abi_version",
+                                                                              "prcnn_wpack_floats"):
             return fn
 
         def wrapped(*args):

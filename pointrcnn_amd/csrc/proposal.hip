@@ -57,12 +57,24 @@ __global__ __launch_bounds__(64) void decode_kernel(DecodeParams P) {
     const int C = P.C, ld = C | 1;
     const float* __restrict__ src = P.reg + row0 * C;
     const int total = nrows * C;
-    int r = 0, c = lane;
-    while (c >= C) { c -= C; r++; }
-    for (int e = lane; e < total; e += 64) {
-        rows[r * ld + c] = src[e];
-        c += 64;
+    if ((C & 3) == 0 && ((uintptr_t)P.reg & 15) == 0) {      // 16-byte loads; a float4 never straddles two rows
+        int r = 0, c = lane * 4;
         while (c >= C) { c -= C; r++; }
+        for (int e = lane * 4; e < total; e += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(src + e);
+            float* d = rows + r * ld + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            c += 256;
+            while (c >= C) { c -= C; r++; }
+        }
+    } else {
+        int r = 0, c = lane;
+        while (c >= C) { c -= C; r++; }
+        for (int e = lane; e < total; e += 64) {
+            rows[r * ld + c] = src[e];
+            c += 64;
+            while (c >= C) { c -= C; r++; }
+        }
     }
     __syncthreads();
     if (lane >= nrows) return;

@@ -13,7 +13,8 @@ for root in sys.argv[1:]:
             d = per.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"].split("(")[0].replace("void ", ""), "c": collections.Counter()})
             d["c"][r["Counter_Name"]] += float(r["Counter_Value"])
         ds = list(per.values())
-        last = [i for i, d in enumerate(ds) if "fps_reg_kernel<1024" in d["name"]][-1]
+        last = ([i - 1 for i, d in enumerate(ds) if "fps_pruned_kernel<16>" in d["name"]] or
+                [i for i, d in enumerate(ds) if "fps_reg_kernel<1024" in d["name"]])[-1]
         for i, d in enumerate(ds[last:]):
             e = disp.setdefault(i, {"name": d["name"], "c": collections.Counter()})
             assert e["name"] == d["name"]

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Regenerates the artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'
+# Outputs land in gpurun_out/refresh/; copy the summaries into profiles/ afterwards (tools/collect_profiles.sh).
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --streams 1 --no-cpu-baseline > $O/bench_streams1.json 2>> $O/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python bench.py --no-cpu-baseline --no-roofline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-cpu-baseline --no-roofline --streams 1 > /dev/null 2>&1
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --graph off --streams 1"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_FETCH_SIZE -- $B > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_WRITE_SIZE -- $B > /dev/null 2>&1
+python -m pointrcnn_amd.opbench > $O/opbench.jsonl 2> $O/opbench.err
+python profiles/summarize_rocprof.py $O/kt3 "default: python bench.py (3 batches in flight, hipGraph replay)" > $O/kernel_stats.txt
+python profiles/summarize_rocprof.py $O/kt1 "python bench.py --streams 1 (one batch in flight)" > $O/kernel_stats_streams1.txt
+python profiles/derive_hbm_traffic.py $O/pmc_ $O/hbm_traffic.json > $O/hbm_traffic.txt 2>&1
+# keep the merge small: only summaries travel back
+find $O -name "*.csv" -size +2M -delete
+tail -c 600 $O/bench_default.json; echo; tail -3 $O/hbm_traffic.txt; head -12 $O/kernel_stats_streams1.txt
