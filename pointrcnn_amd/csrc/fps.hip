@@ -19,7 +19,7 @@
 //   <=16 partials redundantly (4 DPP steps + ballot).  Slots are double-buffered by iteration parity, which
 //   is what makes a single barrier per iteration sufficient.
 // Single-wave configurations (N <= 1024) skip LDS and the barrier entirely.
-#include "common.h"
+#include "lds_sort.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int PPT> struct fvec_t { typedef float type __attribute__((ext_vector_type(PPT))); };
@@ -167,14 +167,15 @@ __device__ __forceinline__ unsigned morton_spread10(unsigned v) {       // 10 bi
 }
 
 // One workgroup per frame: perm[s] = original index of the s-th point in Morton order (stable on the index).
-// Bitonic sort of 64-bit keys (morton << 32 | index) in LDS; NP = power of two >= N (<= 16384 -> 128 KB).
+// 64-bit keys (morton << 32 | index) sorted by the shared LDS bitonic sort (lds_sort.h: strides <= 8 in registers);
+// NP = power of two >= N (<= 16384 -> 136 KB of LDS); blockDim = max(64, NP / 16) threads.
 __global__ __launch_bounds__(1024) void fps_sort_kernel(const float* __restrict__ xyz, int N, int NP, int32_t* __restrict__ perm) {
-    extern __shared__ unsigned long long keys[];
+    extern __shared__ u64 keys[];
     __shared__ float red[6][16];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const float* __restrict__ p = xyz + (size_t)b * N * 3;
     float lo[3] = {FPS_BIG, FPS_BIG, FPS_BIG}, hi[3] = {-FPS_BIG, -FPS_BIG, -FPS_BIG};
-    for (int k = tid; k < N; k += 1024)
+    for (int k = tid; k < N; k += blockDim.x)
 #pragma unroll
         for (int a = 0; a < 3; a++) { float v = p[k * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
 #pragma unroll
@@ -187,35 +188,34 @@ __global__ __launch_bounds__(1024) void fps_sort_kernel(const float* __restrict_
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         float l = red[a][0], h = red[3 + a][0];
-        for (int w = 1; w < 16; w++) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+        for (int w = 1; w < nw; w++) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
         lo[a] = l;
         scale[a] = (h > l) ? 1023.0f / (h - l) : 0.f;
     }
-    for (int k = tid; k < NP; k += 1024) {
-        unsigned long long key = ~0ULL;                     // padding sorts to the end
-        if (k < N) {
-            unsigned qx = (unsigned)((p[k * 3 + 0] - lo[0]) * scale[0]);
-            unsigned qy = (unsigned)((p[k * 3 + 1] - lo[1]) * scale[1]);
-            unsigned qz = (unsigned)((p[k * 3 + 2] - lo[2]) * scale[2]);
-            unsigned m = (morton_spread10(qx) << 2) | (morton_spread10(qz) << 1) | morton_spread10(qy);
-            key = ((unsigned long long)m << 32) | (unsigned)k;
-        }
-        keys[k] = key;
-    }
-    __syncthreads();
-    for (int kk = 2; kk <= NP; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < NP; i += 1024) {
-                int ixj = i ^ j;
-                if (ixj > i) {
-                    unsigned long long a = keys[i], c = keys[ixj];
-                    bool up = (i & kk) == 0;
-                    if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
-                }
+    u64 v[16];
+    if (tid * 16 < NP) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int k = tid * 16 + e;
+            u64 key = ~0ULL;                                // padding sorts to the end
+            if (k < N) {
+                unsigned qx = (unsigned)((p[k * 3 + 0] - lo[0]) * scale[0]);
+                unsigned qy = (unsigned)((p[k * 3 + 1] - lo[1]) * scale[1]);
+                unsigned qz = (unsigned)((p[k * 3 + 2] - lo[2]) * scale[2]);
+                unsigned m = (morton_spread10(qx) << 2) | (morton_spread10(qz) << 1) | morton_spread10(qy);
+                key = ((u64)m << 32) | (unsigned)k;
             }
-            __syncthreads();
+            v[e] = key;
         }
-    for (int k = tid; k < N; k += 1024) perm[(size_t)b * N + k] = (int32_t)(unsigned)keys[k];
+    }
+    block_sort16(v, keys, NP, tid);
+    if (tid * 16 < NP) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int k = tid * 16 + e;
+            if (k < N) perm[(size_t)b * N + k] = (int32_t)(unsigned)v[e];
+        }
+    }
 }
 
 #define FPS_DPP_MIN(v, ctrl) asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 " ctrl : "+v"(v))
@@ -423,7 +423,14 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
         int NP = 1;
         while (NP < N) NP <<= 1;
         int32_t* perm = reinterpret_cast<int32_t*>(tmp);
-        hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(1024), (size_t)NP * 8, s, xyz, N, NP, perm);
+        static bool sort_attr = false;
+        if (!sort_attr) {
+            if (hipFuncSetAttribute((const void*)fps_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the sort kernel");
+            sort_attr = true;
+        }
+        const int sort_threads = NP / 16 < 64 ? 64 : NP / 16;
+        hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(sort_threads), lds_sort_bytes(NP), s, xyz, N, NP, perm);
         PRCNN_LAUNCH_CHECK("prcnn_fps(sort)");
         if (N <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4>), dim3(B), dim3(1024), 0, s, xyz, perm, N, npoint, idx);
         else if (N <= 8192) hipLaunchKernelGGL((fps_pruned_kernel<8>), dim3(B), dim3(1024), 0, s, xyz, perm, N, npoint, idx);

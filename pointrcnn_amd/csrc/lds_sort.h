@@ -1,0 +1,75 @@
+// lds_sort.h -- workgroup-wide bitonic sort of 64-bit keys held in LDS, 16 keys per owning thread.
+//
+// Strides >= 16 are compare-exchanged through LDS (one barrier per stride), strides 8..1 and the first four stages
+// entirely in the owning thread's registers: 16 384 keys take 55 LDS passes + 10 register phases instead of the 105
+// LDS passes of a textbook bitonic network.  LDS layout: key i lives at word i + (i >> 4) (one pad word per 16 keys),
+// so that a thread streaming its 16 consecutive keys and the strided compare-exchange passes are both conflict-free;
+// 16 384 keys + padding = 136 KB of the CU's 160 KB.  Used by proposal.hip (score order) and fps.hip (Morton order).
+#pragma once
+#include "common.h"
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ int lds_phys(int i) { return i + (i >> 4); }     // one pad word per 16 keys
+
+__device__ __forceinline__ void cswap(u64& a, u64& b, bool up) {
+    const bool gt = a > b;
+    if (gt == up) { u64 t = a; a = b; b = t; }
+}
+
+// strides 8,4,2,1 of one merge stage on the 16 keys a thread owns (all 16 share the direction once k >= 32)
+__device__ __forceinline__ void merge16(u64 (&v)[16], bool up) {
+#pragma unroll
+    for (int j = 8; j >= 1; j >>= 1)
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            if ((e & j) == 0) cswap(v[e], v[e | j], up);
+}
+
+// bytes of LDS `keys` needs for Npad keys (Npad a power of two >= 16)
+static inline size_t lds_sort_bytes(int Npad) { return ((size_t)(Npad + (Npad >> 4)) + 1) * sizeof(u64); }
+
+// Sort Npad keys ascending.  Thread t < Npad/16 owns positions 16t .. 16t+15: it passes their keys in v and receives the
+// sorted keys of the same positions back in v (the sorted sequence is also left in LDS, lds_phys layout).  EVERY thread of
+// the workgroup must call this (barriers inside); threads with t >= Npad/16 only take part in the barriers.
+__device__ __forceinline__ void block_sort16(u64 (&v)[16], u64* keys, int Npad, int t) {
+    const int nact = Npad >> 4;
+    const bool active = t < nact;
+    if (active) {
+        // stages k = 2..16 entirely in registers; element i sorts ascending when (i & k) == 0
+#pragma unroll
+        for (int k = 2; k <= 16; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j >= 1; j >>= 1)
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    if ((e & j) == 0) cswap(v[e], v[e | j], k < 16 ? ((e & k) == 0) : ((t & 1) == 0));
+#pragma unroll
+        for (int e = 0; e < 16; e++) keys[lds_phys(t * 16 + e)] = v[e];
+    }
+    __syncthreads();
+    for (int k = 32; k <= Npad; k <<= 1) {
+        for (int j = k >> 1; j >= 16; j >>= 1) {        // strides >= 16 through LDS: 8 pairs per owning thread
+            if (active) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int p = q * nact + t;
+                    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                    const int pa = lds_phys(i), pb = lds_phys(i + j);
+                    u64 a = keys[pa], c = keys[pb];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { keys[pa] = c; keys[pb] = a; }
+                }
+            }
+            __syncthreads();
+        }
+        if (active) {                                   // strides 8..1 in registers
+#pragma unroll
+            for (int e = 0; e < 16; e++) v[e] = keys[lds_phys(t * 16 + e)];
+            merge16(v, ((t * 16) & k) == 0);
+#pragma unroll
+            for (int e = 0; e < 16; e++) keys[lds_phys(t * 16 + e)] = v[e];
+        }
+        __syncthreads();
+    }
+}

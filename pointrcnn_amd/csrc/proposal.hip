@@ -18,8 +18,7 @@
 // Arithmetic follows oracle/prcnn_oracle.c (prcnn_cpu_decode_bbox_target / prcnn_cpu_proposal_layer /
 // prcnn_cpu_nms_batched) operation for operation; results are bit-identical to it.
 #include "iou3d_geom.h"
-
-typedef unsigned long long u64;
+#include "lds_sort.h"
 
 // ====================================================================================================
 // decode_bbox_target
@@ -151,22 +150,6 @@ __device__ __forceinline__ u64 sort_key(float s, int idx) {
     return ((u64)(~ok) << 32) | (unsigned)idx;
 }
 
-__device__ __forceinline__ int lds_phys(int i) { return i + (i >> 4); }     // one pad word per 16 keys
-
-__device__ __forceinline__ void cswap(u64& a, u64& b, bool up) {
-    const bool gt = a > b;
-    if (gt == up) { u64 t = a; a = b; b = t; }
-}
-
-// strides 8,4,2,1 of one merge stage on the 16 keys a thread owns (all 16 share the direction once k >= 32)
-__device__ __forceinline__ void merge16(u64 (&v)[16], bool up) {
-#pragma unroll
-    for (int j = 8; j >= 1; j >>= 1)
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-            if ((e & j) == 0) cswap(v[e], v[e | j], up);
-}
-
 __global__ __launch_bounds__(1024) void sort_split_kernel(SortParams P) {
     extern __shared__ u64 keys[];                       // lds_phys(Npad) keys, then 40 words of scan scratch
     const int b = blockIdx.x, t = threadIdx.x, T = blockDim.x;
@@ -182,42 +165,8 @@ __global__ __launch_bounds__(1024) void sort_split_kernel(SortParams P) {
             const int i = t * 16 + e;
             v[e] = i < N ? sort_key(sc[i], i) : ~0ULL;
         }
-        // stages k = 2..16 entirely in registers; element i sorts ascending when (i & k) == 0
-#pragma unroll
-        for (int k = 2; k <= 16; k <<= 1)
-#pragma unroll
-            for (int j = k >> 1; j >= 1; j >>= 1)
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    if ((e & j) == 0) cswap(v[e], v[e | j], k < 16 ? ((e & k) == 0) : ((t & 1) == 0));
-#pragma unroll
-        for (int e = 0; e < 16; e++) keys[lds_phys(t * 16 + e)] = v[e];
     }
-    __syncthreads();
-    for (int k = 32; k <= Npad; k <<= 1) {
-        for (int j = k >> 1; j >= 16; j >>= 1) {        // strides >= 16 through LDS: 8 pairs per owning thread
-            if (active) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int p = q * nact + t;
-                    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                    const int pa = lds_phys(i), pb = lds_phys(i + j);
-                    u64 a = keys[pa], c = keys[pb];
-                    const bool up = (i & k) == 0;
-                    if ((a > c) == up) { keys[pa] = c; keys[pb] = a; }
-                }
-            }
-            __syncthreads();
-        }
-        if (active) {                                   // strides 8..1 in registers
-#pragma unroll
-            for (int e = 0; e < 16; e++) v[e] = keys[lds_phys(t * 16 + e)];
-            merge16(v, ((t * 16) & k) == 0);
-#pragma unroll
-            for (int e = 0; e < 16; e++) keys[lds_phys(t * 16 + e)] = v[e];
-        }
-        __syncthreads();
-    }
+    block_sort16(v, keys, Npad, t);
     // ---- split the ordered list into areas (proposal_layer.py:78-98): per-thread flags, block exclusive scan ----
     unsigned f1 = 0, f2 = 0;
     int idx[16];
@@ -561,7 +510,7 @@ PRCNN_API int prcnn_decode_bbox_target(const float* roi, int roi_cols, const flo
 static int launch_sort_split(const char* op, SortParams& P, int B, hipStream_t s) {
     P.Npad = pow2_at_least(P.N, 16);
     const int threads = max(64, ((P.Npad >> 4) + 63) / 64 * 64);
-    const size_t lds = ((size_t)(P.Npad + (P.Npad >> 4)) + 1) * sizeof(u64) + 40 * sizeof(unsigned);
+    const size_t lds = lds_sort_bytes(P.Npad) + 40 * sizeof(unsigned);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)sort_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess)
