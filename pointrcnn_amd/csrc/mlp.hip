@@ -456,6 +456,10 @@ struct ChainParams {
 };
 
 #define CH_DPP_FMAX(v, ctrl) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
+#define CH_DPP_FMAX4(v, ctrl)                                                                                   \
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl "\n\tv_max_f32_dpp %1, %1, %1 " ctrl               \
+                 "\n\tv_max_f32_dpp %2, %2, %2 " ctrl "\n\tv_max_f32_dpp %3, %3, %3 " ctrl                       \
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]))
 
 __device__ __forceinline__ float4 ldw(const float* __restrict__ wpack, int KB, int ob, int kb, int lane) {
     return ld4(wpack + (((long)ob * KB + kb) * 64 + lane) * 4);
@@ -585,18 +589,15 @@ __device__ __forceinline__ void chain_store(const ChainParams& C, f32x16 (&acc)[
     for (int ob = 0; ob < NB; ob++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            float v[4];
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                float x = acc[ob][4 * q + s];
-                CH_DPP_FMAX(x, "row_shr:1 row_mask:0xf bank_mask:0xf");
-                CH_DPP_FMAX(x, "row_shr:2 row_mask:0xf bank_mask:0xf");
-                CH_DPP_FMAX(x, "row_shr:4 row_mask:0xf bank_mask:0xf");
-                CH_DPP_FMAX(x, "row_shr:8 row_mask:0xf bank_mask:0xf");
-                if (P.pool_ns == 32) CH_DPP_FMAX(x, "row_bcast:15 row_mask:0xa bank_mask:0xf");
-                asm volatile("s_nop 1");
-                v[s] = x;
-            }
+            // the four registers of a (block, q) group walk the DPP steps in lock-step: each value's next step is four
+            // VALU instructions after its previous one, so the DPP read-after-write hazard needs no s_nop per step
+            float v[4] = {acc[ob][4 * q], acc[ob][4 * q + 1], acc[ob][4 * q + 2], acc[ob][4 * q + 3]};
+            CH_DPP_FMAX4(v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+            CH_DPP_FMAX4(v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+            CH_DPP_FMAX4(v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+            CH_DPP_FMAX4(v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+            if (P.pool_ns == 32) CH_DPP_FMAX4(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+            asm volatile("s_nop 1");
             int c = ob * 32 + 8 * q + 4 * h;
             if (writer && valid && group < groups && c < Nlast) {
                 if (vec && c + 4 <= Nlast) *reinterpret_cast<float4*>(o + c) = make_float4(v[0], v[1], v[2], v[3]);
