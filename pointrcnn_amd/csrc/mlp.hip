@@ -861,6 +861,117 @@ __global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C
     }
 }
 
+// =====================================================================================================
+// SA level 0 (no input features: the grouped row is just the centred xyz, K = 3): widths 16/16/32 and 32/32/64.
+// The generic chain kernel spends ~4 700 instructions around 52 MFMAs per 32-row tile here (bounds-checked fetches, a
+// weight stage + barrier per layer, one workgroup launch per 128 rows).  All weights and biases of such a stack fit in
+// registers (<= 52 + 64 VGPRs), so this variant keeps them there, runs a PERSISTENT loop over 32-row tiles per wave --
+// no LDS, no barriers -- and requests the next tile's neighbour index / coordinates while the current tile multiplies.
+// Same MFMA order, bias/ReLU arithmetic and pooling as mlp_chain_kernel: bit-identical results.
+// =====================================================================================================
+template <int KB1, int KB2, int NB2, int NS>
+__global__ __launch_bounds__(256) void sa_xyz_chain_kernel(const ChainParams C) {
+    const MlpParams& P = C.a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const float4 w0 = ldw(P.wpack, 1, 0, 0, lane);
+    float4 w1[KB1], w2[NB2][KB2], b0[4], b1[4], b2[NB2][4];
+#pragma unroll
+    for (int kb = 0; kb < KB1; kb++) w1[kb] = ldw(C.wpack1, KB1, 0, kb, lane);
+#pragma unroll
+    for (int ob = 0; ob < NB2; ob++)
+#pragma unroll
+        for (int kb = 0; kb < KB2; kb++) w2[ob][kb] = ldw(C.wpack2, KB2, ob, kb, lane);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        b0[q] = P.bias ? ld4(P.bias + 8 * q + 4 * h) : zero4;
+        b1[q] = C.bias1 ? ld4(C.bias1 + 8 * q + 4 * h) : zero4;
+#pragma unroll
+        for (int ob = 0; ob < NB2; ob++) b2[ob][q] = C.bias2 ? ld4(C.bias2 + ob * 32 + 8 * q + 4 * h) : zero4;
+    }
+    const long ntiles = (P.rows + 31) >> 5;
+    const long stride = (long)gridDim.x * 4;
+    long tile = (long)blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    // neighbour index two tiles ahead, coordinates one tile ahead
+    auto row_of = [&](long t) { long r = (t < ntiles ? t : ntiles - 1) * 32 + j; return r < P.rows ? r : P.rows - 1; };
+    auto load_pt = [&](long r, int p, float (&v)[6]) {
+        const int cen = (int)(r / NS), b = cen / P.M;
+        const float* x = P.xyz + ((long)b * P.N + p) * 3;
+        const float* q = P.new_xyz + (long)cen * 3;
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = q[0]; v[4] = q[1]; v[5] = q[2];
+    };
+    float cur[6], nxt[6];
+    long r_cur = row_of(tile), r_nxt = row_of(tile + stride);
+    int p_nxt = P.idx[r_nxt];
+    load_pt(r_cur, P.idx[r_cur], cur);
+    for (; tile < ntiles; tile += stride) {
+        const long r_nn = row_of(tile + 2 * stride);
+        const int p_nn = P.idx[r_nn];
+        load_pt(r_nxt, p_nxt, nxt);
+        const long row = tile * 32 + j;
+        const bool valid = row < P.rows;
+        // ---- layer 0: B operand = (dx, dy, dz, 0) in the h = 0 half, zeros in the h = 1 half (k = 4..7 >= K) ----
+        const float dx = cur[0] - cur[3], dy = cur[1] - cur[4], dz = cur[2] - cur[5];
+        f32x16 a0 = (f32x16){0};
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, h ? 0.f : dx, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, h ? 0.f : dy, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, h ? 0.f : dz, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, 0.f, a0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float v0 = a0[4 * q] + b0[q].x, v1 = a0[4 * q + 1] + b0[q].y, v2 = a0[4 * q + 2] + b0[q].z, v3 = a0[4 * q + 3] + b0[q].w;
+            if (P.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            a0[4 * q] = v0; a0[4 * q + 1] = v1; a0[4 * q + 2] = v2; a0[4 * q + 3] = v3;
+        }
+        // ---- layer 1 ----
+        f32x16 a1 = (f32x16){0};
+#pragma unroll
+        for (int kb = 0; kb < KB1; kb++) {
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[kb].x, a0[4 * kb + 0], a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[kb].y, a0[4 * kb + 1], a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[kb].z, a0[4 * kb + 2], a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[kb].w, a0[4 * kb + 3], a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float v0 = a1[4 * q] + b1[q].x, v1 = a1[4 * q + 1] + b1[q].y, v2 = a1[4 * q + 2] + b1[q].z, v3 = a1[4 * q + 3] + b1[q].w;
+            if (C.relu1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            a1[4 * q] = v0; a1[4 * q + 1] = v1; a1[4 * q + 2] = v2; a1[4 * q + 3] = v3;
+        }
+        // ---- layer 2 ----
+        f32x16 a2[NB2];
+#pragma unroll
+        for (int ob = 0; ob < NB2; ob++) a2[ob] = (f32x16){0};
+#pragma unroll
+        for (int kb = 0; kb < KB2; kb++) {
+#pragma unroll
+            for (int ob = 0; ob < NB2; ob++) a2[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[ob][kb].x, a1[4 * kb + 0], a2[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NB2; ob++) a2[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[ob][kb].y, a1[4 * kb + 1], a2[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NB2; ob++) a2[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[ob][kb].z, a1[4 * kb + 2], a2[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NB2; ob++) a2[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[ob][kb].w, a1[4 * kb + 3], a2[ob], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ob = 0; ob < NB2; ob++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float v0 = a2[ob][4 * q] + b2[ob][q].x, v1 = a2[ob][4 * q + 1] + b2[ob][q].y;
+                float v2 = a2[ob][4 * q + 2] + b2[ob][q].z, v3 = a2[ob][4 * q + 3] + b2[ob][q].w;
+                if (C.relu2) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                a2[ob][4 * q] = v0; a2[ob][4 * q + 1] = v1; a2[ob][4 * q + 2] = v2; a2[ob][4 * q + 3] = v3;
+            }
+        chain_store<NB2>(C, a2, C.N2, row, valid, lane, h);
+        // rotate the prefetch pipeline
+#pragma unroll
+        for (int e = 0; e < 6; e++) cur[e] = nxt[e];
+        r_nxt = r_nn; p_nxt = p_nn;
+    }
+}
+
 __global__ void pack_weight_kernel(const float* __restrict__ w, int Nout, int K, int k_rot, int KB, int NB,
                                    float* __restrict__ wpack) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1088,6 +1199,20 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
     if (C.nlayers > 1) C.KB1 = (P.Nout + 7) / 8;
     if (C.nlayers > 2) C.KB2 = (C.N1 + 7) / 8;
     if (P.rows == 0) return PRCNN_OK;
+    // SA level 0: xyz-only rows, three narrow layers, pooled -- persistent register-weight kernel
+    if (mode == MODE_GROUP && P.C == 0 && !P.act && P.K == 3 && C.nlayers == 3 && P.new_xyz && P.pool_ns == P.ns && C.N2 % 4 == 0) {
+        // persistent: one resident workgroup per occupancy slot (256 CUs x 3 or 2 workgroups at 115 / 243 registers)
+#define SA0_CASE(W0, W1, NBL, NSV)                                                                                        \
+        if (P.Nout == W0 && C.N1 == W1 && n2 == NBL && P.ns == NSV) {                                                   \
+            const int grid = (int)min((long)(NBL == 1 ? 768 : 512), (long)prcnn_divup(P.rows, 128));                     \
+            hipLaunchKernelGGL((sa_xyz_chain_kernel<W0 / 8, W1 / 8, NBL, NSV>), dim3(grid), dim3(256), 0, s, C);          \
+            PRCNN_LAUNCH_CHECK("prcnn_mlp_chain(sa0)");                                                                  \
+            return PRCNN_OK;                                                                                             \
+        }
+        SA0_CASE(16, 16, 1, 16)
+        SA0_CASE(32, 32, 2, 32)
+#undef SA0_CASE
+    }
     if (chain_fast_ok(mode, C, n0, n1, n2)) {
 #define FAST_CASE(M, A, B, CC) if (mode == M && n0 == A && n1 == B && n2 == CC) { launch_chain_fast<M, A, B, CC>(C, s); PRCNN_LAUNCH_CHECK("prcnn_mlp_chain(fast)"); return PRCNN_OK; }
         FAST_CASE(MODE_GROUP, 2, 4, 0)
