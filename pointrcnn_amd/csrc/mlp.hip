@@ -19,6 +19,7 @@
 // Pipeline: global loads for chunk c+1 are issued before the MFMAs of chunk c and written to the other
 // LDS buffer after them (one barrier per chunk).
 #include "common.h"
+#include <stdlib.h>
 
 #define MLP_BM 128
 #define MLP_BN 64
@@ -862,6 +863,129 @@ __global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C
 }
 
 // =====================================================================================================
+// PERSISTENT chain: the fast chain's arithmetic with ALL layers' packed weights resident in LDS for the lifetime of the
+// workgroup (48-128 KB of the CU's 160 KB; one 8-wave workgroup per CU = 2 waves per SIMD sharing one copy).  Each
+// wave then loops over 32-row tiles on its own: no weight staging, no barriers, no workgroup launch per 128 rows, and
+// the next tile's neighbour metadata and first input pieces are requested while the current tile multiplies.
+// Same MFMA order and activation arithmetic as mlp_chain_fast_kernel / mlp_chain_kernel: bit-identical results.
+// =====================================================================================================
+#define PERS_WAVES 8
+template <int KB, int NB>
+__device__ __forceinline__ void pers_load_layer(float* dst, const float* __restrict__ wpack, int wave, int lane) {
+    for (int t = wave; t < KB * NB; t += PERS_WAVES) {          // LDS tile index = kb * NB + ob (what lds_w expects)
+        const int kb = t / NB, ob = t - kb * NB;
+        *reinterpret_cast<float4*>(dst + (t * 64 + lane) * 4) = ldw(wpack, KB, ob, kb, lane);
+    }
+}
+template <int NBI, int NBO>
+__device__ __forceinline__ void pers_layer(const f32x16 (&in)[NBI], f32x16 (&out)[NBO], const float* wl, int lane) {
+#pragma unroll
+    for (int ob = 0; ob < NBO; ob++) out[ob] = (f32x16){0};
+#pragma unroll
+    for (int kb = 0; kb < NBI * 4; kb++) {
+        const int pb = kb / 4, q = kb % 4;
+        float4 w[NBO];
+#pragma unroll
+        for (int ob = 0; ob < NBO; ob++) w[ob] = lds_w(wl, kb * NBO + ob, lane);
+#pragma unroll
+        for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].x, in[pb][4 * q + 0], out[ob], 0, 0, 0);
+#pragma unroll
+        for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].y, in[pb][4 * q + 1], out[ob], 0, 0, 0);
+#pragma unroll
+        for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].z, in[pb][4 * q + 2], out[ob], 0, 0, 0);
+#pragma unroll
+        for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].w, in[pb][4 * q + 3], out[ob], 0, 0, 0);
+    }
+}
+
+template <int MODE, int KB0, int NB0, int NB1, int NB2>
+static constexpr size_t pers_lds_bytes() {
+    return ((size_t)(KB0 * NB0 + 4 * NB0 * NB1 + 4 * NB1 * NB2) * 256 + (MODE == MODE_PLAIN ? 0 : (FAST_MAX_K + 16) * 4)) * sizeof(float);
+}
+
+template <int MODE, int KB0, int NB0, int NB1, int NB2>
+__global__ __launch_bounds__(PERS_WAVES * 64) void mlp_chain_pers_kernel(const ChainParams C) {
+    const MlpParams& P = C.a;
+    extern __shared__ __attribute__((aligned(16))) float Wl[];
+    constexpr int T0 = KB0 * NB0, T1 = 4 * NB0 * NB1, T2 = 4 * NB1 * NB2;
+    float* W0 = Wl;
+    float* W1 = W0 + T0 * 256;
+    float* W2 = W1 + T1 * 256;
+    float* s_wx = W2 + T2 * 256;                        // (K,3) act_wx, then act_bias (MODE_GROUP / MODE_INTERP only)
+    float* s_b = s_wx + (FAST_MAX_K + 16) * 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    pers_load_layer<KB0, NB0>(W0, P.wpack, wave, lane);
+    if (NB1 > 0) pers_load_layer<NB0 * 4, (NB1 ? NB1 : 1)>(W1, C.wpack1, wave, lane);
+    if (NB2 > 0) pers_load_layer<(NB1 ? NB1 : 1) * 4, (NB2 ? NB2 : 1)>(W2, C.wpack2, wave, lane);
+    if (MODE == MODE_GROUP)
+        for (int t = threadIdx.x; t < P.K * 3; t += PERS_WAVES * 64) s_wx[t] = P.act_wx[t];
+    if (MODE != MODE_PLAIN)
+        for (int t = threadIdx.x; t < P.K; t += PERS_WAVES * 64) s_b[t] = P.act_bias[t];
+    __syncthreads();
+
+    const long ntiles = (P.rows + 31) >> 5;
+    const long stride = (long)gridDim.x * PERS_WAVES;
+    long tile = (long)blockIdx.x * PERS_WAVES + wave;
+    if (tile >= ntiles) return;
+    auto row_of = [&](long t) { long r = (t < ntiles ? t : ntiles - 1) * 32 + j; return r < P.rows ? r : P.rows - 1; };
+    constexpr int K0 = KB0 * 8;
+    const int klast = K0 - 8 + 4 * h;
+    RowMeta<MODE> meta, meta_n;
+    Raw<MODE> r0, r1;
+    make_meta<MODE>(P, row_of(tile), meta);
+    fast_fetch<MODE>(P, meta, 4 * h, r0);
+    fast_fetch<MODE>(P, meta, 8 + 4 * h, r1);
+    for (; tile < ntiles; tile += stride) {
+        const long row = tile * 32 + j;
+        const bool valid = row < P.rows;
+        make_meta<MODE>(P, row_of(tile + stride), meta_n);           // next tile: index -> coordinates, in flight during layer 0
+        f32x16 a0[NB0];
+#pragma unroll
+        for (int ob = 0; ob < NB0; ob++) a0[ob] = (f32x16){0};
+        float4 bcur = fast_finish<MODE>(meta, 4 * h, r0, s_wx, s_b);
+#pragma unroll
+        for (int kb = 0; kb < KB0; kb++) {
+            Raw<MODE> r2;
+            fast_fetch<MODE>(P, meta, min(8 * (kb + 2) + 4 * h, klast), r2);
+            float4 w[NB0];
+#pragma unroll
+            for (int ob = 0; ob < NB0; ob++) w[ob] = lds_w(W0, kb * NB0 + ob, lane);
+#pragma unroll
+            for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].x, bcur.x, a0[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].y, bcur.y, a0[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].z, bcur.z, a0[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].w, bcur.w, a0[ob], 0, 0, 0);
+            bcur = fast_finish<MODE>(meta, min(8 * (kb + 1) + 4 * h, klast), r1, s_wx, s_b);
+            r1 = r2;
+        }
+        // first two input pieces of the next tile: requested now, consumed at the top of the next iteration
+        fast_fetch<MODE>(P, meta_n, 4 * h, r0);
+        fast_fetch<MODE>(P, meta_n, 8 + 4 * h, r1);
+        bias_act<NB0>(a0, P.bias, P.relu, h);
+        if constexpr (NB1 == 0) {
+            chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
+        } else {
+            f32x16 a1[NB1];
+            pers_layer<NB0, NB1>(a0, a1, W1, lane);
+            bias_act<NB1>(a1, C.bias1, C.relu1, h);
+            if constexpr (NB2 == 0) {
+                chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
+            } else {
+                f32x16 a2[NB2];
+                pers_layer<NB1, NB2>(a1, a2, W2, lane);
+                bias_act<NB2>(a2, C.bias2, C.relu2, h);
+                chain_store<NB2>(C, a2, C.N2, row, valid, lane, h);
+            }
+        }
+        meta = meta_n;
+    }
+}
+
+// =====================================================================================================
 // SA level 0 (no input features: the grouped row is just the centred xyz, K = 3): widths 16/16/32 and 32/32/64.
 // The generic chain kernel spends ~4 700 instructions around 52 MFMAs per 32-row tile here (bounds-checked fetches, a
 // weight stage + barrier per layer, one workgroup launch per 128 rows).  All weights and biases of such a stack fit in
@@ -1200,7 +1324,8 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
     if (C.nlayers > 2) C.KB2 = (C.N1 + 7) / 8;
     if (P.rows == 0) return PRCNN_OK;
     // SA level 0: xyz-only rows, three narrow layers, pooled -- persistent register-weight kernel
-    if (mode == MODE_GROUP && P.C == 0 && !P.act && P.K == 3 && C.nlayers == 3 && P.new_xyz && P.pool_ns == P.ns && C.N2 % 4 == 0) {
+    if (mode == MODE_GROUP && P.C == 0 && !P.act && P.K == 3 && C.nlayers == 3 && P.new_xyz && P.pool_ns == P.ns && C.N2 % 4 == 0 &&
+        getenv("PRCNN_NO_SA0") == nullptr) {              // (A/B switch; the generic chain kernel gives the same bits)
         // persistent: one resident workgroup per occupancy slot (256 CUs x 3 or 2 workgroups at 115 / 243 registers)
 #define SA0_CASE(W0, W1, NBL, NSV)                                                                                        \
         if (P.Nout == W0 && C.N1 == W1 && n2 == NBL && P.ns == NSV) {                                                   \
@@ -1213,7 +1338,34 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
         SA0_CASE(32, 32, 2, 32)
 #undef SA0_CASE
     }
-    if (chain_fast_ok(mode, C, n0, n1, n2)) {
+    // Opt-in (PRCNN_PERSISTENT_CHAIN=1): 6-12 % faster per launch with ONE batch in flight, but a persistent workgroup
+    // holds its CU's LDS for the whole kernel, which starves the other in-flight batches' kernels (FPS sort, layer tiles):
+    // measured -6 % RPN throughput at 3 batches in flight, so the default keeps the per-tile workgroups.
+    if (chain_fast_ok(mode, C, n0, n1, n2) && getenv("PRCNN_PERSISTENT_CHAIN") != nullptr) {
+        // persistent form: weights of the whole stack resident in LDS, one 8-wave workgroup per CU
+#define PERS_CASE(M, KB0V, A, B, CC)                                                                                         \
+        if (mode == M && P.KB == KB0V && n0 == A && n1 == B && n2 == CC) {                                                    \
+            constexpr size_t lds = pers_lds_bytes<M, KB0V, A, B, CC>();                                                       \
+            static bool attr = false;                                                                                        \
+            if (!attr) {                                                                                                     \
+                if (hipFuncSetAttribute((const void*)mlp_chain_pers_kernel<M, KB0V, A, B, CC>,                               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                 \
+                    return prcnn_fail(PRCNN_EHIP, "prcnn_mlp_chain: cannot raise the dynamic LDS limit");                    \
+                attr = true;                                                                                                 \
+            }                                                                                                                \
+            const int grid = (int)min((long)256, (long)prcnn_divup(P.rows, 32 * PERS_WAVES));                                \
+            hipLaunchKernelGGL((mlp_chain_pers_kernel<M, KB0V, A, B, CC>), dim3(grid), dim3(PERS_WAVES * 64), lds, s, C);     \
+            PRCNN_LAUNCH_CHECK("prcnn_mlp_chain(persistent)");                                                               \
+            return PRCNN_OK;                                                                                                 \
+        }
+        PERS_CASE(MODE_GROUP, 8, 2, 4, 0)
+        PERS_CASE(MODE_GROUP, 8, 3, 4, 0)
+        PERS_CASE(MODE_INTERP, 16, 4, 0, 0)
+        PERS_CASE(MODE_PLAIN, 16, 4, 1, 0)
+        PERS_CASE(MODE_PLAIN, 16, 4, 3, 0)
+#undef PERS_CASE
+    }
+    if (chain_fast_ok(mode, C, n0, n1, n2) && getenv("PRCNN_NO_FAST_CHAIN") == nullptr) {      // (A/B switch, same bits)
 #define FAST_CASE(M, A, B, CC) if (mode == M && n0 == A && n1 == B && n2 == CC) { launch_chain_fast<M, A, B, CC>(C, s); PRCNN_LAUNCH_CHECK("prcnn_mlp_chain(fast)"); return PRCNN_OK; }
         FAST_CASE(MODE_GROUP, 2, 4, 0)
         FAST_CASE(MODE_GROUP, 3, 4, 0)

@@ -278,3 +278,61 @@ def test_hoisted_interp_equals_unhoisted_oracle(dev, cpu):
     got_t = ops.mlp_interp(y, T(idx3, dev), T(w3, dev), None, l1, act_bias=b0).cpu().numpy()
     np.testing.assert_allclose(got_c, want, atol=mlp_tol(want), rtol=0)
     np.testing.assert_allclose(got_t, want, atol=mlp_tol(want), rtol=0)
+
+
+def test_chain_kernel_variants_are_bit_identical(dev, cpu, monkeypatch):
+    """The register-chain has four code paths for the same arithmetic -- generic (bounds-checked), straight-line "fast",
+    persistent with LDS-resident weights (opt-in) and the persistent register-weight kernel of SA level 0 -- selected
+    by shape and environment.  They must agree bit for bit (same MFMA order, same activation expressions)."""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(33)
+    B, N, M = 2, 1500, 70
+
+    def run_all(fn):
+        outs = {}
+        for name, env in (("default", {}), ("generic", {"PRCNN_NO_FAST_CHAIN": "1", "PRCNN_NO_SA0": "1"}),
+                          ("persistent", {"PRCNN_PERSISTENT_CHAIN": "1"})):
+            for k in ("PRCNN_NO_FAST_CHAIN", "PRCNN_NO_SA0", "PRCNN_PERSISTENT_CHAIN"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            outs[name] = fn().clone()
+        for k in ("PRCNN_NO_FAST_CHAIN", "PRCNN_NO_SA0", "PRCNN_PERSISTENT_CHAIN"):
+            monkeypatch.delenv(k, raising=False)
+        assert torch.equal(outs["default"], outs["generic"]) and torch.equal(outs["default"], outs["persistent"])
+        return outs["default"]
+
+    xyz = T(unit_cloud(B, N, seed=8), dev)
+    new_xyz = xyz[:, :M].contiguous()
+    # hoisted SA2-type stacks (activated gather -> 2 layers -> pool), both scale shapes
+    for ns, widths in ((16, (64, 64, 128)), (32, (64, 96, 128))):
+        idx = ops.ball_query(0.3, ns, xyz, new_xyz)
+        z = T(r.normal(size=(B, N, widths[0])).astype(np.float32), dev)
+        ws, bs = _stack(r, widths, 0.15)
+        act = (T(r.normal(size=(widths[0], 3)).astype(np.float32), dev), T(r.normal(size=(widths[0],)).astype(np.float32), dev))
+        layers = [lin(dev, w, b, True) for w, b in zip(ws, bs)]
+        run_all(lambda: ops.mlp_chain_group(xyz, new_xyz, idx, z, layers, pool_ns=ns, act=act))
+    # SA level 0 stacks (xyz only)
+    for ns, widths in ((16, (3, 16, 16, 32)), (32, (3, 32, 32, 64))):
+        idx = ops.ball_query(0.3, ns, xyz, new_xyz)
+        ws, bs = _stack(r, widths, 0.3)
+        layers = [lin(dev, w, b, True) for w, b in zip(ws, bs)]
+        got = run_all(lambda: ops.mlp_chain_group(xyz, new_xyz, idx, None, layers, pool_ns=ns))
+        gx = cpu.group(xyz.cpu().numpy().transpose(0, 2, 1), idx.cpu().numpy()) - new_xyz.cpu().numpy().transpose(0, 2, 1)[..., None]
+        rows = gx.transpose(0, 2, 3, 1).reshape(-1, 3)
+        for w, b in zip(ws, bs):
+            rows = cpu.linear_rows(rows, w, b, True)
+        want = rows.reshape(B * M, ns, -1).max(1)
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=mlp_tol(want), rtol=0)
+    # hoisted FP0 (interp of Y, one layer) and the two heads (plain rows, 128 -> 128 -> 1 / 76)
+    kn = T(unit_cloud(B, 300, seed=9), dev)
+    d2, idx3, w3 = ops.three_nn(xyz, kn, want_weight=True)
+    y = T(r.normal(size=(B, 300, 128)).astype(np.float32), dev)
+    ws, bs = _stack(r, (128, 128), 0.1)
+    b0 = T(r.normal(size=(128,)).astype(np.float32), dev)
+    l1 = lin(dev, ws[0], bs[0], True)
+    feat = run_all(lambda: ops.mlp_chain_interp(y, idx3, w3, None, [l1], act_bias=b0))
+    for nout in (1, 76):
+        ws, bs = _stack(r, (128, 128, nout), 0.1)
+        layers = [lin(dev, ws[0], bs[0], True), lin(dev, ws[1], bs[1], False)]
+        run_all(lambda: ops.mlp_chain_rows(feat, layers))
