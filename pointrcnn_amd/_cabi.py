@@ -76,6 +76,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE this library is
+    # loaded, so that the library's DT_NEEDED libamdhip64 resolves to the same runtime instance; loaded the other way
+    # round the process ends up with two runtimes and the second one reports "no ROCm-capable device".
+    import torch  # noqa: F401
     path = _build.LIB
     if not os.path.exists(path):
         # Build only when the library is MISSING (never silently on a stale check: under torchrun every rank gets
