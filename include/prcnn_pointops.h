@@ -288,6 +288,31 @@ int prcnn_ball_query2_grid(const void* grid, const float* new_xyz, int B, int N,
 int prcnn_three_nn_grid(const void* grid, const float* unknown, int B, int n, int m, float* dist2, int32_t* idx, float* weight,
                         prcnn_stream_t stream);
 
+/* ======================================================================================================
+ * KITTI object evaluation kernels (host side: pointrcnn_amd/kitti_eval.py).
+ * Oracle twins: prcnn_cpu_rotate_iou_eval / prcnn_cpu_kitti_overlaps / prcnn_cpu_kitti_statistics.
+ * ====================================================================================================== */
+/* tools/kitti_object_eval_python/rotate_iou.py:287-329 rotate_iou_gpu_eval(boxes, query_boxes, criterion):
+ * boxes (N,5), query (K,5) rows [cx, cy, dx, dy, angle] -> out (N,K).  criterion -1: IoU, 0: inter / area(query),
+ * 1: inter / area(box), 2: intersection area (the numba kernel evaluates devRotateIoUEval(query_k, box_n), :282-284). */
+int prcnn_rotate_iou_eval(const float* boxes, int N, const float* query, int K, int criterion, float* out, prcnn_stream_t stream);
+/* Per-frame overlap blocks of eval.py:326-397 calculate_iou_partly for F frames in one launch: rows = first box set
+ * ("dt"), columns = second ("gt").  metric 0: 2-D IoU of image boxes (.,4); 1: rotated BEV IoU, 2: 3-D IoU of camera
+ * boxes (.,7) [x, y, z, l, h, w, ry] (float64 in, like the annotation arrays).  dt_off / gt_off (F+1) i32 row offsets,
+ * ov_off (F+1) i64 offsets of the row-major blocks inside out (float64). */
+int prcnn_kitti_overlaps(int metric, const double* dt, const int32_t* dt_off, const double* gt, const int32_t* gt_off,
+                         const int64_t* ov_off, int F, double* out, prcnn_stream_t stream);
+/* eval.py:155-324 compute_statistics_jit for every (frame, threshold): res (F, T, 4) = tp, fp, fn, similarity
+ * (similarity -1 as in the reference when undefined).  gt_datas (G,5) [bbox, alpha], dt_datas (D,6) [bbox, alpha, score],
+ * ign_gt (G) / ign_det (D) from clean_data, dc (DC,4) DontCare boxes, offsets (F+1).  compute_fp = 0 is the
+ * reference's first pass (thresh ignored): matched (G) f64, optional, receives the score of the detection that made gt i
+ * a true positive, NaN otherwise.  max_det_per_frame: caller-known bound (<= 1024, PRCNN_EUNSUPPORTED above). */
+int prcnn_kitti_statistics(const double* overlaps, const int64_t* ov_off, const double* gt_datas, const int32_t* gt_off,
+                           const double* dt_datas, const int32_t* dt_off, const int32_t* ign_gt, const int32_t* ign_det,
+                           const double* dc, const int32_t* dc_off, int F, int max_det_per_frame, int metric, double min_overlap,
+                           const double* thresholds, int T, int compute_fp, int compute_aos, double* res, double* matched,
+                           prcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

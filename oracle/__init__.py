@@ -300,6 +300,45 @@ class _Ref:
         return pp, pf, empty
 
 
+class KittiBackend:
+    """compute backend for pointrcnn_amd.kitti_eval running on the CPU oracle (tests only)"""
+
+    def __init__(self):
+        self.lib = cpu().lib
+
+    def overlaps(self, metric, dt, dt_off, gt, gt_off, ov_off):
+        D = ctypes.POINTER(ctypes.c_double)
+        dt, gt = np.ascontiguousarray(dt, np.float64), np.ascontiguousarray(gt, np.float64)
+        dt_off, gt_off = _i32(dt_off), _i32(gt_off)
+        ov_off = np.ascontiguousarray(ov_off, np.int64)
+        out = np.zeros(int(ov_off[-1]), np.float64)
+        self.lib.prcnn_cpu_kitti_overlaps(int(metric), _p(dt, D), _p(dt_off, _I), _p(gt, D), _p(gt_off, _I), _p(ov_off, _L),
+                                          len(dt_off) - 1, _p(out, D))
+        return out
+
+    def statistics(self, overlaps, ov_off, gt_datas, gt_off, dt_datas, dt_off, ign_gt, ign_det, dc, dc_off, metric, min_overlap,
+                   thresholds, compute_fp, compute_aos):
+        D = ctypes.POINTER(ctypes.c_double)
+        f64 = lambda a: np.ascontiguousarray(a, np.float64)      # noqa: E731
+        overlaps, gt_datas, dt_datas, dc, thresholds = f64(overlaps), f64(gt_datas), f64(dt_datas), f64(dc), f64(thresholds)
+        gt_off, dt_off, dc_off, ign_gt, ign_det = _i32(gt_off), _i32(dt_off), _i32(dc_off), _i32(ign_gt), _i32(ign_det)
+        ov_off = np.ascontiguousarray(ov_off, np.int64)
+        F, T = len(gt_off) - 1, len(thresholds)
+        res = np.zeros((F, T, 4), np.float64)
+        matched = np.full(int(gt_off[-1]), np.nan, np.float64)
+        self.lib.prcnn_cpu_kitti_statistics(_p(overlaps, D), _p(ov_off, _L), _p(gt_datas, D), _p(gt_off, _I), _p(dt_datas, D),
+                                            _p(dt_off, _I), _p(ign_gt, _I), _p(ign_det, _I), _p(dc, D), _p(dc_off, _I), F, int(metric),
+                                            ctypes.c_double(min_overlap), _p(thresholds, D), T, int(compute_fp), int(compute_aos),
+                                            _p(res, D), _p(matched, D))
+        return res, matched
+
+    def rotate_iou_eval(self, boxes, query, criterion=-1):
+        boxes, query = _f32(boxes), _f32(query)
+        out = np.zeros((boxes.shape[0], query.shape[0]), np.float32)
+        self.lib.prcnn_cpu_rotate_iou_eval(_p(boxes, _F), boxes.shape[0], _p(query, _F), query.shape[0], int(criterion), _p(out, _F))
+        return out
+
+
 _cpu = None
 _ref = None
 

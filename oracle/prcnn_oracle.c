@@ -750,3 +750,218 @@ PRCNN_EXPORT void prcnn_cpu_canonical_transform(float* pooled, const float* rois
         }
     }
 }
+
+/* ======================================================================================================
+ * KITTI object evaluation: tools/kitti_object_eval_python/{rotate_iou,eval}.py.
+ *   PINNED -- tests/golden/kitti_eval_ref.npz holds the outputs of the reference's own Python (numba decorators
+ *   stubbed to identity, the single CUDA launch replaced by a loop over its own device function; see
+ *   tests/golden/ref_kitti_eval.py).  The matching / counting logic is reproduced exactly (integer tp/fp/fn); IoU
+ *   arithmetic to ~1e-6 (numba's float32/float64 type inference cannot be reproduced without numba).
+ * Canonical IoU arithmetic (shared with kitti_eval.hip): fp32, every operation individually rounded, cos/sin of the
+ * box angle evaluated in double and rounded once.
+ * ====================================================================================================== */
+static void kr_corners(const float* r, float* c) {                      /* rotate_iou.py:203-227 rbbox_to_corners */
+    float a_cos = (float)cos((double)r[4]), a_sin = (float)sin((double)r[4]);
+    float xd = r[2], yd = r[3];
+    float cx[4] = {-xd / 2, -xd / 2, xd / 2, xd / 2}, cy[4] = {-yd / 2, yd / 2, yd / 2, -yd / 2};
+    for (int i = 0; i < 4; i++) {
+        c[2 * i] = a_cos * cx[i] + a_sin * cy[i] + r[0];
+        c[2 * i + 1] = -a_sin * cx[i] + a_cos * cy[i] + r[1];
+    }
+}
+static int kr_point_in_quad(float px, float py, const float* c) {       /* :161-177 */
+    float ab0 = c[2] - c[0], ab1 = c[3] - c[1], ad0 = c[6] - c[0], ad1 = c[7] - c[1];
+    float ap0 = px - c[0], ap1 = py - c[1];
+    float abab = ab0 * ab0 + ab1 * ab1, abap = ab0 * ap0 + ab1 * ap1;
+    float adad = ad0 * ad0 + ad1 * ad1, adap = ad0 * ap0 + ad1 * ap1;
+    return abab >= abap && abap >= 0 && adad >= adap && adap >= 0;
+}
+static int kr_seg_intersection(const float* p1, const float* p2, int i, int j, float* t) {    /* :77-115 */
+    float A0 = p1[2 * i], A1 = p1[2 * i + 1], B0 = p1[2 * ((i + 1) % 4)], B1 = p1[2 * ((i + 1) % 4) + 1];
+    float C0 = p2[2 * j], C1 = p2[2 * j + 1], D0 = p2[2 * ((j + 1) % 4)], D1 = p2[2 * ((j + 1) % 4) + 1];
+    float BA0 = B0 - A0, BA1 = B1 - A1, DA0 = D0 - A0, CA0 = C0 - A0, DA1 = D1 - A1, CA1 = C1 - A1;
+    int acd = DA1 * CA0 > CA1 * DA0;
+    int bcd = (D1 - B1) * (C0 - B0) > (C1 - B1) * (D0 - B0);
+    if (acd != bcd) {
+        int abc = CA1 * BA0 > BA1 * CA0, abd = DA1 * BA0 > BA1 * DA0;
+        if (abc != abd) {
+            float DC0 = D0 - C0, DC1 = D1 - C1;
+            float ABBA = A0 * B1 - B0 * A1, CDDC = C0 * D1 - D0 * C1;
+            float DH = BA1 * DC0 - BA0 * DC1, Dx = ABBA * DC0 - BA0 * CDDC, Dy = ABBA * DC1 - BA1 * CDDC;
+            t[0] = Dx / DH; t[1] = Dy / DH;
+            return 1;
+        }
+    }
+    return 0;
+}
+#define KR_MAXPTS 24     /* the reference's local array holds 8 points (int_pts[16]); 24 can never overflow */
+static float kr_inter(const float* r1, const float* r2) {               /* :230-245 inter */
+    float c1[8], c2[8], ip[2 * KR_MAXPTS], vs[KR_MAXPTS], t[2];
+    kr_corners(r1, c1); kr_corners(r2, c2);
+    int n = 0;
+    for (int i = 0; i < 4; i++) {                                        /* :180-200 quadrilateral_intersection */
+        if (kr_point_in_quad(c1[2 * i], c1[2 * i + 1], c2)) { ip[2 * n] = c1[2 * i]; ip[2 * n + 1] = c1[2 * i + 1]; n++; }
+        if (kr_point_in_quad(c2[2 * i], c2[2 * i + 1], c1)) { ip[2 * n] = c2[2 * i]; ip[2 * n + 1] = c2[2 * i + 1]; n++; }
+    }
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            if (n < KR_MAXPTS && kr_seg_intersection(c1, c2, i, j, t)) { ip[2 * n] = t[0]; ip[2 * n + 1] = t[1]; n++; }
+    if (n > 0) {                                                         /* :33-74 sort_vertex_in_convex_polygon */
+        float cx = 0.f, cy = 0.f;
+        for (int i = 0; i < n; i++) { cx += ip[2 * i]; cy += ip[2 * i + 1]; }
+        cx /= (float)n; cy /= (float)n;
+        for (int i = 0; i < n; i++) {
+            float v0 = ip[2 * i] - cx, v1 = ip[2 * i + 1] - cy;
+            float d = sqrtf(v0 * v0 + v1 * v1);
+            v0 = v0 / d; v1 = v1 / d;
+            if (v1 < 0) v0 = -2 - v0;
+            vs[i] = v0;
+        }
+        for (int i = 1; i < n; i++)
+            if (vs[i - 1] > vs[i]) {
+                float temp = vs[i], tx = ip[2 * i], ty = ip[2 * i + 1];
+                int j = i;
+                while (j > 0 && vs[j - 1] > temp) {
+                    vs[j] = vs[j - 1]; ip[2 * j] = ip[2 * j - 2]; ip[2 * j + 1] = ip[2 * j - 1];
+                    j--;
+                }
+                vs[j] = temp; ip[2 * j] = tx; ip[2 * j + 1] = ty;
+            }
+    }
+    float area = 0.f;                                                    /* :24-31 area (triangle fan) */
+    for (int i = 0; i < n - 2; i++) {
+        const float *a = ip, *b = ip + 2 * i + 2, *c = ip + 2 * i + 4;
+        area += fabsf(((a[0] - c[0]) * (b[1] - c[1]) - (a[1] - c[1]) * (b[0] - c[0])) / 2.0f);
+    }
+    return area;
+}
+static float kr_iou_eval(const float* r1, const float* r2, int criterion) {      /* :248-260 devRotateIoUEval */
+    float area1 = r1[2] * r1[3], area2 = r2[2] * r2[3], ai = kr_inter(r1, r2);
+    if (criterion == -1) return ai / (area1 + area2 - ai);
+    if (criterion == 0) return ai / area1;
+    if (criterion == 1) return ai / area2;
+    return ai;
+}
+/* rotate_iou.py:287-329 rotate_iou_gpu_eval: boxes (N,5), query (K,5) [cx, cy, dx, dy, angle] -> iou (N,K);
+ * the kernel evaluates devRotateIoUEval(query_k, box_n) (:282-284) */
+PRCNN_EXPORT void prcnn_cpu_rotate_iou_eval(const float* boxes, int N, const float* query, int K, int criterion, float* out) {
+    for (int n = 0; n < N; n++)
+        for (int k = 0; k < K; k++) out[(size_t)n * K + k] = kr_iou_eval(query + 5 * k, boxes + 5 * n, criterion);
+}
+
+/* Per-frame overlap blocks as eval.py:326-397 calculate_iou_partly produces them for eval_class (which passes
+ * (dt_annos, gt_annos): rows = detections, columns = ground truth).  metric 0: image_box_overlap on bbox (., 4)
+ * (:87-113, float64); 1: bev_box_overlap on (x, z, l, w, ry) (:116-118, float32 result); 2: d3_box_overlap (:121-152:
+ * rotated intersection area x height overlap / union volume, float64 math on a float32 area, stored as float32).
+ * dt / gt: (.,4) for metric 0, (.,7) [x, y, z, l, h, w, ry] otherwise; offsets (F+1); out: concatenated row-major blocks. */
+PRCNN_EXPORT void prcnn_cpu_kitti_overlaps(int metric, const double* dt, const int32_t* dt_off, const double* gt,
+                                           const int32_t* gt_off, const int64_t* ov_off, int F, double* out) {
+    for (int f = 0; f < F; f++) {
+        int nd = dt_off[f + 1] - dt_off[f], ng = gt_off[f + 1] - gt_off[f];
+        double* o = out + ov_off[f];
+        for (int n = 0; n < nd; n++)
+            for (int k = 0; k < ng; k++) {
+                double v = 0.0;
+                if (metric == 0) {
+                    const double *b = dt + (size_t)(dt_off[f] + n) * 4, *q = gt + (size_t)(gt_off[f] + k) * 4;
+                    double qarea = (q[2] - q[0]) * (q[3] - q[1]);
+                    double iw = fmin(b[2], q[2]) - fmax(b[0], q[0]);
+                    if (iw > 0) {
+                        double ih = fmin(b[3], q[3]) - fmax(b[1], q[1]);
+                        if (ih > 0) { double ua = (b[2] - b[0]) * (b[3] - b[1]) + qarea - iw * ih; v = iw * ih / ua; }
+                    }
+                } else {
+                    const double *b = dt + (size_t)(dt_off[f] + n) * 7, *q = gt + (size_t)(gt_off[f] + k) * 7;
+                    float rb[5] = {(float)b[0], (float)b[2], (float)b[3], (float)b[5], (float)b[6]};
+                    float rq[5] = {(float)q[0], (float)q[2], (float)q[3], (float)q[5], (float)q[6]};
+                    if (metric == 1) v = (double)kr_iou_eval(rq, rb, -1);
+                    else {
+                        float rinc = kr_iou_eval(rq, rb, 2);
+                        if (rinc > 0) {
+                            double iw = fmin(b[1], q[1]) - fmax(b[1] - b[4], q[1] - q[4]);
+                            if (iw > 0) {
+                                double area1 = b[3] * b[4] * b[5], area2 = q[3] * q[4] * q[5];
+                                double inc = iw * (double)rinc;
+                                v = (double)(float)(inc / (area1 + area2 - inc));
+                            }
+                        }
+                    }
+                }
+                o[(size_t)n * ng + k] = v;
+            }
+    }
+}
+
+/* eval.py:155-268 compute_statistics_jit for ONE frame and ONE score threshold.
+ * overlaps (nd, ng) row-major; gt_datas (ng,5) [bbox, alpha]; dt_datas (nd,6) [bbox, alpha, score]; dc (ndc,4).
+ * returns tp, fp, fn, similarity in res[4]; matched (ng) receives the score of the detection that made gt i a true
+ * positive, NaN elsewhere (the `thresholds` list of the reference, in gt order). */
+static void kitti_stats_frame(const double* ov, const double* gtd, int ng, const double* dtd, int nd, const int32_t* ign_gt,
+                              const int32_t* ign_det, const double* dc, int ndc, int metric, double min_overlap, double thresh,
+                              int compute_fp, int compute_aos, double* res, double* matched) {
+    unsigned char* assigned = (unsigned char*)calloc((size_t)(nd > 0 ? nd : 1), 1);
+    unsigned char* ign_thr = (unsigned char*)calloc((size_t)(nd > 0 ? nd : 1), 1);
+    if (compute_fp)
+        for (int j = 0; j < nd; j++) ign_thr[j] = dtd[j * 6 + 5] < thresh;
+    const double NO_DETECTION = -10000000;
+    double tp = 0, fp = 0, fn = 0, sim_sum = 0;
+    for (int i = 0; i < ng; i++) {
+        if (matched) matched[i] = NAN;
+        if (ign_gt[i] == -1) continue;
+        int det_idx = -1, assigned_ignored = 0;
+        double valid_detection = NO_DETECTION, max_overlap = 0;
+        for (int j = 0; j < nd; j++) {
+            if (ign_det[j] == -1 || assigned[j] || ign_thr[j]) continue;
+            double overlap = ov[(size_t)j * ng + i], score = dtd[j * 6 + 5];
+            if (!compute_fp && overlap > min_overlap && score > valid_detection) { det_idx = j; valid_detection = score; }
+            else if (compute_fp && overlap > min_overlap && (overlap > max_overlap || assigned_ignored) && ign_det[j] == 0) {
+                max_overlap = overlap; det_idx = j; valid_detection = 1; assigned_ignored = 0;
+            } else if (compute_fp && overlap > min_overlap && valid_detection == NO_DETECTION && ign_det[j] == 1) {
+                det_idx = j; valid_detection = 1; assigned_ignored = 1;
+            }
+        }
+        if (valid_detection == NO_DETECTION && ign_gt[i] == 0) fn += 1;
+        else if (valid_detection != NO_DETECTION && (ign_gt[i] == 1 || ign_det[det_idx] == 1)) assigned[det_idx] = 1;
+        else if (valid_detection != NO_DETECTION) {
+            tp += 1;
+            if (matched) matched[i] = dtd[det_idx * 6 + 5];
+            if (compute_aos) sim_sum += (1.0 + cos(gtd[i * 5 + 4] - dtd[det_idx * 6 + 4])) / 2.0;
+            assigned[det_idx] = 1;
+        }
+    }
+    double similarity = 0;
+    if (compute_fp) {
+        for (int j = 0; j < nd; j++)
+            if (!(assigned[j] || ign_det[j] == -1 || ign_det[j] == 1 || ign_thr[j])) fp += 1;
+        int nstuff = 0;
+        if (metric == 0)
+            for (int i = 0; i < ndc; i++)
+                for (int j = 0; j < nd; j++) {
+                    if (assigned[j] || ign_det[j] == -1 || ign_det[j] == 1 || ign_thr[j]) continue;
+                    const double *b = dtd + j * 6, *q = dc + i * 4;      /* image_box_overlap(dt, dc, criterion 0) */
+                    double o = 0, iw = fmin(b[2], q[2]) - fmax(b[0], q[0]);
+                    if (iw > 0) {
+                        double ih = fmin(b[3], q[3]) - fmax(b[1], q[1]);
+                        if (ih > 0) o = iw * ih / ((b[2] - b[0]) * (b[3] - b[1]));
+                    }
+                    if (o > min_overlap) { assigned[j] = 1; nstuff++; }
+                }
+        fp -= nstuff;
+        if (compute_aos) similarity = (tp > 0 || fp > 0) ? sim_sum : -1;
+    }
+    res[0] = tp; res[1] = fp; res[2] = fn; res[3] = similarity;
+    free(assigned); free(ign_thr);
+}
+/* all frames x all thresholds: res (F, T, 4); matched (G) or NULL (written for t == 0 only) */
+PRCNN_EXPORT void prcnn_cpu_kitti_statistics(const double* overlaps, const int64_t* ov_off, const double* gt_datas,
+                                             const int32_t* gt_off, const double* dt_datas, const int32_t* dt_off,
+                                             const int32_t* ign_gt, const int32_t* ign_det, const double* dc, const int32_t* dc_off,
+                                             int F, int metric, double min_overlap, const double* thresholds, int T, int compute_fp,
+                                             int compute_aos, double* res, double* matched) {
+    for (int f = 0; f < F; f++)
+        for (int t = 0; t < T; t++)
+            kitti_stats_frame(overlaps + ov_off[f], gt_datas + (size_t)gt_off[f] * 5, gt_off[f + 1] - gt_off[f],
+                              dt_datas + (size_t)dt_off[f] * 6, dt_off[f + 1] - dt_off[f], ign_gt + gt_off[f], ign_det + dt_off[f],
+                              dc + (size_t)dc_off[f] * 4, dc_off[f + 1] - dc_off[f], metric, min_overlap, thresholds[t], compute_fp,
+                              compute_aos, res + ((size_t)f * T + t) * 4, (matched && t == 0) ? matched + gt_off[f] : NULL);
+}

@@ -57,6 +57,9 @@ SIGNATURES = {
     "prcnn_grid_build": (_I, [_P, _I, _I, _F, _P, _Z, _P]),
     "prcnn_ball_query2_grid": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _F, _I, _P, _P]),
     "prcnn_three_nn_grid": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "prcnn_rotate_iou_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    "prcnn_kitti_overlaps": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "prcnn_kitti_statistics": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _D, _P, _I, _I, _I, _P, _P, _P]),
     "prcnn_nms_batched": (_I, [_P, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
 }
 

@@ -559,3 +559,41 @@ def nms_batched(boxes3d, scores, valid=None, thresh=0.1, rotated=True, max_keep=
     _cabi.check(L.prcnn_nms_batched(_p(boxes3d), _p(scores), _p(valid) if valid is not None else None, B, M, float(thresh),
                                     0 if rotated else 1, mk, _p(keep), _p(num), _p(ws), wsb, _stream()), "prcnn_nms_batched")
     return keep[:, :mk], num
+
+
+# ---------------------------------------------------------------------------------------------------------
+# KITTI evaluation kernels (host logic in pointrcnn_amd/kitti_eval.py)
+# ---------------------------------------------------------------------------------------------------------
+def rotate_iou_eval(boxes, query_boxes, criterion=-1):
+    """rotate_iou.py:287-329 rotate_iou_gpu_eval: (N,5), (K,5) [cx, cy, dx, dy, angle] -> (N,K)"""
+    _chk(boxes, "boxes", ndim=2); _chk(query_boxes, "query_boxes", ndim=2)
+    N, K = boxes.shape[0], query_boxes.shape[0]
+    out = torch.zeros((N, K), dtype=_F32, device=boxes.device)
+    _cabi.check(_cabi.lib().prcnn_rotate_iou_eval(_p(boxes), N, _p(query_boxes), K, int(criterion), _p(out), _stream()),
+                "prcnn_rotate_iou_eval")
+    return out
+
+
+def kitti_overlaps(metric, dt, dt_off, gt, gt_off, ov_off, total):
+    """per-frame overlap blocks (rows = dt, columns = gt) of all frames, flat float64 (see include/prcnn_pointops.h)"""
+    F = dt_off.shape[0] - 1
+    out = torch.zeros((max(int(total), 1),), dtype=torch.float64, device=dt_off.device)
+    _cabi.check(_cabi.lib().prcnn_kitti_overlaps(int(metric), _p(dt), _p(dt_off), _p(gt), _p(gt_off), _p(ov_off), F, _p(out), _stream()),
+                "prcnn_kitti_overlaps")
+    return out[:int(total)]
+
+
+def kitti_statistics(overlaps, ov_off, gt_datas, gt_off, dt_datas, dt_off, ign_gt, ign_det, dc, dc_off, metric, min_overlap,
+                     thresholds, compute_fp, compute_aos):
+    """compute_statistics_jit for every (frame, threshold) -> res (F,T,4) f64, matched (G) f64"""
+    F, T = gt_off.shape[0] - 1, thresholds.shape[0]
+    dev = gt_off.device
+    res = torch.zeros((F, T, 4), dtype=torch.float64, device=dev)
+    G = gt_datas.shape[0]
+    matched = torch.full((max(G, 1),), float("nan"), dtype=torch.float64, device=dev)
+    max_det = int((dt_off[1:] - dt_off[:-1]).max().item()) if F > 0 else 0
+    _cabi.check(_cabi.lib().prcnn_kitti_statistics(_p(overlaps), _p(ov_off), _p(gt_datas), _p(gt_off), _p(dt_datas), _p(dt_off),
+                                                   _p(ign_gt), _p(ign_det), _p(dc), _p(dc_off), F, max_det, int(metric),
+                                                   float(min_overlap), _p(thresholds), T, int(compute_fp), int(compute_aos), _p(res),
+                                                   _p(matched), _stream()), "prcnn_kitti_statistics")
+    return res, matched[:G]

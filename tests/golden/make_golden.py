@@ -7,6 +7,11 @@
     proposal_ref.npz -- outputs of the REFERENCE'S OWN Python proposal stage (lib/utils/bbox_transform.py
         decode_bbox_target, lib/rpn/proposal_layer.py ProposalLayer) imported on CPU by ref_proposal.py, with the NMS
         extension calls routed to oracle/_ref.  Inputs are regenerated from seeds (tests/util.py); their CRCs are stored.
+    canonical_ref.npz -- rcnn_net.py:143-150 (centre subtract + kitti_utils.rotate_pc_along_y_torch) run by the reference's
+        own Python on the reference's pooled tensor.
+    kitti_eval_ref.npz -- outputs of the reference's own tools/kitti_object_eval_python evaluator (result strings, AP
+        dictionaries, precision / recall arrays, per-frame overlaps, rotate_iou_gpu_eval matrices) on seeded synthetic
+        annotations; numba is stubbed to identity (ref_kitti_eval.py), the code that runs is the reference's.
     pointnet2_oracle.npz -- outputs of the CPU oracle (oracle/prcnn_oracle.c) for the PointNet++ ops, whose
         reference source is an empty git submodule (parity unpinned: these pin the ORACLE's behaviour across
         refactors, not the reference's).
@@ -79,6 +84,51 @@ def make_proposal_golden():
     np.savez_compressed(os.path.join(HERE, "proposal_ref.npz"), **out)
 
 
+def kitti_eval_inputs():
+    """shared by make_golden.py and the tests"""
+    from util import kitti_annos
+    gt = kitti_annos(120, seed=1)
+    dt = kitti_annos(120, seed=2, with_score=True, gt=gt)
+    return gt, dt
+
+
+def annos_crc(annos):
+    return crc(*[np.asarray(a[k], np.float64) for a in annos for k in ("bbox", "dimensions", "location", "rotation_y", "alpha", "score")])
+
+
+def make_kitti_eval_golden():
+    """outputs of the reference's own tools/kitti_object_eval_python (numba stubbed, see ref_kitti_eval.py)"""
+    import ref_kitti_eval
+    ev, kc = ref_kitti_eval.load()
+    gt, dt = kitti_eval_inputs()
+    out = {"crc": np.array([annos_crc(gt), annos_crc(dt)])}
+    res, d = ev.get_official_eval_result(gt, dt, [0, 1, 2])
+    out["official_str"] = np.array(res)
+    out["official_keys"] = np.array(sorted(d))
+    out["official_vals"] = np.array([d[k] for k in sorted(d)])
+    out["official_car_str"] = np.array(ev.get_official_eval_result(gt, dt, 0)[0])
+    _lin = np.linspace
+    np.linspace = lambda a, b, n=50, **k: _lin(a, b, int(n), **k)        # eval.py:593 passes num as a float
+    out["coco_str"] = np.array(ev.get_coco_eval_result(gt, dt, [0, 1]))
+    np.linspace = _lin
+    mo = np.stack([np.array([[0.7, 0.5, 0.5]] * 3), np.array([[0.5, 0.25, 0.25]] * 3)], 0)
+    for metric in (0, 1, 2):
+        blocks = ev.calculate_iou_partly(dt, gt, metric, 50)[0]
+        out["ov%d" % metric] = np.concatenate([b.reshape(-1) for b in blocks]) if blocks else np.zeros(0)
+        r = ev.eval_class(gt, dt, [0, 1, 2], [0, 1, 2], metric, mo, compute_aos=(metric == 0))
+        for k in ("recall", "precision", "orientation"):
+            out["m%d_%s" % (metric, k)] = r[k]
+    rr = np.random.default_rng(5)
+    boxes = np.concatenate([rr.uniform(-4, 4, (40, 2)), rr.uniform(1, 4, (40, 2)), rr.uniform(-3.2, 3.2, (40, 1))], 1).astype(np.float32)
+    query = np.concatenate([rr.uniform(-4, 4, (30, 2)), rr.uniform(1, 4, (30, 2)), rr.uniform(-3.2, 3.2, (30, 1))], 1).astype(np.float32)
+    query[:5] = boxes[:5]                                                 # identical boxes: degenerate clipping
+    query[5, :4], query[5, 4] = boxes[5, :4], boxes[5, 4] + np.float32(np.pi / 2)
+    out["riou_boxes"], out["riou_query"] = boxes, query
+    for c in (-1, 0, 1, 2):
+        out["riou_c%d" % c] = ev.rotate_iou_gpu_eval(boxes, query, c)
+    np.savez_compressed(os.path.join(HERE, "kitti_eval_ref.npz"), **out)
+
+
 def make_canonical_golden(ref):
     """rcnn_net.py:143-150 run with the reference's own kitti_utils.rotate_pc_along_y_torch on the reference's pooled tensor"""
     import torch
@@ -131,6 +181,7 @@ def main():
                         nn_dist2=d2, nn_idx=i3, nn_w=cpu.three_weights(d2))
     make_proposal_golden()
     make_canonical_golden(ref)
+    make_kitti_eval_golden()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 

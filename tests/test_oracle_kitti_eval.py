@@ -1,0 +1,78 @@
+"""KITTI evaluator: the host logic of pointrcnn_amd.kitti_eval on the CPU-oracle backend against golden
+vectors produced by the REFERENCE'S OWN tools/kitti_object_eval_python (tests/golden/ref_kitti_eval.py), and -- in the
+build container, where the reference checkout exists -- against the reference's label parser run live."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from kitti_cases import check_against_golden, golden, kitti_eval_inputs, write_kitti_txt
+from util import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def backend():
+    import oracle
+    return oracle.KittiBackend()
+
+
+def test_evaluator_equals_reference_python(backend):
+    from pointrcnn_amd import kitti_eval
+    check_against_golden(kitti_eval, backend, golden())
+
+
+def test_rotate_iou_eval_equals_reference_python(backend):
+    g = golden()
+    for c in (-1, 0, 1, 2):
+        got = backend.rotate_iou_eval(g["riou_boxes"], g["riou_query"], c)
+        np.testing.assert_allclose(got, g["riou_c%d" % c], rtol=0, atol=2e-6)
+    # reference quirk, reproduced: for two EXACTLY identical boxes every corner is collected twice and no edge pair
+    # "crosses", the triangle fan over the duplicated vertices covers half the box: IoU = 0.5 / 1.5
+    iou = backend.rotate_iou_eval(g["riou_boxes"][:2], g["riou_boxes"][:2], -1)
+    np.testing.assert_allclose(np.diag(iou), 1.0 / 3.0, atol=1e-6)
+    assert np.array_equal(backend.rotate_iou_eval(g["riou_boxes"], g["riou_query"], -1)[:2, :2], iou)
+
+
+def test_label_files_round_trip_and_evaluate_entry_point(backend, tmp_path):
+    """write the annotations as KITTI txt files, parse them back (kitti_common.get_label_annos), run evaluate()"""
+    from pointrcnn_amd import kitti_eval
+    gt, dt = kitti_eval_inputs()
+    write_kitti_txt(gt, tmp_path / "label_2", False)
+    write_kitti_txt(dt, tmp_path / "pred", True)
+    split = tmp_path / "val.txt"
+    split.write_text("".join("%06d\n" % i for i in range(len(gt))))
+    gt2 = kitti_eval.get_label_annos(str(tmp_path / "label_2"), list(range(len(gt))))
+    dt2 = kitti_eval.get_label_annos(str(tmp_path / "pred"))
+    for a, b in zip(gt + dt, gt2 + dt2):
+        for k in ("bbox", "dimensions", "location", "rotation_y", "alpha", "truncated", "score"):
+            assert np.array_equal(np.asarray(a[k], np.float64).reshape(np.asarray(b[k]).shape), b[k]), k
+        assert list(a["name"]) == list(b["name"]) and np.array_equal(np.asarray(a["occluded"]), b["occluded"])
+    res, d = kitti_eval.evaluate(str(tmp_path / "label_2"), str(tmp_path / "pred"), str(split), current_class=0, backend=backend)
+    assert res == str(golden()["official_car_str"])
+    filtered = kitti_eval.evaluate(str(tmp_path / "label_2"), str(tmp_path / "pred"), str(split), current_class=0, score_thresh=0.5,
+                                   backend=backend)[1]
+    assert filtered["Car_3d_hard"] <= d["Car_3d_hard"] + 1e-9
+    ref_dir = os.environ.get("PRCNN_REFERENCE", "/root/reference")
+    if os.path.isdir(os.path.join(ref_dir, "tools", "kitti_object_eval_python")):
+        sys.path.insert(0, GOLDEN)
+        import ref_kitti_eval
+        _, kc = ref_kitti_eval.load()
+        for a, b in zip(kc.get_label_annos(str(tmp_path / "pred")), dt2):        # the reference's own parser, live
+            for k in a:
+                assert np.array_equal(a[k], b[k]), k
+
+
+def test_edge_cases(backend):
+    from pointrcnn_amd import kitti_eval
+    gt, dt = kitti_eval_inputs()
+    empty = {k: v[:0] for k, v in gt[0].items()}
+    # frames without ground truth / without detections, and a class nobody predicted
+    gt2, dt2 = [empty] + gt[:60], [dt[0]] + dt[:60]
+    dt2[5] = {k: v[:0] for k, v in dt[5].items()}
+    res, d = kitti_eval.get_official_eval_result(gt2, dt2, [0, 2], backend=backend)
+    assert "Car AP@0.70" in res and "Cyclist AP@0.50" in res and np.isfinite(list(d.values())).all()
+    only_cars = [{k: v[np.asarray(a["name"]) == "Car"] for k, v in a.items()} for a in dt[:60]]
+    r = kitti_eval.eval_class(gt[:60], only_cars, [1], [0, 1, 2], 2, np.full((1, 3, 1), 0.5), backend=backend)
+    assert (r["precision"] == 0).all()                                          # no pedestrian detections at all
+    assert kitti_eval.get_thresholds(np.array([0.9, 0.8, 0.7, 0.1]), 4) == [0.9, 0.8, 0.7, 0.1]

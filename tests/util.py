@@ -97,3 +97,44 @@ def rpn_like_scene(B, N, seed=0, nobj=24, fg_frac=0.4, z_max=70.4):
         reg[b] = encode_rpn_reg(pts.astype(np.float64), tgt, r)[perm]
         scores[b] = np.concatenate([r.normal(2.5, 1.0, nfg), r.normal(-3.0, 1.0, N - nfg)]).astype(np.float32)[perm]
     return xyz, scores, reg
+
+
+def kitti_annos(nframes, seed=0, with_score=False, gt=None):
+    """Synthetic KITTI annotation dicts (tools/kitti_object_eval_python/kitti_common.py:get_label_anno layout:
+    dimensions already reordered to l,h,w).  with_score: detections = jittered copies of `gt` objects + false positives."""
+    r = np.random.default_rng(seed)
+    names = np.array(["Car", "Car", "Car", "Van", "Pedestrian", "Cyclist", "DontCare", "Person_sitting"])
+    annos = []
+    for f in range(nframes):
+        if not with_score:
+            n = int(r.integers(0, 9))
+            nm = names[r.integers(0, len(names), n)]
+            x1, y1 = r.uniform(0, 1100, n), r.uniform(100, 250, n)
+            hgt = r.choice([20.0, 30.0, 45.0, 60.0, 80.0, 140.0], n)
+            bbox = np.stack([x1, y1, x1 + hgt * r.uniform(1.0, 2.5, n), y1 + hgt], 1)
+            loc = np.stack([r.uniform(-20, 20, n), r.uniform(1.2, 2.0, n), r.uniform(5, 60, n)], 1)
+            dims = np.stack([r.uniform(3.2, 4.6, n), r.uniform(1.4, 1.9, n), r.uniform(1.5, 1.9, n)], 1)     # l, h, w
+            a = dict(name=nm, truncated=r.choice([0.0, 0.0, 0.1, 0.2, 0.4, 0.6], n), occluded=r.choice([0, 0, 0, 1, 1, 2, 3], n),
+                     alpha=r.uniform(-3.1, 3.1, n), bbox=bbox, dimensions=dims, location=loc,
+                     rotation_y=r.uniform(-3.1, 3.1, n), score=np.zeros(n))
+        else:
+            g = gt[f]
+            keep = [i for i in range(len(g["name"])) if g["name"][i] != "DontCare" and r.random() < 0.9]
+            nfp = int(r.integers(0, 4))
+            n = len(keep) + nfp
+            jit = lambda s, m: r.normal(0, s, m)        # noqa: E731
+            nm = np.concatenate([g["name"][keep], names[r.integers(0, 6, nfp)]]) if n else np.array([], dtype="<U16")
+            nm = np.where(nm == "Van", "Car", nm)
+            bbox = np.concatenate([g["bbox"][keep] + jit(2.5, (len(keep), 4)),
+                                   np.stack([r.uniform(0, 1100, nfp), r.uniform(100, 250, nfp), r.uniform(0, 1100, nfp) + 60,
+                                             r.uniform(100, 250, nfp) + 50], 1).reshape(nfp, 4)])
+            loc = np.concatenate([g["location"][keep] + jit(0.07, (len(keep), 3)),
+                                  np.stack([r.uniform(-20, 20, nfp), r.uniform(1.2, 2.0, nfp), r.uniform(5, 60, nfp)], 1).reshape(nfp, 3)])
+            dims = np.concatenate([g["dimensions"][keep] * (1 + jit(0.025, (len(keep), 3))),
+                                   np.stack([r.uniform(3.2, 4.6, nfp), r.uniform(1.4, 1.9, nfp), r.uniform(1.5, 1.9, nfp)], 1).reshape(nfp, 3)])
+            ry = np.concatenate([g["rotation_y"][keep] + jit(0.04, len(keep)), r.uniform(-3.1, 3.1, nfp)])
+            al = np.concatenate([g["alpha"][keep] + jit(0.1, len(keep)), r.uniform(-3.1, 3.1, nfp)])
+            a = dict(name=nm, truncated=np.zeros(n), occluded=np.zeros(n, np.int64), alpha=al, bbox=bbox, dimensions=dims,
+                     location=loc, rotation_y=ry, score=r.uniform(0.05, 1.0, n))
+        annos.append(a)
+    return annos
