@@ -127,7 +127,39 @@ def cpu_baseline(model, clouds_cpu, gpu_out):
         ref = out[k]
         got = gpu_out[k][0].float().cpu().numpy()
         err[k] = float(abs(got - ref).max() / max(1.0, abs(ref).max()))
-    return {"value": round(nframes / dt, 5), "unit": "frames/s", "cores": 1, "kind": "port",
+    # the reference's ONLY CPU fallback on the path, its own lib/utils/roipool3d/src/roipool3d.cpp compiled for the host
+    # (oracle/_ref): one frame of config-3 pooling (16384 pts x 130 features, 100 RoIs, 512 samples), next to the HIP kernel
+    ref_roipool = None
+    ref = oracle.ref()
+    if ref is not None:
+        import numpy as np
+        from pointrcnn_amd import ops
+        rng = np.random.default_rng(0)
+        pts = clouds_cpu[0].numpy()
+        ctr = pts[rng.integers(0, pts.shape[0], 100)]
+        boxes = np.concatenate([ctr[:, :1], ctr[:, 1:2] + 1.8, ctr[:, 2:3], np.tile([3.6, 3.7, 6.0], (100, 1)),
+                                rng.uniform(-3.14, 3.14, (100, 1))], 1).astype(np.float32)
+        feat = rng.normal(size=(pts.shape[0], 130)).astype(np.float32)
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            pp, pf, pe = ref.roipool3d_cpu(pts, boxes, feat, 512)
+        cpu_s = (time.perf_counter() - t1) / reps
+        dev = gpu_out["rpn_cls"].device
+        tx, tb, tf = (torch.from_numpy(a[None]).to(dev) for a in (pts, boxes, feat))
+        pooled, _ = ops.roipool3d(tx, tb, tf, 512)
+        torch.cuda.synchronize()
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        for _ in range(20):
+            ops.roipool3d(tx, tb, tf, 512)
+        e_.record()
+        torch.cuda.synchronize()
+        same = bool(np.array_equal(pooled[0, :, :, 3:].cpu().numpy(), pf) and np.array_equal(pooled[0, :, :, :3].cpu().numpy(), pp))
+        ref_roipool = {"kind": "reference", "op": "roipool3d_cpu (lib/utils/roipool3d/src/roipool3d.cpp:127-195), 1 frame, 100 RoIs x 512 x 133",
+                       "cpu_ms_per_frame": round(cpu_s * 1e3, 2), "cores": 1,
+                       "gpu_ms_per_frame_single_frame_launch": round(s_.elapsed_time(e_) / 20, 4), "outputs_identical": same}
+    return {"value": round(nframes / dt, 5), "unit": "frames/s", "cores": 1, "kind": "port", "reference_roipool3d": ref_roipool,
             "sample": "%d frames (16384 pts each) of the same RPN graph through oracle/rpn_cpu.py, %.1f s" % (nframes, dt),
             "host_cores_available": os.cpu_count(),
             "breakdown_s": {k: round(v, 2) for k, v in sorted(timings.items())},
