@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--proposals", choices=["off", "normal", "rotate"], default="normal",
                     help="also run the proposal layer (decode + sort + distance split + NMS + top-100, lib/rpn/proposal_layer.py) "
                          "inside every step, as tools/eval_rcnn.py --eval_mode rpn does after the heads")
+    ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform",
+                    help="uniform = the BASELINE metric's synthetic clouds; lidar = range-dependent density + ground band + car "
+                         "clusters (same bounds): a robustness check for the spatially pruned / grid kernels")
     ap.add_argument("--h2d", action="store_true",
                     help="also copy every batch's clouds from pinned host memory inside the timed region (PCIe-inclusive rate; "
                          "the default keeps inputs resident in HBM, as the bench contract asks)")
@@ -190,10 +193,11 @@ def main():
     torch.manual_seed(1234)
     model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
     nstreams = max(1, args.streams)
-    clouds_cpu = rpn.synthetic_clouds(args.batch, args.npoints, seed0=100 + rank * args.batch)
+    make_clouds = rpn.synthetic_clouds if args.clouds == "uniform" else rpn.lidar_like_clouds
+    clouds_cpu = make_clouds(args.batch, args.npoints, seed0=100 + rank * args.batch)
     batches = [{"pts_input": clouds_cpu.to(dev)}]
     for s_ in range(1, nstreams):          # every in-flight slot owns its (resident) input batch
-        batches.append({"pts_input": rpn.synthetic_clouds(args.batch, args.npoints,
+        batches.append({"pts_input": make_clouds(args.batch, args.npoints,
                                                           seed0=100 + (world * s_ + rank) * args.batch).to(dev)})
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
 
@@ -280,7 +284,8 @@ def main():
                    "frames_per_gpu": args.batch, "npoints": args.npoints, "parallelism": "frames sharded, dp%d" % world,
                    "launch": "hipGraph replay" if graph is not None else "eager", "streams": nstreams,
                    "proposal_layer": args.proposals,
-                   "inputs": "host (pinned) -> HBM copy inside the timed region" if args.h2d else "resident in HBM"},
+                   "inputs": "host (pinned) -> HBM copy inside the timed region" if args.h2d else "resident in HBM",
+                   "clouds": args.clouds},
     }
 
     if rank == 0 and not args.no_roofline:

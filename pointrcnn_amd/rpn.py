@@ -151,6 +151,30 @@ def synthetic_clouds(batch, npoints=16384, seed0=100, device="cpu"):
     return out.to(device)
 
 
+def lidar_like_clouds(batch, npoints=16384, seed0=100, device="cpu"):
+    """A driving-scene-like distribution inside the same PC_AREA_SCOPE (SURVEY.md 8(d), config 2 note): point density falls
+    off with range as a spinning LiDAR's does (range ~ sqrt-uniform, 90-degree frontal fan), 85 % of the points on a ground
+    band around y = 1.6 m, the rest on 30 car-sized clusters.  Dense near the sensor, sparse far away -- the regime that
+    exercises ball-query saturation, crowded grid cells and the FPS pruning differently from the uniform clouds."""
+    out = torch.empty((batch, npoints, 3), dtype=torch.float32)
+    for f in range(batch):
+        g = torch.Generator().manual_seed(seed0 + f)
+        n_obj = int(npoints * 0.15)
+        n_gnd = npoints - n_obj
+        rng = 2.0 + 68.0 * torch.rand(n_gnd, generator=g) ** 1.5
+        ang = (torch.rand(n_gnd, generator=g) - 0.5) * 1.5708
+        gnd = torch.stack([rng * torch.sin(ang), 1.6 + 0.05 * torch.randn(n_gnd, generator=g), rng * torch.cos(ang)], 1)
+        ctr_r = 4.0 + 55.0 * torch.rand(30, generator=g)
+        ctr_a = (torch.rand(30, generator=g) - 0.5) * 1.4
+        ctr = torch.stack([ctr_r * torch.sin(ctr_a), torch.full((30,), 0.9), ctr_r * torch.cos(ctr_a)], 1)
+        own = torch.randint(0, 30, (n_obj,), generator=g)
+        obj = ctr[own] + torch.randn(n_obj, 3, generator=g) * torch.tensor([0.8, 0.4, 1.6])
+        pts = torch.cat([gnd, obj])[torch.randperm(npoints, generator=g)]
+        pts[:, 0].clamp_(-40.0, 40.0); pts[:, 1].clamp_(-1.0, 3.0); pts[:, 2].clamp_(0.0, 70.4)
+        out[f] = pts
+    return out.to(device)
+
+
 def rpn_flops_per_frame(cfg=RPNConfig):
     """Algorithmic MLP FLOPs per frame (2*MACs) of the RPN inference graph -- SURVEY.md 8(d): 14.95 GFLOP."""
     macs = 0
