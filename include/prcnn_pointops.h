@@ -234,7 +234,7 @@ int prcnn_decode_bbox_target(const float* roi, int roi_cols, const float* pred_r
                              float* out, prcnn_stream_t stream);
 
 /* workspace for prcnn_proposal_layer: pre_max = max(pre1, pre2), post_max = max(post1, post2) */
-size_t prcnn_proposal_workspace_bytes(int B, int pre_max, int post_max);
+size_t prcnn_proposal_workspace_bytes(int B, int N, int pre_max, int post_max);
 /* lib/rpn/proposal_layer.py:35-141 on decoded boxes3d (B, N, 7) and raw scores (B, N), whole batch, no host sync:
  * per frame order rows by descending score (NaN first, ties by ascending row -- torch.sort leaves tie order open),
  *   use_range != 0 (distance_based_proposal :58-117): area 1 = rows with r0 < z <= r1, area 2 = r1 < z <= r2; keep the
@@ -243,7 +243,8 @@ size_t prcnn_proposal_workspace_bytes(int B, int pre_max, int post_max);
  * greedy NMS (nms_kind, nms_thresh) on the BEV boxes (kitti_utils.py:134-147) of each list, first post1 / post2 survivors,
  * concatenated into out_boxes (B, post1+post2, 7) / out_scores (B, post1+post2), zero padded (:38-39).
  * out_count (B) i32, optional: rows filled per frame.  An empty area contributes nothing (the reference asserts, :90).
- * N <= 16384 (PRCNN_EUNSUPPORTED above: the sort is LDS-resident). */
+ * Frames of up to 16384 rows are sorted entirely in LDS; larger frames run the same bitonic network in 16384-key chunks with
+ * the long strides through the workspace in HBM. */
 int prcnn_proposal_layer(const float* scores, const float* boxes3d, int B, int N, int use_range, float r0, float r1, float r2,
                          int pre1, int pre2, int post1, int post2, float nms_thresh, int nms_kind, float* out_boxes,
                          float* out_scores, int32_t* out_count, void* workspace, size_t workspace_bytes, prcnn_stream_t stream);

@@ -49,7 +49,7 @@ SIGNATURES = {
     "prcnn_nms_workspace_bytes": (_Z, [_I]),
     "prcnn_nms": (_I, [_P, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
     "prcnn_decode_bbox_target": (_I, [_P, _I, _P, ctypes.c_long, _I, _D, _D, _I, _P, _I, _I, _D, _D, _I, _I, _P, _P]),
-    "prcnn_proposal_workspace_bytes": (_Z, [_I, _I, _I]),
+    "prcnn_proposal_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "prcnn_proposal_layer": (_I, [_P, _P, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "prcnn_nms_batched_workspace_bytes": (_Z, [_I, _I]),
     "prcnn_roipool3d_canonical": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),

@@ -73,3 +73,33 @@ __device__ __forceinline__ void block_sort16(u64 (&v)[16], u64* keys, int Npad, 
         __syncthreads();
     }
 }
+
+// One merge stage on Npad (<= 16384) keys that form a bitonic sequence: strides Npad/2 .. 16 through LDS, 8 .. 1 in registers,
+// ascending.  Same calling convention as block_sort16 (v holds the thread's 16 keys on entry and on exit).
+__device__ __forceinline__ void block_merge16(u64 (&v)[16], u64* keys, int Npad, int t) {
+    const int nact = Npad >> 4;
+    const bool active = t < nact;
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) keys[lds_phys(t * 16 + e)] = v[e];
+    }
+    __syncthreads();
+    for (int j = Npad >> 1; j >= 16; j >>= 1) {
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int p = q * nact + t;
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int pa = lds_phys(i), pb = lds_phys(i + j);
+                u64 a = keys[pa], c = keys[pb];
+                if (a > c) { keys[pa] = c; keys[pb] = a; }
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) v[e] = keys[lds_phys(t * 16 + e)];
+        merge16(v, true);
+    }
+}

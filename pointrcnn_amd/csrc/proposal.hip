@@ -235,6 +235,128 @@ __global__ __launch_bounds__(1024) void sort_split_kernel(SortParams P) {
     }
 }
 
+// ---- frames with more than 16384 rows: the same bitonic network, spilled to HBM between LDS-sized chunks -----------
+// 16384-key chunks are sorted in LDS (chunk c ascending when (c & 1) == 0, else descending: the bitonic building blocks),
+// every later stage k does its strides >= 16384 as a global compare-exchange pass and its strides < 16384 as one LDS merge
+// per chunk.  A descending sort / merge is an ascending one on the complemented keys.
+#define LARGE_CHUNK 16384
+__global__ __launch_bounds__(1024) void large_local_sort_kernel(const float* __restrict__ scores, int N, int Ntot, u64* __restrict__ ws) {
+    extern __shared__ u64 keys[];
+    const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const float* __restrict__ sc = scores + (size_t)b * N;
+    const bool desc = c & 1;
+    u64 v[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int i = c * LARGE_CHUNK + t * 16 + e;
+        const u64 k = i < N ? sort_key(sc[i], i) : ~0ULL;
+        v[e] = desc ? ~k : k;
+    }
+    block_sort16(v, keys, LARGE_CHUNK, t);
+    u64* o = ws + (size_t)b * Ntot + (size_t)c * LARGE_CHUNK + t * 16;
+#pragma unroll
+    for (int e = 0; e < 16; e++) o[e] = desc ? ~v[e] : v[e];
+}
+__global__ __launch_bounds__(256) void large_cx_kernel(u64* __restrict__ ws, int Ntot, int j, int k) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= (Ntot >> 1)) return;
+    u64* w = ws + (size_t)b * Ntot;
+    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+    const u64 a = w[i], c = w[i + j];
+    const bool up = (i & k) == 0;
+    if ((a > c) == up) { w[i] = c; w[i + j] = a; }
+}
+__global__ __launch_bounds__(1024) void large_local_merge_kernel(u64* __restrict__ ws, int Ntot, int k) {
+    extern __shared__ u64 keys[];
+    const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const bool desc = ((c * LARGE_CHUNK) & k) != 0;
+    u64* o = ws + (size_t)b * Ntot + (size_t)c * LARGE_CHUNK + t * 16;
+    u64 v[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = desc ? ~o[e] : o[e];
+    block_merge16(v, keys, LARGE_CHUNK, t);
+#pragma unroll
+    for (int e = 0; e < 16; e++) o[e] = desc ? ~v[e] : v[e];
+}
+// area split over the HBM-resident order: pass 0 counts, pass 1 writes (the borrow rule needs the far area's total first)
+__global__ __launch_bounds__(1024) void large_split_kernel(SortParams P, const u64* __restrict__ ws, int Ntot) {
+    __shared__ unsigned scratch[40];
+    const int b = blockIdx.x, t = threadIdx.x, N = P.N;
+    const int lane = t & 63, wave = t >> 6;
+    const u64* __restrict__ w = ws + (size_t)b * Ntot;
+    int32_t* c1 = P.cand + (size_t)b * P.nseg * P.cand_ld;
+    int32_t* c2 = c1 + P.cand_ld;
+    int tot1 = 0, tot2 = 0;
+    bool borrow = false;
+    for (int pass = 0; pass < 2; pass++) {
+        int run1 = 0, run2 = 0;
+        for (int base = 0; base < Ntot; base += LARGE_CHUNK) {
+            unsigned f1 = 0, f2 = 0;
+            int idx[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const u64 key = w[base + t * 16 + e];
+                idx[e] = (int)(unsigned)key;
+                if (key == ~0ULL) continue;
+                if (P.mode == SPLIT_RANGE) {
+                    const float z = P.boxes3d[((size_t)b * N + idx[e]) * 7 + 2];
+                    if (z > P.r0 && z <= P.r1) f1 |= 1u << e;
+                    if (z > P.r1 && z <= P.r2) f2 |= 1u << e;
+                } else if (P.mode == SPLIT_VALID) {
+                    if (P.valid[(size_t)b * N + idx[e]]) f1 |= 1u << e;
+                } else {
+                    f1 |= 1u << e;
+                }
+            }
+            const unsigned mine = (unsigned)__popc(f1) | ((unsigned)__popc(f2) << 16);
+            unsigned inc = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                unsigned o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            __syncthreads();
+            if (lane == 63) scratch[wave] = inc;
+            __syncthreads();
+            if (wave == 0) {
+                unsigned wv = lane < 16 ? scratch[lane] : 0u, winc = wv;
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    unsigned o = __shfl_up(winc, d, 64);
+                    if (lane >= d) winc += o;
+                }
+                if (lane < 16) scratch[16 + lane] = winc - wv;
+                if (lane == 15) scratch[32] = winc;
+            }
+            __syncthreads();
+            const unsigned excl = scratch[16 + wave] + inc - mine, tot = scratch[32];
+            if (pass == 1) {
+                int r1 = run1 + (int)(excl & 0xFFFFu), r2 = run2 + (int)(excl >> 16);
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    if ((f1 >> e) & 1u) {
+                        if (r1 < P.pre1) c1[r1] = idx[e];
+                        else if (borrow && r1 - P.pre1 < P.pre2) c2[r1 - P.pre1] = idx[e];
+                        r1++;
+                    }
+                    if ((f2 >> e) & 1u) {
+                        if (r2 < P.pre2) c2[r2] = idx[e];
+                        r2++;
+                    }
+                }
+            }
+            run1 += (int)(tot & 0xFFFFu);
+            run2 += (int)(tot >> 16);
+        }
+        if (pass == 0) { tot1 = run1; tot2 = run2; borrow = P.mode == SPLIT_RANGE && tot2 == 0; }
+    }
+    if (t == 0) {
+        P.cnt[b * P.nseg] = min(tot1, P.pre1);
+        if (P.nseg > 1) P.cnt[b * P.nseg + 1] = borrow ? max(0, min(tot1 - P.pre1, P.pre2)) : min(tot2, P.pre2);
+    }
+}
+
 // ====================================================================================================
 // greedy NMS against the kept list
 // ====================================================================================================
@@ -507,7 +629,32 @@ PRCNN_API int prcnn_decode_bbox_target(const float* roi, int roi_cols, const flo
     return PRCNN_OK;
 }
 
-static int launch_sort_split(const char* op, SortParams& P, int B, hipStream_t s) {
+static size_t large_sort_bytes(int B, int N) {
+    if (N <= PROPOSAL_MAX_SORT) return 0;
+    return (size_t)B * (size_t)pow2_at_least(N, LARGE_CHUNK) * sizeof(u64);
+}
+
+static int launch_sort_split(const char* op, SortParams& P, int B, hipStream_t s, u64* large_ws) {
+    if (P.N > PROPOSAL_MAX_SORT) {
+        const int Ntot = pow2_at_least(P.N, LARGE_CHUNK), nchunks = Ntot / LARGE_CHUNK;
+        static bool attr_large = false;
+        if (!attr_large) {
+            if (hipFuncSetAttribute((const void*)large_local_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess ||
+                hipFuncSetAttribute((const void*)large_local_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess)
+                return prcnn_fail(PRCNN_EHIP, "%s: cannot raise the dynamic LDS limit", op);
+            attr_large = true;
+        }
+        const size_t lds = lds_sort_bytes(LARGE_CHUNK);
+        hipLaunchKernelGGL(large_local_sort_kernel, dim3(nchunks, B), dim3(1024), lds, s, P.scores, P.N, Ntot, large_ws);
+        for (int k = 2 * LARGE_CHUNK; k <= Ntot; k <<= 1) {
+            for (int j = k >> 1; j >= LARGE_CHUNK; j >>= 1)
+                hipLaunchKernelGGL(large_cx_kernel, dim3(prcnn_divup(Ntot / 2, 256), B), dim3(256), 0, s, large_ws, Ntot, j, k);
+            hipLaunchKernelGGL(large_local_merge_kernel, dim3(nchunks, B), dim3(1024), lds, s, large_ws, Ntot, k);
+        }
+        hipLaunchKernelGGL(large_split_kernel, dim3(B), dim3(1024), 0, s, P, large_ws, Ntot);
+        PRCNN_LAUNCH_CHECK(op);
+        return PRCNN_OK;
+    }
     P.Npad = pow2_at_least(P.N, 16);
     const int threads = max(64, ((P.Npad >> 4) + 63) / 64 * 64);
     const size_t lds = lds_sort_bytes(P.Npad) + 40 * sizeof(unsigned);
@@ -545,10 +692,10 @@ static int launch_greedy_nms(const char* op, int kind, const NmsParams& P, int B
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-PRCNN_API size_t prcnn_proposal_workspace_bytes(int B, int pre_max, int post_max) {
+PRCNN_API size_t prcnn_proposal_workspace_bytes(int B, int N, int pre_max, int post_max) {
     if (B <= 0) return 0;
     return align256((size_t)B * 2 * (size_t)max(pre_max, 1) * 4) + align256((size_t)B * 2 * 4) +
-           align256((size_t)B * 2 * (size_t)max(post_max, 1) * 4) + align256((size_t)B * 2 * 4);
+           align256((size_t)B * 2 * (size_t)max(post_max, 1) * 4) + align256((size_t)B * 2 * 4) + align256(large_sort_bytes(B, N));
 }
 
 PRCNN_API int prcnn_proposal_layer(const float* scores, const float* boxes3d, int B, int N, int use_range, float r0, float r1,
@@ -571,21 +718,21 @@ PRCNN_API int prcnn_proposal_layer(const float* scores, const float* boxes3d, in
         return PRCNN_OK;
     }
     PRCNN_REQUIRE(scores && boxes3d && workspace, "%s: null pointer", op);
-    if (N > PROPOSAL_MAX_SORT)
-        return prcnn_fail(PRCNN_EUNSUPPORTED, "%s: N=%d > %d rows per frame (the score sort is LDS-resident)", op, N, PROPOSAL_MAX_SORT);
     const int pre_max = max(pre1, pre2), post_max = max(post1, post2);
-    PRCNN_REQUIRE(workspace_bytes >= prcnn_proposal_workspace_bytes(B, pre_max, post_max), "%s: workspace %zu < %zu bytes", op,
-                  workspace_bytes, prcnn_proposal_workspace_bytes(B, pre_max, post_max));
+    PRCNN_REQUIRE(workspace_bytes >= prcnn_proposal_workspace_bytes(B, N, pre_max, post_max), "%s: workspace %zu < %zu bytes", op,
+                  workspace_bytes, prcnn_proposal_workspace_bytes(B, N, pre_max, post_max));
+    PRCNN_REQUIRE(((uintptr_t)workspace & 7) == 0, "%s: workspace must be 8-byte aligned", op);
     char* w = (char*)workspace;
     int32_t* cand = (int32_t*)w; w += align256((size_t)B * 2 * (size_t)max(pre_max, 1) * 4);
     int32_t* cnt = (int32_t*)w; w += align256((size_t)B * 2 * 4);
     int32_t* kept = (int32_t*)w; w += align256((size_t)B * 2 * (size_t)max(post_max, 1) * 4);
-    int32_t* kept_cnt = (int32_t*)w;
+    int32_t* kept_cnt = (int32_t*)w; w += align256((size_t)B * 2 * 4);
+    u64* large_ws = (u64*)w;                      // only touched when N > 16384
     SortParams S;
     S.scores = scores; S.boxes3d = boxes3d; S.valid = nullptr; S.cand = cand; S.cnt = cnt;
     S.N = N; S.mode = use_range ? SPLIT_RANGE : SPLIT_ALL; S.nseg = 2; S.cand_ld = max(pre_max, 1);
     S.pre1 = pre1; S.pre2 = use_range ? pre2 : 0; S.r0 = r0; S.r1 = r1; S.r2 = r2;
-    int rc = launch_sort_split(op, S, B, s);
+    int rc = launch_sort_split(op, S, B, s, large_ws);
     if (rc) return rc;
     NmsParams Q;
     Q.boxes3d = boxes3d; Q.cand = cand; Q.cnt = cnt; Q.kept = kept; Q.kept_cnt = kept_cnt;
@@ -602,7 +749,7 @@ PRCNN_API int prcnn_proposal_layer(const float* scores, const float* boxes3d, in
 
 PRCNN_API size_t prcnn_nms_batched_workspace_bytes(int B, int M) {
     if (B <= 0 || M <= 0) return 0;
-    return align256((size_t)B * M * 4) + align256((size_t)B * 4);
+    return align256((size_t)B * M * 4) + align256((size_t)B * 4) + align256(large_sort_bytes(B, M));
 }
 
 PRCNN_API int prcnn_nms_batched(const float* boxes3d, const float* scores, const uint8_t* valid, int B, int M, float thresh, int kind,
@@ -620,17 +767,16 @@ PRCNN_API int prcnn_nms_batched(const float* boxes3d, const float* scores, const
     }
     if (max_keep == 0 || max_keep > M) max_keep = M;
     PRCNN_REQUIRE(boxes3d && scores && keep && workspace, "%s: null pointer", op);
-    if (M > PROPOSAL_MAX_SORT)
-        return prcnn_fail(PRCNN_EUNSUPPORTED, "%s: M=%d > %d rows per frame (the score sort is LDS-resident)", op, M, PROPOSAL_MAX_SORT);
     PRCNN_REQUIRE(workspace_bytes >= prcnn_nms_batched_workspace_bytes(B, M), "%s: workspace %zu < %zu bytes", op, workspace_bytes,
                   prcnn_nms_batched_workspace_bytes(B, M));
     char* w = (char*)workspace;
     int32_t* cand = (int32_t*)w; w += align256((size_t)B * M * 4);
-    int32_t* cnt = (int32_t*)w;
+    int32_t* cnt = (int32_t*)w; w += align256((size_t)B * 4);
+    u64* large_ws = (u64*)w;
     SortParams S;
     S.scores = scores; S.boxes3d = boxes3d; S.valid = valid; S.cand = cand; S.cnt = cnt;
     S.N = M; S.mode = valid ? SPLIT_VALID : SPLIT_ALL; S.nseg = 1; S.cand_ld = M; S.pre1 = M; S.pre2 = 0; S.r0 = S.r1 = S.r2 = 0.f;
-    int rc = launch_sort_split(op, S, B, s);
+    int rc = launch_sort_split(op, S, B, s, large_ws);
     if (rc) return rc;
     NmsParams Q;
     Q.boxes3d = boxes3d; Q.cand = cand; Q.cnt = cnt; Q.kept = keep; Q.kept_cnt = num_keep;

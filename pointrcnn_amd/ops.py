@@ -527,7 +527,7 @@ def proposal_layer(scores, boxes3d, pre, post, nms_thresh, rotated=False, ranges
     rois = torch.empty((B, tot, 7), dtype=torch.float32, device=dev)
     roi_scores = torch.empty((B, tot), dtype=torch.float32, device=dev)
     count = torch.empty((B,), dtype=_INT, device=dev)
-    wsb = L.prcnn_proposal_workspace_bytes(B, max(pre), max(post))
+    wsb = L.prcnn_proposal_workspace_bytes(B, N, max(pre), max(post))
     ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=dev)
     r = ranges if ranges is not None else (0.0, 0.0, 0.0)
     _cabi.check(L.prcnn_proposal_layer(_p(scores), _p(boxes3d), B, N, int(ranges is not None), float(r[0]), float(r[1]),

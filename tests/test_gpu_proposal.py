@@ -67,8 +67,6 @@ def test_decode_and_proposal_argument_errors(dev):
         ops.decode_bbox_target(z((4, 3), device=dev), z((4, 75), device=dev), 3.0, 0.5, 12, ANCHOR)
     with pytest.raises(PointOpsError):
         ops.decode_bbox_target(z((4, 5), device=dev), z((4, 76), device=dev), 3.0, 0.5, 12, ANCHOR)
-    with pytest.raises(PointOpsError):          # the LDS-resident sort holds 16384 rows
-        ops.proposal_layer(z((1, 20000), device=dev), z((1, 20000, 7), device=dev), (6300, 2700), (70, 30), 0.8)
     with pytest.raises(RuntimeError):
         ops.proposal_layer(z((1, 8)), z((1, 8, 7)), (6, 2), (2, 1), 0.8)          # CPU tensors: no CPU path
     # empty problems are fine
@@ -174,4 +172,24 @@ def test_point_rcnn_end_to_end_config3(dev, cpu):
         raw_c = raw.cpu().numpy()
         valid = torch.sigmoid(raw).cpu().numpy() > 0.3
         ok, on = cpu.nms_batched(o_pred, raw_c, valid, 0.1, "rotated")
+        assert np.array_equal(keep.cpu().numpy(), ok) and np.array_equal(num.cpu().numpy(), on)
+
+
+@pytest.mark.parametrize("N", [16385, 20000, 40000, 65536])
+def test_frames_larger_than_the_lds_sort(dev, cpu, N):
+    """more than 16384 rows per frame (BASELINE config 5: 65 536 points): the bitonic network runs in 16384-key chunks with
+    the long strides through HBM -- same proposals as the oracle, including score ties and the borrow rule"""
+    from pointrcnn_amd import ops
+    xyz, sc, reg = rpn_like_scene(2, N, seed=N % 97, z_max=70.4 if N != 40000 else 38.0)      # 40000: far area empty
+    sc[0, ::7] = sc[0, 3]                                                                        # many exact ties
+    boxes = cpu.decode_bbox_target(xyz.reshape(-1, 3), reg.reshape(-1, 76), 3.0, 0.5, 12, ANCHOR, y_to_bottom=True).reshape(2, N, 7)
+    for kind in ("normal", "rotated"):
+        rois, scores, cnt = ops.proposal_layer(_t(sc, dev), _t(boxes, dev), (6300, 2700), (70, 30), 0.8, rotated=kind == "rotated")
+        o = cpu.proposal_layer(sc, boxes, (6300, 2700), (70, 30), 0.8, kind)
+        assert np.array_equal(rois.cpu().numpy(), o[0]) and np.array_equal(scores.cpu().numpy(), o[1]) and \
+            np.array_equal(cnt.cpu().numpy(), o[2]), (N, kind)
+    if N == 20000:
+        valid = sc > 1.0
+        keep, num = ops.nms_batched(_t(boxes, dev), _t(sc, dev), _t(valid, dev), 0.5, rotated=False, max_keep=200)
+        ok, on = cpu.nms_batched(boxes, sc, valid, 0.5, "normal", 200)
         assert np.array_equal(keep.cpu().numpy(), ok) and np.array_equal(num.cpu().numpy(), on)
