@@ -263,8 +263,16 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
 
     Raw<MODE> ra[4];
     float4 rb[QN];
+    // hoisted GROUP rows: the activated-gather parameters of the NEXT chunk's 4 channels travel with its gather instead of
+    // being loaded (a dependent L1/L2 round trip) at the moment the chunk is written to LDS
+    const bool group_act = MODE == MODE_GROUP && P.act != 0;
+    float4 aw0 = make_float4(0.f, 0.f, 0.f, 0.f), aw1 = aw0, aw2 = aw0, ab = aw0;
     auto load_chunk = [&](int c) {
         const int k = c * MLP_BK + c4 * 4;
+        if (group_act && k < P.K) {
+            aw0 = ld4(P.act_wx + (long)k * 3); aw1 = ld4(P.act_wx + (long)k * 3 + 4); aw2 = ld4(P.act_wx + (long)k * 3 + 8);
+            ab = ld4(P.act_bias + k);
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) fetch<MODE>(P, meta[u], k, ra[u]);
 #pragma unroll
@@ -280,7 +288,24 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
         const int k = c * MLP_BK + c4 * 4;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            float4 v = finish<MODE>(P, meta[u], k, ra[u]);
+            float4 v;
+            if constexpr (MODE == MODE_GROUP) {
+                if (group_act && meta[u].valid && k < P.K) {          // == finish<MODE_GROUP> with the prefetched parameters
+                    const float dx = meta[u].dx, dy = meta[u].dy, dz = meta[u].dz;
+                    const float4 z = ra[u].a;
+                    v.x = fmaxf(z.x + (aw0.x * dx + aw0.y * dy + aw0.z * dz) + ab.x, 0.f);
+                    v.y = fmaxf(z.y + (aw0.w * dx + aw1.x * dy + aw1.y * dz) + ab.y, 0.f);
+                    v.z = fmaxf(z.z + (aw1.z * dx + aw1.w * dy + aw2.x * dz) + ab.z, 0.f);
+                    v.w = fmaxf(z.w + (aw2.y * dx + aw2.z * dy + aw2.w * dz) + ab.w, 0.f);
+                    if (k + 1 >= P.K) v.y = 0.f;
+                    if (k + 2 >= P.K) v.z = 0.f;
+                    if (k + 3 >= P.K) v.w = 0.f;
+                } else {
+                    v = finish<MODE>(P, meta[u], k, ra[u]);
+                }
+            } else {
+                v = finish<MODE>(P, meta[u], k, ra[u]);
+            }
             *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * u) * MLP_ALD + c4 * 4]) = v;
         }
 #pragma unroll
