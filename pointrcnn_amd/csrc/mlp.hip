@@ -818,10 +818,17 @@ __global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C
     __shared__ __attribute__((aligned(16))) float Ws[2][CH_STAGE_TILES * 256];
     __shared__ __attribute__((aligned(16))) float s_wx[(FAST_MAX_K + 16) * 3];
     __shared__ __attribute__((aligned(16))) float s_b[FAST_MAX_K + 16];
+    __shared__ __attribute__((aligned(16))) float s_bias[3][128];      // layer biases: an LDS read at use instead of an L1/L2 trip
     if (MODE == MODE_GROUP)
         for (int t = threadIdx.x; t < P.K * 3; t += 256) s_wx[t] = P.act_wx[t];
     if (MODE != MODE_PLAIN)
         for (int t = threadIdx.x; t < P.K; t += 256) s_b[t] = P.act_bias[t];
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x;
+        s_bias[0][t] = (P.bias && t < NB0 * 32) ? P.bias[t] : 0.f;
+        s_bias[1][t] = (NB1 > 0 && C.bias1 && t < NB1 * 32) ? C.bias1[t] : 0.f;
+        s_bias[2][t] = (NB2 > 0 && C.bias2 && t < NB2 * 32) ? C.bias2[t] : 0.f;
+    }
 
     f32x16 a0[NB0];
 #pragma unroll
@@ -869,19 +876,19 @@ __global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C
             __syncthreads();
         }
     }
-    bias_act<NB0>(a0, P.bias, P.relu, h);
+    bias_act<NB0>(a0, s_bias[0], P.relu, h);
     if constexpr (NB1 == 0) {
         chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
     } else {
         f32x16 a1[NB1];
         fchain_layer<NB0, NB1, NB2>(a0, a1, C.wpack1, Ws, wave, lane, w1s, C.wpack2, w2s);
-        bias_act<NB1>(a1, C.bias1, C.relu1, h);
+        bias_act<NB1>(a1, s_bias[1], C.relu1, h);
         if constexpr (NB2 == 0) {
             chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
         } else {
             f32x16 a2[NB2];
             fchain_layer<NB1, NB2, 0>(a1, a2, C.wpack2, Ws, wave, lane, w2s, nullptr, w1s);
-            bias_act<NB2>(a2, C.bias2, C.relu2, h);
+            bias_act<NB2>(a2, s_bias[2], C.relu2, h);
             chain_store<NB2>(C, a2, C.N2, row, valid, lane, h);
         }
     }
