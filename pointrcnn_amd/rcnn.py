@@ -8,8 +8,8 @@ GroupAll, nsample 64) -> cls / reg Conv1d heads.  Attribute names follow the ref
 
 The two pieces of torch glue it needs are restated from lib/utils/kitti_utils.py (enlarge_box3d :150-160,
 rotate_pc_along_y_torch :45-63, boxes3d_to_bev_torch :134-147); they are elementwise torch, outside the hot path
-(SURVEY.md 8(a) a16).  The proposal layer / bbox decode (lib/rpn/proposal_layer.py, lib/utils/bbox_transform.py) is
-not mirrored: callers supply RoIs.
+(SURVEY.md 8(a) a16); the inference path does not use them (prcnn_roipool3d_canonical builds the stage's inputs in one
+kernel).  RoIs come from pointrcnn_amd/proposal_layer.py (see pointrcnn_amd/point_rcnn.py for the whole two-stage graph).
 """
 import torch
 import torch.nn as nn

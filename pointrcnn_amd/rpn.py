@@ -3,8 +3,8 @@
 Mirrors lib/net/pointnet2_msg.py:12-70 (Pointnet2MSG: 4 SA-MSG + 4 FP) and lib/net/rpn.py:12-82 (RPN: backbone
 + classification / regression Conv1d heads) with the shapes of tools/cfgs/default.yaml:23-64, using the SAME
 attribute names (`backbone_net.SA_modules`, `FP_modules`, `rpn_cls_layer`, `rpn_reg_layer`) so that the `rpn.*`
-entries of a reference checkpoint load with `load_state_dict`.  Only the inference subset is mirrored: losses
-and the proposal layer are torch glue outside the hot path.
+entries of a reference checkpoint load with `load_state_dict`.  Only the inference subset is mirrored (no losses); the
+proposal layer lives in pointrcnn_amd/proposal_layer.py and is attached by pointrcnn_amd/point_rcnn.py.
 
 This is what bench.py times; the reference's own unchanged lib/net/rpn.py builds the same graph through
 `pointrcnn_amd.install()` (INTEGRATION.md).
