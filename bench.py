@@ -37,8 +37,10 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32-input MFMA peak (/opt/ski
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=96,
+                    help="timed steps; with 3 batches in flight the first/last ~2 steps fill and drain the pipeline (one batch's "
+                         "latency is ~11 ms), so short runs under-report the steady state by a few percent")
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (BASELINE metric: bs32)")
     ap.add_argument("--npoints", type=int, default=16384)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the step from a hipGraph")

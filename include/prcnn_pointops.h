@@ -274,14 +274,16 @@ int prcnn_roipool3d_canonical(const float* xyz, const float* pool_boxes3d, const
 
 /* ======================================================================================================
  * Grid-accelerated neighbour search: the same results as prcnn_ball_query / prcnn_ball_query2 / prcnn_three_nn
- * (bit for bit), computed over a per-frame 64x64 x-z grid instead of a scan of all N points.
+ * (bit for bit), computed over a per-frame x-z grid (64 or 128 cells per axis) instead of a scan of all N points.
  * ====================================================================================================== */
 /* bytes of the grid buffer for B frames of N points */
 size_t prcnn_grid_bytes(int B, int N);
-/* bin xyz (B,N,3) per frame: bounds -> cell size max(min_cell, extent/64) -> counting sort into cell-contiguous
+/* bin xyz (B,N,3) per frame: bounds -> cell size max(min_cell, extent/cells_per_axis) -> counting sort into cell-contiguous
  * float4 (x,y,z,index).  grid: 16-byte aligned device buffer of prcnn_grid_bytes(B,N).  min_cell: the largest search
- * radius that will be used (keeps a ball within 3x3 cells); 0 for three_nn. */
-int prcnn_grid_build(const float* xyz, int B, int N, float min_cell, void* grid, size_t grid_bytes, prcnn_stream_t stream);
+ * radius that will be used (keeps a ball within 3x3 cells); 0 for three_nn.  cells_per_axis: 64 or 128 (finer cells keep
+ * crowded near-sensor regions cheap for the ball query; ~1 point per cell suits the three_nn ring search). */
+int prcnn_grid_build(const float* xyz, int B, int N, float min_cell, int cells_per_axis, void* grid, size_t grid_bytes,
+                     prcnn_stream_t stream);
 /* == prcnn_ball_query2 on the binned points (N = points per frame the grid was built with); nsample_b = 0: one radius */
 int prcnn_ball_query2_grid(const void* grid, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a,
                            int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, prcnn_stream_t stream);

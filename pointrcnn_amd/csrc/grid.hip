@@ -4,7 +4,7 @@
 // The reference (and neighbor.hip) test every query against every point of the frame: 67 M distance evaluations per
 // frame for SA1's ball query and again for FP0's three_nn -- brute force already runs near the packed
 // fp32 VALU limit here, so the only way further is to not do the work.  Points are binned once per frame into a 64x64
-// grid over the x-z plane (the LiDAR ground plane; y spans a few metres) and stored cell-contiguous as float4
+// (three_nn) or 128x128 (ball query) grid over the x-z plane (the LiDAR ground plane; y spans a few metres) and stored cell-contiguous as float4
 // (x, y, z, original index); a query then visits the 3x3-ish block of cells its ball overlaps (ball_query) or grows a
 // square ring by ring until the third-best distance is provably final (three_nn): ~30 candidates instead of 16 384.
 //
@@ -17,31 +17,31 @@
 // -- so the output is bit-identical to the scan regardless of the (arbitrary) order of points inside a cell.
 #include "common.h"
 
-#define GRID_DIM 64
-#define GRID_CELLS (GRID_DIM * GRID_DIM)
+#define GRID_DIM_MAX 128                         // cells per axis: 64 (three_nn: ~1 known point per cell) or 128 (ball query:
+#define GRID_CELLS_MAX (GRID_DIM_MAX * GRID_DIM_MAX)   //  crowded near-sensor cells stay small); buffers are sized for 128
 #define GRID_BUILD_THREADS 1024
 
 struct GridHeader {
     float x0, z0, inv_cs, cs;
-    int n_finite, pad0, pad1, pad2;
+    int dim, pad0, pad1, pad2;                    // dim = cells per axis of THIS grid
 };
-// per-frame block inside the caller's buffer: header | cell_start[GRID_CELLS + 1] | sorted[N] float4
+// per-frame block inside the caller's buffer: header | cell_start[128*128 + 1] | sorted[N] float4
 static inline size_t grid_frame_bytes(int N) {
-    size_t b = sizeof(GridHeader) + (size_t)(GRID_CELLS + 1) * 4;
+    size_t b = sizeof(GridHeader) + (size_t)(GRID_CELLS_MAX + 1) * 4;
     b = (b + 15) & ~(size_t)15;
     return b + (size_t)N * 16;
 }
 __device__ __forceinline__ const GridHeader* grid_header(const void* g, size_t fb, int b) { return (const GridHeader*)((const char*)g + fb * b); }
 __device__ __forceinline__ const int32_t* grid_cells(const void* g, size_t fb, int b) { return (const int32_t*)((const char*)g + fb * b + sizeof(GridHeader)); }
 __device__ __forceinline__ const float4* grid_points(const void* g, size_t fb, int b) {
-    size_t off = (sizeof(GridHeader) + (size_t)(GRID_CELLS + 1) * 4 + 15) & ~(size_t)15;
+    size_t off = (sizeof(GridHeader) + (size_t)(GRID_CELLS_MAX + 1) * 4 + 15) & ~(size_t)15;
     return (const float4*)((const char*)g + fb * b + off);
 }
 
 // monotone non-decreasing in v for fixed (o, inv): fp32 subtract, multiply by a positive constant, truncate, clamp
-__device__ __forceinline__ int cell_coord(float v, float o, float inv) {
+__device__ __forceinline__ int cell_coord(float v, float o, float inv, int dim) {
     float t = (v - o) * inv;
-    t = fminf(fmaxf(t, 0.0f), (float)(GRID_DIM - 1));       // NaN -> 0
+    t = fminf(fmaxf(t, 0.0f), (float)(dim - 1));            // NaN -> 0
     return (int)t;
 }
 
@@ -60,9 +60,10 @@ __device__ __forceinline__ float block_reduce(float v, bool is_min, float* scrat
     return r;
 }
 
-__global__ __launch_bounds__(GRID_BUILD_THREADS) void grid_build_kernel(const float* __restrict__ xyz, int N, float min_cell,
+__global__ __launch_bounds__(GRID_BUILD_THREADS) void grid_build_kernel(const float* __restrict__ xyz, int N, float min_cell, int dim,
                                                                         void* grid, size_t fb) {
-    __shared__ int cnt[GRID_CELLS];
+    extern __shared__ int cnt[];                  // dim * dim counters / scatter cursors
+    const int ncell = dim * dim, per_thread = ncell / GRID_BUILD_THREADS;       // 4 or 16
     __shared__ float red[16];
     __shared__ int wsum[16];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -81,20 +82,19 @@ __global__ __launch_bounds__(GRID_BUILD_THREADS) void grid_build_kernel(const fl
     mnx = block_reduce(mnx, true, red); mxx = block_reduce(mxx, false, red);
     mnz = block_reduce(mnz, true, red); mxz = block_reduce(mxz, false, red);
     if (!(mnx <= mxx)) { mnx = mxx = 0.f; mnz = mxz = 0.f; }           // no finite point at all
-    float cs = fmaxf(fmaxf(mxx - mnx, mxz - mnz) / (float)GRID_DIM * 1.0001f, fmaxf(min_cell, 1e-3f));
+    float cs = fmaxf(fmaxf(mxx - mnx, mxz - mnz) / (float)dim * 1.0001f, fmaxf(min_cell, 1e-3f));
     const float inv = 1.0f / cs;
-    for (int c = tid; c < GRID_CELLS; c += GRID_BUILD_THREADS) cnt[c] = 0;
+    for (int c = tid; c < ncell; c += GRID_BUILD_THREADS) cnt[c] = 0;
     __syncthreads();
     for (int i = tid; i < N; i += GRID_BUILD_THREADS) {
-        int c = cell_coord(p[i * 3 + 2], mnz, inv) * GRID_DIM + cell_coord(p[i * 3], mnx, inv);
+        int c = cell_coord(p[i * 3 + 2], mnz, inv, dim) * dim + cell_coord(p[i * 3], mnx, inv, dim);
         atomicAdd(&cnt[c], 1);
     }
     __syncthreads();
-    // exclusive scan of the 4096 counts: 4 per thread, wave scan, wave offsets
-    int c4[4], s = 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) { c4[u] = cnt[tid * 4 + u]; s += c4[u]; }
-    int inc = s;
+    // exclusive scan of the counts: per_thread consecutive cells per thread, wave scan, wave offsets
+    int ssum = 0;
+    for (int u = 0; u < per_thread; u++) ssum += cnt[tid * per_thread + u];
+    int inc = ssum;
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -105,19 +105,19 @@ __global__ __launch_bounds__(GRID_BUILD_THREADS) void grid_build_kernel(const fl
     __syncthreads();
     int woff = 0;
     for (int w = 0; w < wave; w++) woff += wsum[w];
-    int run = woff + inc - s;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        cstart[tid * 4 + u] = run;
-        cnt[tid * 4 + u] = run;                  // becomes the scatter cursor
-        run += c4[u];
+    int run = woff + inc - ssum;
+    for (int u = 0; u < per_thread; u++) {
+        const int c = cnt[tid * per_thread + u];
+        cstart[tid * per_thread + u] = run;
+        cnt[tid * per_thread + u] = run;         // becomes the scatter cursor
+        run += c;
     }
-    if (tid == GRID_BUILD_THREADS - 1) cstart[GRID_CELLS] = run;
-    if (tid == 0) { H->x0 = mnx; H->z0 = mnz; H->inv_cs = inv; H->cs = cs; H->n_finite = N; }
+    if (tid == GRID_BUILD_THREADS - 1) cstart[ncell] = run;
+    if (tid == 0) { H->x0 = mnx; H->z0 = mnz; H->inv_cs = inv; H->cs = cs; H->dim = dim; }
     __syncthreads();
     for (int i = tid; i < N; i += GRID_BUILD_THREADS) {
         float x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
-        int c = cell_coord(z, mnz, inv) * GRID_DIM + cell_coord(x, mnx, inv);
+        int c = cell_coord(z, mnz, inv, dim) * dim + cell_coord(x, mnx, inv, dim);
         int pos = atomicAdd(&cnt[c], 1);
         sorted[pos] = make_float4(x, y, z, __int_as_float(i));
     }
@@ -161,10 +161,11 @@ __global__ __launch_bounds__(GBQ_THREADS) void grid_ball_query_kernel(const void
     // relative margin that dwarfs the rounding of r*r and of the subtraction; cell_coord is monotone
     const float rs = rmax * 1.001f + 1e-6f;
     if (qx == qx && qz == qz && r2max > 0.0f) {   // NaN centroid: no hits
-        const int cx0 = cell_coord(qx - rs, H.x0, H.inv_cs), cx1 = cell_coord(qx + rs, H.x0, H.inv_cs);
-        const int cz0 = cell_coord(qz - rs, H.z0, H.inv_cs), cz1 = cell_coord(qz + rs, H.z0, H.inv_cs);
+        const int dim = H.dim;
+        const int cx0 = cell_coord(qx - rs, H.x0, H.inv_cs, dim), cx1 = cell_coord(qx + rs, H.x0, H.inv_cs, dim);
+        const int cz0 = cell_coord(qz - rs, H.z0, H.inv_cs, dim), cz1 = cell_coord(qz + rs, H.z0, H.inv_cs, dim);
         for (int cz = cz0; cz <= cz1; cz++) {
-            const int beg = cstart[cz * GRID_DIM + cx0], end = cstart[cz * GRID_DIM + cx1 + 1];   // one contiguous run per row
+            const int beg = cstart[cz * dim + cx0], end = cstart[cz * dim + cx1 + 1];   // one contiguous run per row
             for (int t = beg; t < end; t++) {
                 const float4 c = pts[t];
                 const float d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
@@ -202,8 +203,9 @@ __global__ __launch_bounds__(GNN_THREADS) void grid_three_nn_kernel(const void* 
     const float ux = u[0], uy = u[1], uz = u[2];
     float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
     int i1 = 0, i2 = 0, i3 = 0;
+    const int GD = H.dim;
     auto visit = [&](int cz, int cxa, int cxb) {          // cells [cxa, cxb] of row cz (all inside the grid)
-        const int beg = cstart[cz * GRID_DIM + cxa], end = cstart[cz * GRID_DIM + cxb + 1];
+        const int beg = cstart[cz * GD + cxa], end = cstart[cz * GD + cxb + 1];
         for (int t = beg; t < end; t++) {
             const float4 c = pts[t];
             const float dd = sqdist3(ux, uy, uz, c.x, c.y, c.z);
@@ -223,27 +225,27 @@ __global__ __launch_bounds__(GNN_THREADS) void grid_three_nn_kernel(const void* 
         const int qcx = (int)floorf(fminf(fmaxf(fx, -1.0e6f), 1.0e6f)), qcz = (int)floorf(fminf(fmaxf(fz, -1.0e6f), 1.0e6f));
         for (int R = 0;; R++) {
             const int x0 = qcx - R, x1 = qcx + R, z0 = qcz - R, z1 = qcz + R;
-            const int cxa = max(x0, 0), cxb = min(x1, GRID_DIM - 1);
+            const int cxa = max(x0, 0), cxb = min(x1, GD - 1);
             if (cxa <= cxb) {
-                if (z0 >= 0 && z0 < GRID_DIM) visit(z0, cxa, cxb);                      // bottom row of the ring
-                if (R > 0 && z1 >= 0 && z1 < GRID_DIM) visit(z1, cxa, cxb);             // top row
+                if (z0 >= 0 && z0 < GD) visit(z0, cxa, cxb);                      // bottom row of the ring
+                if (R > 0 && z1 >= 0 && z1 < GD) visit(z1, cxa, cxb);             // top row
             }
             if (R > 0) {                                                                  // left / right columns
-                const int za = max(z0 + 1, 0), zb = min(z1 - 1, GRID_DIM - 1);
+                const int za = max(z0 + 1, 0), zb = min(z1 - 1, GD - 1);
                 for (int cz = za; cz <= zb; cz++) {
-                    if (x0 >= 0 && x0 < GRID_DIM) visit(cz, x0, x0);
-                    if (x1 >= 0 && x1 < GRID_DIM) visit(cz, x1, x1);
+                    if (x0 >= 0 && x0 < GD) visit(cz, x0, x0);
+                    if (x1 >= 0 && x1 < GD) visit(cz, x1, x1);
                 }
             }
-            if (x0 <= 0 && z0 <= 0 && x1 >= GRID_DIM - 1 && z1 >= GRID_DIM - 1) break;    // whole grid visited
+            if (x0 <= 0 && z0 <= 0 && x1 >= GD - 1 && z1 >= GD - 1) break;    // whole grid visited
             // every point not yet visited lies outside the square of cells [x0,x1] x [z0,z1]; points are binned by a
             // CLAMPED coordinate, so only sides strictly inside the grid bound anything.  Planar distance from the
             // query to the nearest such side, shrunk by a margin far above the rounding of the cell arithmetic:
             float lb = INFINITY;
             if (x0 > 0) lb = fminf(lb, ux - (H.x0 + (float)x0 * H.cs));
-            if (x1 < GRID_DIM - 1) lb = fminf(lb, (H.x0 + (float)(x1 + 1) * H.cs) - ux);
+            if (x1 < GD - 1) lb = fminf(lb, (H.x0 + (float)(x1 + 1) * H.cs) - ux);
             if (z0 > 0) lb = fminf(lb, uz - (H.z0 + (float)z0 * H.cs));
-            if (z1 < GRID_DIM - 1) lb = fminf(lb, (H.z0 + (float)(z1 + 1) * H.cs) - uz);
+            if (z1 < GD - 1) lb = fminf(lb, (H.z0 + (float)(z1 + 1) * H.cs) - uz);
             lb = lb * 0.999f - 1e-4f * H.cs;
             if (lb > 0.0f && b3 < lb * lb) break;
         }
@@ -266,14 +268,22 @@ PRCNN_API size_t prcnn_grid_bytes(int B, int N) {
     return grid_frame_bytes(N) * (size_t)B;
 }
 
-PRCNN_API int prcnn_grid_build(const float* xyz, int B, int N, float min_cell, void* grid, size_t grid_bytes, prcnn_stream_t stream) {
+PRCNN_API int prcnn_grid_build(const float* xyz, int B, int N, float min_cell, int cells_per_axis, void* grid, size_t grid_bytes,
+                               prcnn_stream_t stream) {
     PRCNN_REQUIRE(B >= 0 && N > 0 && min_cell >= 0.0f, "prcnn_grid_build: bad shape B=%d N=%d min_cell=%g", B, N, (double)min_cell);
+    PRCNN_REQUIRE(cells_per_axis == 64 || cells_per_axis == 128, "prcnn_grid_build: cells_per_axis must be 64 or 128, got %d", cells_per_axis);
     if (B == 0) return PRCNN_OK;
     PRCNN_REQUIRE(xyz && grid, "prcnn_grid_build: null pointer");
     PRCNN_REQUIRE(((uintptr_t)grid & 15) == 0, "prcnn_grid_build: grid buffer must be 16-byte aligned");
     PRCNN_REQUIRE(grid_bytes >= prcnn_grid_bytes(B, N), "prcnn_grid_build: buffer %zu < %zu bytes", grid_bytes, prcnn_grid_bytes(B, N));
-    hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(GRID_BUILD_THREADS), 0, (hipStream_t)stream, xyz, N, min_cell, grid,
-                       grid_frame_bytes(N));
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)grid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GRID_CELLS_MAX * 4) != hipSuccess)
+            return prcnn_fail(PRCNN_EHIP, "prcnn_grid_build: cannot raise the dynamic LDS limit");
+        attr = true;
+    }
+    hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(GRID_BUILD_THREADS), (size_t)cells_per_axis * cells_per_axis * 4, (hipStream_t)stream,
+                       xyz, N, min_cell, cells_per_axis, grid, grid_frame_bytes(N));
     PRCNN_LAUNCH_CHECK("prcnn_grid_build");
     return PRCNN_OK;
 }

@@ -87,18 +87,20 @@ def gather_rows(in_cl, idx):
 # Frames with at least this many points are searched through a per-frame grid (csrc/grid.hip) instead of a full scan:
 # identical results, ~N/30 of the distance evaluations.  PRCNN_GRID_SEARCH=0 forces the scans (A/B, debugging).
 GRID_MIN_POINTS = 2048 if os.environ.get("PRCNN_GRID_SEARCH", "1") != "0" else 1 << 62
+BQ_GRID_CELLS = int(os.environ.get("PRCNN_BQ_GRID_CELLS", "128"))       # cells per axis of the ball-query grid (64 | 128)
 
 
 class Grid:
     """points of B frames binned into per-frame 64x64 x-z grids (prcnn_grid_build)"""
 
-    def __init__(self, xyz, min_cell=0.0):
+    def __init__(self, xyz, min_cell=0.0, cells_per_axis=64):
         _chk(xyz, "xyz", ndim=3)
         self.B, self.N = xyz.shape[0], xyz.shape[1]
         L = _cabi.lib()
         nbytes = L.prcnn_grid_bytes(self.B, self.N)
         self.buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=xyz.device)
-        _cabi.check(L.prcnn_grid_build(_p(xyz), self.B, self.N, float(min_cell), _p(self.buf), nbytes, _stream()), "prcnn_grid_build")
+        _cabi.check(L.prcnn_grid_build(_p(xyz), self.B, self.N, float(min_cell), int(cells_per_axis), _p(self.buf), nbytes, _stream()),
+                    "prcnn_grid_build")
 
 
 def ball_query_grid(grid, new_xyz, radius_a, nsample_a, radius_b=0.0, nsample_b=0):
@@ -120,7 +122,7 @@ def ball_query(radius, nsample, xyz, new_xyz):
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
     if N >= GRID_MIN_POINTS and B > 0 and M > 0:
-        return ball_query_grid(Grid(xyz, radius), new_xyz, radius, nsample)
+        return ball_query_grid(Grid(xyz, radius, BQ_GRID_CELLS), new_xyz, radius, nsample)
     idx = torch.empty((B, M, nsample), dtype=_INT, device=xyz.device)
     _cabi.check(_cabi.lib().prcnn_ball_query(_p(xyz), _p(new_xyz), B, N, M, float(radius), nsample, _p(idx), _stream()),
                 "prcnn_ball_query")
@@ -133,7 +135,7 @@ def ball_query2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz):
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
     if N >= GRID_MIN_POINTS and B > 0 and M > 0:
-        return ball_query_grid(Grid(xyz, max(radius_a, radius_b)), new_xyz, radius_a, nsample_a, radius_b, nsample_b)
+        return ball_query_grid(Grid(xyz, max(radius_a, radius_b), BQ_GRID_CELLS), new_xyz, radius_a, nsample_a, radius_b, nsample_b)
     ia = torch.empty((B, M, nsample_a), dtype=_INT, device=xyz.device)
     ib = torch.empty((B, M, nsample_b), dtype=_INT, device=xyz.device)
     _cabi.check(_cabi.lib().prcnn_ball_query2(_p(xyz), _p(new_xyz), B, N, M, float(radius_a), nsample_a, _p(ia),

@@ -43,8 +43,8 @@ def test_grid_ball_query_and_three_nn_equal_scan_and_oracle(dev, cpu, name):
     q_np = np.ascontiguousarray(pts[:, ::N // M][:, :M])
     q = torch.from_numpy(q_np).to(dev)
     lib = ops._cabi.lib()
-    for (ra, nsa, rb, nsb) in ((0.1, 16, 0.5, 32), (0.5, 16, 1.0, 32), (2.0, 8, 4.0, 64)):
-        g = ops.Grid(x, max(ra, rb))
+    for cells, (ra, nsa, rb, nsb) in ((128, (0.1, 16, 0.5, 32)), (64, (0.5, 16, 1.0, 32)), (128, (2.0, 8, 4.0, 64))):
+        g = ops.Grid(x, max(ra, rb), cells)
         ga, gb = ops.ball_query_grid(g, q, ra, nsa, rb, nsb)
         sa = torch.empty_like(ga)
         sb = torch.empty_like(gb)
@@ -60,7 +60,7 @@ def test_grid_ball_query_and_three_nn_equal_scan_and_oracle(dev, cpu, name):
         unk_np[0, 3] = np.nan
         unk_np[1, 9, 0] = np.inf
     unk = torch.from_numpy(unk_np).to(dev)
-    g = ops.Grid(x, 0.0)
+    g = ops.Grid(x, 0.0, 64 if name != "lidar" else 128)
     d2 = torch.empty((B, 3000, 3), device=dev)
     i3 = torch.empty((B, 3000, 3), dtype=torch.int32, device=dev)
     w3 = torch.empty((B, 3000, 3), device=dev)
