@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--proposals", choices=["off", "normal", "rotate"], default="normal",
                     help="also run the proposal layer (decode + sort + distance split + NMS + top-100, lib/rpn/proposal_layer.py) "
                          "inside every step, as tools/eval_rcnn.py --eval_mode rpn does after the heads")
+    ap.add_argument("--workload", choices=["rpn", "rcnn"], default="rpn",
+                    help="rpn = the BASELINE metric (RPN inference end-to-end); rcnn = BASELINE config 3, the whole two-stage detector "
+                         "(RPN -> proposals -> roipool3d -> RCNN -> box decode -> rotated NMS), 100 RoIs per frame")
     ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform",
                     help="uniform = the BASELINE metric's synthetic clouds; lidar = range-dependent density + ground band + car "
                          "clusters (same bounds): a robustness check for the spatially pruned / grid kernels")
@@ -193,7 +196,12 @@ def main():
     from pointrcnn_amd import _cabi, rpn
     _cabi.lib()
     torch.manual_seed(1234)
-    model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
+    if args.workload == "rcnn":
+        from pointrcnn_amd.point_rcnn import PointRCNN
+        model = rpn.randomize_bn_stats(PointRCNN(mode="TEST"), seed=7).to(dev).eval()
+        args.proposals = "off"                     # the two-stage model runs its own proposal layer
+    else:
+        model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
     nstreams = max(1, args.streams)
     make_clouds = rpn.synthetic_clouds if args.clouds == "uniform" else rpn.lidar_like_clouds
     clouds_cpu = make_clouds(args.batch, args.npoints, seed0=100 + rank * args.batch)
@@ -213,6 +221,8 @@ def main():
             o = model(batches[slot])
             if proposal_layer is not None:
                 o["rois"], o["roi_scores_raw"] = proposal_layer(o["rpn_cls"][:, :, 0], o["rpn_reg"], o["backbone_xyz"])
+            if args.workload == "rcnn":
+                o["pred_boxes3d"], o["raw_scores"], o["keep"], o["num_keep"] = model.detections(o)
             return o
 
     for _ in range(max(1, args.warmup)):        # packs weights, fills the caching allocator
@@ -277,12 +287,16 @@ def main():
 
     frames = args.batch * world * args.steps
     line = {
-        "metric": "KITTI frames/sec, RPN inference end-to-end (16384 pts/frame, bs%d per GPU)" % args.batch,
+        "metric": ("KITTI frames/sec, RPN inference end-to-end (16384 pts/frame, bs%d per GPU)" % args.batch) if args.workload == "rpn"
+        else ("KITTI frames/sec, full two-stage PointRCNN inference (16384 pts/frame, 100 RoIs/frame, bs%d per GPU)" % args.batch),
         "value": round(frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Full RPN PointNet++ backbone (4 SA-MSG + 4 FP) + cls/reg heads, tools/cfgs/default.yaml, "
-                               "%d pts/frame, batch %d per GPU, random-init weights, eval-mode BN" % (args.npoints, args.batch),
+        "config": {"workload": ("Full RPN PointNet++ backbone (4 SA-MSG + 4 FP) + cls/reg heads, tools/cfgs/default.yaml, "
+                                "%d pts/frame, batch %d per GPU, random-init weights, eval-mode BN" % (args.npoints, args.batch))
+                   if args.workload == "rpn" else
+                   ("BASELINE config 3: RPN + proposal layer + roipool3d + RCNN (3 SA levels on 100 RoIs x 512 pts) + box decode + "
+                    "rotated NMS, tools/cfgs/default.yaml, %d pts/frame, batch %d per GPU, random-init weights" % (args.npoints, args.batch)),
                    "frames_per_gpu": args.batch, "npoints": args.npoints, "parallelism": "frames sharded, dp%d" % world,
                    "launch": "hipGraph replay" if graph is not None else "eager", "streams": nstreams,
                    "proposal_layer": args.proposals,
@@ -290,7 +304,7 @@ def main():
                    "clouds": args.clouds},
     }
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.workload == "rpn":
         prof = EventProfiler(_cabi._lib)
         real = _cabi._lib
         _cabi._lib = prof
@@ -330,7 +344,7 @@ def main():
                                   "Gevals_per_s": round(evals / (fam["fps"]["ms"] / nprof * 1e-3) / 1e9, 1),
                                   "note": "serial chain, 1 workgroup/frame (32 of 256 CUs); hidden by --streams"}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "rpn":
         line["cpu_baseline"] = cpu_baseline(model, clouds_cpu, out)
 
     if rank == 0:
