@@ -120,9 +120,13 @@ size_t prcnn_wpack_floats(int Nout, int K);
  * QueryAndGroup order is [dxyz(3), features(C)]: pass k_rot=3 for those layers, 0 otherwise). */
 int prcnn_pack_weight(const float* w, int Nout, int K, int k_rot, float* wpack, prcnn_stream_t stream);
 
-/* A = in (rows, K), row stride ld_in */
+/* A = in (rows, K), row stride ld_in.
+ * rows_dev (device i32, may be NULL) / rows_unit: DEVICE-side row count -- the kernel processes
+ * min(rows, *rows_dev * rows_unit) rows and the launch (sized for `rows`) exits early past that; used with the
+ * compact group lists of prcnn_group_compact, whose lengths are only known on the device. */
 int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const float* bias, int Nout,
-                   int relu, float* out, int ld_out, int col_off, int pool_ns, prcnn_stream_t stream);
+                   int relu, float* out, int ld_out, int col_off, int pool_ns, const int32_t* rows_dev, int rows_unit,
+                   prcnn_stream_t stream);
 
 /* A row (b,m,s) = [ feat_cl[b, idx[b,m,s], 0:C],  xyz[b, idx[b,m,s]] - new_xyz[b,m] ]  (K = C+3;
  * C may be 0 with feat_cl NULL).  new_xyz NULL => GroupAll semantics (no centroid subtraction).
@@ -136,7 +140,8 @@ int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, const float*
 int prcnn_mlp_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl, int ld_feat,
                     int B, int N, int M, int nsample, int C, const float* act_wx, const float* act_bias,
                     const float* wpack, const float* bias, int Nout, int relu, float* out, int ld_out, int col_off,
-                    int pool_ns, prcnn_stream_t stream);
+                    int pool_ns, const int32_t* groups_dev, prcnn_stream_t stream);   /* groups_dev: device count of groups
+                    (<= B*M) actually present, or NULL -- see prcnn_mlp_rows / prcnn_group_compact */
 
 /* A row (b,i) = [ sum_j w3[b,i,j] * known_cl[b, idx3[b,i,j], 0:C2],  skip_cl[b,i,0:C1] ]  (K = C2+C1;
  * C1 may be 0 with skip_cl NULL).  rows = B*n.
@@ -174,7 +179,7 @@ int prcnn_mlp_chain_group(const float* xyz, const float* new_xyz, const int32_t*
                           int ld_feat, int B, int N, int M, int nsample, int C, const float* act_wx,
                           const float* act_bias, int nlayers,
                           const float* const* wpack, const float* const* bias, const int* nout, const int* relu,
-                          float* out, int ld_out, int col_off, int pool_ns, prcnn_stream_t stream);
+                          float* out, int ld_out, int col_off, int pool_ns, const int32_t* groups_dev, prcnn_stream_t stream);
 int prcnn_mlp_chain_interp(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3,
                            const float* skip_cl, int ld_skip, int B, int n, int m, int C2, int C1,
                            const float* act_bias, int nlayers, const float* const* wpack, const float* const* bias, const int* nout, const int* relu,
@@ -315,6 +320,22 @@ int prcnn_kitti_statistics(const double* overlaps, const int64_t* ov_off, const 
                            const double* dc, const int32_t* dc_off, int F, int max_det_per_frame, int metric, double min_overlap,
                            const double* thresholds, int T, int compute_fp, int compute_aos, double* res, double* matched,
                            prcnn_stream_t stream);
+
+/* ======================================================================================================
+ * Padding-free grouping (dedup.hip).  ball_query pads short groups by repeating their first hit; the rows of a group
+ * beyond its real hits are copies and cannot change the max-pooled result.  prcnn_group_compact splits the G = B*M
+ * groups of one ball query, on the device, into
+ *   singles (exactly one real row): idx1 (G) global point index b*N + p, nx1 (G,3) centroid, list1 (G) group id;
+ *   multis  (2..nsample real rows): idxn (G, nsample) global indices of ALL nsample rows, nxn (G,3), listn (G);
+ * counts[0] / counts[1] (device i32) = lengths of the two lists (their order is arbitrary).  All outputs are sized for
+ * the worst case G.  Run the MLP on each list as one frame (B = 1, N = B*N, M = G) with groups_dev = &counts[k] --
+ * singles with nsample = 1 and no pooling -- and place the result rows with prcnn_scatter_rows.
+ * ====================================================================================================== */
+int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int B, int N, int M, int nsample, int32_t* idx1, float* nx1,
+                        int32_t* list1, int32_t* idxn, float* nxn, int32_t* listn, int32_t* counts, prcnn_stream_t stream);
+/* dst[list[r], col_off : col_off + C] = src[r, 0:C] for r < *count (count: device i32; max_rows sizes the launch) */
+int prcnn_scatter_rows(const float* src, int ld_src, const int32_t* list, const int32_t* count, int max_rows, int C, float* dst,
+                       int ld_dst, int col_off, prcnn_stream_t stream);
 
 #ifdef __cplusplus
 }

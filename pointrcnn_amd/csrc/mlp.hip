@@ -65,7 +65,17 @@ struct MlpParams {
     // epilogue add (MODE_PLAIN, no pooling): out += sum_j w3[row,j] * addY[b*m + idx3[row,j], n]  (before ReLU)
     const float* addY;
     int ldY;
+    // device-side row count (dedup.hip): the launch is sized for `rows` (the worst case), the kernel processes
+    // min(rows, *rows_dev * rows_unit) and workgroups past that exit at once.  NULL: rows is exact.
+    const int32_t* rows_dev;
+    int rows_unit;
 };
+
+__device__ __forceinline__ long effective_rows(const MlpParams& P) {
+    if (!P.rows_dev) return P.rows;
+    const long r = (long)(*P.rows_dev) * P.rows_unit;
+    return r < P.rows ? r : P.rows;
+}
 
 template <int MODE> struct RowMeta;
 template <> struct RowMeta<MODE_PLAIN> { long off; bool valid; };
@@ -242,7 +252,10 @@ __device__ __forceinline__ float interp_gather(const MlpParams& P, long row, int
 // WNB = 32-column blocks per wave: 1 -> workgroup tile 128x64 (narrow layers), 2 -> 128x128 (wide layers: twice
 // the MFMAs per LDS operand read, and a gathered / interpolated A tile is rebuilt for half as many column tiles).
 template <int MODE, int WNB>
-__global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams P) {
+__global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams Pin) {
+    MlpParams P = Pin;
+    P.rows = effective_rows(Pin);
+    if ((long)blockIdx.x * MLP_BM >= P.rows) return;     // workgroup-uniform (device-side row count)
     constexpr int QN = 2 * WNB;                          // n-blocks per workgroup
     __shared__ __attribute__((aligned(16))) float As[2][MLP_BM * MLP_ALD];
     __shared__ __attribute__((aligned(16))) float Bs[2][QN * 4 * 256];
@@ -637,8 +650,11 @@ __device__ __forceinline__ void chain_store(const ChainParams& C, f32x16 (&acc)[
 }
 
 template <int MODE, int NB0, int NB1, int NB2>
-__global__ __launch_bounds__(256) void mlp_chain_kernel(const ChainParams C) {
+__global__ __launch_bounds__(256) void mlp_chain_kernel(const ChainParams Cin) {
+    ChainParams C = Cin;
+    C.a.rows = effective_rows(Cin.a);
     const MlpParams& P = C.a;
+    if ((long)blockIdx.x * 128 >= P.rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
     const long row = ((long)blockIdx.x * 4 + wave) * 32 + j;
@@ -806,8 +822,11 @@ __device__ __forceinline__ void fchain_layer(const f32x16 (&in)[NBI], f32x16 (&o
 
 #define FAST_MAX_K 128
 template <int MODE, int NB0, int NB1, int NB2>
-__global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C) {
+__global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams Cin) {
+    ChainParams C = Cin;
+    C.a.rows = effective_rows(Cin.a);
     const MlpParams& P = C.a;
+    if ((long)blockIdx.x * 128 >= P.rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
     const long row = ((long)blockIdx.x * 4 + wave) * 32 + j;
@@ -936,7 +955,9 @@ static constexpr size_t pers_lds_bytes() {
 }
 
 template <int MODE, int KB0, int NB0, int NB1, int NB2>
-__global__ __launch_bounds__(PERS_WAVES * 64) void mlp_chain_pers_kernel(const ChainParams C) {
+__global__ __launch_bounds__(PERS_WAVES * 64) void mlp_chain_pers_kernel(const ChainParams Cin) {
+    ChainParams C = Cin;
+    C.a.rows = effective_rows(Cin.a);
     const MlpParams& P = C.a;
     extern __shared__ __attribute__((aligned(16))) float Wl[];
     constexpr int T0 = KB0 * NB0, T1 = 4 * NB0 * NB1, T2 = 4 * NB1 * NB2;
@@ -1026,7 +1047,9 @@ __global__ __launch_bounds__(PERS_WAVES * 64) void mlp_chain_pers_kernel(const C
 // Same MFMA order, bias/ReLU arithmetic and pooling as mlp_chain_kernel: bit-identical results.
 // =====================================================================================================
 template <int KB1, int KB2, int NB2, int NS>
-__global__ __launch_bounds__(256) void sa_xyz_chain_kernel(const ChainParams C) {
+__global__ __launch_bounds__(256) void sa_xyz_chain_kernel(const ChainParams Cin) {
+    ChainParams C = Cin;
+    C.a.rows = effective_rows(Cin.a);
     const MlpParams& P = C.a;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
@@ -1202,7 +1225,7 @@ PRCNN_API int prcnn_pack_weight(const float* w, int Nout, int K, int k_rot, floa
 
 PRCNN_API int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const float* bias,
                              int Nout, int relu, float* out, int ld_out, int col_off, int pool_ns,
-                             prcnn_stream_t stream) {
+                             const int32_t* rows_dev, int rows_unit, prcnn_stream_t stream) {
     PRCNN_REQUIRE(in, "prcnn_mlp_rows: null input");
     PRCNN_REQUIRE(ld_in >= K && ld_out >= col_off + Nout, "prcnn_mlp_rows: bad strides ld_in=%d K=%d ld_out=%d", ld_in, K, ld_out);
     MlpParams P = {};
@@ -1210,6 +1233,7 @@ PRCNN_API int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, co
     P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.pool_ns = pool_ns;
     P.in = in; P.ld_in = ld_in;
     P.vec_a = aligned16(in) && (ld_in % 4 == 0);
+    P.rows_dev = rows_dev; P.rows_unit = rows_unit > 0 ? rows_unit : 1;
     return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
 }
 
@@ -1242,7 +1266,7 @@ PRCNN_API int prcnn_mlp_rows_addinterp(const float* in, int ld_in, int K, const 
 PRCNN_API int prcnn_mlp_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl,
                               int ld_feat, int B, int N, int M, int nsample, int C, const float* act_wx,
                               const float* act_bias, const float* wpack, const float* bias, int Nout, int relu,
-                              float* out, int ld_out, int col_off, int pool_ns, prcnn_stream_t stream) {
+                              float* out, int ld_out, int col_off, int pool_ns, const int32_t* groups_dev, prcnn_stream_t stream) {
     PRCNN_REQUIRE(xyz && idx, "prcnn_mlp_group: null pointer");
     PRCNN_REQUIRE(C == 0 || feat_cl, "prcnn_mlp_group: C=%d but feat_cl is null", C);
     PRCNN_REQUIRE(B >= 0 && N > 0 && M > 0 && nsample > 0 && C >= 0 && (C == 0 || ld_feat >= C),
@@ -1251,6 +1275,7 @@ PRCNN_API int prcnn_mlp_group(const float* xyz, const float* new_xyz, const int3
     MlpParams P = {};
     P.rows = (long)B * M * nsample; P.K = C + 3; P.wpack = wpack; P.bias = bias; P.Nout = Nout; P.relu = relu;
     P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.pool_ns = pool_ns;
+    P.rows_dev = groups_dev; P.rows_unit = nsample;
     P.xyz = xyz; P.new_xyz = new_xyz; P.idx = idx; P.feat = feat_cl; P.ld_feat = ld_feat;
     P.N = N; P.M = M; P.ns = nsample; P.C = C;
     P.vec_a = C > 0 && aligned16(feat_cl) && (ld_feat % 4 == 0);
@@ -1463,7 +1488,7 @@ PRCNN_API int prcnn_mlp_chain_group(const float* xyz, const float* new_xyz, cons
                                     const float* act_bias, int nlayers,
                                     const float* const* wpack, const float* const* bias, const int* nout,
                                     const int* relu, float* out, int ld_out, int col_off, int pool_ns,
-                                    prcnn_stream_t stream) {
+                                    const int32_t* groups_dev, prcnn_stream_t stream) {
     PRCNN_REQUIRE(xyz && idx && (C_ == 0 || feat_cl), "prcnn_mlp_chain_group: null pointer");
     PRCNN_REQUIRE(B >= 0 && N > 0 && M > 0 && nsample > 0 && C_ >= 0 && (C_ == 0 || ld_feat >= C_), "prcnn_mlp_chain_group: bad shape");
     ChainParams C = {};
@@ -1471,6 +1496,7 @@ PRCNN_API int prcnn_mlp_chain_group(const float* xyz, const float* new_xyz, cons
     if (rc) return rc;
     PRCNN_REQUIRE(pool_ns == 0 || pool_ns == nsample, "prcnn_mlp_chain_group: pool_ns must equal nsample");
     C.a.rows = (long)B * M * nsample; C.a.K = C_ + 3;
+    C.a.rows_dev = groups_dev; C.a.rows_unit = nsample;
     C.a.xyz = xyz; C.a.new_xyz = new_xyz; C.a.idx = idx; C.a.feat = feat_cl; C.a.ld_feat = ld_feat;
     C.a.N = N; C.a.M = M; C.a.ns = nsample; C.a.C = C_;
     C.a.vec_a = C_ > 0 && aligned16(feat_cl) && (ld_feat % 4 == 0);

@@ -11,6 +11,8 @@ Two execution paths with identical results:
     output -- no (B,C+3,npoint,nsample) tensor, no cat, no transposes.  Outputs are returned as (B,C,N)
     VIEWS of channels-last buffers so the next module picks them up without a copy.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -22,6 +24,7 @@ from . import pytorch_utils as pt_utils
 _POOL_FUSED = (16, 32, 64)
 # exact-algebra optimisation of the fused inference path (see _forward_fused); switchable for A/B tests
 HOIST_FIRST_LAYER = True
+GROUP_DEDUP = os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"       # padding-free grouping (csrc/dedup.hip); 0 = A/B switch, same bits
 
 
 def _channels_last(features):
@@ -38,6 +41,29 @@ def _run_mlp_tail(x_rows, layers, start, out, pool_ns):
         last = li == n - 1
         x_rows = ops.mlp_rows(x_rows, layers[li], out=out if last else None, pool_ns=pool_ns if last else 0)
     return x_rows
+
+
+def _flatten_frames(x):
+    """(B, N, C) rows with a uniform row stride -> (1, B*N, C) view (frames become one long cloud; indices b*N + p)"""
+    B, N, C = x.shape
+    assert x.stride(2) == 1 and (B == 1 or x.stride(0) == N * x.stride(1)), "rows must have one uniform stride"
+    return x.as_strided((1, B * N, C), (B * N * x.stride(1), x.stride(1), 1), x.storage_offset())
+
+
+def _run_scale(xyz, ctr, idx, src, layers, act, out, ns, pool, groups_dev):
+    """One grouping scale: gather + SharedMLP (+ max-pool over the nsample rows when `pool`), the register-resident chain
+    kernel where an instance exists, LDS-tiled layer kernels otherwise.  groups_dev: device-side group count (dedup)."""
+    pool_ns = ns if pool else 0
+    if (ns == 1 or (pool and ns in (16, 32))) and ops.chain_supported(1, layers, pool_ns):
+        return ops.mlp_chain_group(xyz, ctr, idx, src, layers, out=out, pool_ns=pool_ns, act=act, groups_dev=groups_dev)
+    if len(layers) == 1:
+        return ops.mlp_group(xyz, ctr, idx, src, layers[0], out=out, pool_ns=pool_ns, act=act, groups_dev=groups_dev)
+    x = ops.mlp_group(xyz, ctr, idx, src, layers[0], act=act, groups_dev=groups_dev)
+    n = len(layers)
+    for li in range(1, n):
+        last = li == n - 1
+        x = ops.mlp_rows(x, layers[li], out=out if last else None, pool_ns=pool_ns if last else 0, rows_dev=groups_dev, rows_unit=ns)
+    return x
 
 
 class _PointnetSAModuleBase(nn.Module):
@@ -137,19 +163,23 @@ class _PointnetSAModuleBase(nn.Module):
                 src, act = feat_cl, None
                 # torch's grouped channel order is [dxyz(3), feat(C)]; the kernel's A row is [feat(C), dxyz(3)]
                 layers = [mods[0].packed(k_rot=3 if feat_cl is not None else 0)] + [m.packed() for m in mods[1:]]
-            if fused_pool and ns in (16, 32) and ops.chain_supported(1, layers, ns):
-                # whole (remaining) SharedMLP + max-pool in one register-resident kernel
-                ops.mlp_chain_group(xyz, ctr, idxs[i], src, layers, out=dst, pool_ns=ns, act=act)
-                col += c_outs[i]
-                continue
-            if len(layers) == 1:
-                x = ops.mlp_group(xyz, ctr, idxs[i], src, layers[0], out=dst if fused_pool else None,
-                                  pool_ns=ns if fused_pool else 0, act=act)
+            if GROUP_DEDUP and not group_all and fused_pool:
+                # Padding-free grouping: a group with fewer than nsample neighbours repeats its first hit, and the max
+                # over copies of a row is the row -- run single-hit groups as ONE row each (no pooling), dense groups as
+                # they are, each list with a device-side length; then scatter both back.  Same bits, far fewer rows.
+                sp = ops.GroupSplit(idxs[i], new_xyz, N)
+                xyz_f = xyz.view(1, B * N, 3)
+                src_f = None if src is None else _flatten_frames(src)
+                t1 = torch.empty((sp.G, c_outs[i]), dtype=torch.float32, device=xyz.device)
+                tn = torch.empty((sp.G, c_outs[i]), dtype=torch.float32, device=xyz.device)
+                _run_scale(xyz_f, sp.nx1, sp.idx1, src_f, layers, act, (t1, 0), 1, False, sp.count1)
+                _run_scale(xyz_f, sp.nxn, sp.idxn, src_f, layers, act, (tn, 0), ns, True, sp.countn)
+                ops.scatter_rows(t1, sp.list1, sp.count1, dst[0], col)
+                ops.scatter_rows(tn, sp.listn, sp.countn, dst[0], col)
             else:
-                x = ops.mlp_group(xyz, ctr, idxs[i], src, layers[0], act=act)
-                x = _run_mlp_tail(x, layers, 1, dst if fused_pool else None, ns if fused_pool else 0)
-            if not fused_pool:
-                ops.maxpool_rows(x, ns, out=dst)
+                x = _run_scale(xyz, ctr, idxs[i], src, layers, act, dst if fused_pool else None, ns, fused_pool, None)
+                if not fused_pool:
+                    ops.maxpool_rows(x, ns, out=dst)
             col += c_outs[i]
         return new_xyz, out_cl.transpose(1, 2)
 

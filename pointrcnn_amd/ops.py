@@ -274,7 +274,7 @@ def mlp_chain_rows(x, layers, out=None, pool_ns=0):
     return buf
 
 
-def mlp_chain_group(xyz, new_xyz, idx, feat_cl, layers, out=None, pool_ns=0, act=None):
+def mlp_chain_group(xyz, new_xyz, idx, feat_cl, layers, out=None, pool_ns=0, act=None, groups_dev=None):
     B, N, _ = xyz.shape
     _, M, ns = idx.shape
     C = 0 if feat_cl is None else feat_cl.shape[-1]
@@ -286,7 +286,7 @@ def mlp_chain_group(xyz, new_xyz, idx, feat_cl, layers, out=None, pool_ns=0, act
     awx, ab = (None, None) if act is None else act
     _cabi.check(_cabi.lib().prcnn_mlp_chain_group(_p(xyz), _p(new_xyz), _p(idx), _p(feat_cl), ld_feat, B, N, M, ns, C, _p(awx), _p(ab), a.n,
                                                   a.wpack, a.bias, a.nout, a.relu, _p(buf), ld_out, col_off, pool_ns,
-                                                  _stream()), "prcnn_mlp_chain_group")
+                                                  _p(groups_dev), _stream()), "prcnn_mlp_chain_group")
     return buf
 
 
@@ -319,9 +319,10 @@ def _out_buf(out, rows, lin, device):
     return buf, _row_stride(buf), col_off
 
 
-def mlp_rows(x, lin, out=None, pool_ns=0):
+def mlp_rows(x, lin, out=None, pool_ns=0, rows_dev=None, rows_unit=1):
     """x (..., K) channels-last rows (last dim contiguous, uniform row stride) -> (rows[/pool_ns], Nout).
-    out = (buffer, col_off) writes into a wider channels-last buffer instead of allocating."""
+    out = (buffer, col_off) writes into a wider channels-last buffer instead of allocating.
+    rows_dev (1,) int32 device tensor: only the first rows_dev * rows_unit rows are processed (device-side count)."""
     if x.stride(-1) != 1:
         raise RuntimeError("mlp_rows: last dim must be contiguous")
     K = x.shape[-1]
@@ -330,11 +331,11 @@ def mlp_rows(x, lin, out=None, pool_ns=0):
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, lin, x.device)
     _cabi.check(_cabi.lib().prcnn_mlp_rows(_p(x), ld_in, rows, K, _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu),
-                                           _p(buf), ld_out, col_off, pool_ns, _stream()), "prcnn_mlp_rows")
+                                           _p(buf), ld_out, col_off, pool_ns, _p(rows_dev), int(rows_unit), _stream()), "prcnn_mlp_rows")
     return buf
 
 
-def mlp_group(xyz, new_xyz, idx, feat_cl, lin, out=None, pool_ns=0, act=None):
+def mlp_group(xyz, new_xyz, idx, feat_cl, lin, out=None, pool_ns=0, act=None, groups_dev=None):
     """First SA layer fused with ball-query grouping.  xyz (B,N,3), new_xyz (B,M,3) or None (GroupAll),
     idx (B,M,ns) i32, feat_cl (B,N,C) channels-last or None -> (B*M*ns[/pool_ns], Nout).
     act = (act_wx (C,3), act_bias (C)) selects the HOISTED form: feat_cl is Z = W_f.feat per source point and `lin` is
@@ -349,7 +350,7 @@ def mlp_group(xyz, new_xyz, idx, feat_cl, lin, out=None, pool_ns=0, act=None):
     awx, ab = (None, None) if act is None else act
     _cabi.check(_cabi.lib().prcnn_mlp_group(_p(xyz), _p(new_xyz), _p(idx), _p(feat_cl), ld_feat, B, N, M, ns, C, _p(awx), _p(ab),
                                             _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu), _p(buf), ld_out,
-                                            col_off, pool_ns, _stream()), "prcnn_mlp_group")
+                                            col_off, pool_ns, _p(groups_dev), _stream()), "prcnn_mlp_group")
     return buf
 
 
@@ -599,3 +600,36 @@ def kitti_statistics(overlaps, ov_off, gt_datas, gt_off, dt_datas, dt_off, ign_g
                                                    float(min_overlap), _p(thresholds), T, int(compute_fp), int(compute_aos), _p(res),
                                                    _p(matched), _stream()), "prcnn_kitti_statistics")
     return res, matched[:G]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# padding-free grouping (csrc/dedup.hip)
+# ---------------------------------------------------------------------------------------------------------
+class GroupSplit:
+    """The G = B*M groups of one ball query split on the device into singles (one real row) and multis (see
+    prcnn_group_compact).  All tensors are worst-case sized; counts (2,) int32 holds the list lengths."""
+
+    def __init__(self, idx, new_xyz, N):
+        _chk(idx, "idx", _INT, 3)
+        _chk(new_xyz, "new_xyz", ndim=3)
+        B, M, ns = idx.shape
+        G, dev = B * M, idx.device
+        self.G, self.ns = G, ns
+        self.idx1 = torch.empty((1, G, 1), dtype=_INT, device=dev)
+        self.nx1 = torch.empty((1, G, 3), dtype=_F32, device=dev)
+        self.list1 = torch.empty((G,), dtype=_INT, device=dev)
+        self.idxn = torch.empty((1, G, ns), dtype=_INT, device=dev)
+        self.nxn = torch.empty((1, G, 3), dtype=_F32, device=dev)
+        self.listn = torch.empty((G,), dtype=_INT, device=dev)
+        self.counts = torch.empty((2,), dtype=_INT, device=dev)
+        _cabi.check(_cabi.lib().prcnn_group_compact(_p(idx), _p(new_xyz), B, N, M, ns, _p(self.idx1), _p(self.nx1), _p(self.list1),
+                                                    _p(self.idxn), _p(self.nxn), _p(self.listn), _p(self.counts), _stream()),
+                    "prcnn_group_compact")
+        self.count1, self.countn = self.counts[0:1], self.counts[1:2]
+
+
+def scatter_rows(src, rows_list, count, dst, col_off):
+    """dst[rows_list[r], col_off : col_off + C] = src[r] for r < count (count: (1,) int32 device tensor)"""
+    C = src.shape[-1]
+    _cabi.check(_cabi.lib().prcnn_scatter_rows(_p(src), src.stride(-2), _p(rows_list), _p(count), rows_list.shape[0], C, _p(dst),
+                                               dst.stride(-2), int(col_off), _stream()), "prcnn_scatter_rows")

@@ -221,3 +221,53 @@ def test_rpn_backward_composed_path(dev):
     params = list(sa.parameters()) + list(fp.parameters())
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
     assert feat.grad is not None and torch.isfinite(feat.grad).all() and float(feat.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("cloud", ["sparse", "dense", "mixed"])
+def test_sa_padding_free_grouping_is_bit_identical(dev, cloud):
+    """PRCNN_GROUP_DEDUP (csrc/dedup.hip): single-hit groups run as one row, dense groups with all their rows -- the
+    level's output must not change by one bit.  sparse: nearly every group is a single; dense: none; mixed: both
+    lists populated (and the MSG level's two radii split differently)."""
+    from pointnet2_lib.pointnet2 import pointnet2_modules as pm
+    from pointrcnn_amd.rpn import randomize_bn_stats
+    torch.manual_seed(7)
+    B, N = 3, 3000
+    base = unit_cloud(B, N, seed=11)
+    if cloud == "sparse":
+        base = base * 40.0
+    elif cloud == "mixed":
+        base[:, : N // 2] *= 0.15                     # half the points in a dense clump, the rest spread out
+        base[:, N // 2:] *= 12.0
+    xyz = T(base, dev)
+    for mlps, cin in (([[16, 16, 32], [32, 32, 64]], 0), ([[24, 64, 128], [24, 96, 128]], 24), ([[24, 196, 256], [24, 160, 200]], 24)):
+        mod = pm.PointnetSAModuleMSG(npoint=512, radii=[0.25, 0.6], nsamples=[16, 32], mlps=[list(m) for m in mlps], use_xyz=True, bn=True)
+        randomize_bn_stats(mod).to(dev).eval()
+        feat = torch.randn(B, cin, N, device=dev) if cin else None
+        outs = {}
+        for flag in (False, True):
+            pm.GROUP_DEDUP = flag
+            try:
+                with torch.no_grad():
+                    outs[flag] = mod(xyz, feat)[1].clone()
+            finally:
+                pm.GROUP_DEDUP = True
+        assert torch.equal(outs[False], outs[True]), (cloud, mlps)
+
+
+def test_group_compact_lists(dev):
+    """prcnn_group_compact: every group lands in exactly one list, singles carry their one global point index"""
+    from pointrcnn_amd import ops
+    B, N, M, ns = 2, 4000, 700, 16
+    xyz = T(kitti_cloud(B, N, seed=3), dev)
+    new_xyz = ops.gather_rows(xyz, ops.furthest_point_sample(xyz, M))
+    idx = ops.ball_query(1.0, ns, xyz, new_xyz)
+    sp = ops.GroupSplit(idx, new_xyz, N)
+    c1, cn = (int(v) for v in sp.counts.cpu())
+    assert c1 + cn == B * M and c1 > 0 and cn > 0
+    idx_c = idx.cpu().numpy().reshape(B * M, ns)
+    single = (idx_c[:, 1:] == idx_c[:, :1]).all(1)
+    l1, ln = sp.list1[:c1].cpu().numpy(), sp.listn[:cn].cpu().numpy()
+    assert np.array_equal(np.sort(l1), np.nonzero(single)[0]) and np.array_equal(np.sort(ln), np.nonzero(~single)[0])
+    assert np.array_equal(sp.idx1.view(-1)[:c1].cpu().numpy(), (l1 // M) * N + idx_c[l1, 0])
+    assert np.array_equal(sp.idxn.view(-1, ns)[:cn].cpu().numpy(), (ln // M)[:, None] * N + idx_c[ln])
+    assert torch.equal(sp.nx1.view(-1, 3)[:c1], new_xyz.view(-1, 3)[sp.list1[:c1].long()])
