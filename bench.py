@@ -12,9 +12,10 @@ levels, + cls/reg heads; lib/net/rpn.py:68-82 via pointrcnn_amd/rpn.py) -- over 
 and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
 
 Besides the contract fields the line carries
-  roofline     -- for the dominant kernel (the fused per-point MLP layer, fp32 MFMA): algorithmic FLOPs per
-                  launch / its average launch duration, measured with HIP events on the launch stream in an
-                  instrumented pass of the same steps; peak = 157.3 TFLOP/s dense fp32 MFMA.
+  roofline     -- for the dominant kernel family (the fused per-point MLP, fp32 MFMA): the FLOPs its launches execute
+                  (rows actually processed -- device-side counts read back -- x layer widths) / their GPU time, measured
+                  with HIP events on the launch stream in an instrumented pass of the same steps; peak = 157.3 TFLOP/s
+                  dense fp32 MFMA.  reference_graph_TFLOPs prices the reference's dense flop count over the same time.
   cpu_baseline -- the CPU oracle restatement of the SAME graph (oracle/rpn_cpu.py, kind "port", 1 thread)
                   timed on a bounded sample (one frame) on this box's host cores, rank 0 at N=1 only.
   kernels      -- per-op-family GPU time of one step (ms) from the same event pass.
@@ -70,29 +71,31 @@ class EventProfiler:
 
     def __init__(self, lib):
         self._lib = lib
-        self.records = []          # (name, start, end, flops)
+        self.records = []          # (name, start, end, (flops per row, static rows, device row-count pointer, rows per count))
+        self.splits = []           # GroupSplit objects of the pass (kept alive: their device counts are read in summary())
 
     @staticmethod
-    def _flops(name, a):
-        """EXECUTED flops of one call (first-layer hoisting makes this smaller than the reference's algorithmic count)"""
-        def chain(rows, k0, nout):
+    def _work(name, a):
+        """(flops per row, rows, rows_dev pointer, rows per device count) of one call.  EXECUTED work: first-layer
+        hoisting and padding-free grouping make it smaller than the reference graph's count."""
+        def chain(k0, nout):
             widths = [k0] + list(nout)
-            return 2.0 * rows * sum(x * y for x, y in zip(widths[:-1], widths[1:]))
+            return 2.0 * sum(x * y for x, y in zip(widths[:-1], widths[1:]))
         if name == "prcnn_mlp_rows":
-            return 2.0 * a[2] * a[3] * a[6]
+            return 2.0 * a[3] * a[6], a[2], a[12], a[13]
         if name == "prcnn_mlp_rows_addinterp":
-            return 2.0 * (a[11] * a[12]) * (a[2] + 3) * a[5]
+            return 2.0 * (a[2] + 3) * a[5], a[11] * a[12], None, 1
         if name == "prcnn_mlp_group":
-            return 2.0 * (a[5] * a[7] * a[8]) * (a[9] + (0 if a[10] else 3)) * a[14]
+            return 2.0 * (a[9] + (0 if a[10] else 3)) * a[14], a[5] * a[7] * a[8], a[20], a[8]
         if name == "prcnn_mlp_interp":
-            return 2.0 * (a[6] * a[7]) * (a[9] + a[10]) * a[14]
+            return 2.0 * (a[9] + a[10]) * a[14], a[6] * a[7], None, 1
         if name == "prcnn_mlp_chain_rows":
-            return chain(a[2], a[3], a[7])
+            return chain(a[3], a[7]), a[2], None, 1
         if name == "prcnn_mlp_chain_group":
-            return chain(a[5] * a[7] * a[8], a[9] + (0 if a[10] else 3), a[15])
+            return chain(a[9] + (0 if a[10] else 3), a[15]), a[5] * a[7] * a[8], a[21], a[8]
         if name == "prcnn_mlp_chain_interp":
-            return chain(a[6] * a[7], a[9] + a[10], a[15])
-        return 0.0
+            return chain(a[9] + a[10], a[15]), a[6] * a[7], None, 1
+        return 0.0, 0, None, 1
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
@@ -105,19 +108,27 @@ class EventProfiler:
             s.record()
             rc = fn(*args)
             e.record()
-            self.records.append((name, s, e, self._flops(name, args)))
+            self.records.append((name, s, e, self._work(name, args)))
             return rc
         return wrapped
 
     def summary(self):
         torch.cuda.synchronize()
+        dev_counts = {}
+        for sp in self.splits:
+            for k, v in enumerate(sp.counts.cpu().tolist()):
+                dev_counts[sp.counts.data_ptr() + 4 * k] = v
         fam = {}
-        for name, s, e, fl in self.records:
+        for name, s, e, (per_row, rows, ptr, unit) in self.records:
             key = "mlp" if name.startswith("prcnn_mlp_") else name[len("prcnn_"):]
-            d = fam.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0})
+            d = fam.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0, "rows": 0, "rows_launched": 0})
+            ptr = getattr(ptr, "value", ptr)
+            live = min(rows, dev_counts[ptr] * unit) if ptr else rows
             d["ms"] += s.elapsed_time(e)
             d["launches"] += 1
-            d["flops"] += fl
+            d["flops"] += per_row * live
+            d["rows"] += live
+            d["rows_launched"] += rows
         return fam
 
 
@@ -301,32 +312,40 @@ def main():
                    "launch": "hipGraph replay" if graph is not None else "eager", "streams": nstreams,
                    "proposal_layer": args.proposals,
                    "inputs": "host (pinned) -> HBM copy inside the timed region" if args.h2d else "resident in HBM",
-                   "clouds": args.clouds},
+                   "clouds": args.clouds, "group_dedup": os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"},
     }
 
     if rank == 0 and not args.no_roofline and args.workload == "rpn":
+        from pointrcnn_amd import ops as _ops
         prof = EventProfiler(_cabi._lib)
         real = _cabi._lib
-        _cabi._lib = prof
+        _cabi._lib, _ops._split_log = prof, prof.splits
         try:
             nprof = min(3, args.steps)
             for _ in range(nprof):
                 step(0)
             fam = prof.summary()
         finally:
-            _cabi._lib = real
-        mlp = fam.get("mlp", {"ms": 0.0, "launches": 1, "flops": 0.0})
-        # ALGORITHMIC flops = the reference graph's MLP work (14.95 GFLOP/frame), independent of how
-        # many of them the hoisted implementation actually executes
-        alg = rpn.rpn_flops_per_frame() * args.batch * nprof if args.npoints == 16384 else mlp["flops"]
-        achieved = alg / (mlp["ms"] * 1e-3) / 1e12 if mlp["ms"] > 0 else 0.0
-        line["roofline"] = {"kernel": "mlp_chain_kernel + mlp_layer_kernel (fused gather/interp + fp32 MFMA + bias/ReLU/max-pool)",
+            _cabi._lib, _ops._split_log = real, None
+        mlp = fam.get("mlp", {"ms": 0.0, "launches": 1, "flops": 0.0, "rows": 0, "rows_launched": 0})
+        secs = mlp["ms"] * 1e-3
+        # The roofline is priced on the flops the kernels EXECUTE: first-layer hoisting and padding-free grouping (both
+        # exact) remove most of the reference graph's MLP work (14.95 GFLOP/frame, padding rows included),
+        # so the reference-graph rate -- reported next to it -- is a throughput figure, not a utilisation, and may exceed
+        # the peak.
+        ref_flops = rpn.rpn_flops_per_frame() * args.batch * nprof if args.npoints == 16384 else None
+        achieved = mlp["flops"] / secs / 1e12 if secs > 0 else 0.0
+        line["roofline"] = {"kernel": "mlp_chain_* + mlp_layer_kernel (fused gather/interp + fp32 MFMA + bias/ReLU/max-pool)",
                             "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                             "launches_per_step": mlp["launches"] // nprof,
                             "avg_launch_us": round(1e3 * mlp["ms"] / max(1, mlp["launches"]), 2),
-                            "flops_per_step": alg / nprof, "executed_flops_per_step": mlp["flops"] / nprof,
-                            "executed_TFLOPs": round(mlp["flops"] / (mlp["ms"] * 1e-3) / 1e12, 3) if mlp["ms"] > 0 else 0.0}
+                            "flops_per_step": mlp["flops"] / nprof, "rows_per_step": mlp["rows"] // nprof,
+                            "rows_per_step_without_dedup": mlp["rows_launched"] // nprof,
+                            "reference_graph_flops_per_step": ref_flops / nprof if ref_flops else None,
+                            "reference_graph_TFLOPs": round(ref_flops / secs / 1e12, 3) if ref_flops and secs > 0 else None,
+                            "note": "achieved/frac = executed flops (after exact first-layer hoisting and padding-free grouping) / "
+                                    "MLP-family GPU time; reference_graph_TFLOPs = the reference's dense flop count over the same time"}
         line["kernels"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "launches_per_step": v["launches"] // nprof}
                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         # HBM bytes per launch of the same kernel family from the PMC passes committed under profiles/ (rocprofv3

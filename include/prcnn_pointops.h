@@ -323,16 +323,24 @@ int prcnn_kitti_statistics(const double* overlaps, const int64_t* ov_off, const 
 
 /* ======================================================================================================
  * Padding-free grouping (dedup.hip).  ball_query pads short groups by repeating their first hit; the rows of a group
- * beyond its real hits are copies and cannot change the max-pooled result.  prcnn_group_compact splits the G = B*M
+ * beyond its cnt real hits are copies and cannot change the max-pooled result.  prcnn_group_compact splits the G = B*M
  * groups of one ball query, on the device, into
- *   singles (exactly one real row): idx1 (G) global point index b*N + p, nx1 (G,3) centroid, list1 (G) group id;
- *   multis  (2..nsample real rows): idxn (G, nsample) global indices of ALL nsample rows, nxn (G,3), listn (G);
- * counts[0] / counts[1] (device i32) = lengths of the two lists (their order is arbitrary).  All outputs are sized for
- * the worst case G.  Run the MLP on each list as one frame (B = 1, N = B*N, M = G) with groups_dev = &counts[k] --
- * singles with nsample = 1 and no pooling -- and place the result rows with prcnn_scatter_rows.
+ *   sparse groups (cnt <= sparse_max): their real rows are appended to ONE flat row list -- ridx (G*sparse_max) global
+ *       point index b*N + p, rnx (G*sparse_max, 3) the row's group centroid -- and the group is recorded as
+ *       slist (G) group id, soff (G) first flat row, scnt (G) = cnt;
+ *   dense groups (cnt > sparse_max): idxn (G, nsample) global indices of ALL nsample rows (padding included),
+ *       nxn (G,3), listn (G) group id  (may be NULL when sparse_max == nsample: every group is then sparse).
+ * counts (3 device i32): [0] flat rows, [1] dense groups, [2] sparse groups; list order is arbitrary.  All outputs are
+ * sized for the worst case.  Run the MLP on each list as one frame (B = 1, N = B*N): the flat rows with M = G*sparse_max,
+ * nsample = 1, no pooling, groups_dev = &counts[0], then prcnn_segmax_scatter; the dense list with M = G, pooling,
+ * groups_dev = &counts[1], then prcnn_scatter_rows.
  * ====================================================================================================== */
-int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int B, int N, int M, int nsample, int32_t* idx1, float* nx1,
-                        int32_t* list1, int32_t* idxn, float* nxn, int32_t* listn, int32_t* counts, prcnn_stream_t stream);
+int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int B, int N, int M, int nsample, int sparse_max, int32_t* ridx,
+                        float* rnx, int32_t* slist, int32_t* soff, int32_t* scnt, int32_t* idxn, float* nxn, int32_t* listn,
+                        int32_t* counts, prcnn_stream_t stream);
+/* dst[list[j], col_off + c] = max over r < cnt[j] of src[off[j] + r, c]  for j < *count, c < C */
+int prcnn_segmax_scatter(const float* src, int ld_src, const int32_t* list, const int32_t* off, const int32_t* cnt,
+                         const int32_t* count, int max_groups, int C, float* dst, int ld_dst, int col_off, prcnn_stream_t stream);
 /* dst[list[r], col_off : col_off + C] = src[r, 0:C] for r < *count (count: device i32; max_rows sizes the launch) */
 int prcnn_scatter_rows(const float* src, int ld_src, const int32_t* list, const int32_t* count, int max_rows, int C, float* dst,
                        int ld_dst, int col_off, prcnn_stream_t stream);

@@ -60,7 +60,8 @@ SIGNATURES = {
     "prcnn_rotate_iou_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "prcnn_kitti_overlaps": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "prcnn_kitti_statistics": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _D, _P, _I, _I, _I, _P, _P, _P]),
-    "prcnn_group_compact": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prcnn_group_compact": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prcnn_segmax_scatter": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _P]),
     "prcnn_scatter_rows": (_I, [_P, _I, _P, _P, _I, _I, _P, _I, _I, _P]),
     "prcnn_nms_batched": (_I, [_P, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
 }

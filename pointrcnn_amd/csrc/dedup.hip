@@ -8,41 +8,37 @@
 //
 // The split is done once per (level, radius), on the device, with no host round trip:
 //   group_compact_kernel : cnt = number of leading distinct indices of the group (real hits are strictly ascending, the
-//                          padding repeats idx[0]); groups with cnt == 1 go to the SINGLES list (one row each: no pooling
-//                          at all), the others to the MULTI list (their full nsample rows, padding included -- they are
-//                          the few dense groups).  Lists are appended with wave-aggregated atomics; their order is
-//                          arbitrary, the results are not (every group's output row is written by exactly one of them).
+//                          padding repeats idx[0]).  Groups with cnt <= T go to the SPARSE list: their cnt real rows are
+//                          appended to one flat row list (global point index + the group's centroid per row), the group
+//                          remembers (first row, cnt).  Groups with cnt > T go to the DENSE list with their full nsample
+//                          rows, padding included -- a full tile pooled in the MLP epilogue is cheaper for them than a
+//                          round trip of cnt result rows through HBM.  Lists are appended with wave-aggregated atomics;
+//                          their order is arbitrary, the results are not (every group's output row is written exactly once).
 //   the MLP kernels take the list lengths as DEVICE-side row counts (MlpParams::rows_dev): launched for the worst case,
 //   workgroups past the end exit at once;
-//   scatter_rows_kernel  : compact result rows -> the groups' rows of the level's output.
+//   segmax_scatter_kernel : max over each sparse group's result rows -> the group's row of the level's output;
+//   scatter_rows_kernel   : pooled dense-list rows -> the groups' rows of the level's output.
 // Bit-identical to the un-split path: same rows, same arithmetic, max over a multiset == max over its support.
 #include "common.h"
 
 struct CompactParams {
     const int32_t* idx;      // (B, M, ns) ball-query result
     const float* new_xyz;    // (B, M, 3)
-    int32_t* idx1;           // (G)      global index (b*N + p) of the single row, G = B*M
-    float* nx1;              // (G, 3)   its centroid
-    int32_t* list1;          // (G)      group ids of the singles
-    int32_t* idxn;           // (G, ns)  global indices of the multi groups' rows
+    int32_t* ridx;           // (G*T)    sparse list: global index (b*N + p) of every real row, G = B*M
+    float* rnx;              // (G*T, 3) the row's group centroid
+    int32_t* slist;          // (G)      sparse groups: group id,
+    int32_t* soff;           // (G)        first row in the flat list,
+    int32_t* scnt;           // (G)        row count (1..T)
+    int32_t* idxn;           // (G, ns)  dense list: global indices of the groups' nsample rows
     float* nxn;              // (G, 3)
     int32_t* listn;          // (G)
-    int32_t* counts;         // [0] singles, [1] multis (zeroed by the launcher)
-    int G, N, M, ns;
+    int32_t* counts;         // [0] flat rows, [1] dense groups, [2] sparse groups (zeroed by the launcher)
+    int G, N, M, ns, T;
 };
-
-__device__ __forceinline__ int wave_append(bool pass, int32_t* counter) {
-    const unsigned long long bm = __ballot(pass);
-    if (bm == 0ULL) return -1;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(counter, (int)__popcll(bm));
-    base = __builtin_amdgcn_readfirstlane(base);
-    return pass ? base + (int)__popcll(bm & ((1ULL << lane) - 1ULL)) : -1;
-}
 
 __global__ __launch_bounds__(256) void group_compact_kernel(CompactParams P) {
     const int g = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const bool ok = g < P.G;
     int cnt = 0, first = 0;
     const int32_t* row = P.idx + (size_t)(ok ? g : 0) * P.ns;
@@ -53,19 +49,46 @@ __global__ __launch_bounds__(256) void group_compact_kernel(CompactParams P) {
             if (row[s] == first) { cnt = s; break; }          // real hits are strictly ascending: a repeat of idx[0] is padding
     }
     const int b = (ok ? g : 0) / P.M;
-    const int p1 = wave_append(ok && cnt == 1, P.counts);
-    const int pn = wave_append(ok && cnt > 1, P.counts + 1);
-    if (p1 >= 0) {
-        P.list1[p1] = g;
-        P.idx1[p1] = b * P.N + first;
+    const bool sparse = ok && cnt <= P.T, dense = ok && cnt > P.T;
+    // sparse: wave-wide exclusive scan of the row counts, one atomic per wave and list
+    const int v = sparse ? cnt : 0;
+    int incl = v;
 #pragma unroll
-        for (int c = 0; c < 3; c++) P.nx1[(size_t)p1 * 3 + c] = P.new_xyz[(size_t)g * 3 + c];
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
     }
-    if (pn >= 0) {
+    const int total = __shfl(incl, 63);
+    const unsigned long long bs = __ballot(sparse), bd = __ballot(dense);
+    int base_rows = 0, base_s = 0, base_d = 0;
+    if (lane == 0) {
+        if (total > 0) { base_rows = atomicAdd(P.counts, total); base_s = atomicAdd(P.counts + 2, (int)__popcll(bs)); }
+        if (bd != 0ULL) base_d = atomicAdd(P.counts + 1, (int)__popcll(bd));
+    }
+    base_rows = __builtin_amdgcn_readfirstlane(base_rows);
+    base_s = __builtin_amdgcn_readfirstlane(base_s);
+    base_d = __builtin_amdgcn_readfirstlane(base_d);
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    float c3[3] = {0.f, 0.f, 0.f};
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) c3[c] = P.new_xyz[(size_t)g * 3 + c];
+    }
+    if (sparse) {
+        const int j = base_s + (int)__popcll(bs & below), r0 = base_rows + incl - v;
+        P.slist[j] = g; P.soff[j] = r0; P.scnt[j] = cnt;
+        for (int s = 0; s < cnt; s++) {
+            P.ridx[r0 + s] = b * P.N + row[s];
+#pragma unroll
+            for (int c = 0; c < 3; c++) P.rnx[(size_t)(r0 + s) * 3 + c] = c3[c];
+        }
+    }
+    if (dense) {
+        const int pn = base_d + (int)__popcll(bd & below);
         P.listn[pn] = g;
         for (int s = 0; s < P.ns; s++) P.idxn[(size_t)pn * P.ns + s] = b * P.N + row[s];
 #pragma unroll
-        for (int c = 0; c < 3; c++) P.nxn[(size_t)pn * 3 + c] = P.new_xyz[(size_t)g * 3 + c];
+        for (int c = 0; c < 3; c++) P.nxn[(size_t)pn * 3 + c] = c3[c];
     }
 }
 
@@ -80,20 +103,52 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     dst[(size_t)list[r] * ld_dst + col_off + c] = src[(size_t)r * ld_src + c];
 }
 
-PRCNN_API int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int B, int N, int M, int nsample, int32_t* idx1, float* nx1,
-                                  int32_t* list1, int32_t* idxn, float* nxn, int32_t* listn, int32_t* counts, prcnn_stream_t stream) {
+__global__ __launch_bounds__(256) void segmax_scatter_kernel(const float* __restrict__ src, int ld_src, const int32_t* __restrict__ list,
+                                                             const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
+                                                             const int32_t* __restrict__ count, int C, float* __restrict__ dst,
+                                                             int ld_dst, int col_off) {
+    const int n = *count;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long j = e / C;
+    if (j >= n) return;
+    const int c = (int)(e - j * C);
+    const float* p = src + (size_t)off[j] * ld_src + c;
+    const int rows = cnt[j];
+    float m = p[0];
+    for (int r = 1; r < rows; r++) m = fmaxf(m, p[(size_t)r * ld_src]);
+    dst[(size_t)list[j] * ld_dst + col_off + c] = m;
+}
+
+PRCNN_API int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int B, int N, int M, int nsample, int sparse_max,
+                                  int32_t* ridx, float* rnx, int32_t* slist, int32_t* soff, int32_t* scnt, int32_t* idxn, float* nxn,
+                                  int32_t* listn, int32_t* counts, prcnn_stream_t stream) {
     PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && nsample > 0, "prcnn_group_compact: bad shape B=%d N=%d M=%d nsample=%d", B, N, M, nsample);
+    PRCNN_REQUIRE(sparse_max >= 1 && sparse_max <= nsample, "prcnn_group_compact: sparse_max=%d (1..nsample)", sparse_max);
     PRCNN_REQUIRE(counts, "prcnn_group_compact: null counts");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_group_compact: memset failed");
+    if (hipMemsetAsync(counts, 0, 3 * sizeof(int32_t), s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_group_compact: memset failed");
     if (B == 0 || M == 0) return PRCNN_OK;
-    PRCNN_REQUIRE((long)B * N < 2147483647L, "prcnn_group_compact: B*N overflows the 32-bit global point index");
-    PRCNN_REQUIRE(idx && new_xyz && idx1 && nx1 && list1 && idxn && nxn && listn, "prcnn_group_compact: null pointer");
+    PRCNN_REQUIRE((long)B * N < 2147483647L && (long)B * M * sparse_max < 2147483647L, "prcnn_group_compact: 32-bit row index overflow");
+    PRCNN_REQUIRE(idx && new_xyz && ridx && rnx && slist && soff && scnt, "prcnn_group_compact: null pointer");
+    PRCNN_REQUIRE(sparse_max == nsample || (idxn && nxn && listn), "prcnn_group_compact: null dense-list pointer");
     CompactParams P;
-    P.idx = idx; P.new_xyz = new_xyz; P.idx1 = idx1; P.nx1 = nx1; P.list1 = list1; P.idxn = idxn; P.nxn = nxn; P.listn = listn;
-    P.counts = counts; P.G = B * M; P.N = N; P.M = M; P.ns = nsample;
+    P.idx = idx; P.new_xyz = new_xyz; P.ridx = ridx; P.rnx = rnx; P.slist = slist; P.soff = soff; P.scnt = scnt;
+    P.idxn = idxn; P.nxn = nxn; P.listn = listn;
+    P.counts = counts; P.G = B * M; P.N = N; P.M = M; P.ns = nsample; P.T = sparse_max;
     hipLaunchKernelGGL(group_compact_kernel, dim3(prcnn_divup(P.G, 256)), dim3(256), 0, s, P);
     PRCNN_LAUNCH_CHECK("prcnn_group_compact");
+    return PRCNN_OK;
+}
+
+PRCNN_API int prcnn_segmax_scatter(const float* src, int ld_src, const int32_t* list, const int32_t* off, const int32_t* cnt,
+                                   const int32_t* count, int max_groups, int C, float* dst, int ld_dst, int col_off,
+                                   prcnn_stream_t stream) {
+    PRCNN_REQUIRE(max_groups >= 0 && C > 0 && ld_src >= C && ld_dst >= col_off + C, "prcnn_segmax_scatter: bad shape");
+    if (max_groups == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(src && list && off && cnt && count && dst, "prcnn_segmax_scatter: null pointer");
+    hipLaunchKernelGGL(segmax_scatter_kernel, dim3(prcnn_divup((long)max_groups * C, 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                       list, off, cnt, count, C, dst, ld_dst, col_off);
+    PRCNN_LAUNCH_CHECK("prcnn_segmax_scatter");
     return PRCNN_OK;
 }
 

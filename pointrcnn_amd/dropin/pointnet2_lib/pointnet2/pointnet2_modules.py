@@ -25,6 +25,7 @@ _POOL_FUSED = (16, 32, 64)
 # exact-algebra optimisation of the fused inference path (see _forward_fused); switchable for A/B tests
 HOIST_FIRST_LAYER = True
 GROUP_DEDUP = os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"       # padding-free grouping (csrc/dedup.hip); 0 = A/B switch, same bits
+DEDUP_SPARSE_DIV = int(os.environ.get("PRCNN_DEDUP_SPARSE_DIV", "4"))  # groups with <= nsample/DIV hits run as flat rows
 
 
 def _channels_last(features):
@@ -165,17 +166,18 @@ class _PointnetSAModuleBase(nn.Module):
                 layers = [mods[0].packed(k_rot=3 if feat_cl is not None else 0)] + [m.packed() for m in mods[1:]]
             if GROUP_DEDUP and not group_all and fused_pool:
                 # Padding-free grouping: a group with fewer than nsample neighbours repeats its first hit, and the max
-                # over copies of a row is the row -- run single-hit groups as ONE row each (no pooling), dense groups as
-                # they are, each list with a device-side length; then scatter both back.  Same bits, far fewer rows.
-                sp = ops.GroupSplit(idxs[i], new_xyz, N)
+                # over copies of a row is the row -- sparse groups contribute only their real rows to one flat row list
+                # (segmented max afterwards), dense groups run as they are, each list with a device-side length.
+                # Same bits, far fewer rows.
+                sp = ops.GroupSplit(idxs[i], new_xyz, N, max(1, ns // DEDUP_SPARSE_DIV))
                 xyz_f = xyz.view(1, B * N, 3)
                 src_f = None if src is None else _flatten_frames(src)
-                t1 = torch.empty((sp.G, c_outs[i]), dtype=torch.float32, device=xyz.device)
+                t1 = torch.empty((sp.max_rows, c_outs[i]), dtype=torch.float32, device=xyz.device)
                 tn = torch.empty((sp.G, c_outs[i]), dtype=torch.float32, device=xyz.device)
-                _run_scale(xyz_f, sp.nx1, sp.idx1, src_f, layers, act, (t1, 0), 1, False, sp.count1)
-                _run_scale(xyz_f, sp.nxn, sp.idxn, src_f, layers, act, (tn, 0), ns, True, sp.countn)
-                ops.scatter_rows(t1, sp.list1, sp.count1, dst[0], col)
-                ops.scatter_rows(tn, sp.listn, sp.countn, dst[0], col)
+                _run_scale(xyz_f, sp.rnx, sp.ridx, src_f, layers, act, (t1, 0), 1, False, sp.rows)
+                _run_scale(xyz_f, sp.nxn, sp.idxn, src_f, layers, act, (tn, 0), ns, True, sp.count_dense)
+                ops.segmax_scatter(t1, sp, dst[0], col)
+                ops.scatter_rows(tn, sp.listn, sp.count_dense, dst[0], col)
             else:
                 x = _run_scale(xyz, ctr, idxs[i], src, layers, act, dst if fused_pool else None, ns, fused_pool, None)
                 if not fused_pool:

@@ -605,27 +605,39 @@ def kitti_statistics(overlaps, ov_off, gt_datas, gt_off, dt_datas, dt_off, ign_g
 # ---------------------------------------------------------------------------------------------------------
 # padding-free grouping (csrc/dedup.hip)
 # ---------------------------------------------------------------------------------------------------------
-class GroupSplit:
-    """The G = B*M groups of one ball query split on the device into singles (one real row) and multis (see
-    prcnn_group_compact).  All tensors are worst-case sized; counts (2,) int32 holds the list lengths."""
+_split_log = None      # bench.py's instrumented pass sets this to a list to read the device-side list lengths afterwards
 
-    def __init__(self, idx, new_xyz, N):
+
+class GroupSplit:
+    """The G = B*M groups of one ball query split on the device (prcnn_group_compact) into a flat list of the real rows of
+    the sparse groups (at most sparse_max hits) and the list of dense groups.  All tensors are worst-case sized; counts
+    (3,) int32 holds [flat rows, dense groups, sparse groups]."""
+
+    def __init__(self, idx, new_xyz, N, sparse_max):
         _chk(idx, "idx", _INT, 3)
         _chk(new_xyz, "new_xyz", ndim=3)
         B, M, ns = idx.shape
         G, dev = B * M, idx.device
-        self.G, self.ns = G, ns
-        self.idx1 = torch.empty((1, G, 1), dtype=_INT, device=dev)
-        self.nx1 = torch.empty((1, G, 3), dtype=_F32, device=dev)
-        self.list1 = torch.empty((G,), dtype=_INT, device=dev)
-        self.idxn = torch.empty((1, G, ns), dtype=_INT, device=dev)
-        self.nxn = torch.empty((1, G, 3), dtype=_F32, device=dev)
-        self.listn = torch.empty((G,), dtype=_INT, device=dev)
-        self.counts = torch.empty((2,), dtype=_INT, device=dev)
-        _cabi.check(_cabi.lib().prcnn_group_compact(_p(idx), _p(new_xyz), B, N, M, ns, _p(self.idx1), _p(self.nx1), _p(self.list1),
-                                                    _p(self.idxn), _p(self.nxn), _p(self.listn), _p(self.counts), _stream()),
-                    "prcnn_group_compact")
-        self.count1, self.countn = self.counts[0:1], self.counts[1:2]
+        T = max(1, min(int(sparse_max), ns))
+        self.G, self.ns, self.max_rows = G, ns, G * T
+        e = lambda shape, dt=_INT: torch.empty(shape, dtype=dt, device=dev)      # noqa: E731
+        self.ridx, self.rnx = e((1, G * T, 1)), e((1, G * T, 3), _F32)
+        self.slist, self.soff, self.scnt = e((G,)), e((G,)), e((G,))
+        self.idxn, self.nxn, self.listn = e((1, G, ns)), e((1, G, 3), _F32), e((G,))
+        self.counts = e((3,))
+        _cabi.check(_cabi.lib().prcnn_group_compact(_p(idx), _p(new_xyz), B, N, M, ns, T, _p(self.ridx), _p(self.rnx), _p(self.slist),
+                                                    _p(self.soff), _p(self.scnt), _p(self.idxn), _p(self.nxn), _p(self.listn),
+                                                    _p(self.counts), _stream()), "prcnn_group_compact")
+        self.rows, self.count_dense, self.count_sparse = self.counts[0:1], self.counts[1:2], self.counts[2:3]
+        if _split_log is not None:
+            _split_log.append(self)
+
+
+def segmax_scatter(src, sp, dst, col_off):
+    """dst[g, col_off : col_off + C] = max over the flat result rows of every sparse group g of the GroupSplit sp"""
+    C = src.shape[-1]
+    _cabi.check(_cabi.lib().prcnn_segmax_scatter(_p(src), src.stride(-2), _p(sp.slist), _p(sp.soff), _p(sp.scnt), _p(sp.count_sparse),
+                                                 sp.G, C, _p(dst), dst.stride(-2), int(col_off), _stream()), "prcnn_segmax_scatter")
 
 
 def scatter_rows(src, rows_list, count, dst, col_off):

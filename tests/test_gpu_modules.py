@@ -223,11 +223,13 @@ def test_rpn_backward_composed_path(dev):
     assert feat.grad is not None and torch.isfinite(feat.grad).all() and float(feat.grad.abs().sum()) > 0
 
 
+@pytest.mark.parametrize("div", [1, 4, 32])
 @pytest.mark.parametrize("cloud", ["sparse", "dense", "mixed"])
-def test_sa_padding_free_grouping_is_bit_identical(dev, cloud):
-    """PRCNN_GROUP_DEDUP (csrc/dedup.hip): single-hit groups run as one row, dense groups with all their rows -- the
-    level's output must not change by one bit.  sparse: nearly every group is a single; dense: none; mixed: both
-    lists populated (and the MSG level's two radii split differently)."""
+def test_sa_padding_free_grouping_is_bit_identical(dev, cloud, div):
+    """PRCNN_GROUP_DEDUP (csrc/dedup.hip): sparse groups (<= nsample/div hits) run as their real rows only, dense
+    groups with all their rows -- the level's output must not change by one bit.  sparse cloud: nearly every group has
+    one hit; dense: all full; mixed: both lists populated (and the MSG level's two radii split differently).
+    div 1 = every group through the flat list, 32 = only single-hit groups."""
     from pointnet2_lib.pointnet2 import pointnet2_modules as pm
     from pointrcnn_amd.rpn import randomize_bn_stats
     torch.manual_seed(7)
@@ -245,29 +247,43 @@ def test_sa_padding_free_grouping_is_bit_identical(dev, cloud):
         feat = torch.randn(B, cin, N, device=dev) if cin else None
         outs = {}
         for flag in (False, True):
-            pm.GROUP_DEDUP = flag
+            pm.GROUP_DEDUP, keep = flag, pm.DEDUP_SPARSE_DIV
+            pm.DEDUP_SPARSE_DIV = div
             try:
                 with torch.no_grad():
                     outs[flag] = mod(xyz, feat)[1].clone()
             finally:
-                pm.GROUP_DEDUP = True
+                pm.GROUP_DEDUP, pm.DEDUP_SPARSE_DIV = True, keep
         assert torch.equal(outs[False], outs[True]), (cloud, mlps)
 
 
-def test_group_compact_lists(dev):
-    """prcnn_group_compact: every group lands in exactly one list, singles carry their one global point index"""
+@pytest.mark.parametrize("smax", [1, 4, 16])
+def test_group_compact_lists(dev, smax):
+    """prcnn_group_compact: every group lands in exactly one list; sparse groups own cnt consecutive flat rows holding
+    their real hits (global point indices) and their centroid; dense groups keep all nsample rows"""
     from pointrcnn_amd import ops
     B, N, M, ns = 2, 4000, 700, 16
-    xyz = T(kitti_cloud(B, N, seed=3), dev)
+    pts = kitti_cloud(B, N, seed=3)
+    pts[:, : N // 2] *= 0.25                              # half the points 16x denser: full groups next to single-hit ones
+    xyz = T(pts, dev)
     new_xyz = ops.gather_rows(xyz, ops.furthest_point_sample(xyz, M))
-    idx = ops.ball_query(1.0, ns, xyz, new_xyz)
-    sp = ops.GroupSplit(idx, new_xyz, N)
-    c1, cn = (int(v) for v in sp.counts.cpu())
-    assert c1 + cn == B * M and c1 > 0 and cn > 0
+    idx = ops.ball_query(1.2, ns, xyz, new_xyz)
+    sp = ops.GroupSplit(idx, new_xyz, N, smax)
+    rows, cd, cs = (int(v) for v in sp.counts.cpu())
     idx_c = idx.cpu().numpy().reshape(B * M, ns)
-    single = (idx_c[:, 1:] == idx_c[:, :1]).all(1)
-    l1, ln = sp.list1[:c1].cpu().numpy(), sp.listn[:cn].cpu().numpy()
-    assert np.array_equal(np.sort(l1), np.nonzero(single)[0]) and np.array_equal(np.sort(ln), np.nonzero(~single)[0])
-    assert np.array_equal(sp.idx1.view(-1)[:c1].cpu().numpy(), (l1 // M) * N + idx_c[l1, 0])
-    assert np.array_equal(sp.idxn.view(-1, ns)[:cn].cpu().numpy(), (ln // M)[:, None] * N + idx_c[ln])
-    assert torch.equal(sp.nx1.view(-1, 3)[:c1], new_xyz.view(-1, 3)[sp.list1[:c1].long()])
+    cnt = np.array([ns if not (r[1:] == r[0]).any() else 1 + int(np.argmax(r[1:] == r[0])) for r in idx_c])
+    sparse = cnt <= smax
+    assert cs == sparse.sum() and cd == (~sparse).sum() and rows == cnt[sparse].sum() and cs > 0 and (cd > 0 or smax == ns)
+    sl, so, sc = (t[:cs].cpu().numpy() for t in (sp.slist, sp.soff, sp.scnt))
+    ln = sp.listn[:cd].cpu().numpy()
+    assert np.array_equal(np.sort(sl), np.nonzero(sparse)[0]) and np.array_equal(np.sort(ln), np.nonzero(~sparse)[0])
+    assert np.array_equal(sc, cnt[sl])
+    order = np.argsort(so)
+    assert so[order][0] == 0 and np.array_equal(so[order][1:], np.cumsum(sc[order])[:-1])       # a partition of the flat rows
+    ridx, rnx, nx = sp.ridx.view(-1).cpu().numpy(), sp.rnx.view(-1, 3).cpu().numpy(), new_xyz.view(-1, 3).cpu().numpy()
+    for j in range(0, cs, 7):
+        g = sl[j]
+        assert np.array_equal(ridx[so[j]:so[j] + sc[j]], (g // M) * N + idx_c[g, :sc[j]])
+        assert np.array_equal(rnx[so[j]:so[j] + sc[j]], np.repeat(nx[g][None], sc[j], 0))
+    assert np.array_equal(sp.idxn.view(-1, ns)[:cd].cpu().numpy(), (ln // M)[:, None] * N + idx_c[ln])
+    assert torch.equal(sp.nxn.view(-1, 3)[:cd], new_xyz.view(-1, 3)[sp.listn[:cd].long()])
