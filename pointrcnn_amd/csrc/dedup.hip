@@ -36,17 +36,38 @@ struct CompactParams {
     int G, N, M, ns, T;
 };
 
-__global__ __launch_bounds__(256) void group_compact_kernel(CompactParams P) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
+constexpr int COMPACT_THREADS = 1024;
+
+// NS > 0: nsample known at compile time (a multiple of 4) -- the group's index row is fetched with 16-byte loads, all in
+// flight at once, instead of a dependent scalar walk
+template <int NS>
+__global__ __launch_bounds__(COMPACT_THREADS) void group_compact_kernel(CompactParams P) {
+    const int g = blockIdx.x * COMPACT_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool ok = g < P.G;
+    const int ns = NS > 0 ? NS : P.ns;
     int cnt = 0, first = 0;
-    const int32_t* row = P.idx + (size_t)(ok ? g : 0) * P.ns;
+    const int32_t* row = P.idx + (size_t)(ok ? g : 0) * ns;
     if (ok) {
-        first = row[0];
-        cnt = P.ns;
-        for (int s = 1; s < P.ns; s++)
-            if (row[s] == first) { cnt = s; break; }          // real hits are strictly ascending: a repeat of idx[0] is padding
+        if constexpr (NS > 0) {
+            int4 v[NS / 4];
+#pragma unroll
+            for (int q = 0; q < NS / 4; q++) v[q] = reinterpret_cast<const int4*>(row)[q];
+            first = v[0].x;
+            cnt = NS;
+#pragma unroll
+            for (int q = NS / 4 - 1; q >= 0; q--) {          // downwards: the smallest repeat position wins
+                if (v[q].w == first) cnt = 4 * q + 3;
+                if (v[q].z == first) cnt = 4 * q + 2;
+                if (v[q].y == first) cnt = 4 * q + 1;
+                if (q > 0 && v[q].x == first) cnt = 4 * q;
+            }
+        } else {
+            first = row[0];
+            cnt = ns;
+            for (int s = 1; s < ns; s++)
+                if (row[s] == first) { cnt = s; break; }      // real hits are strictly ascending: a repeat of idx[0] is padding
+        }
     }
     const int b = (ok ? g : 0) / P.M;
     const bool sparse = ok && cnt <= P.T, dense = ok && cnt > P.T;
@@ -60,14 +81,20 @@ __global__ __launch_bounds__(256) void group_compact_kernel(CompactParams P) {
     }
     const int total = __shfl(incl, 63);
     const unsigned long long bs = __ballot(sparse), bd = __ballot(dense);
-    int base_rows = 0, base_s = 0, base_d = 0;
-    if (lane == 0) {
-        if (total > 0) { base_rows = atomicAdd(P.counts, total); base_s = atomicAdd(P.counts + 2, (int)__popcll(bs)); }
-        if (bd != 0ULL) base_d = atomicAdd(P.counts + 1, (int)__popcll(bd));
+    // one atomic per BLOCK and list (same-address atomics serialise in L2: per-wave appends made this kernel latency-bound)
+    __shared__ int wsum[COMPACT_THREADS / 64][3];
+    __shared__ int bbase[3];
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) { wsum[wave][0] = total; wsum[wave][1] = (int)__popcll(bd); wsum[wave][2] = (int)__popcll(bs); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int t = 0;
+        for (int w = 0; w < COMPACT_THREADS / 64; w++) t += wsum[w][threadIdx.x];
+        bbase[threadIdx.x] = t > 0 ? atomicAdd(P.counts + threadIdx.x, t) : 0;
     }
-    base_rows = __builtin_amdgcn_readfirstlane(base_rows);
-    base_s = __builtin_amdgcn_readfirstlane(base_s);
-    base_d = __builtin_amdgcn_readfirstlane(base_d);
+    __syncthreads();
+    int base_rows = bbase[0], base_d = bbase[1], base_s = bbase[2];
+    for (int w = 0; w < wave; w++) { base_rows += wsum[w][0]; base_d += wsum[w][1]; base_s += wsum[w][2]; }
     const unsigned long long below = (1ULL << lane) - 1ULL;
     float c3[3] = {0.f, 0.f, 0.f};
     if (ok) {
@@ -86,7 +113,7 @@ __global__ __launch_bounds__(256) void group_compact_kernel(CompactParams P) {
     if (dense) {
         const int pn = base_d + (int)__popcll(bd & below);
         P.listn[pn] = g;
-        for (int s = 0; s < P.ns; s++) P.idxn[(size_t)pn * P.ns + s] = b * P.N + row[s];
+        for (int s = 0; s < ns; s++) P.idxn[(size_t)pn * ns + s] = b * P.N + row[s];
 #pragma unroll
         for (int c = 0; c < 3; c++) P.nxn[(size_t)pn * 3 + c] = c3[c];
     }
@@ -135,7 +162,12 @@ PRCNN_API int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int 
     P.idx = idx; P.new_xyz = new_xyz; P.ridx = ridx; P.rnx = rnx; P.slist = slist; P.soff = soff; P.scnt = scnt;
     P.idxn = idxn; P.nxn = nxn; P.listn = listn;
     P.counts = counts; P.G = B * M; P.N = N; P.M = M; P.ns = nsample; P.T = sparse_max;
-    hipLaunchKernelGGL(group_compact_kernel, dim3(prcnn_divup(P.G, 256)), dim3(256), 0, s, P);
+    const dim3 grid(prcnn_divup(P.G, COMPACT_THREADS));
+    const bool vec = ((uintptr_t)idx % 16) == 0;
+    if (vec && nsample == 16) hipLaunchKernelGGL(group_compact_kernel<16>, grid, dim3(COMPACT_THREADS), 0, s, P);
+    else if (vec && nsample == 32) hipLaunchKernelGGL(group_compact_kernel<32>, grid, dim3(COMPACT_THREADS), 0, s, P);
+    else if (vec && nsample == 64) hipLaunchKernelGGL(group_compact_kernel<64>, grid, dim3(COMPACT_THREADS), 0, s, P);
+    else hipLaunchKernelGGL(group_compact_kernel<0>, grid, dim3(COMPACT_THREADS), 0, s, P);
     PRCNN_LAUNCH_CHECK("prcnn_group_compact");
     return PRCNN_OK;
 }

@@ -1192,7 +1192,8 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     P.NB = (P.Nout + 31) / 32;
     // >= 97 output channels: 128x128 workgroup tile -- unless that leaves most of the 256 CUs without a workgroup
     // (few rows, e.g. FP3's 2048 known points): then the 128x64 tile doubles the number of workgroups
-    const bool wide = P.NB >= 4 && (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4) >= 192;
+    // (a device-side row count means a compacted list: P.rows is its worst case, the live part is expected to be small)
+    const bool wide = P.NB >= 4 && !P.rows_dev && (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4) >= 192;
     dim3 grid(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, wide ? 4 : 2));
 #define MLP_LAUNCH(M)                                                                                         \
     do {                                                                                                      \

@@ -257,12 +257,13 @@ def test_sa_padding_free_grouping_is_bit_identical(dev, cloud, div):
         assert torch.equal(outs[False], outs[True]), (cloud, mlps)
 
 
-@pytest.mark.parametrize("smax", [1, 4, 16])
-def test_group_compact_lists(dev, smax):
+@pytest.mark.parametrize("ns", [16, 12, 32])
+@pytest.mark.parametrize("smax", [1, 4, 12])
+def test_group_compact_lists(dev, smax, ns):
     """prcnn_group_compact: every group lands in exactly one list; sparse groups own cnt consecutive flat rows holding
     their real hits (global point indices) and their centroid; dense groups keep all nsample rows"""
     from pointrcnn_amd import ops
-    B, N, M, ns = 2, 4000, 700, 16
+    B, N, M = 2, 4000, 700
     pts = kitti_cloud(B, N, seed=3)
     pts[:, : N // 2] *= 0.25                              # half the points 16x denser: full groups next to single-hit ones
     xyz = T(pts, dev)

@@ -22,20 +22,25 @@ with torch.no_grad():
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
+    from pointrcnn_amd import ops
     prof = bench.EventProfiler(_cabi._lib)
     real = _cabi._lib
-    _cabi._lib = prof
-    raw = []
-    orig_getattr = bench.EventProfiler.__getattr__
+    _cabi._lib, ops._split_log = prof, prof.splits
     try:
         fn()
     finally:
-        _cabi._lib = real
+        _cabi._lib, ops._split_log = real, None
 torch.cuda.synchronize()
+counts = {}
+for sp in prof.splits:
+    for k, v in enumerate(sp.counts.cpu().tolist()):
+        counts[sp.counts.data_ptr() + 4 * k] = v
 tot = 0.0
-for name, s, e, fl in prof.records:
+for name, s, e, (per_row, rows, ptr, unit) in prof.records:
     ms = s.elapsed_time(e)
     tot += ms
+    live = min(rows, counts[ptr] * unit) if ptr else rows
+    fl = per_row * live
     if name.startswith("prcnn_mlp") or ms > 0.05:
-        print("%-28s %8.1f us  %7.2f GFLOP  %6.1f TF/s" % (name[6:], ms * 1e3, fl / 1e9, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
+        print("%-28s %8.1f us  rows %8d / %8d  %6.0f flop/row %7.2f GFLOP  %6.1f TF/s" % (name[6:], ms * 1e3, live, rows, per_row, fl / 1e9, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
 print("total %.2f ms" % tot)
