@@ -31,7 +31,7 @@ def main():
     assert [d["name"] for d in f] == [d["name"] for d in w], "dispatch order differs between the two passes"
     fam = collections.OrderedDict()
     for a, b in zip(f, w):
-        key = "mlp" if a["name"].startswith("mlp_") else a["name"].split("<")[0]
+        key = "mlp" if a["name"].startswith(("mlp_", "sa_xyz_chain")) else a["name"].split("<")[0]
         d = fam.setdefault(key, {"launches": 0, "fetch": 0.0, "write": 0.0})
         d["launches"] += 1
         d["fetch"] += a["v"]
