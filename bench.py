@@ -26,7 +26,11 @@ import os
 import sys
 import time
 
-import torch
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue
+# serialise: with the default, a 4th in-flight batch doubled the step time.  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -39,14 +43,15 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96,
-                    help="timed steps; with 3 batches in flight the first/last ~2 steps fill and drain the pipeline (one batch's "
-                         "latency is ~11 ms), so short runs under-report the steady state by a few percent")
-    ap.add_argument("--warmup", type=int, default=6)
+                    help="timed steps; with 8 batches in flight the first/last steps fill and drain the pipeline (one batch's "
+                         "latency is ~25 ms under load), so short runs under-report the steady state by a few percent")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (BASELINE metric: bs32)")
     ap.add_argument("--npoints", type=int, default=16384)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the step from a hipGraph")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="batches in flight per GPU: step k runs on HIP stream k %% streams, so one batch's FPS "
+    ap.add_argument("--streams", type=int, default=8,
+                    help="batches in flight per GPU (each on its own HIP stream AND hardware queue, see GPU_MAX_HW_QUEUES "
+                         "above): step k runs on HIP stream k %% streams, so one batch's FPS "
                          "(1 workgroup per frame = 32 of 256 CUs) overlaps another batch's MLP / neighbour kernels")
     ap.add_argument("--proposals", choices=["off", "normal", "rotate"], default="normal",
                     help="also run the proposal layer (decode + sort + distance split + NMS + top-100, lib/rpn/proposal_layer.py) "
@@ -310,6 +315,7 @@ def main():
                     "rotated NMS, tools/cfgs/default.yaml, %d pts/frame, batch %d per GPU, random-init weights" % (args.npoints, args.batch)),
                    "frames_per_gpu": args.batch, "npoints": args.npoints, "parallelism": "frames sharded, dp%d" % world,
                    "launch": "hipGraph replay" if graph is not None else "eager", "streams": nstreams,
+                   "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "proposal_layer": args.proposals,
                    "inputs": "host (pinned) -> HBM copy inside the timed region" if args.h2d else "resident in HBM",
                    "clouds": args.clouds, "group_dedup": os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"},
