@@ -65,6 +65,11 @@ def parse():
     ap.add_argument("--h2d", action="store_true",
                     help="also copy every batch's clouds from pinned host memory inside the timed region (PCIe-inclusive rate; "
                          "the default keeps inputs resident in HBM, as the bench contract asks)")
+    ap.add_argument("--input", choices=["clouds", "raw"], default="clouds",
+                    help="clouds = prepared (npoints,3) clouds resident in HBM (the bench contract); raw = every step starts from "
+                         "raw velodyne scans (~118k points x 16 B per frame) in pinned host memory: H2D copy + the on-device input "
+                         "builder (prcnn_scene_prepare: lidar->rect, image/range crop, 16384-point draw) inside the timed region")
+    ap.add_argument("--raw-points", type=int, default=118000, help="raw points per synthetic scan for --input raw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -227,6 +232,21 @@ def main():
                                                           seed0=100 + (world * s_ + rank) * args.batch).to(dev)})
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
 
+    raw_slots = None
+    if args.input == "raw":
+        # one packed batch of synthetic scans per in-flight slot: pinned on the host, preallocated on the device
+        import numpy as np
+        from pointrcnn_amd import kitti_input, ops as _pops
+        calib0 = kitti_input.Calibration.from_text(kitti_input.KITTI_CALIB_TXT)
+        prep = kitti_input.ScenePreparer(npoints=args.npoints, device=dev)
+        raw_slots = []
+        for s_ in range(nstreams):
+            scans = [kitti_input.synthetic_scan(args.raw_points - 37 * f, seed=1000 + (world * s_ + rank) * args.batch + f, fov_frac=0.2,
+                                                far_frac=0.1) for f in range(args.batch)]
+            host_pack = prep.pack(scans, [calib0] * args.batch, [(375, 1242)] * args.batch)
+            raw_slots.append({"host": host_pack, "dev": {k: host_pack[k].to(dev) for k in ("raw", "offsets", "calib", "img_hw")},
+                              "max_points": host_pack["max_points"], "seed": 17 + s_})
+
     proposal_layer = None
     if args.proposals != "off":
         from pointrcnn_amd.proposal_layer import ProposalConfig, ProposalLayer
@@ -234,7 +254,13 @@ def main():
 
     def step(slot=0):
         with torch.no_grad():
-            o = model(batches[slot])
+            if raw_slots is not None:
+                r = raw_slots[slot]
+                xyz, _, _, _, r["status"] = _pops.scene_prepare(r["dev"]["raw"], r["dev"]["offsets"], r["max_points"], r["dev"]["calib"],
+                                                                r["dev"]["img_hw"], prep.scope, args.npoints, r["seed"])
+                o = model({"pts_input": xyz})
+            else:
+                o = model(batches[slot])
             if proposal_layer is not None:
                 o["rois"], o["roi_scores_raw"] = proposal_layer(o["rpn_cls"][:, :, 0], o["rpn_reg"], o["backbone_xyz"])
             if args.workload == "rcnn":
@@ -277,6 +303,8 @@ def main():
         with torch.cuda.stream(streams[slot]):
             if host is not None:
                 batches[slot]["pts_input"].copy_(host[slot], non_blocking=True)
+            if raw_slots is not None:
+                raw_slots[slot]["dev"]["raw"].copy_(raw_slots[slot]["host"]["raw"], non_blocking=True)
             if graphs is not None:
                 graphs[slot].replay()
             else:
@@ -317,7 +345,9 @@ def main():
                    "launch": "hipGraph replay" if graph is not None else "eager", "streams": nstreams,
                    "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "proposal_layer": args.proposals,
-                   "inputs": "host (pinned) -> HBM copy inside the timed region" if args.h2d else "resident in HBM",
+                   "inputs": ("raw velodyne scans (%d pts x 16 B per frame) in pinned host memory -> H2D -> prcnn_scene_prepare, all inside "
+                              "the timed region" % args.raw_points) if args.input == "raw" else
+                             ("host (pinned) -> HBM copy inside the timed region" if args.h2d else "resident in HBM"),
                    "clouds": args.clouds, "group_dedup": os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"},
     }
 
@@ -369,8 +399,25 @@ def main():
                                   "Gevals_per_s": round(evals / (fam["fps"]["ms"] / nprof * 1e-3) / 1e9, 1),
                                   "note": "serial chain, 1 workgroup/frame (32 of 256 CUs); hidden by --streams"}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "rpn":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "rpn" and args.input == "clouds":
         line["cpu_baseline"] = cpu_baseline(model, clouds_cpu, out)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and raw_slots is not None:
+        # the input builder's CPU oracle (one thread) on the first frames of slot 0, and a bit-for-bit check of the GPU rows
+        import oracle
+        hp = raw_slots[0]["host"]
+        nf = min(4, args.batch)
+        off = hp["offsets"].numpy()[:nf + 1]
+        t1 = time.perf_counter()
+        ref = oracle.scene_prepare(hp["raw"].numpy()[:off[-1]], off, hp["calib"].numpy()[:nf], hp["img_hw"].numpy()[:nf], prep.scope,
+                                   args.npoints, raw_slots[0]["seed"])
+        dt = time.perf_counter() - t1
+        with torch.no_grad():
+            got = _pops.scene_prepare(raw_slots[0]["dev"]["raw"], raw_slots[0]["dev"]["offsets"], raw_slots[0]["max_points"],
+                                      raw_slots[0]["dev"]["calib"], raw_slots[0]["dev"]["img_hw"], prep.scope, args.npoints, raw_slots[0]["seed"])
+        line["cpu_baseline"] = {"value": round(nf / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                                "sample": "%d raw scans through oracle scene_prepare (input builder only), %.2f s" % (nf, dt),
+                                "gpu_rows_identical": bool(np.array_equal(got[0][:nf].cpu().numpy(), ref[0]) and
+                                                           np.array_equal(got[2][:nf].cpu().numpy(), ref[2]))}
 
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -345,6 +345,29 @@ int prcnn_segmax_scatter(const float* src, int ld_src, const int32_t* list, cons
 int prcnn_scatter_rows(const float* src, int ld_src, const int32_t* list, const int32_t* count, int max_rows, int C, float* dst,
                        int ld_dst, int col_off, prcnn_stream_t stream);
 
+/* ======================================================================================================
+ * RPN input builder (scene.hip) -- SURVEY 8(f) rank 4.  Replaces the inference branch of
+ * lib/datasets/kitti_rcnn_dataset.py:246-310 (get_rpn_sample): calibration.py:51-70 lidar_to_rect + rect_to_img,
+ * get_valid_flag (kitti_rcnn_dataset.py:198-219), mask compaction and the npoints sampling of :285-306, for a whole batch.
+ *   raw      (total_points, 4) f32 device: the frames' velodyne scans [x y z intensity] back to back (kitti_dataset.py:40-43)
+ *   offsets  (B+1) i64 device: first raw point of every frame; max_points_per_frame: host-known bound on the frame sizes
+ *   calib    (B, 24) f32 device: M = V2C^T . R0^T (4x3 row-major, calibration.py:57) then P2 (3x4 row-major)
+ *   img_hw   (B, 2) i32 device: image height, width (kitti_dataset.py:34-39)
+ *   scope    6 doubles on the HOST [x0 x1 y0 y1 z0 z1] = cfg.PC_AREA_SCOPE, or NULL (cfg.PC_REDUCE_BY_RANGE false)
+ *   out_xyz (B, npoints, 3), out_intensity (B, npoints) = intensity - 0.5, out_src (B, npoints) raw index of every row,
+ *   nvalid (B) number of valid points, status (B): 0 ok; 1 = the reference raises for this frame (more than npoints
+ *   far points, or fewer than npoints/2 valid ones) -- rows are still produced; 2 = no valid point (rows zero, src -1).
+ * Every point at rect depth >= 40 m is kept, the rest drawn without replacement, the result shuffled; short frames are
+ * topped up with a draw without replacement from themselves.  The draw uses a counter-based generator keyed by
+ * (seed, frame, raw index) -- see scene.hip -- so results are reproducible and independent of launch geometry
+ * (the reference uses numpy's unseeded global stream).  npoints <= 16384.
+ * ====================================================================================================== */
+size_t prcnn_scene_workspace_bytes(int64_t total_points, int B);
+int prcnn_scene_prepare(const float* raw, const int64_t* offsets, int B, int64_t total_points, int max_points_per_frame,
+                        const float* calib, const int32_t* img_hw, const double* scope, int npoints, uint32_t seed,
+                        float* out_xyz, float* out_intensity, int32_t* out_src, int32_t* nvalid, int32_t* status,
+                        void* workspace, size_t workspace_bytes, prcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -300,6 +300,31 @@ class _Ref:
         return pp, pf, empty
 
 
+def scene_project(raw, calib24, H, W, scope):
+    """oracle of calibration.py:51-70 + get_valid_flag for one frame -> rect (n,3), img (n,2), depth (n), flag (n) bool"""
+    lib = cpu().lib
+    raw, calib24 = _f32(raw), _f32(calib24)
+    n = raw.shape[0]
+    rect, img, depth, flag = np.zeros((n, 3), np.float32), np.zeros((n, 2), np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    sc = None if scope is None else (ctypes.c_double * 6)(*[float(v) for v in scope])
+    lib.prcnn_cpu_scene_project(_p(raw, _F), n, _p(calib24, _F), int(H), int(W), sc, _p(rect, _F), _p(img, _F), _p(depth, _F), _p(flag, _I))
+    return rect, img, depth, flag.astype(bool)
+
+
+def scene_prepare(raw, offsets, calib, img_hw, scope, npoints, seed):
+    """oracle of prcnn_scene_prepare -> xyz (B,npoints,3), intensity (B,npoints), src (B,npoints), nvalid (B), status (B)"""
+    lib = cpu().lib
+    raw, calib, img_hw = _f32(raw), _f32(calib), _i32(img_hw)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    B = len(offsets) - 1
+    xyz, inten = np.zeros((B, npoints, 3), np.float32), np.zeros((B, npoints), np.float32)
+    src, nvalid, status = np.zeros((B, npoints), np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+    sc = None if scope is None else (ctypes.c_double * 6)(*[float(v) for v in scope])
+    lib.prcnn_cpu_scene_prepare(_p(raw, _F), _p(offsets, _L), B, _p(calib, _F), _p(img_hw, _I), sc, int(npoints),
+                                ctypes.c_uint32(int(seed) & 0xFFFFFFFF), _p(xyz, _F), _p(inten, _F), _p(src, _I), _p(nvalid, _I), _p(status, _I))
+    return xyz, inten, src, nvalid, status
+
+
 class KittiBackend:
     """compute backend for pointrcnn_amd.kitti_eval running on the CPU oracle (tests only)"""
 

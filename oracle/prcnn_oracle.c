@@ -965,3 +965,111 @@ PRCNN_EXPORT void prcnn_cpu_kitti_statistics(const double* overlaps, const int64
                               dc + (size_t)dc_off[f] * 4, dc_off[f + 1] - dc_off[f], metric, min_overlap, thresholds[t], compute_fp,
                               compute_aos, res + ((size_t)f * T + t) * 4, (matched && t == 0) ? matched + gt_off[f] : NULL);
 }
+
+/* ===================================================================================================
+ * RPN input builder -- restates, per frame, the inference branch of
+ * lib/datasets/kitti_rcnn_dataset.py:246-310 with lib/utils/calibration.py:51-70 and get_valid_flag (:198-219).
+ * PINNED (deterministic part) against the reference's own Python run in the build container: tests/golden/ref_scene.py
+ * -> tests/golden/scene_ref.npz (rect / image coordinates within fp32 rounding of the BLAS sgemm the reference calls,
+ * valid flags identical away from the crop boundaries).  The random draw is RE-SPECIFIED (the reference uses numpy's
+ * unseeded global Mersenne-Twister stream): see the contract in pointrcnn_amd/csrc/scene.hip, restated here.
+ * =================================================================================================== */
+static uint32_t scene_mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+static uint32_t scene_rand(uint32_t seed, uint32_t stream, uint32_t frame, uint32_t i) {
+    return scene_mix(i ^ scene_mix(frame * 0x9E3779B9U + scene_mix(seed + stream * 0x85EBCA6BU)));
+}
+
+/* calibration.py:51-70 + kitti_rcnn_dataset.py:198-219 for n points of one frame.
+ * calib: M (4x3 row-major = V2C^T . R0^T, calibration.py:57) then P2 (3x4).  scope: 6 doubles or NULL. */
+PRCNN_EXPORT void prcnn_cpu_scene_project(const float* raw, int n, const float* calib, int H, int W, const double* scope,
+                                          float* rect, float* img, float* depth, int32_t* flag) {
+    const float* c = calib;
+    const float* P = calib + 12;
+    for (int i = 0; i < n; i++) {
+        const float x = raw[i * 4], y = raw[i * 4 + 1], z = raw[i * 4 + 2];
+        float r[3];
+        for (int a = 0; a < 3; a++) r[a] = ((x * c[a] + y * c[3 + a]) + z * c[6 + a]) + c[9 + a];     /* calibration.py:56-57 */
+        float h[3];
+        for (int a = 0; a < 3; a++) h[a] = ((r[0] * P[a * 4] + r[1] * P[a * 4 + 1]) + r[2] * P[a * 4 + 2]) + P[a * 4 + 3];   /* :66-67 */
+        const float u = h[0] / r[2], v = h[1] / r[2];      /* :68 divides by the RECT z */
+        const float d = h[2] - P[11];                      /* :69 */
+        int ok = (u >= 0.f) && (u < (float)W) && (v >= 0.f) && (v < (float)H) && (d >= 0.f);            /* :207-210 */
+        if (scope)                                          /* :212-218, float32 vs double bounds compare in double */
+            ok = ok && ((double)r[0] >= scope[0]) && ((double)r[0] <= scope[1]) && ((double)r[1] >= scope[2]) &&
+                 ((double)r[1] <= scope[3]) && ((double)r[2] >= scope[4]) && ((double)r[2] <= scope[5]);
+        if (rect) { rect[i * 3] = r[0]; rect[i * 3 + 1] = r[1]; rect[i * 3 + 2] = r[2]; }
+        if (img) { img[i * 2] = u; img[i * 2 + 1] = v; }
+        if (depth) depth[i] = d;
+        flag[i] = ok;
+    }
+}
+
+typedef struct { uint64_t key; } scene_key;
+static int scene_cmp(const void* a, const void* b) {
+    const uint64_t x = ((const scene_key*)a)->key, y = ((const scene_key*)b)->key;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* kitti_rcnn_dataset.py:285-310 for a batch; the draw per the re-specified contract. */
+PRCNN_EXPORT void prcnn_cpu_scene_prepare(const float* raw, const int64_t* off, int B, const float* calib, const int32_t* img_hw,
+                                          const double* scope, int npoints, uint32_t seed, float* out_xyz, float* out_int,
+                                          int32_t* out_src, int32_t* nvalid, int32_t* status) {
+    for (int b = 0; b < B; b++) {
+        const float* R = raw + off[b] * 4;
+        const int n_raw = (int)(off[b + 1] - off[b]);
+        const float* c = calib + b * 24;
+        float* rect = (float*)malloc((size_t)(n_raw > 0 ? n_raw : 1) * 3 * sizeof(float));
+        int32_t* flag = (int32_t*)malloc((size_t)(n_raw > 0 ? n_raw : 1) * sizeof(int32_t));
+        prcnn_cpu_scene_project(R, n_raw, c, img_hw[b * 2], img_hw[b * 2 + 1], scope, rect, NULL, NULL, flag);
+        int n = 0, f = 0;
+        for (int i = 0; i < n_raw; i++)
+            if (flag[i]) { n++; if (!(rect[i * 3 + 2] < 40.0f)) f++; }           /* :287-288 near = depth < 40.0 */
+        nvalid[b] = n;
+        float* ox = out_xyz + (size_t)b * npoints * 3;
+        float* oi = out_int + (size_t)b * npoints;
+        int32_t* os = out_src + (size_t)b * npoints;
+        if (n == 0) {
+            for (int j = 0; j < npoints; j++) { ox[j * 3] = ox[j * 3 + 1] = ox[j * 3 + 2] = 0.f; oi[j] = 0.f; os[j] = -1; }
+            status[b] = 2;
+            free(rect); free(flag);
+            continue;
+        }
+        int st = 0, k, keep_far, keep_all;
+        if (n > npoints) {                                   /* :286-294 */
+            keep_all = 0;
+            if (f > npoints) { st = 1; keep_far = 0; k = npoints; }
+            else { keep_far = 1; k = npoints - f; }
+        } else {                                             /* :296-301 */
+            keep_all = 1; keep_far = 0;
+            k = npoints - n;
+            if (k > n) { st = 1; k = n; }
+        }
+        /* candidates ordered by (30-bit draw key, raw index): the first k are drawn */
+        scene_key* cand = (scene_key*)malloc((size_t)n * sizeof(scene_key));
+        scene_key* sel = (scene_key*)malloc((size_t)(npoints + 1) * sizeof(scene_key));
+        int nc = 0, ns = 0;
+        for (int i = 0; i < n_raw; i++) {
+            if (!flag[i]) continue;
+            const int far = !(rect[i * 3 + 2] < 40.0f);
+            if (!(keep_far && far)) cand[nc++].key = ((uint64_t)(scene_rand(seed, 0u, (uint32_t)b, (uint32_t)i) >> 2) << 32) | (uint32_t)i;
+            if (keep_all || (keep_far && far)) sel[ns++].key = ((uint64_t)scene_rand(seed, 1u, (uint32_t)b, (uint32_t)i) << 32) | (uint32_t)i;
+        }
+        qsort(cand, (size_t)nc, sizeof(scene_key), scene_cmp);
+        for (int q = 0; q < k && q < nc; q++) {
+            const uint32_t i = (uint32_t)cand[q].key;
+            sel[ns++].key = ((uint64_t)scene_rand(seed, keep_all ? 2u : 1u, (uint32_t)b, i) << 32) | i;
+        }
+        qsort(sel, (size_t)ns, sizeof(scene_key), scene_cmp);          /* the shuffle (:293 / :302) */
+        for (int j = 0; j < npoints; j++) {
+            const uint32_t i = (uint32_t)sel[j < ns ? j : j % ns].key;
+            ox[j * 3] = rect[i * 3]; ox[j * 3 + 1] = rect[i * 3 + 1]; ox[j * 3 + 2] = rect[i * 3 + 2];     /* :304 */
+            oi[j] = R[i * 4 + 3] - 0.5f;                                /* :305 */
+            os[j] = (int32_t)i;
+        }
+        status[b] = st;
+        free(cand); free(sel); free(rect); free(flag);
+    }
+}

@@ -63,6 +63,8 @@ SIGNATURES = {
     "prcnn_group_compact": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prcnn_segmax_scatter": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _P]),
     "prcnn_scatter_rows": (_I, [_P, _I, _P, _P, _I, _I, _P, _I, _I, _P]),
+    "prcnn_scene_workspace_bytes": (_Z, [_L, _I]),
+    "prcnn_scene_prepare": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _I, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "prcnn_nms_batched": (_I, [_P, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
 }
 

@@ -645,3 +645,35 @@ def scatter_rows(src, rows_list, count, dst, col_off):
     C = src.shape[-1]
     _cabi.check(_cabi.lib().prcnn_scatter_rows(_p(src), src.stride(-2), _p(rows_list), _p(count), rows_list.shape[0], C, _p(dst),
                                                dst.stride(-2), int(col_off), _stream()), "prcnn_scatter_rows")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# RPN input builder (csrc/scene.hip)
+# ---------------------------------------------------------------------------------------------------------
+def scene_prepare(raw, offsets, max_points_per_frame, calib, img_hw, scope, npoints, seed):
+    """raw (total,4) f32 scans back to back, offsets (B+1) i64, calib (B,24) f32 [M 4x3 | P2 3x4], img_hw (B,2) i32 -- all on
+    the device; scope: 6 host floats [x0 x1 y0 y1 z0 z1] or None.
+    -> pts_rect (B,npoints,3), intensity - 0.5 (B,npoints), src index (B,npoints) i32, nvalid (B) i32, status (B) i32
+    [lib/datasets/kitti_rcnn_dataset.py:246-310 for a whole batch; see prcnn_scene_prepare]"""
+    _chk(raw, "raw", ndim=2)
+    _chk(calib, "calib", ndim=2)
+    _chk(img_hw, "img_hw", _INT, 2)
+    if offsets.dtype != torch.int64 or not offsets.is_contiguous() or offsets.device != raw.device:
+        raise RuntimeError("offsets must be a contiguous int64 tensor on the device of raw")
+    if raw.shape[1] != 4 or calib.shape[1] != 24 or img_hw.shape[1] != 2:
+        raise RuntimeError("expected raw (total,4), calib (B,24), img_hw (B,2)")
+    B, total, dev = offsets.shape[0] - 1, raw.shape[0], raw.device
+    if calib.shape[0] != B or img_hw.shape[0] != B:
+        raise RuntimeError("calib / img_hw must have one row per frame")
+    L = _cabi.lib()
+    ws = torch.empty((int(L.prcnn_scene_workspace_bytes(total, B)),), dtype=torch.uint8, device=dev)
+    xyz = torch.empty((B, npoints, 3), dtype=_F32, device=dev)
+    inten = torch.empty((B, npoints), dtype=_F32, device=dev)
+    src = torch.empty((B, npoints), dtype=_INT, device=dev)
+    nvalid = torch.empty((B,), dtype=_INT, device=dev)
+    status = torch.empty((B,), dtype=_INT, device=dev)
+    sc = None if scope is None else (ctypes.c_double * 6)(*[float(v) for v in scope])
+    _cabi.check(L.prcnn_scene_prepare(_p(raw), _p(offsets), B, total, int(max_points_per_frame), _p(calib), _p(img_hw), sc, int(npoints),
+                                      int(seed) & 0xFFFFFFFF, _p(xyz), _p(inten), _p(src), _p(nvalid), _p(status), _p(ws), ws.numel(),
+                                      _stream()), "prcnn_scene_prepare")
+    return xyz, inten, src, nvalid, status

@@ -138,3 +138,28 @@ def kitti_annos(nframes, seed=0, with_score=False, gt=None):
                      location=loc, rotation_y=ry, score=r.uniform(0.05, 1.0, n))
         annos.append(a)
     return annos
+
+
+# ---- RPN input builder ------------------------------------------------------------------
+from pointrcnn_amd.kitti_input import KITTI_CALIB_TXT, synthetic_scan          # noqa: E402,F401  (shared with bench.py --input raw)
+
+
+def scene_invariants(out_rect, out_int, valid_rect, valid_int, npoints):
+    """What kitti_rcnn_dataset.py:285-306 guarantees about a sample, whatever the random stream: checks it and returns
+    the multiplicity of every valid point in the sample.  valid_rect (n,3) / valid_int (n) = the frame's valid points and
+    their (intensity - 0.5) in scan order; out_* = the sample."""
+    assert out_rect.shape == (npoints, 3) and out_int.shape == (npoints,)
+    n = valid_rect.shape[0]
+    rows = np.concatenate([valid_rect, valid_int[:, None]], 1).astype(np.float32)
+    key = {r.tobytes(): k for k, r in enumerate(rows)}
+    assert len(key) == n, "synthetic scan has duplicate points"
+    mult = np.zeros(n, np.int64)
+    for r in np.concatenate([out_rect, out_int[:, None]], 1).astype(np.float32):
+        mult[key[r.tobytes()]] += 1                               # KeyError = a row that is not a valid point of the frame
+    far = ~(valid_rect[:, 2] < 40.0)
+    if n > npoints:
+        assert mult.max() == 1 and mult.sum() == npoints          # a draw without replacement ...
+        assert (mult[far] == 1).all()                              # ... that keeps every far point
+    else:
+        assert mult.min() >= 1 and mult.max() <= 2 and mult.sum() == npoints    # everything, topped up without replacement
+    return mult
