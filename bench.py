@@ -28,7 +28,7 @@ import time
 
 # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue
 # serialise: with the default, a 4th in-flight batch doubled the step time.  Must be set before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import torch  # noqa: E402
 
@@ -43,14 +43,14 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96,
-                    help="timed steps; with 8 batches in flight the first/last steps fill and drain the pipeline (one batch's "
-                         "latency is ~25 ms under load), so short runs under-report the steady state by a few percent")
-    ap.add_argument("--warmup", type=int, default=8)
+                    help="timed steps; with 16 batches in flight the first/last steps fill and drain the pipeline (one batch's "
+                         "latency is ~45 ms under load), so short runs under-report the steady state by a few percent")
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (BASELINE metric: bs32)")
     ap.add_argument("--npoints", type=int, default=16384)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the step from a hipGraph")
-    ap.add_argument("--streams", type=int, default=8,
-                    help="batches in flight per GPU (each on its own HIP stream AND hardware queue, see GPU_MAX_HW_QUEUES "
+    ap.add_argument("--streams", type=int, default=None,
+                    help="batches in flight per GPU, default 16 (rpn) / 6 (rcnn) (each on its own HIP stream AND hardware queue, see GPU_MAX_HW_QUEUES "
                          "above): step k runs on HIP stream k %% streams, so one batch's FPS "
                          "(1 workgroup per frame = 32 of 256 CUs) overlaps another batch's MLP / neighbour kernels")
     ap.add_argument("--proposals", choices=["off", "normal", "rotate"], default="normal",
@@ -223,6 +223,8 @@ def main():
         args.proposals = "off"                     # the two-stage model runs its own proposal layer
     else:
         model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
+    if args.streams is None:      # rcnn: each in-flight batch holds ~15 GB of RoI-stage intermediates, 16 of them thrash the allocator
+        args.streams = 16 if args.workload == "rpn" else 6
     nstreams = max(1, args.streams)
     make_clouds = rpn.synthetic_clouds if args.clouds == "uniform" else rpn.lidar_like_clouds
     clouds_cpu = make_clouds(args.batch, args.npoints, seed0=100 + rank * args.batch)

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
     typedef typename fvec_t<PPT>::type fvec;
     typedef int ivec __attribute__((ext_vector_type(PPT >= 2 ? PPT : 2)));
     __shared__ float slot[2][NW][8];   // val, orig(bits), x, y, z
+    __builtin_amdgcn_s_setprio(3);     // the serial chain every batch waits for: its few instructions go first
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ p = xyz + (size_t)b * N * 3;

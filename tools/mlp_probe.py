@@ -12,6 +12,16 @@ _cabi.lib()
 if which == "rpn":
     model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
     data = {"pts_input": rpn.synthetic_clouds(32, 16384, device=dev)}
+    import os
+    if os.environ.get("MORTON"):       # experiment: input cloud pre-sorted along a z-order curve (x-z cells)
+        def spread(v):
+            v = (v | (v << 8)) & 0x00FF00FF; v = (v | (v << 4)) & 0x0F0F0F0F; v = (v | (v << 2)) & 0x33333333; v = (v | (v << 1)) & 0x55555555
+            return v
+        pts = data["pts_input"]
+        qx = ((pts[..., 0] + 40) / 80 * 1023).long().clamp(0, 1023); qz = (pts[..., 2] / 70.4 * 1023).long().clamp(0, 1023)
+        key = spread(qx) | (spread(qz) << 1)
+        order = key.argsort(dim=1)
+        data = {"pts_input": torch.gather(pts, 1, order.unsqueeze(-1).expand(-1, -1, 3)).contiguous()}
     fn = lambda: model(data)
 else:
     from pointrcnn_amd.point_rcnn import PointRCNN
