@@ -126,7 +126,12 @@ int prcnn_pack_weight(const float* w, int Nout, int K, int k_rot, float* wpack, 
  * compact group lists of prcnn_group_compact, whose lengths are only known on the device. */
 int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const float* bias, int Nout,
                    int relu, float* out, int ld_out, int col_off, int pool_ns, const int32_t* rows_dev, int rows_unit,
-                   prcnn_stream_t stream);
+                   const int32_t* seg_cnt, int seg_rows, prcnn_stream_t stream);
+/* seg_cnt (device i32, may be NULL) / seg_rows: SEGMENT-PREFIX LIVE ROWS -- rows come in segments of seg_rows rows
+ * (a multiple of 128 dividing rows) and only the first seg_cnt[s] rows of segment s are ever read by anyone: roipool3d
+ * pads an RoI holding fewer points than it samples with copies of its first rows (prcnn_roipool3d_canonical's
+ * `distinct` output).  128-row tiles lying entirely in the dead tail of their segment are skipped; their output rows are
+ * left unwritten. */
 
 /* A row (b,m,s) = [ feat_cl[b, idx[b,m,s], 0:C],  xyz[b, idx[b,m,s]] - new_xyz[b,m] ]  (K = C+3;
  * C may be 0 with feat_cl NULL).  new_xyz NULL => GroupAll semantics (no centroid subtraction).
@@ -174,7 +179,8 @@ int prcnn_mlp_rows_addinterp(const float* in, int ld_in, int K, const float* wpa
 int prcnn_mlp_chain_supported(int mode, int nlayers, const int* nout, int pool_ns);
 int prcnn_mlp_chain_rows(const float* in, int ld_in, int64_t rows, int K, int nlayers, const float* const* wpack,
                          const float* const* bias, const int* nout, const int* relu, float* out, int ld_out,
-                         int col_off, int pool_ns, prcnn_stream_t stream);
+                         int col_off, int pool_ns, const int32_t* seg_cnt, int seg_rows, prcnn_stream_t stream);
+                         /* seg_cnt / seg_rows: as for prcnn_mlp_rows */
 int prcnn_mlp_chain_group(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl,
                           int ld_feat, int B, int N, int M, int nsample, int C, const float* act_wx,
                           const float* act_bias, int nlayers,
@@ -272,10 +278,16 @@ int prcnn_nms_batched(const float* boxes3d, const float* scores, const uint8_t* 
  * out_pts : B*M*S rows of stride ld_pts, columns [x',y',z',extra0,extra1];
  * out_feat: B*M*S rows of stride ld_out, C columns written at this pointer (point it INTO a wider buffer to place the
  *           features where the next layer wants them).  empty (B,M) i32.  An empty RoI yields zeros run through the
- *           same transform (i.e. -centre rotated), exactly what the reference's in-place ops produce. */
+ *           same transform (i.e. -centre rotated), exactly what the reference's in-place ops produce.
+ * distinct (B,M) i32, may be NULL: when given it receives the number of DISTINCT rows of every RoI -- min(points in the
+ *           box, S), 1 for an empty RoI (all its rows are equal); rows distinct .. S-1 are wrap-copies of rows
+ *           0 .. distinct-1 (roipool3d.cpp:171-177).  out_pts is still written in full (FPS and ball_query of the next
+ *           level see the padded cloud), but the FEATURE rows of the copies are NOT written: hand `distinct` to the
+ *           consumers as seg_cnt (prcnn_mlp_rows / prcnn_mlp_chain_rows) and valid_n (prcnn_group_compact). */
 int prcnn_roipool3d_canonical(const float* xyz, const float* pool_boxes3d, const float* rois, const float* extra0,
                               const float* extra1, const float* feat, int ld_feat, int B, int N, int M, int C, int S,
-                              float* out_pts, int ld_pts, float* out_feat, int ld_out, int32_t* empty, prcnn_stream_t stream);
+                              float* out_pts, int ld_pts, float* out_feat, int ld_out, int32_t* empty, int32_t* distinct,
+                              prcnn_stream_t stream);
 
 /* ======================================================================================================
  * Grid-accelerated neighbour search: the same results as prcnn_ball_query / prcnn_ball_query2 / prcnn_three_nn
@@ -335,9 +347,13 @@ int prcnn_kitti_statistics(const double* overlaps, const int64_t* ov_off, const 
  * nsample = 1, no pooling, groups_dev = &counts[0], then prcnn_segmax_scatter; the dense list with M = G, pooling,
  * groups_dev = &counts[1], then prcnn_scatter_rows.
  * ====================================================================================================== */
-int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int B, int N, int M, int nsample, int sparse_max, int32_t* ridx,
-                        float* rnx, int32_t* slist, int32_t* soff, int32_t* scnt, int32_t* idxn, float* nxn, int32_t* listn,
-                        int32_t* counts, prcnn_stream_t stream);
+int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int B, int N, int M, int nsample, int sparse_max,
+                        const int32_t* valid_n, int32_t* ridx, float* rnx, int32_t* slist, int32_t* soff, int32_t* scnt,
+                        int32_t* idxn, float* nxn, int32_t* listn, int32_t* counts, prcnn_stream_t stream);
+/* valid_n (B) i32, may be NULL: only points 0 .. valid_n[b]-1 of frame b are distinct, the rest of the frame are wrap-copies
+ * of them in order (prcnn_roipool3d_canonical's `distinct`): ball_query lists ascending indices, so a hit >= valid_n[b] is a
+ * copy of an earlier hit of the same group -- it ends the group's real rows like padding does, and in the dense list it is
+ * replaced by the group's first hit, so that no consumer ever reads a copy's (unwritten) feature row. */
 /* dst[list[j], col_off + c] = max over r < cnt[j] of src[off[j] + r, c]  for j < *count, c < C */
 int prcnn_segmax_scatter(const float* src, int ld_src, const int32_t* list, const int32_t* off, const int32_t* cnt,
                          const int32_t* count, int max_groups, int C, float* dst, int ld_dst, int col_off, prcnn_stream_t stream);

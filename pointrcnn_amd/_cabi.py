@@ -33,12 +33,12 @@ SIGNATURES = {
     "prcnn_three_interp_grad": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "prcnn_wpack_floats": (_Z, [_I, _I]),
     "prcnn_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
-    "prcnn_mlp_rows": (_I, [_P, _I, _L, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
+    "prcnn_mlp_rows": (_I, [_P, _I, _L, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P]),
     "prcnn_mlp_group": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P]),
     "prcnn_mlp_interp": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P]),
     "prcnn_mlp_rows_addinterp": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
     "prcnn_mlp_chain_supported": (_I, [_I, _I, _P, _I]),
-    "prcnn_mlp_chain_rows": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "prcnn_mlp_chain_rows": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "prcnn_mlp_chain_group": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "prcnn_mlp_chain_interp": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "prcnn_maxpool_rows": (_I, [_P, _I, _L, _I, _I, _P, _I, _I, _P]),
@@ -52,7 +52,7 @@ SIGNATURES = {
     "prcnn_proposal_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "prcnn_proposal_layer": (_I, [_P, _P, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "prcnn_nms_batched_workspace_bytes": (_Z, [_I, _I]),
-    "prcnn_roipool3d_canonical": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
+    "prcnn_roipool3d_canonical": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
     "prcnn_grid_bytes": (_Z, [_I, _I]),
     "prcnn_grid_build": (_I, [_P, _I, _I, _F, _I, _P, _Z, _P]),
     "prcnn_ball_query2_grid": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _F, _I, _P, _P]),
@@ -60,7 +60,7 @@ SIGNATURES = {
     "prcnn_rotate_iou_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "prcnn_kitti_overlaps": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "prcnn_kitti_statistics": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _D, _P, _I, _I, _I, _P, _P, _P]),
-    "prcnn_group_compact": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prcnn_group_compact": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prcnn_segmax_scatter": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _P]),
     "prcnn_scatter_rows": (_I, [_P, _I, _P, _P, _I, _I, _P, _I, _I, _P]),
     "prcnn_scene_workspace_bytes": (_Z, [_L, _I]),

@@ -13,4 +13,4 @@ int prcnn_fail(int code, const char* fmt, ...) {
 }
 
 PRCNN_API const char* prcnn_last_error(void) { return g_err; }
-PRCNN_API int prcnn_abi_version(void) { return 2; }
+PRCNN_API int prcnn_abi_version(void) { return 3; }

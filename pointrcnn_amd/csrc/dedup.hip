@@ -33,6 +33,7 @@ struct CompactParams {
     float* nxn;              // (G, 3)
     int32_t* listn;          // (G)
     int32_t* counts;         // [0] flat rows, [1] dense groups, [2] sparse groups (zeroed by the launcher)
+    const int32_t* valid_n;  // (B) or NULL: points >= valid_n[b] of frame b are wrap-copies of earlier points (roipool3d)
     int G, N, M, ns, T;
 };
 
@@ -70,6 +71,13 @@ __global__ __launch_bounds__(COMPACT_THREADS) void group_compact_kernel(CompactP
         }
     }
     const int b = (ok ? g : 0) / P.M;
+    const int vn = P.valid_n ? P.valid_n[b] : P.N;
+    if (ok && P.valid_n) {
+        // ascending hits: every first copy (index < vn) precedes every wrap-copy, so the copies end the real rows
+        int c2 = 0;
+        while (c2 < cnt && row[c2] < vn) c2++;
+        cnt = c2 > 0 ? c2 : 1;                       // (a group always holds its own centroid's first copy; 1 = defensive)
+    }
     const bool sparse = ok && cnt <= P.T, dense = ok && cnt > P.T;
     // sparse: wave-wide exclusive scan of the row counts, one atomic per wave and list
     const int v = sparse ? cnt : 0;
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void group_compact_kernel(CompactP
     if (dense) {
         const int pn = base_d + (int)__popcll(bd & below);
         P.listn[pn] = g;
-        for (int s = 0; s < ns; s++) P.idxn[(size_t)pn * ns + s] = b * P.N + row[s];
+        for (int s = 0; s < ns; s++) P.idxn[(size_t)pn * ns + s] = b * P.N + (row[s] < vn ? row[s] : first);
 #pragma unroll
         for (int c = 0; c < 3; c++) P.nxn[(size_t)pn * 3 + c] = c3[c];
     }
@@ -147,8 +155,8 @@ __global__ __launch_bounds__(256) void segmax_scatter_kernel(const float* __rest
 }
 
 PRCNN_API int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int B, int N, int M, int nsample, int sparse_max,
-                                  int32_t* ridx, float* rnx, int32_t* slist, int32_t* soff, int32_t* scnt, int32_t* idxn, float* nxn,
-                                  int32_t* listn, int32_t* counts, prcnn_stream_t stream) {
+                                  const int32_t* valid_n, int32_t* ridx, float* rnx, int32_t* slist, int32_t* soff, int32_t* scnt,
+                                  int32_t* idxn, float* nxn, int32_t* listn, int32_t* counts, prcnn_stream_t stream) {
     PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && nsample > 0, "prcnn_group_compact: bad shape B=%d N=%d M=%d nsample=%d", B, N, M, nsample);
     PRCNN_REQUIRE(sparse_max >= 1 && sparse_max <= nsample, "prcnn_group_compact: sparse_max=%d (1..nsample)", sparse_max);
     PRCNN_REQUIRE(counts, "prcnn_group_compact: null counts");
@@ -161,7 +169,7 @@ PRCNN_API int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int 
     CompactParams P;
     P.idx = idx; P.new_xyz = new_xyz; P.ridx = ridx; P.rnx = rnx; P.slist = slist; P.soff = soff; P.scnt = scnt;
     P.idxn = idxn; P.nxn = nxn; P.listn = listn;
-    P.counts = counts; P.G = B * M; P.N = N; P.M = M; P.ns = nsample; P.T = sparse_max;
+    P.counts = counts; P.valid_n = valid_n; P.G = B * M; P.N = N; P.M = M; P.ns = nsample; P.T = sparse_max;
     const dim3 grid(prcnn_divup(P.G, COMPACT_THREADS));
     const bool vec = ((uintptr_t)idx % 16) == 0;
     if (vec && nsample == 16) hipLaunchKernelGGL(group_compact_kernel<16>, grid, dim3(COMPACT_THREADS), 0, s, P);

@@ -69,8 +69,18 @@ struct MlpParams {
     // min(rows, *rows_dev * rows_unit) and workgroups past that exit at once.  NULL: rows is exact.
     const int32_t* rows_dev;
     int rows_unit;
+    // segment-prefix live rows (MODE_PLAIN): rows come in segments of seg_rows, only the first seg_cnt[s] rows of segment s
+    // carry data anyone reads (roipool3d pads an RoI that holds fewer points than it samples with copies of its first
+    // rows); 128-row tiles that lie entirely in the dead tail of their segment are skipped.  NULL: every row is live.
+    const int32_t* seg_cnt;
+    int seg_rows;
 };
 
+__device__ __forceinline__ bool tile_dead(const MlpParams& P, long row0) {
+    if (!P.seg_cnt) return false;
+    const long s = row0 / P.seg_rows;
+    return (int)(row0 - s * P.seg_rows) >= P.seg_cnt[s];
+}
 __device__ __forceinline__ long effective_rows(const MlpParams& P) {
     if (!P.rows_dev) return P.rows;
     const long r = (long)(*P.rows_dev) * P.rows_unit;
@@ -256,6 +266,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
     MlpParams P = Pin;
     P.rows = effective_rows(Pin);
     if ((long)blockIdx.x * MLP_BM >= P.rows) return;     // workgroup-uniform (device-side row count)
+    if (tile_dead(P, (long)blockIdx.x * MLP_BM)) return;
     constexpr int QN = 2 * WNB;                          // n-blocks per workgroup
     __shared__ __attribute__((aligned(16))) float As[2][MLP_BM * MLP_ALD];
     __shared__ __attribute__((aligned(16))) float Bs[2][QN * 4 * 256];
@@ -655,6 +666,7 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(const ChainParams Cin) {
     C.a.rows = effective_rows(Cin.a);
     const MlpParams& P = C.a;
     if ((long)blockIdx.x * 128 >= P.rows) return;
+    if (tile_dead(P, (long)blockIdx.x * 128)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
     const long row = ((long)blockIdx.x * 4 + wave) * 32 + j;
@@ -827,6 +839,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C
     C.a.rows = effective_rows(Cin.a);
     const MlpParams& P = C.a;
     if ((long)blockIdx.x * 128 >= P.rows) return;
+    if (tile_dead(P, (long)blockIdx.x * 128)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
     const long row = ((long)blockIdx.x * 4 + wave) * 32 + j;
@@ -1226,7 +1239,8 @@ PRCNN_API int prcnn_pack_weight(const float* w, int Nout, int K, int k_rot, floa
 
 PRCNN_API int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const float* bias,
                              int Nout, int relu, float* out, int ld_out, int col_off, int pool_ns,
-                             const int32_t* rows_dev, int rows_unit, prcnn_stream_t stream) {
+                             const int32_t* rows_dev, int rows_unit, const int32_t* seg_cnt, int seg_rows,
+                             prcnn_stream_t stream) {
     PRCNN_REQUIRE(in, "prcnn_mlp_rows: null input");
     PRCNN_REQUIRE(ld_in >= K && ld_out >= col_off + Nout, "prcnn_mlp_rows: bad strides ld_in=%d K=%d ld_out=%d", ld_in, K, ld_out);
     MlpParams P = {};
@@ -1235,6 +1249,9 @@ PRCNN_API int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, co
     P.in = in; P.ld_in = ld_in;
     P.vec_a = aligned16(in) && (ld_in % 4 == 0);
     P.rows_dev = rows_dev; P.rows_unit = rows_unit > 0 ? rows_unit : 1;
+    PRCNN_REQUIRE(!seg_cnt || (seg_rows > 0 && seg_rows % MLP_BM == 0 && rows % seg_rows == 0 && pool_ns == 0),
+                  "prcnn_mlp_rows: seg_rows=%d must be a multiple of %d dividing rows (and no pooling)", seg_rows, MLP_BM);
+    P.seg_cnt = seg_cnt; P.seg_rows = seg_rows;
     return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
 }
 
@@ -1401,7 +1418,7 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
     // Opt-in (PRCNN_PERSISTENT_CHAIN=1): 6-12 % faster per launch with ONE batch in flight, but a persistent workgroup
     // holds its CU's LDS for the whole kernel, which starves the other in-flight batches' kernels (FPS sort, layer tiles):
     // measured -6 % RPN throughput at 3 batches in flight, so the default keeps the per-tile workgroups.
-    if (chain_fast_ok(mode, C, n0, n1, n2) && getenv("PRCNN_PERSISTENT_CHAIN") != nullptr) {
+    if (chain_fast_ok(mode, C, n0, n1, n2) && !P.seg_cnt && getenv("PRCNN_PERSISTENT_CHAIN") != nullptr) {
         // persistent form: weights of the whole stack resident in LDS, one 8-wave workgroup per CU
 #define PERS_CASE(M, KB0V, A, B, CC)                                                                                         \
         if (mode == M && P.KB == KB0V && n0 == A && n1 == B && n2 == CC) {                                                    \
@@ -1473,14 +1490,17 @@ static int fill_chain(ChainParams& C, int nlayers, const float* const* wpack, co
 PRCNN_API int prcnn_mlp_chain_rows(const float* in, int ld_in, int64_t rows, int K, int nlayers,
                                    const float* const* wpack, const float* const* bias, const int* nout,
                                    const int* relu, float* out, int ld_out, int col_off, int pool_ns,
-                                   prcnn_stream_t stream) {
+                                   const int32_t* seg_cnt, int seg_rows, prcnn_stream_t stream) {
     PRCNN_REQUIRE(in && ld_in >= K && K > 0 && rows >= 0, "prcnn_mlp_chain_rows: bad input");
+    PRCNN_REQUIRE(!seg_cnt || (seg_rows > 0 && seg_rows % 128 == 0 && rows % seg_rows == 0 && pool_ns == 0),
+                  "prcnn_mlp_chain_rows: seg_rows=%d must be a multiple of 128 dividing rows (and no pooling)", seg_rows);
     ChainParams C = {};
     int rc = fill_chain(C, nlayers, wpack, bias, nout, relu, out, ld_out, col_off, pool_ns);
     if (rc) return rc;
     PRCNN_REQUIRE(pool_ns == 0 || rows % pool_ns == 0, "prcnn_mlp_chain_rows: rows not a multiple of pool_ns");
     C.a.rows = rows; C.a.K = K; C.a.in = in; C.a.ld_in = ld_in;
     C.a.vec_a = aligned16(in) && (ld_in % 4 == 0);
+    C.a.seg_cnt = seg_cnt; C.a.seg_rows = seg_rows;
     return dispatch_chain(MODE_PLAIN, C, (hipStream_t)stream);
 }
 

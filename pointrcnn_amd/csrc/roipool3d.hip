@@ -136,6 +136,7 @@ struct CanonParams {
     float* out_pts;          // (B*M*S) rows, stride ld_pts, 3 + n_extra columns written
     float* out_feat;         // (B*M*S) rows, stride ld_out, C columns written from column 0 of this pointer
     int32_t* empty;          // (B, M)
+    int32_t* distinct;       // (B, M) or NULL: number of distinct rows; feature rows of the wrap-copies are then not written
     int N, M, C, S, n_extra, ld_feat, ld_pts, ld_out;
 };
 
@@ -189,7 +190,10 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(CanonPa
     for (int i = lane; i < wcnt[wave]; i += 64)
         if (off + i < S) sel[off + i] = mylist[i];
     __syncthreads();
-    if (tid == 0) P.empty[(size_t)b * P.M + m] = total == 0 ? 1 : 0;
+    if (tid == 0) {
+        P.empty[(size_t)b * P.M + m] = total == 0 ? 1 : 0;
+        if (P.distinct) P.distinct[(size_t)b * P.M + m] = total > 0 ? total : 1;      // an empty RoI: S equal rows
+    }
     for (int s2 = total + tid; s2 < S; s2 += RP_THREADS) sel[s2] = total ? sel[s2 % total] : -1;
     __syncthreads();
 
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(CanonPa
     if (C > 0) {
         const float* __restrict__ f = P.feat + (size_t)b * N * P.ld_feat;
         float* __restrict__ of = P.out_feat + row0 * P.ld_out;
-        const int total_e = S * C;
+        const int total_e = (P.distinct ? (total > 0 ? total : 1) : S) * C;
         const int qstep = RP_THREADS / C, rstep = RP_THREADS - qstep * C;
         int srow = tid / C, scol = tid - srow * C;
 #pragma unroll 4
@@ -267,7 +271,7 @@ PRCNN_API int prcnn_pts_in_boxes3d(const float* pts, const float* boxes3d, int N
 
 PRCNN_API int prcnn_roipool3d_canonical(const float* xyz, const float* pool_boxes3d, const float* rois, const float* extra0,
                                         const float* extra1, const float* feat, int ld_feat, int B, int N, int M, int C, int S,
-                                        float* out_pts, int ld_pts, float* out_feat, int ld_out, int32_t* empty,
+                                        float* out_pts, int ld_pts, float* out_feat, int ld_out, int32_t* empty, int32_t* distinct,
                                         prcnn_stream_t stream) {
     const char* op = "prcnn_roipool3d_canonical";
     PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && C >= 0 && S > 0, "%s: bad shape B=%d N=%d M=%d C=%d S=%d", op, B, N, M, C, S);
@@ -280,7 +284,7 @@ PRCNN_API int prcnn_roipool3d_canonical(const float* xyz, const float* pool_boxe
     PRCNN_REQUIRE(lds_bytes <= 60 * 1024, "%s: sampled_pt_num %d too large for the LDS index lists", op, S);
     CanonParams P;
     P.xyz = xyz; P.pool_boxes = pool_boxes3d; P.rois = rois; P.extra[0] = extra0; P.extra[1] = extra1; P.feat = feat;
-    P.out_pts = out_pts; P.out_feat = out_feat; P.empty = empty;
+    P.out_pts = out_pts; P.out_feat = out_feat; P.empty = empty; P.distinct = distinct;
     P.N = N; P.M = M; P.C = C; P.S = S; P.n_extra = n_extra; P.ld_feat = ld_feat; P.ld_pts = ld_pts; P.ld_out = ld_out;
     hipLaunchKernelGGL(roipool3d_canonical_kernel, dim3(M, B), dim3(RP_THREADS), lds_bytes, (hipStream_t)stream, P);
     PRCNN_LAUNCH_CHECK(op);

@@ -109,6 +109,9 @@ class _PointnetSAModuleBase(nn.Module):
 
     # ---- fused inference path -----------------------------------------------------------------
     def _forward_fused(self, xyz, features, new_xyz):
+        # rcnn.py tags a roipool3d-padded cloud with the number of distinct points per frame (the rest are wrap-copies whose
+        # feature rows were never computed): only usable when every scale takes the padding-free path below
+        valid_n = getattr(xyz, "_prcnn_valid_n", None)
         xyz = xyz.contiguous()
         B, N, _ = xyz.shape
         feat_cl = _channels_last(features)
@@ -143,7 +146,7 @@ class _PointnetSAModuleBase(nn.Module):
                 key = tuple(id(p[0]) for p in parts)
                 if getattr(self, "_prcnn_zlin", (None, None))[0] != key:
                     self._prcnn_zlin = (key, ops.PackedLinear(torch.cat([p[0] for p in parts], 0).contiguous(), None, relu=False))
-                z_all = ops.mlp_rows(feat_cl, self._prcnn_zlin[1]).view(B, N, -1)
+                z_all = ops.mlp_rows(feat_cl, self._prcnn_zlin[1], seg=None if valid_n is None else (valid_n, N)).view(B, N, -1)
                 hoist, zoff = [], 0
                 for p in parts:
                     hoist.append((z_all[..., zoff:zoff + p[0].shape[0]], (p[1], p[2])))
@@ -164,12 +167,14 @@ class _PointnetSAModuleBase(nn.Module):
                 src, act = feat_cl, None
                 # torch's grouped channel order is [dxyz(3), feat(C)]; the kernel's A row is [feat(C), dxyz(3)]
                 layers = [mods[0].packed(k_rot=3 if feat_cl is not None else 0)] + [m.packed() for m in mods[1:]]
+            if valid_n is not None and not (GROUP_DEDUP and not group_all and fused_pool):
+                raise RuntimeError("a cloud tagged with _prcnn_valid_n needs the padding-free grouping path on every scale")
             if GROUP_DEDUP and not group_all and fused_pool:
                 # Padding-free grouping: a group with fewer than nsample neighbours repeats its first hit, and the max
                 # over copies of a row is the row -- sparse groups contribute only their real rows to one flat row list
                 # (segmented max afterwards), dense groups run as they are, each list with a device-side length.
                 # Same bits, far fewer rows.
-                sp = ops.GroupSplit(idxs[i], new_xyz, N, max(1, ns // DEDUP_SPARSE_DIV))
+                sp = ops.GroupSplit(idxs[i], new_xyz, N, max(1, ns // DEDUP_SPARSE_DIV), valid_n=valid_n)
                 xyz_f = xyz.view(1, B * N, 3)
                 src_f = None if src is None else _flatten_frames(src)
                 t1 = torch.empty((sp.max_rows, c_outs[i]), dtype=torch.float32, device=xyz.device)

@@ -259,8 +259,8 @@ def _chain_args(layers):
     return hit[1]
 
 
-def mlp_chain_rows(x, layers, out=None, pool_ns=0):
-    """whole stack on channels-last rows in one kernel (see mlp_rows for the layout contract)"""
+def mlp_chain_rows(x, layers, out=None, pool_ns=0, seg=None):
+    """whole stack on channels-last rows in one kernel (see mlp_rows for the layout contract; seg as there)"""
     if x.stride(-1) != 1:
         raise RuntimeError("mlp_chain_rows: last dim must be contiguous")
     K = x.shape[-1]
@@ -269,8 +269,9 @@ def mlp_chain_rows(x, layers, out=None, pool_ns=0):
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, layers[-1], x.device)
     a = _chain_args(layers)
+    seg_cnt, seg_rows = (None, 0) if seg is None else (seg[0], int(seg[1]))
     _cabi.check(_cabi.lib().prcnn_mlp_chain_rows(_p(x), ld_in, rows, K, a.n, a.wpack, a.bias, a.nout, a.relu, _p(buf),
-                                                 ld_out, col_off, pool_ns, _stream()), "prcnn_mlp_chain_rows")
+                                                 ld_out, col_off, pool_ns, _p(seg_cnt), seg_rows, _stream()), "prcnn_mlp_chain_rows")
     return buf
 
 
@@ -319,10 +320,12 @@ def _out_buf(out, rows, lin, device):
     return buf, _row_stride(buf), col_off
 
 
-def mlp_rows(x, lin, out=None, pool_ns=0, rows_dev=None, rows_unit=1):
+def mlp_rows(x, lin, out=None, pool_ns=0, rows_dev=None, rows_unit=1, seg=None):
     """x (..., K) channels-last rows (last dim contiguous, uniform row stride) -> (rows[/pool_ns], Nout).
     out = (buffer, col_off) writes into a wider channels-last buffer instead of allocating.
-    rows_dev (1,) int32 device tensor: only the first rows_dev * rows_unit rows are processed (device-side count)."""
+    rows_dev (1,) int32 device tensor: only the first rows_dev * rows_unit rows are processed (device-side count).
+    seg = (seg_cnt (nseg,) int32 device tensor, seg_rows): segment-prefix live rows -- of every run of seg_rows rows only the
+    first seg_cnt[s] are live (roipool3d wrap-copies); tiles in a segment's dead tail are skipped, their outputs unwritten."""
     if x.stride(-1) != 1:
         raise RuntimeError("mlp_rows: last dim must be contiguous")
     K = x.shape[-1]
@@ -331,7 +334,8 @@ def mlp_rows(x, lin, out=None, pool_ns=0, rows_dev=None, rows_unit=1):
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, lin, x.device)
     _cabi.check(_cabi.lib().prcnn_mlp_rows(_p(x), ld_in, rows, K, _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu),
-                                           _p(buf), ld_out, col_off, pool_ns, _p(rows_dev), int(rows_unit), _stream()), "prcnn_mlp_rows")
+                                           _p(buf), ld_out, col_off, pool_ns, _p(rows_dev), int(rows_unit),
+                                           _p(None if seg is None else seg[0]), 0 if seg is None else int(seg[1]), _stream()), "prcnn_mlp_rows")
     return buf
 
 
@@ -410,13 +414,15 @@ def roipool3d(xyz, boxes3d_enlarged, pts_feature, sampled_pt_num):
     return pooled, empty
 
 
-def roipool3d_canonical(xyz, pool_boxes3d, rois, extras, feat_cl, sampled_pt_num, out_feat=None):
+def roipool3d_canonical(xyz, pool_boxes3d, rois, extras, feat_cl, sampled_pt_num, out_feat=None, want_distinct=False):
     """Fused lib/net/rcnn_net.py:127-154: pool [extras..., feat] per RoI and move the pooled xyz into the RoI's
     canonical frame, writing each consumer's operand directly.
     xyz (B,N,3); pool_boxes3d (B,M,7) enlarged; rois (B,M,7) or None; extras: list of <= 2 (B,N) tensors;
     feat_cl (B,N,C) channels-last rows (unit last stride).  out_feat = (buffer (B*M*S, W), col): write the C pooled
     features at that column of a wider rows buffer (default: a fresh (B*M*S, C) tensor).
-    -> pts (B*M, S, 3+len(extras)), feat buffer, empty (B,M) i32"""
+    want_distinct: also return distinct (B,M) i32 = number of distinct rows per RoI (the rest are wrap-copies); the feature
+    rows of the copies are then NOT written (see prcnn_roipool3d_canonical).
+    -> pts (B*M, S, 3+len(extras)), feat buffer, empty (B,M) i32 [, distinct]"""
     _chk(xyz, "xyz", ndim=3); _chk(pool_boxes3d, "pool_boxes3d", ndim=3)
     B, N, _ = xyz.shape
     if not (isinstance(feat_cl, torch.Tensor) and feat_cl.is_cuda and feat_cl.dtype == _F32 and feat_cl.dim() == 3
@@ -438,13 +444,14 @@ def roipool3d_canonical(xyz, pool_boxes3d, rois, extras, feat_cl, sampled_pt_num
         if fbuf.dim() != 2 or fbuf.shape[0] != B * M * S or fbuf.stride(1) != 1 or col + C > fbuf.shape[1]:
             raise ValueError("roipool3d_canonical: out_feat buffer must be (B*M*S, >= col + C) rows")
     empty = torch.empty((B, M), dtype=_INT, device=dev)
+    distinct = torch.empty((B, M), dtype=_INT, device=dev) if want_distinct else None
     if rois is not None:
         _chk(rois, "rois", ndim=3)
     _cabi.check(_cabi.lib().prcnn_roipool3d_canonical(
         _p(xyz), _p(pool_boxes3d), _p(rois), _p(ex[0]) if ex else None, _p(ex[1]) if len(ex) > 1 else None, _p(feat_cl),
-        _row_stride(feat_cl), B, N, M, C, S, _p(pts), P, fbuf.data_ptr() + 4 * col, fbuf.stride(0), _p(empty), _stream()),
-        "prcnn_roipool3d_canonical")
-    return pts, fbuf, empty
+        _row_stride(feat_cl), B, N, M, C, S, _p(pts), P, fbuf.data_ptr() + 4 * col, fbuf.stride(0), _p(empty), _p(distinct),
+        _stream()), "prcnn_roipool3d_canonical")
+    return (pts, fbuf, empty, distinct) if want_distinct else (pts, fbuf, empty)
 
 
 def pts_in_boxes3d(pts, boxes3d):
@@ -613,7 +620,7 @@ class GroupSplit:
     the sparse groups (at most sparse_max hits) and the list of dense groups.  All tensors are worst-case sized; counts
     (3,) int32 holds [flat rows, dense groups, sparse groups]."""
 
-    def __init__(self, idx, new_xyz, N, sparse_max):
+    def __init__(self, idx, new_xyz, N, sparse_max, valid_n=None):
         _chk(idx, "idx", _INT, 3)
         _chk(new_xyz, "new_xyz", ndim=3)
         B, M, ns = idx.shape
@@ -625,7 +632,9 @@ class GroupSplit:
         self.slist, self.soff, self.scnt = e((G,)), e((G,)), e((G,))
         self.idxn, self.nxn, self.listn = e((1, G, ns)), e((1, G, 3), _F32), e((G,))
         self.counts = e((3,))
-        _cabi.check(_cabi.lib().prcnn_group_compact(_p(idx), _p(new_xyz), B, N, M, ns, T, _p(self.ridx), _p(self.rnx), _p(self.slist),
+        if valid_n is not None and (valid_n.dtype != _INT or valid_n.numel() != B or not valid_n.is_contiguous()):
+            raise RuntimeError("valid_n must be a contiguous (B,) int32 tensor")
+        _cabi.check(_cabi.lib().prcnn_group_compact(_p(idx), _p(new_xyz), B, N, M, ns, T, _p(valid_n), _p(self.ridx), _p(self.rnx), _p(self.slist),
                                                     _p(self.soff), _p(self.scnt), _p(self.idxn), _p(self.nxn), _p(self.listn),
                                                     _p(self.counts), _stream()), "prcnn_group_compact")
         self.rows, self.count_dense, self.count_sparse = self.counts[0:1], self.counts[1:2], self.counts[2:3]

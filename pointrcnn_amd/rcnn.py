@@ -11,6 +11,8 @@ rotate_pc_along_y_torch :45-63, boxes3d_to_bev_torch :134-147); they are element
 (SURVEY.md 8(a) a16); the inference path does not use them (prcnn_roipool3d_canonical builds the stage's inputs in one
 kernel).  RoIs come from pointrcnn_amd/proposal_layer.py (see pointrcnn_amd/point_rcnn.py for the whole two-stage graph).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -19,7 +21,11 @@ import pointrcnn_amd
 pointrcnn_amd.install()
 from pointnet2_lib.pointnet2.pointnet2_modules import PointnetSAModule  # noqa: E402
 import pointnet2_lib.pointnet2.pytorch_utils as pt_utils  # noqa: E402
+from pointnet2_lib.pointnet2 import pointnet2_modules as pn2_modules  # noqa: E402
 from . import ops  # noqa: E402
+
+# RoI duplicate elimination in the fused inference path (see _forward_fused); 0 = A/B switch, same bits
+ROI_DEDUP = os.environ.get("PRCNN_ROI_DEDUP", "1") != "0"
 
 
 class RCNNConfig:
@@ -162,18 +168,33 @@ class RCNNNet(nn.Module):
         c_up, C = cfg.XYZ_UP_LAYER[-1], feat_cl.shape[-1]
         merged_in = torch.empty((B * M * S, c_up + C), dtype=torch.float32, device=rpn_xyz.device)
         pool_boxes = enlarge_box3d(rois.view(-1, 7), cfg.POOL_EXTRA_WIDTH).view(B, M, 7)
-        pts, _, empty = ops.roipool3d_canonical(rpn_xyz, pool_boxes, rois, extras, feat_cl, S, out_feat=(merged_in, c_up))
+        # RoI duplicate elimination: an RoI holding fewer than S points is padded by roipool3d with copies of its first rows.
+        # The per-point layers skip the copies (seg), the first SA level never gathers them (valid_n) -- same outputs.
+        sa0 = self.SA_modules[0]
+        dedup = ROI_DEDUP and pn2_modules.GROUP_DEDUP and S % 128 == 0 and sa0.npoint is not None and \
+            all(g.nsample in pn2_modules._POOL_FUSED for g in sa0.groupers)
+        if dedup:
+            pts, _, empty, distinct = ops.roipool3d_canonical(rpn_xyz, pool_boxes, rois, extras, feat_cl, S, out_feat=(merged_in, c_up),
+                                                              want_distinct=True)
+            seg = (distinct.view(-1), S)
+        else:
+            pts, _, empty = ops.roipool3d_canonical(rpn_xyz, pool_boxes, rois, extras, feat_cl, S, out_feat=(merged_in, c_up))
+            seg = None
         up = [m.packed() for m in self.xyz_up_layer.layers()]
         if len(up) > 1 and ops.chain_supported(0, up, 0):
-            ops.mlp_chain_rows(pts, up, out=(merged_in, 0))
+            ops.mlp_chain_rows(pts, up, out=(merged_in, 0), seg=seg)
         else:
             x = pts
             for li, lin in enumerate(up):
-                x = ops.mlp_rows(x, lin, out=(merged_in, 0) if li == len(up) - 1 else None)
+                x = ops.mlp_rows(x, lin, out=(merged_in, 0) if li == len(up) - 1 else None, seg=seg)
         x = merged_in
         for m in self.merge_down_layer.layers():
-            x = ops.mlp_rows(x, m.packed())
-        l_xyz, l_features = [pts[..., 0:3]], [x.view(B * M, S, -1).transpose(1, 2)]
+            x = ops.mlp_rows(x, m.packed(), seg=seg)
+        xyz0 = pts[..., 0:3]
+        if dedup:
+            xyz0 = xyz0.contiguous()
+            xyz0._prcnn_valid_n = seg[0]
+        l_xyz, l_features = [xyz0], [x.view(B * M, S, -1).transpose(1, 2)]
         for i in range(len(self.SA_modules)):
             li_xyz, li_features = self.SA_modules[i](l_xyz[i], l_features[i])
             l_xyz.append(li_xyz)

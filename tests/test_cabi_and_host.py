@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_pure_host_queries():
     from pointrcnn_amd import _cabi
     lib = _cabi.lib()
-    assert lib.prcnn_abi_version() == 2
+    assert lib.prcnn_abi_version() == 3
     assert lib.prcnn_wpack_floats(64, 99) == 2 * 13 * 256
     assert lib.prcnn_wpack_floats(0, 5) == 0
     assert lib.prcnn_nms_workspace_bytes(6300) == 6300 * 99 * 8
@@ -54,7 +54,7 @@ def test_argument_errors_return_codes_not_exit():
     assert lib.prcnn_fps(dummy, 1, 16, 32, None, dummy, None) == -1           # npoint > N
     assert b"npoint" in lib.prcnn_last_error()
     assert lib.prcnn_fps(dummy, 1, 20000, 4, None, dummy, None) == -1         # large N needs tmp
-    assert lib.prcnn_mlp_rows(dummy, 8, 128, 8, dummy, None, 16, 1, dummy, 16, 0, 20, None, 1, None) == -1   # pool_ns=20
+    assert lib.prcnn_mlp_rows(dummy, 8, 128, 8, dummy, None, 16, 1, dummy, 16, 0, 20, None, 1, None, 0, None) == -1   # pool_ns=20
     assert b"pool_ns" in lib.prcnn_last_error()
     assert lib.prcnn_nms(dummy, 10, 0.5, 7, 0, dummy, dummy, dummy, 1 << 20, None) == -1            # bad kind
     assert lib.prcnn_nms(dummy, 100, 0.5, 0, 0, dummy, dummy, dummy, 8, None) == -1                  # workspace too small

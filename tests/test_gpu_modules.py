@@ -288,3 +288,43 @@ def test_group_compact_lists(dev, smax, ns):
         assert np.array_equal(rnx[so[j]:so[j] + sc[j]], np.repeat(nx[g][None], sc[j], 0))
     assert np.array_equal(sp.idxn.view(-1, ns)[:cd].cpu().numpy(), (ln // M)[:, None] * N + idx_c[ln])
     assert torch.equal(sp.nxn.view(-1, 3)[:cd], new_xyz.view(-1, 3)[sp.listn[:cd].long()])
+
+
+def test_rcnn_roi_duplicate_elimination_is_bit_identical(dev, cpu):
+    """PRCNN_ROI_DEDUP: an RoI with fewer than 512 points is padded with copies of its first rows; the fused stage skips the
+    copies in the per-point layers and never gathers them in the first SA level.  RoIs from empty to > 512 points: the
+    stage's outputs must not change by one bit, and `distinct` must be the oracle's point count."""
+    from pointrcnn_amd import ops, rcnn
+    torch.manual_seed(8)
+    B, N, M = 2, 16384, 24
+    pts = kitti_cloud(B, N, seed=310)
+    pts[:, :3000] = pts[:, :3000] * np.float32(0.08) + np.array([5.0, 1.0, 20.0], np.float32)      # a dense clump: RoIs with > 512 points
+    xyz = T(pts, dev)
+    rois = _synthetic_rois(xyz, M, seed=9)
+    rois[:, 0, :3] = torch.tensor([0.0, -30.0, 5.0])           # an RoI far above the scene: empty
+    rois[:, 1, :3] = torch.tensor([5.3, 1.8, 21.5])            # inside the clump
+    rois[:, 1, 3:6] = torch.tensor([2.5, 3.0, 6.0])
+    rois[:, 2, :] = torch.tensor([5.0, 1.3, 22.8, 0.5, 0.2, 0.2, 0.3])        # a sliver of the clump: a few hundred points
+    rois = rois.to(dev)
+    data = {"rpn_xyz": xyz, "rpn_features": torch.randn(B, N, 128, device=dev), "seg_mask": (torch.rand(B, N, device=dev) > 0.5).float(),
+            "pts_depth": torch.norm(xyz, p=2, dim=2), "roi_boxes3d": rois}
+    net = rcnn.RCNNNet().to(dev).eval()
+    outs = {}
+    for flag in (False, True):
+        rcnn.ROI_DEDUP = flag
+        try:
+            with torch.no_grad():
+                outs[flag] = {k: v.clone() for k, v in net(data).items()}
+        finally:
+            rcnn.ROI_DEDUP = True
+    for k in ("rcnn_cls", "rcnn_reg", "pooled_empty_flag"):
+        assert torch.equal(outs[False][k], outs[True][k]), k
+    # distinct == min(points inside the enlarged box, 512), 1 for the empty RoI
+    pool_boxes = rcnn.enlarge_box3d(rois.view(-1, 7), 1.0).view(B, M, 7)
+    feat_cl = data["rpn_features"]
+    _, _, empty, distinct = ops.roipool3d_canonical(xyz, pool_boxes, rois, [data["seg_mask"]], feat_cl, 512, want_distinct=True)
+    flags = np.stack([cpu.pts_in_boxes3d(pts[b], pool_boxes[b].cpu().numpy()) for b in range(B)])        # (B, M, N)
+    want = np.minimum(flags.sum(2), 512)
+    assert np.array_equal(empty.cpu().numpy(), (want == 0).astype(np.int32))
+    assert np.array_equal(distinct.cpu().numpy(), np.maximum(want, 1))
+    assert want.max() == 512 and want.min() == 0 and ((want > 0) & (want < 128)).any() and ((want > 128) & (want < 512)).any()
