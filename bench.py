@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--npoints", type=int, default=16384)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the step from a hipGraph")
     ap.add_argument("--streams", type=int, default=None,
-                    help="batches in flight per GPU, default 16 (rpn) / 6 (rcnn) (each on its own HIP stream AND hardware queue, see GPU_MAX_HW_QUEUES "
+                    help="batches in flight per GPU, default 16 (rpn) / 10 (rcnn) (each on its own HIP stream AND hardware queue, see GPU_MAX_HW_QUEUES "
                          "above): step k runs on HIP stream k %% streams, so one batch's FPS "
                          "(1 workgroup per frame = 32 of 256 CUs) overlaps another batch's MLP / neighbour kernels")
     ap.add_argument("--proposals", choices=["off", "normal", "rotate"], default="normal",
@@ -223,8 +223,8 @@ def main():
         args.proposals = "off"                     # the two-stage model runs its own proposal layer
     else:
         model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
-    if args.streams is None:      # rcnn: each in-flight batch holds ~15 GB of RoI-stage intermediates, 16 of them thrash the allocator
-        args.streams = 16 if args.workload == "rpn" else 6
+    if args.streams is None:      # rcnn: each in-flight batch holds several GB of worst-case-sized RoI-stage buffers
+        args.streams = 16 if args.workload == "rpn" else 10
     nstreams = max(1, args.streams)
     make_clouds = rpn.synthetic_clouds if args.clouds == "uniform" else rpn.lidar_like_clouds
     clouds_cpu = make_clouds(args.batch, args.npoints, seed0=100 + rank * args.batch)
@@ -350,7 +350,8 @@ def main():
                    "inputs": ("raw velodyne scans (%d pts x 16 B per frame) in pinned host memory -> H2D -> prcnn_scene_prepare, all inside "
                               "the timed region" % args.raw_points) if args.input == "raw" else
                              ("host (pinned) -> HBM copy inside the timed region" if args.h2d else "resident in HBM"),
-                   "clouds": args.clouds, "group_dedup": os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"},
+                   "clouds": args.clouds, "group_dedup": os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0",
+                   "roi_dedup": os.environ.get("PRCNN_ROI_DEDUP", "1") != "0"},
     }
 
     if rank == 0 and not args.no_roofline and args.workload == "rpn":

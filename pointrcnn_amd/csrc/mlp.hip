@@ -76,6 +76,16 @@ struct MlpParams {
     int seg_rows;
 };
 
+// With live-row segments the 128-row tile a workgroup works on is NOT blockIdx.x: the live tiles are the first one or two
+// of every segment, i.e. blockIdx.x = 0 mod (seg_rows / 128), and consecutive workgroups go round-robin over the 8 XCDs --
+// with seg_rows = 512 all live tiles would land on 2 of the 8 XCDs (measured: 25 % of the tiles cost 80 % of the time).
+// Tile q of segment s is taken by workgroup q * nseg + s: the live tiles form a dense prefix of the grid.
+__device__ __forceinline__ long tile_of_block(const MlpParams& P, long bid) {
+    if (!P.seg_cnt) return bid;
+    const long nseg = P.rows / P.seg_rows, tps = P.seg_rows / 128;     // P.rows: the launch's row count (seg excludes rows_dev)
+    const long q = bid / nseg, sg = bid - q * nseg;
+    return sg * tps + q;
+}
 __device__ __forceinline__ bool tile_dead(const MlpParams& P, long row0) {
     if (!P.seg_cnt) return false;
     const long s = row0 / P.seg_rows;
@@ -265,8 +275,9 @@ template <int MODE, int WNB>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams Pin) {
     MlpParams P = Pin;
     P.rows = effective_rows(Pin);
-    if ((long)blockIdx.x * MLP_BM >= P.rows) return;     // workgroup-uniform (device-side row count)
-    if (tile_dead(P, (long)blockIdx.x * MLP_BM)) return;
+    const long tile_id = tile_of_block(P, blockIdx.x);
+    if (tile_id * MLP_BM >= P.rows) return;              // workgroup-uniform (device-side row count)
+    if (tile_dead(P, tile_id * MLP_BM)) return;
     constexpr int QN = 2 * WNB;                          // n-blocks per workgroup
     __shared__ __attribute__((aligned(16))) float As[2][MLP_BM * MLP_ALD];
     __shared__ __attribute__((aligned(16))) float Bs[2][QN * 4 * 256];
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, j = lane & 31;
-    const long row0 = (long)blockIdx.x * MLP_BM;
+    const long row0 = tile_id * MLP_BM;
     const int nb0 = blockIdx.y * QN;
     const int nchunks = (P.KB + 3) >> 2;
 
@@ -665,11 +676,12 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(const ChainParams Cin) {
     ChainParams C = Cin;
     C.a.rows = effective_rows(Cin.a);
     const MlpParams& P = C.a;
-    if ((long)blockIdx.x * 128 >= P.rows) return;
-    if (tile_dead(P, (long)blockIdx.x * 128)) return;
+    const long tile_id = tile_of_block(P, blockIdx.x);
+    if (tile_id * 128 >= P.rows) return;
+    if (tile_dead(P, tile_id * 128)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const long row = ((long)blockIdx.x * 4 + wave) * 32 + j;
+    const long row = (tile_id * 4 + wave) * 32 + j;
     RowMeta<MODE> meta;
     make_meta<MODE>(P, row, meta);
 
@@ -838,11 +850,12 @@ __global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C
     ChainParams C = Cin;
     C.a.rows = effective_rows(Cin.a);
     const MlpParams& P = C.a;
-    if ((long)blockIdx.x * 128 >= P.rows) return;
-    if (tile_dead(P, (long)blockIdx.x * 128)) return;
+    const long tile_id = tile_of_block(P, blockIdx.x);
+    if (tile_id * 128 >= P.rows) return;
+    if (tile_dead(P, tile_id * 128)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const long row = ((long)blockIdx.x * 4 + wave) * 32 + j;
+    const long row = (tile_id * 4 + wave) * 32 + j;
     const bool valid = row < P.rows;
     RowMeta<MODE> meta;
     make_meta<MODE>(P, valid ? row : P.rows - 1, meta);
@@ -1249,8 +1262,8 @@ PRCNN_API int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, co
     P.in = in; P.ld_in = ld_in;
     P.vec_a = aligned16(in) && (ld_in % 4 == 0);
     P.rows_dev = rows_dev; P.rows_unit = rows_unit > 0 ? rows_unit : 1;
-    PRCNN_REQUIRE(!seg_cnt || (seg_rows > 0 && seg_rows % MLP_BM == 0 && rows % seg_rows == 0 && pool_ns == 0),
-                  "prcnn_mlp_rows: seg_rows=%d must be a multiple of %d dividing rows (and no pooling)", seg_rows, MLP_BM);
+    PRCNN_REQUIRE(!seg_cnt || (seg_rows > 0 && seg_rows % MLP_BM == 0 && rows % seg_rows == 0 && pool_ns == 0 && !rows_dev),
+                  "prcnn_mlp_rows: seg_rows=%d must be a multiple of %d dividing rows (no pooling, no rows_dev)", seg_rows, MLP_BM);
     P.seg_cnt = seg_cnt; P.seg_rows = seg_rows;
     return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
 }
