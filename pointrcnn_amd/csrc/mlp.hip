@@ -74,6 +74,10 @@ struct MlpParams {
     // rows); 128-row tiles that lie entirely in the dead tail of their segment are skipped.  NULL: every row is live.
     const int32_t* seg_cnt;
     int seg_rows;
+    // XCD-aware tile order (gather modes): consecutive workgroups go round-robin over the 8 XCDs, each with its own 4 MB L2.
+    // With xcd_tpf = 128-row tiles per frame (> 0), XCD x works through frames x, x+8, ... one after the other, so the
+    // frame's gather source (Z / Y rows, 1-2 MB) stays resident in THAT XCD's L2 instead of every XCD streaming every frame.
+    int xcd_tpf;
 };
 
 // With live-row segments the 128-row tile a workgroup works on is NOT blockIdx.x: the live tiles are the first one or two
@@ -81,6 +85,11 @@ struct MlpParams {
 // with seg_rows = 512 all live tiles would land on 2 of the 8 XCDs (measured: 25 % of the tiles cost 80 % of the time).
 // Tile q of segment s is taken by workgroup q * nseg + s: the live tiles form a dense prefix of the grid.
 __device__ __forceinline__ long tile_of_block(const MlpParams& P, long bid) {
+    if (P.xcd_tpf > 0) {
+        const long xcd = bid & 7, slot = bid >> 3;
+        const long k = slot / P.xcd_tpf, t = slot - k * P.xcd_tpf;
+        return (k * 8 + xcd) * P.xcd_tpf + t;
+    }
     if (!P.seg_cnt) return bid;
     const long nseg = P.rows / P.seg_rows, tps = P.seg_rows / 128;     // P.rows: the launch's row count (seg excludes rows_dev)
     const long q = bid / nseg, sg = bid - q * nseg;
@@ -1556,5 +1565,6 @@ PRCNN_API int prcnn_mlp_chain_interp(const float* known_cl, int ld_known, const 
     C.a.vec_b = C1 > 0 && aligned16(skip_cl) && (ld_skip % 4 == 0) && (C2 % 4 == 0);
     rc = set_interp_act(C.a, act_bias, C2, C1);
     if (rc) return rc;
+    if (B % 8 == 0 && n % 128 == 0 && getenv("PRCNN_NO_XCD_ORDER") == nullptr) C.a.xcd_tpf = n / 128;
     return dispatch_chain(MODE_INTERP, C, (hipStream_t)stream);
 }
