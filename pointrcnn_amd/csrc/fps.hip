@@ -253,6 +253,10 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
     typedef typename fvec_t<PPT>::type fvec;
     typedef int ivec __attribute__((ext_vector_type(PPT >= 2 ? PPT : 2)));
     __shared__ float slot[2][NW][8];   // val, orig(bits), x, y, z
+    // original indices of the points a lane holds: only the winner's is ever needed, so they live in LDS (slot-major:
+    // s_po[i * 1024 + tid]) instead of PPT more VGPRs per lane -- at 96 VGPRs the four FPS waves of a SIMD left 128
+    // registers, too few for ANY of the MLP kernels (160-216), i.e. a CU hosting an FPS workgroup was lost to them
+    extern __shared__ int s_po[];
     __builtin_amdgcn_s_setprio(3);     // the serial chain every batch waits for: its few instructions go first
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -261,14 +265,13 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
     int32_t* __restrict__ out = idx_out + (size_t)b * npoint;
 
     fvec px, py, pz, pt;
-    ivec po;
     float lox = FPS_BIG, loy = FPS_BIG, loz = FPS_BIG, hix = -FPS_BIG, hiy = -FPS_BIG, hiz = -FPS_BIG;
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
         int s = tid * PPT + i;                      // position in Morton order
         bool ok = s < N;
         int o = ok ? pm[s] : 0x7fffffff;
-        po[i] = o;
+        s_po[i * BLOCK + tid] = o;
         px[i] = ok ? p[o * 3 + 0] : 0.f;
         py[i] = ok ? p[o * 3 + 1] : 0.f;
         pz[i] = ok ? p[o * 3 + 2] : 0.f;
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
             if (total == 1) {
                 istar = __builtin_amdgcn_readfirstlane(istar);
                 const int owner = __builtin_ctzll(anym);
-                corig = __builtin_amdgcn_readlane(po[istar], owner);
+                corig = s_po[istar * BLOCK + (wave << 6) + owner];          // own wave's entries: no barrier needed
                 float sx = px[istar], sy = py[istar], sz = pz[istar];
                 cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), owner));
                 cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), owner));
@@ -343,8 +346,10 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
                 int bo = 0x7fffffff; float bx = 0.f, by = 0.f, bz = 0.f;
                 if (best == wmaxf) {
 #pragma unroll
-                    for (int i = PPT - 1; i >= 0; i--)
-                        if (pt[i] == wmaxf && po[i] <= bo) { bo = po[i]; bx = px[i]; by = py[i]; bz = pz[i]; }
+                    for (int i = PPT - 1; i >= 0; i--) {
+                        const int oi = s_po[i * BLOCK + tid];
+                        if (pt[i] == wmaxf && oi <= bo) { bo = oi; bx = px[i]; by = py[i]; bz = pz[i]; }
+                    }
                 }
                 corig = wave_min_i32_fused(bo);
                 const int owner = __builtin_ctzll(__ballot(bo == corig));
@@ -433,9 +438,15 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
         const int sort_threads = NP / 16 < 64 ? 64 : NP / 16;
         hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(sort_threads), lds_sort_bytes(NP), s, xyz, N, NP, perm);
         PRCNN_LAUNCH_CHECK("prcnn_fps(sort)");
-        if (N <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4>), dim3(B), dim3(1024), 0, s, xyz, perm, N, npoint, idx);
-        else if (N <= 8192) hipLaunchKernelGGL((fps_pruned_kernel<8>), dim3(B), dim3(1024), 0, s, xyz, perm, N, npoint, idx);
-        else hipLaunchKernelGGL((fps_pruned_kernel<16>), dim3(B), dim3(1024), 0, s, xyz, perm, N, npoint, idx);
+        static bool pruned_attr = false;
+        if (!pruned_attr) {
+            if (hipFuncSetAttribute((const void*)fps_pruned_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 4096) != hipSuccess)
+                return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the pruned kernel");
+            pruned_attr = true;
+        }
+        if (N <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4>), dim3(B), dim3(1024), 4 * 4096, s, xyz, perm, N, npoint, idx);
+        else if (N <= 8192) hipLaunchKernelGGL((fps_pruned_kernel<8>), dim3(B), dim3(1024), 8 * 4096, s, xyz, perm, N, npoint, idx);
+        else hipLaunchKernelGGL((fps_pruned_kernel<16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);
     }
     else if (N <= 64) launch_fps<64, 1>(xyz, B, N, npoint, idx, s);
     else if (N <= 128) launch_fps<64, 2>(xyz, B, N, npoint, idx, s);
