@@ -42,7 +42,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32-input MFMA peak (/opt/ski
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96,
+    ap.add_argument("--steps", type=int, default=320,
                     help="timed steps; with 16 batches in flight the first/last steps fill and drain the pipeline (one batch's "
                          "latency is ~45 ms under load), so short runs under-report the steady state by a few percent")
     ap.add_argument("--warmup", type=int, default=16)

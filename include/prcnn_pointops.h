@@ -43,7 +43,8 @@ typedef void* prcnn_stream_t; /* hipStream_t */
 #define PRCNN_EHIP (-2)         /* HIP runtime / launch failure */
 #define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-int prcnn_abi_version(void);
+int prcnn_abi_version(void);   /* 3: + padding-free grouping (rows_dev / groups_dev, prcnn_group_compact, ...), RoI duplicate
+                                 * elimination (seg_cnt / seg_rows, distinct, valid_n), prcnn_scene_prepare */
 const char* prcnn_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------

@@ -1228,7 +1228,9 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     // >= 97 output channels: 128x128 workgroup tile -- unless that leaves most of the 256 CUs without a workgroup
     // (few rows, e.g. FP3's 2048 known points): then the 128x64 tile doubles the number of workgroups
     // (a device-side row count means a compacted list: P.rows is its worst case, the live part is expected to be small)
-    const bool wide = P.NB >= 4 && !P.rows_dev && (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4) >= 192;
+    static const long wide_min = getenv("PRCNN_WIDE_MIN_TILES") ? atol(getenv("PRCNN_WIDE_MIN_TILES")) : 192;
+    static const bool wide_lists = getenv("PRCNN_WIDE_LISTS") != nullptr;
+    const bool wide = P.NB >= 4 && (!P.rows_dev || wide_lists) && (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4) >= wide_min;
     dim3 grid(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, wide ? 4 : 2));
 #define MLP_LAUNCH(M)                                                                                         \
     do {                                                                                                      \
