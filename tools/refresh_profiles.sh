@@ -18,7 +18,7 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --streams 1 --no-cpu-baseline > $O/bench_streams1.json 2>> $O/bench_default.err
 python bench.py --clouds lidar --no-cpu-baseline > $O/bench_lidar.json 2>> $O/bench_default.err
 python bench.py --input raw > $O/bench_raw_input.json 2>> $O/bench_default.err
-python bench.py --workload rcnn --steps 48 > $O/bench_rcnn.json 2>> $O/bench_default.err
+python bench.py --workload rcnn > $O/bench_rcnn.json 2>> $O/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python bench.py --no-cpu-baseline --no-roofline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-cpu-baseline --no-roofline --streams 1 > /dev/null 2>&1
 python -m pointrcnn_amd.opbench > $O/opbench.jsonl 2> $O/opbench.err
