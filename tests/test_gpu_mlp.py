@@ -336,3 +336,37 @@ def test_chain_kernel_variants_are_bit_identical(dev, cpu, monkeypatch):
         ws, bs = _stack(r, (128, 128, nout), 0.1)
         layers = [lin(dev, ws[0], bs[0], True), lin(dev, ws[1], bs[1], False)]
         run_all(lambda: ops.mlp_chain_rows(feat, layers))
+
+
+def test_tile_order_remaps_are_bit_identical(dev, monkeypatch):
+    """Workgroup -> tile remaps must not change a byte: the XCD-aware frame order of the interp chain (B % 8 == 0, n % 128 == 0:
+    XCD x walks frames x, x+8, ...) and the live-prefix order of segment-skipping launches (tile q of segment s taken by
+    workgroup q * nseg + s).  Dead rows are compared only where they are live."""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(44)
+    B, n, m = 16, 384, 96                        # 3 tiles per frame, 16 frames: every XCD gets two frames
+    unknown, known = T(unit_cloud(B, n, seed=3), dev), T(unit_cloud(B, m, seed=4), dev)
+    _, idx3, w3 = ops.three_nn(unknown, known, want_weight=True)
+    y = T(r.normal(size=(B, m, 128)).astype(np.float32), dev)
+    ws, bs = _stack(r, (128, 128), 0.1)
+    b0 = T(r.normal(size=(128,)).astype(np.float32), dev)
+    l1 = lin(dev, ws[0], bs[0], True)
+    monkeypatch.delenv("PRCNN_NO_XCD_ORDER", raising=False)
+    a = ops.mlp_chain_interp(y, idx3, w3, None, [l1], act_bias=b0).clone()
+    monkeypatch.setenv("PRCNN_NO_XCD_ORDER", "1")
+    b = ops.mlp_chain_interp(y, idx3, w3, None, [l1], act_bias=b0).clone()
+    monkeypatch.delenv("PRCNN_NO_XCD_ORDER", raising=False)
+    assert torch.equal(a, b)
+    # segment-prefix live rows: 40 segments of 256 rows, live counts from 1 to 256 (both tiles of a segment live or not)
+    S, nseg = 256, 40
+    cnt = torch.tensor([1, 127, 128, 129, 255, 256] + list(r.integers(1, 257, nseg - 6)), dtype=torch.int32, device=dev)
+    x = T(r.normal(size=(nseg * S, 96)).astype(np.float32), dev)
+    w2, b2 = _stack(r, (96, 160), 0.1)
+    l2 = lin(dev, w2[0], b2[0], True)
+    live = (torch.arange(S, device=dev)[None, :] < cnt[:, None].long()).view(-1)
+    full = ops.mlp_rows(x, l2)
+    part = ops.mlp_rows(x, l2, seg=(cnt, S))
+    assert torch.equal(full[live], part[live])
+    up = [lin(dev, w, b, True) for w, b in zip(*_stack(r, (5, 128, 128), 0.2))]
+    pts = T(r.normal(size=(nseg * S, 5)).astype(np.float32), dev)
+    assert torch.equal(ops.mlp_chain_rows(pts, up)[live], ops.mlp_chain_rows(pts, up, seg=(cnt, S))[live])
