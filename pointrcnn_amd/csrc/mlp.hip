@@ -832,6 +832,7 @@ __device__ __forceinline__ void fchain_layer(const f32x16 (&in)[NBI], f32x16 (&o
 #pragma unroll
     for (int st = 0; st < NST; st++) {
         if (st + 1 < NST) fstage_load<NBO>(wpack, KB, st + 1, wave, lane, wr);
+        __builtin_amdgcn_sched_barrier(0);                 // (as in layer 0: keep the weight request ahead of the MFMAs)
         const float* ws = Ws[st & 1];
 #pragma unroll
         for (int kbl = 0; kbl < G; kbl++) {
@@ -854,6 +855,16 @@ __device__ __forceinline__ void fchain_layer(const f32x16 (&in)[NBI], f32x16 (&o
 }
 
 #define FAST_MAX_K 128
+#ifndef FAST_RING_PLAIN
+#define FAST_RING_PLAIN 3
+#endif
+#ifndef FAST_RING_GROUP
+#define FAST_RING_GROUP 2
+#endif
+#ifndef FAST_RING_INTERP
+#define FAST_RING_INTERP 2
+#endif
+template <int MODE> struct FAST_RING { static constexpr int D = MODE == MODE_PLAIN ? FAST_RING_PLAIN : (MODE == MODE_GROUP ? FAST_RING_GROUP : FAST_RING_INTERP); };
 template <int MODE, int NB0, int NB1, int NB2>
 __global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams Cin) {
     ChainParams C = Cin;
@@ -894,11 +905,14 @@ __global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C
         const int klast = P.K - 8 + 4 * h;                     // last legal piece of this lane's k sub-range
         float4 wr[4];
         fstage_load<NB0>(P.wpack, P.KB, 0, wave, lane, wr);
-        // two pieces ahead: r1 = raw row piece of kb+1 (arrived), r2 = piece of kb+2 (requested in this block)
-        // (a deeper ring of 4 pieces measured no faster: the L2-resident sources answer within one k-block)
-        Raw<MODE> r0, r1;
+        // RD pieces ahead: ring[0] = raw row piece of kb+1 (arrived) ... ring[RD-1] = kb+RD; kb+RD+1 is requested in this block.
+        // Plain rows stream from HBM (~2 us away under load) and cost 4 registers a piece; gathered rows come from L2 / MALL
+        // and cost 4 (group) or 12 (interp) registers a piece.
+        constexpr int RD = FAST_RING<MODE>::D;
+        Raw<MODE> r0, ring[RD];
         fast_fetch<MODE>(P, meta, 4 * h, r0);
-        fast_fetch<MODE>(P, meta, min(8 + 4 * h, klast), r1);
+#pragma unroll
+        for (int q = 0; q < RD; q++) fast_fetch<MODE>(P, meta, min(8 * (q + 1) + 4 * h, klast), ring[q]);
         fstage_store<NB0>(Ws[0], wave, lane, wr);
         __syncthreads();                                       // Ws[0], s_wx, s_b visible
         if (NB1 > 0) fstage_load<(NB1 ? NB1 : 1)>(C.wpack1, NB0 * 4, 0, wave, lane, w1s);
@@ -906,12 +920,16 @@ __global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C
         for (int st = 0; st < nst; st++) {
             const bool more_st = st + 1 < nst;
             if (more_st) fstage_load<NB0>(P.wpack, P.KB, st + 1, wave, lane, wr);
+            __builtin_amdgcn_sched_barrier(0);
             const float* ws = Ws[st & 1];
 #pragma unroll
             for (int kbl = 0; kbl < G; kbl++) {
                 const int kb = st * G + kbl;
-                Raw<MODE> r2;
-                fast_fetch<MODE>(P, meta, min(8 * (kb + 2) + 4 * h, klast), r2);
+                Raw<MODE> rn;
+                fast_fetch<MODE>(P, meta, min(8 * (kb + 1 + RD) + 4 * h, klast), rn);
+                // keep the request HERE: left alone, the scheduler sinks these loads to just before their first use (one
+                // k-block later), which turns the two-piece ring into a load-use stall of a full L2 round trip per k-block
+                __builtin_amdgcn_sched_barrier(0);
                 float4 w[NB0];
 #pragma unroll
                 for (int ob = 0; ob < NB0; ob++) w[ob] = lds_w(ws, kbl * NB0 + ob, lane);
@@ -923,8 +941,10 @@ __global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams C
                 for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].z, bcur.z, a0[ob], 0, 0, 0);
 #pragma unroll
                 for (int ob = 0; ob < NB0; ob++) a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ob].w, bcur.w, a0[ob], 0, 0, 0);
-                bcur = fast_finish<MODE>(meta, min(8 * (kb + 1) + 4 * h, klast), r1, s_wx, s_b);   // B operand of kb+1
-                r1 = r2;
+                bcur = fast_finish<MODE>(meta, min(8 * (kb + 1) + 4 * h, klast), ring[0], s_wx, s_b);   // B operand of kb+1
+#pragma unroll
+                for (int q = 0; q + 1 < RD; q++) ring[q] = ring[q + 1];
+                ring[RD - 1] = rn;
             }
             if (more_st) fstage_store<NB0>(Ws[(st + 1) & 1], wave, lane, wr);
             __syncthreads();
