@@ -12,8 +12,10 @@
 //                          appended to one flat row list (global point index + the group's centroid per row), the group
 //                          remembers (first row, cnt).  Groups with cnt > T go to the DENSE list with their full nsample
 //                          rows, padding included -- a full tile pooled in the MLP epilogue is cheaper for them than a
-//                          round trip of cnt result rows through HBM.  Lists are appended with wave-aggregated atomics;
-//                          their order is arbitrary, the results are not (every group's output row is written exactly once).
+//                          round trip of cnt result rows through HBM.  Lists are appended with ONE atomic per 1024-thread
+//                          block and list; their order is arbitrary, the results are not (every group's output row is
+//                          written exactly once).  With valid_n (roipool3d-padded clouds) a hit that is a wrap-copy of an
+//                          earlier point ends the group's real rows exactly like padding does.
 //   the MLP kernels take the list lengths as DEVICE-side row counts (MlpParams::rows_dev): launched for the worst case,
 //   workgroups past the end exit at once;
 //   segmax_scatter_kernel : max over each sparse group's result rows -> the group's row of the level's output;
