@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- RPN inference throughput of the MI355X point-ops hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: re-executes itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -16,9 +16,19 @@ Besides the contract fields the line carries
                   (rows actually processed -- device-side counts read back -- x layer widths) / their GPU time, measured
                   with HIP events on the launch stream in an instrumented pass of the same steps; peak = 157.3 TFLOP/s
                   dense fp32 MFMA.  reference_graph_TFLOPs prices the reference's dense flop count over the same time.
-  cpu_baseline -- the CPU oracle restatement of the SAME graph (oracle/rpn_cpu.py, kind "port", 1 thread)
-                  timed on a bounded sample (one frame) on this box's host cores, rank 0 at N=1 only.
+  cpu_baseline -- the SAME graph on this box's host cores the way SURVEY 8(d) specifies: index operators = the C oracle
+                  (single-threaded C, one frame per process), MLPs = torch-CPU sgemm, one batch of frames spread over worker
+                  processes that together use every core; median of 5 runs after a warm-up (oracle/cpu_baseline.py, run as a
+                  subprocess so that it forks before any HIP state exists); plus the reference's own roipool3d_cpu.
   kernels      -- per-op-family GPU time of one step (ms) from the same event pass.
+  value_h2d_inclusive, value_dedup_off, value_saturated -- the same command with every batch's clouds copied from pinned host
+                  memory inside the timed region / with padding-free grouping switched off / on clouds whose every ball is
+                  full: the throughput is data-dependent (exact first-layer hoisting + padding-free grouping remove most of the
+                  reference graph's MLP rows on sparse clouds) and these are its best / typical / worst cases.
+
+`--workload train` (BASELINE config 4): one RPN training iteration per step (forward, the reference's loss, backward through
+the HIP operator kernels, DistributedDataParallel gradient all-reduce over RCCL, grad-norm clip, optimizer step), 16 frames
+per GPU.
 """
 import argparse
 import json
@@ -39,14 +49,14 @@ if ROOT not in sys.path:
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32-input MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=320,
+    ap.add_argument("--steps", type=int, default=None,
                     help="timed steps; with 16 batches in flight the first/last steps fill and drain the pipeline (one batch's "
                          "latency is ~45 ms under load), so short runs under-report the steady state by a few percent")
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (BASELINE metric: bs32)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (BASELINE metric: bs32; train: 16 = config 4)")
     ap.add_argument("--npoints", type=int, default=16384)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the step from a hipGraph")
     ap.add_argument("--streams", type=int, default=None,
@@ -56,12 +66,16 @@ def parse():
     ap.add_argument("--proposals", choices=["off", "normal", "rotate"], default="normal",
                     help="also run the proposal layer (decode + sort + distance split + NMS + top-100, lib/rpn/proposal_layer.py) "
                          "inside every step, as tools/eval_rcnn.py --eval_mode rpn does after the heads")
-    ap.add_argument("--workload", choices=["rpn", "rcnn"], default="rpn",
+    ap.add_argument("--workload", choices=["rpn", "rcnn", "train"], default="rpn",
                     help="rpn = the BASELINE metric (RPN inference end-to-end); rcnn = BASELINE config 3, the whole two-stage detector "
-                         "(RPN -> proposals -> roipool3d -> RCNN -> box decode -> rotated NMS), 100 RoIs per frame")
-    ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform",
+                         "(RPN -> proposals -> roipool3d -> RCNN -> box decode -> rotated NMS), 100 RoIs per frame; train = BASELINE "
+                         "config 4, one RPN training iteration per step under DistributedDataParallel (RCCL)")
+    ap.add_argument("--clouds", choices=["uniform", "lidar", "saturated"], default="uniform",
                     help="uniform = the BASELINE metric's synthetic clouds; lidar = range-dependent density + ground band + car "
-                         "clusters (same bounds): a robustness check for the spatially pruned / grid kernels")
+                         "clusters (same bounds): a robustness check for the spatially pruned / grid kernels; saturated = 16384 "
+                         "points in a 1.6 m cube: every ball of every level is full (the worst case for padding-free grouping)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra timed loops (H2D-inclusive, dedup off, saturated clouds) that report the data dependence")
     ap.add_argument("--h2d", action="store_true",
                     help="also copy every batch's clouds from pinned host memory inside the timed region (PCIe-inclusive rate; "
                          "the default keeps inputs resident in HBM, as the bench contract asks)")
@@ -72,7 +86,66 @@ def parse():
     ap.add_argument("--raw-points", type=int, default=118000, help="raw points per synthetic scan for --input raw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    train = args.workload == "train"
+    if args.steps is None:
+        args.steps = 20 if train else 320
+    if args.warmup is None:
+        args.warmup = 3 if train else 16
+    if args.batch is None:
+        args.batch = 16 if train else 32
+    return args
+
+
+# ---- multi-GPU plumbing (exercised on CPU by tests/test_dist_gloo.py) ------------------------------------------------
+def shard_seed0(rank, world, slot, batch):
+    """first frame seed of the batch that in-flight slot `slot` of rank `rank` owns: frames are sharded by rank (weak
+    scaling, `batch` frames per GPU), disjoint across ranks and slots: rank r, slot s holds global batch s * world + r"""
+    return 100 + (world * slot + rank) * batch
+
+
+def reduce_elapsed(elapsed, dist=None, device="cpu"):
+    """the job's step time is the slowest rank's: MAX over ranks of the barrier-bracketed elapsed time"""
+    if dist is None:
+        return float(elapsed)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_value(batch, world, steps, elapsed):
+    """frames of ALL ranks per second"""
+    return batch * world * steps / elapsed
+
+
+def self_launch_command(gpus, argv, port=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment re-executes itself as one rank per GPU"""
+    import socket
+    if port is None:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus, "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def resolve_world(args, env, ndev):
+    """-> (world, rank, local_rank, relaunch): validates --gpus against the launcher environment and the visible devices"""
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit("bench.py: launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+        rank, local_rank = int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0"))
+        if local_rank >= ndev:
+            raise SystemExit("bench.py: local rank %d but only %d visible GPU(s)" % (local_rank, ndev))
+        return world, rank, local_rank, False
+    if args.gpus > 1:
+        if ndev < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible: refusing to report a %d-GPU number from fewer devices"
+                             % (args.gpus, ndev, args.gpus))
+        return args.gpus, 0, 0, True
+    return 1, 0, 0, False
 
 
 class EventProfiler:
@@ -143,17 +216,34 @@ class EventProfiler:
 
 
 def cpu_baseline(model, clouds_cpu, gpu_out):
-    """the oracle port of the same graph on one frame (bounded sample), single thread"""
+    """SURVEY 8(d) CPU baseline of the same graph (see module docstring) + the reference's own roipool3d_cpu + the relative
+    error of the GPU outputs against the double-accumulating oracle on frame 0"""
+    import pickle
+    import subprocess
+    import tempfile
+    import numpy as np
     import oracle
     from oracle import rpn_cpu
     cpu = oracle.cpu()
     spec = rpn_cpu.extract_rpn_weights(model)
-    timings = {}
-    nframes = min(3, clouds_cpu.shape[0])
-    t0 = time.perf_counter()
-    outs = [rpn_cpu.rpn_forward_frame(cpu, clouds_cpu[f].numpy(), spec, timings) for f in range(nframes)]
-    dt = time.perf_counter() - t0
-    out = outs[0]
+    cores = os.cpu_count() or 1
+    nframes = int(min(clouds_cpu.shape[0], max(8, cores)))
+    res = None
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "spec.pkl"), "wb") as f:
+            pickle.dump(spec, f)
+        np.save(os.path.join(td, "clouds.npy"), clouds_cpu[:nframes].numpy())
+        env = dict(os.environ)
+        env.pop("OMP_NUM_THREADS", None)
+        try:
+            p = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--spec", os.path.join(td, "spec.pkl"), "--clouds",
+                                os.path.join(td, "clouds.npy"), "--repeats", "5", "--budget-s", "40"], cwd=ROOT, env=env,
+                               capture_output=True, text=True, timeout=600)
+            res = json.loads(p.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001
+            print("[bench] cpu_baseline subprocess failed: %s" % e, file=sys.stderr)
+    # frame 0 through the double-accumulating oracle: the parity figure of the line
+    out = rpn_cpu.rpn_forward_frame(cpu, clouds_cpu[0].numpy(), spec, {})
     err = {}
     for k in ("rpn_cls", "rpn_reg"):
         ref = out[k]
@@ -164,7 +254,6 @@ def cpu_baseline(model, clouds_cpu, gpu_out):
     ref_roipool = None
     ref = oracle.ref()
     if ref is not None:
-        import numpy as np
         from pointrcnn_amd import ops
         rng = np.random.default_rng(0)
         pts = clouds_cpu[0].numpy()
@@ -172,11 +261,12 @@ def cpu_baseline(model, clouds_cpu, gpu_out):
         boxes = np.concatenate([ctr[:, :1], ctr[:, 1:2] + 1.8, ctr[:, 2:3], np.tile([3.6, 3.7, 6.0], (100, 1)),
                                 rng.uniform(-3.14, 3.14, (100, 1))], 1).astype(np.float32)
         feat = rng.normal(size=(pts.shape[0], 130)).astype(np.float32)
-        t1 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
+        times = []
+        for _ in range(6):
+            t1 = time.perf_counter()
             pp, pf, pe = ref.roipool3d_cpu(pts, boxes, feat, 512)
-        cpu_s = (time.perf_counter() - t1) / reps
+            times.append(time.perf_counter() - t1)
+        cpu_s = sorted(times[1:])[len(times[1:]) // 2]
         dev = gpu_out["rpn_cls"].device
         tx, tb, tf = (torch.from_numpy(a[None]).to(dev) for a in (pts, boxes, feat))
         pooled, _ = ops.roipool3d(tx, tb, tf, 512)
@@ -189,22 +279,224 @@ def cpu_baseline(model, clouds_cpu, gpu_out):
         torch.cuda.synchronize()
         same = bool(np.array_equal(pooled[0, :, :, 3:].cpu().numpy(), pf) and np.array_equal(pooled[0, :, :, :3].cpu().numpy(), pp))
         ref_roipool = {"kind": "reference", "op": "roipool3d_cpu (lib/utils/roipool3d/src/roipool3d.cpp:127-195), 1 frame, 100 RoIs x 512 x 133",
-                       "cpu_ms_per_frame": round(cpu_s * 1e3, 2), "cores": 1,
+                       "cpu_ms_per_frame": round(cpu_s * 1e3, 2), "cores": 1, "runs": "median of 5 after 1 warm-up",
+                       "cpu_frames_per_s_all_cores": round(cores / cpu_s, 1),
                        "gpu_ms_per_frame_single_frame_launch": round(s_.elapsed_time(e_) / 20, 4), "outputs_identical": same}
-    return {"value": round(nframes / dt, 5), "unit": "frames/s", "cores": 1, "kind": "port", "reference_roipool3d": ref_roipool,
-            "sample": "%d frames (16384 pts each) of the same RPN graph through oracle/rpn_cpu.py, %.1f s" % (nframes, dt),
-            "host_cores_available": os.cpu_count(),
-            "breakdown_s": {k: round(v, 2) for k, v in sorted(timings.items())},
-            "gpu_vs_oracle_rel_err_frame0": err}
+    line = {"value": None, "unit": "frames/s", "cores": cores, "kind": "port",
+            "what": "index operators: C oracle (oracle/prcnn_oracle.c), one frame per worker process; SharedMLP layers: torch-CPU "
+                    "sgemm; worker threads add up to the host's cores (the reference has no CPU path for this graph)",
+            "reference_roipool3d": ref_roipool, "host_cores_available": cores, "gpu_vs_oracle_rel_err_frame0": err}
+    if res is not None:
+        line.update({"value": res["frames_per_s"], "cores": res["cores"],
+                     "sample": "%d frames (16384 pts each) of the same RPN graph, %d worker processes x %d threads, median of %d runs "
+                               "after 1 warm-up (%s s)" % (res["frames"], res["workers"], res["threads_per_worker"], len(res["runs_s"]),
+                                                          res["runs_s"]),
+                     "cpu_seconds_by_op": res["cpu_seconds_by_op"]})
+    return line
+
+
+def make_cloud_fn(kind):
+    from pointrcnn_amd import rpn
+    return {"uniform": rpn.synthetic_clouds, "lidar": rpn.lidar_like_clouds, "saturated": rpn.saturated_clouds}[kind]
+
+
+class InferenceBench:
+    """the timed inference loop: S in-flight slots, each a captured hipGraph of one step on its own stream"""
+
+    def __init__(self, args, model, dev, rank, world, clouds_kind, proposal_layer=None, raw=None):
+        self.args, self.model, self.dev, self.proposal_layer, self.raw = args, model, dev, proposal_layer, raw
+        self.nstreams = max(1, args.streams)
+        make_clouds = make_cloud_fn(clouds_kind)
+        self.clouds_cpu = make_clouds(args.batch, args.npoints, seed0=shard_seed0(rank, world, 0, args.batch))
+        self.batches = [{"pts_input": self.clouds_cpu.to(dev)}]
+        for s_ in range(1, self.nstreams):          # every in-flight slot owns its (resident) input batch
+            self.batches.append({"pts_input": make_clouds(args.batch, args.npoints, seed0=shard_seed0(rank, world, s_, args.batch)).to(dev)})
+        self.streams = [torch.cuda.Stream() for _ in range(self.nstreams)]
+        self.graphs, self.out, self.host = None, None, None
+
+    def step(self, slot=0):
+        args, model = self.args, self.model
+        with torch.no_grad():
+            if self.raw is not None:
+                r = self.raw["slots"][slot]
+                xyz, _, _, _, r["status"] = self.raw["ops"].scene_prepare(r["dev"]["raw"], r["dev"]["offsets"], r["max_points"], r["dev"]["calib"],
+                                                                          r["dev"]["img_hw"], self.raw["prep"].scope, args.npoints, r["seed"])
+                o = model({"pts_input": xyz})
+            else:
+                o = model(self.batches[slot])
+            if self.proposal_layer is not None:
+                o["rois"], o["roi_scores_raw"] = self.proposal_layer(o["rpn_cls"][:, :, 0], o["rpn_reg"], o["backbone_xyz"])
+            if args.workload == "rcnn":
+                o["pred_boxes3d"], o["raw_scores"], o["keep"], o["num_keep"] = model.detections(o)
+            return o
+
+    def prepare(self):
+        args = self.args
+        for _ in range(max(1, min(args.warmup, 4))):        # packs weights, fills the caching allocator
+            self.out = self.step(0)
+        torch.cuda.synchronize()
+        if args.graph != "off":
+            try:
+                graphs, gouts = [], []
+                for slot in range(self.nstreams):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(self.streams[slot]):
+                        self.step(slot)
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g, stream=self.streams[slot]):
+                        gouts.append(self.step(slot))
+                    graphs.append(g)
+                graphs[0].replay()
+                torch.cuda.synchronize()
+                for k in ("rpn_cls", "rpn_reg"):                 # the replayed graph must reproduce the eager result
+                    assert torch.equal(gouts[0][k], self.out[k]), "graph replay differs from eager (%s)" % k
+                self.graphs, self.out = graphs, gouts[0]
+            except Exception as e:  # noqa: BLE001
+                if args.graph == "on":
+                    raise
+                print("[bench] hipGraph capture unavailable (%s); timing eager launches" % str(e).split("\n")[0], file=sys.stderr)
+                self.graphs = None
+                torch.cuda.synchronize()
+        return self
+
+    def run(self, k, h2d=False):
+        slot = k % self.nstreams
+        with torch.cuda.stream(self.streams[slot]):
+            if h2d:
+                self.batches[slot]["pts_input"].copy_(self.host[slot], non_blocking=True)
+            if self.raw is not None:
+                self.raw["slots"][slot]["dev"]["raw"].copy_(self.raw["slots"][slot]["host"]["raw"], non_blocking=True)
+            if self.graphs is not None:
+                self.graphs[slot].replay()
+            else:
+                self.step(slot)
+
+    def timed(self, steps, warmup, dist=None, h2d=False):
+        """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; -> max-over-ranks seconds"""
+        if h2d and self.host is None:
+            self.host = [b["pts_input"].cpu().pin_memory() for b in self.batches]
+        for k in range(warmup):
+            self.run(k, h2d)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.run(k, h2d)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return reduce_elapsed(time.perf_counter() - t0, dist, self.dev)
+
+    def release(self):
+        self.graphs = None
+        self.batches = None
+        self.out = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
+def instrumented_pass(args, bench, nprof):
+    """per-op-family GPU time + EXECUTED MLP flops of `nprof` eager steps (HIP events on the launch stream)"""
+    from pointrcnn_amd import _cabi, ops as _ops
+    prof = EventProfiler(_cabi._lib)
+    real = _cabi._lib
+    _cabi._lib, _ops._split_log = prof, prof.splits
+    try:
+        for _ in range(nprof):
+            bench.step(0)
+        return prof.summary()
+    finally:
+        _cabi._lib, _ops._split_log = real, None
+
+
+def run_train(args, dev, rank, world, local_rank, dist):
+    """BASELINE config 4: RPN training iterations under DDP; -> the JSON line"""
+    from pointrcnn_amd import ops, rpn, train_functions as tf
+    torch.manual_seed(1234)
+    model = tf.init_rpn_head_weights(rpn.randomize_bn_stats(rpn.RPN(), seed=7)).to(dev)
+    trainer = tf.RPNTrainer(model, ddp=dist is not None, device_ids=[local_rank] if dist is not None else None)
+    make_clouds = make_cloud_fn(args.clouds)
+    nslots = 4                                              # a few different resident batches, cycled
+    batches = []
+    g = torch.Generator().manual_seed(99 + rank)
+    for s_ in range(nslots):
+        pts = make_clouds(args.batch, args.npoints, seed0=shard_seed0(rank, world, s_, args.batch)).to(dev)
+        # synthetic GT: 12 car-sized boxes per frame centred on cloud points (enlarged x2 so that the sparse synthetic cloud
+        # yields a few hundred foreground points per frame), labels from the device label kernel (prcnn_rpn_labels)
+        pick = torch.randint(0, args.npoints, (args.batch, 12), generator=g).to(dev)
+        ctr = torch.gather(pts, 1, pick[..., None].expand(-1, -1, 3))
+        hwl = torch.tensor([1.56, 1.6, 3.9], device=dev) * 2.0
+        ry = (torch.rand((args.batch, 12, 1), generator=g) * 6.283 - 3.1416).to(dev)
+        gt = torch.cat([ctr[..., 0:1], ctr[..., 1:2] + hwl[0] / 2, ctr[..., 2:3], hwl.expand(args.batch, 12, 3), ry], 2).contiguous()
+        cls, reg = ops.rpn_labels(pts, gt)
+        batches.append({"pts_input": pts, "rpn_cls_label": cls.long(), "rpn_reg_label": reg})
+    for k in range(max(1, args.warmup)):
+        loss = trainer.step(batches[k % nslots])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        loss = trainer.step(batches[k % nslots])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = reduce_elapsed(time.perf_counter() - t0, dist, dev)
+    nparam = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    allreduce_ms = None
+    if dist is not None:                                     # the gradient all-reduce on its own: one flat fp32 buffer of the same size
+        flat = torch.zeros(nparam, device=dev)
+        for _ in range(3):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        allreduce_ms = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+    # forward / backward / optimizer split of one step (events, rank 0)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    trainer.model.train()
+    trainer.optimizer.zero_grad(set_to_none=True)
+    ev[0].record()
+    loss = trainer.loss(batches[0])
+    ev[1].record()
+    loss.backward()
+    ev[2].record()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), trainer.cfg.GRAD_NORM_CLIP)
+    trainer.optimizer.step()
+    ev[3].record()
+    torch.cuda.synchronize()
+    fg = int((batches[0]["rpn_cls_label"] > 0).sum().item())
+    return {
+        "metric": "KITTI frames/sec, RPN training step (16384 pts/frame, bs%d per GPU, DDP over RCCL)" % args.batch,
+        "value": round(whole_job_value(args.batch, world, args.steps, elapsed), 2), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: train_rcnn.py --train_mode rpn, one iteration per step (forward, focal + bin-based "
+                               "regression loss, backward, gradient all-reduce, grad-norm clip 1.0, AdamW step), tools/cfgs/default.yaml, "
+                               "%d pts/frame, batch %d per GPU, synthetic labels (%d foreground points in batch 0)" % (args.npoints, args.batch, fg),
+                   "frames_per_gpu": args.batch, "global_batch": args.batch * world, "npoints": args.npoints,
+                   "parallelism": "dp%d (DistributedDataParallel, RCCL)" % world if world > 1 else "single GPU (no DDP wrapper)",
+                   "clouds": args.clouds, "launch": "eager (autograd)", "inputs": "resident in HBM"},
+        "train": {"loss_last": round(float(loss.item()), 4), "parameters": nparam, "gradient_bytes": nparam * 4,
+                  "allreduce_ms_flat_buffer": allreduce_ms,
+                  "forward_loss_ms": round(ev[0].elapsed_time(ev[1]), 3), "backward_ms": round(ev[1].elapsed_time(ev[2]), 3),
+                  "clip_optimizer_ms": round(ev[2].elapsed_time(ev[3]), 3),
+                  "note": "point operators (FPS, ball query, grouping, 3-NN, interpolation) forward AND backward are this package's HIP "
+                          "kernels; 1x1 conv + training-mode BatchNorm run through torch (MIOpen/rocBLAS)"}}
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernels are the only implementation of the hot path")
+    world, rank, local_rank, relaunch = resolve_world(args, os.environ, torch.cuda.device_count())
+    if relaunch:
+        cmd = self_launch_command(args.gpus, sys.argv[1:])
+        print("[bench] --gpus %d without a launcher environment: re-executing as %s" % (args.gpus, " ".join(cmd[:8]) + " ..."), file=sys.stderr)
+        os.execv(cmd[0], cmd)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -212,10 +504,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from pointrcnn_amd import _cabi, rpn
     _cabi.lib()
+    if args.workload == "train":
+        line = run_train(args, dev, rank, world, local_rank, dist)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     torch.manual_seed(1234)
     if args.workload == "rcnn":
         from pointrcnn_amd.point_rcnn import PointRCNN
@@ -226,15 +525,8 @@ def main():
     if args.streams is None:      # rcnn: each in-flight batch holds several GB of worst-case-sized RoI-stage buffers
         args.streams = 16 if args.workload == "rpn" else 10
     nstreams = max(1, args.streams)
-    make_clouds = rpn.synthetic_clouds if args.clouds == "uniform" else rpn.lidar_like_clouds
-    clouds_cpu = make_clouds(args.batch, args.npoints, seed0=100 + rank * args.batch)
-    batches = [{"pts_input": clouds_cpu.to(dev)}]
-    for s_ in range(1, nstreams):          # every in-flight slot owns its (resident) input batch
-        batches.append({"pts_input": make_clouds(args.batch, args.npoints,
-                                                          seed0=100 + (world * s_ + rank) * args.batch).to(dev)})
-    streams = [torch.cuda.Stream() for _ in range(nstreams)]
 
-    raw_slots = None
+    raw = None
     if args.input == "raw":
         # one packed batch of synthetic scans per in-flight slot: pinned on the host, preallocated on the device
         import numpy as np
@@ -248,94 +540,21 @@ def main():
             host_pack = prep.pack(scans, [calib0] * args.batch, [(375, 1242)] * args.batch)
             raw_slots.append({"host": host_pack, "dev": {k: host_pack[k].to(dev) for k in ("raw", "offsets", "calib", "img_hw")},
                               "max_points": host_pack["max_points"], "seed": 17 + s_})
+        raw = {"slots": raw_slots, "prep": prep, "ops": _pops}
 
     proposal_layer = None
     if args.proposals != "off":
         from pointrcnn_amd.proposal_layer import ProposalConfig, ProposalLayer
         proposal_layer = ProposalLayer("TEST", cfg=type("Cfg", (ProposalConfig,), {"NMS_TYPE": args.proposals}))
 
-    def step(slot=0):
-        with torch.no_grad():
-            if raw_slots is not None:
-                r = raw_slots[slot]
-                xyz, _, _, _, r["status"] = _pops.scene_prepare(r["dev"]["raw"], r["dev"]["offsets"], r["max_points"], r["dev"]["calib"],
-                                                                r["dev"]["img_hw"], prep.scope, args.npoints, r["seed"])
-                o = model({"pts_input": xyz})
-            else:
-                o = model(batches[slot])
-            if proposal_layer is not None:
-                o["rois"], o["roi_scores_raw"] = proposal_layer(o["rpn_cls"][:, :, 0], o["rpn_reg"], o["backbone_xyz"])
-            if args.workload == "rcnn":
-                o["pred_boxes3d"], o["raw_scores"], o["keep"], o["num_keep"] = model.detections(o)
-            return o
+    bench = InferenceBench(args, model, dev, rank, world, args.clouds, proposal_layer, raw).prepare()
+    elapsed = bench.timed(args.steps, args.warmup, dist, h2d=args.h2d)
+    out, clouds_cpu, graph = bench.out, bench.clouds_cpu, bench.graphs
 
-    for _ in range(max(1, args.warmup)):        # packs weights, fills the caching allocator
-        out = step(0)
-    torch.cuda.synchronize()
-
-    graphs = None
-    if args.graph != "off":
-        try:
-            graphs, gouts = [], []
-            for slot in range(nstreams):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.stream(streams[slot]):
-                    step(slot)
-                torch.cuda.synchronize()
-                with torch.cuda.graph(g, stream=streams[slot]):
-                    gouts.append(step(slot))
-                graphs.append(g)
-            graphs[0].replay()
-            torch.cuda.synchronize()
-            for k in ("rpn_cls", "rpn_reg"):                 # the replayed graph must reproduce the eager result
-                assert torch.equal(gouts[0][k], out[k]), "graph replay differs from eager (%s)" % k
-            out = gouts[0]
-        except Exception as e:  # noqa: BLE001
-            if args.graph == "on":
-                raise
-            print("[bench] hipGraph capture unavailable (%s); timing eager launches" % str(e).split("\n")[0],
-                  file=sys.stderr)
-            graphs = None
-            torch.cuda.synchronize()
-
-    host = [b["pts_input"].cpu().pin_memory() for b in batches] if args.h2d else None
-
-    def run(k):
-        slot = k % nstreams
-        with torch.cuda.stream(streams[slot]):
-            if host is not None:
-                batches[slot]["pts_input"].copy_(host[slot], non_blocking=True)
-            if raw_slots is not None:
-                raw_slots[slot]["dev"]["raw"].copy_(raw_slots[slot]["host"]["raw"], non_blocking=True)
-            if graphs is not None:
-                graphs[slot].replay()
-            else:
-                step(slot)
-
-    for k in range(args.warmup):
-        run(k)
-
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        run(k)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    graph = graphs
-
-    frames = args.batch * world * args.steps
     line = {
         "metric": ("KITTI frames/sec, RPN inference end-to-end (16384 pts/frame, bs%d per GPU)" % args.batch) if args.workload == "rpn"
         else ("KITTI frames/sec, full two-stage PointRCNN inference (16384 pts/frame, 100 RoIs/frame, bs%d per GPU)" % args.batch),
-        "value": round(frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "value": round(whole_job_value(args.batch, world, args.steps, elapsed), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("Full RPN PointNet++ backbone (4 SA-MSG + 4 FP) + cls/reg heads, tools/cfgs/default.yaml, "
@@ -349,23 +568,21 @@ def main():
                    "proposal_layer": args.proposals,
                    "inputs": ("raw velodyne scans (%d pts x 16 B per frame) in pinned host memory -> H2D -> prcnn_scene_prepare, all inside "
                               "the timed region" % args.raw_points) if args.input == "raw" else
-                             ("host (pinned) -> HBM copy inside the timed region" if args.h2d else "resident in HBM"),
+                             ("host (pinned) -> HBM copy inside the timed region" if args.h2d else
+                              "resident in HBM (bench contract); the PCIe-inclusive rate of the same command is value_h2d_inclusive"),
                    "clouds": args.clouds, "group_dedup": os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0",
                    "roi_dedup": os.environ.get("PRCNN_ROI_DEDUP", "1") != "0"},
     }
+    plain = args.workload == "rpn" and args.input == "clouds" and not args.h2d
+    if plain and not args.no_variants:
+        # SURVEY 8(d)(i) counts the H2D copy: same graphs, every batch's clouds copied from pinned host memory on the batch's stream
+        e2 = bench.timed(args.steps, min(args.warmup, nstreams), dist, h2d=True)
+        line["value_h2d_inclusive"] = round(whole_job_value(args.batch, world, args.steps, e2), 2)
 
+    fam = None
     if rank == 0 and not args.no_roofline and args.workload == "rpn":
-        from pointrcnn_amd import ops as _ops
-        prof = EventProfiler(_cabi._lib)
-        real = _cabi._lib
-        _cabi._lib, _ops._split_log = prof, prof.splits
-        try:
-            nprof = min(3, args.steps)
-            for _ in range(nprof):
-                step(0)
-            fam = prof.summary()
-        finally:
-            _cabi._lib, _ops._split_log = real, None
+        nprof = min(3, args.steps)
+        fam = instrumented_pass(args, bench, nprof)
         mlp = fam.get("mlp", {"ms": 0.0, "launches": 1, "flops": 0.0, "rows": 0, "rows_launched": 0})
         secs = mlp["ms"] * 1e-3
         # The roofline is priced on the flops the kernels EXECUTE: first-layer hoisting and padding-free grouping (both
@@ -389,13 +606,15 @@ def main():
                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         # HBM bytes per launch of the same kernel family from the PMC passes committed under profiles/ (rocprofv3
         # --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied there); null when absent.
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath) and args.batch == 32 and args.npoints == 16384:
-            try:
-                line["roofline"]["traffic"] = json.load(open(tpath))["per_step_bs32"]["mlp"]["hbm_bytes_per_launch_corrected"]
-                line["roofline"]["traffic_unit"] = "bytes/launch (PMC, profiles/r01_hbm_traffic.json)"
-            except (KeyError, ValueError):
-                pass
+        for tname in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and args.batch == 32 and args.npoints == 16384:
+                try:
+                    line["roofline"]["traffic"] = json.load(open(tpath))["per_step_bs32"]["mlp"]["hbm_bytes_per_launch_corrected"]
+                    line["roofline"]["traffic_unit"] = "bytes/launch (PMC, profiles/%s)" % tname
+                    break
+                except (KeyError, ValueError):
+                    pass
         if "fps" in fam:      # the longest single kernel is latency/VALU-bound, neither HBM nor MFMA: report its rate
             evals = args.batch * sum(n * m for n, m in zip([args.npoints] + rpn.RPNConfig.SA_NPOINTS[:-1], rpn.RPNConfig.SA_NPOINTS))
             line["fps_kernel"] = {"ms_per_step": round(fam["fps"]["ms"] / nprof, 3), "distance_evals_per_step": evals,
@@ -404,9 +623,11 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "rpn" and args.input == "clouds":
         line["cpu_baseline"] = cpu_baseline(model, clouds_cpu, out)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and raw_slots is not None:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and raw is not None:
         # the input builder's CPU oracle (one thread) on the first frames of slot 0, and a bit-for-bit check of the GPU rows
+        import numpy as np
         import oracle
+        raw_slots, prep, _pops = raw["slots"], raw["prep"], raw["ops"]
         hp = raw_slots[0]["host"]
         nf = min(4, args.batch)
         off = hp["offsets"].numpy()[:nf + 1]
@@ -421,6 +642,33 @@ def main():
                                 "sample": "%d raw scans through oracle scene_prepare (input builder only), %.2f s" % (nf, dt),
                                 "gpu_rows_identical": bool(np.array_equal(got[0][:nf].cpu().numpy(), ref[0]) and
                                                            np.array_equal(got[2][:nf].cpu().numpy(), ref[2]))}
+
+    if plain and not args.no_variants and args.clouds == "uniform":
+        # The headline depends on the data: padding-free grouping removes the rows ball_query pads with, and the synthetic
+        # uniform clouds are sparse (most balls hold 1-3 points).  Two more timed loops of the SAME command make that visible:
+        #   value_dedup_off  -- every padded row computed, as the reference does (typical-cloud cost without the optimisation)
+        #   value_saturated  -- clouds whose every ball is full: nothing to remove, the split is pure overhead (worst case)
+        from pointnet2_lib.pointnet2 import pointnet2_modules as pm
+        bench.release()
+        vsteps, variants = min(args.steps, 96), {}
+        for name, kind, dedup in (("dedup_off", "uniform", False), ("saturated", "saturated", True)):
+            pm.GROUP_DEDUP = dedup
+            vb = InferenceBench(args, model, dev, rank, world, kind, proposal_layer, None).prepare()
+            ev = vb.timed(vsteps, nstreams, dist)
+            variants[name] = {"value": round(whole_job_value(args.batch, world, vsteps, ev), 2), "steps": vsteps}
+            if rank == 0 and not args.no_roofline:
+                f2 = instrumented_pass(args, vb, 1).get("mlp")
+                if f2:
+                    variants[name].update({"mlp_rows_per_step": f2["rows"], "mlp_rows_launched_per_step": f2["rows_launched"],
+                                           "mlp_ms_per_step": round(f2["ms"], 3),
+                                           "mlp_TFLOPs_executed": round(f2["flops"] / (f2["ms"] * 1e-3) / 1e12, 2) if f2["ms"] > 0 else None})
+            vb.release()
+        pm.GROUP_DEDUP = os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"
+        line["value_dedup_off"], line["value_saturated"] = variants["dedup_off"]["value"], variants["saturated"]["value"]
+        line["data_dependence"] = {"typical (uniform clouds, this line's value)": {"value": line["value"],
+                                                                                   "mlp_rows_per_step": line.get("roofline", {}).get("rows_per_step")},
+                                   "dedup_off (uniform clouds, every padded row computed)": variants["dedup_off"],
+                                   "saturated (16384 pts in a 1.6 m cube: every ball full)": variants["saturated"]}
 
     if rank == 0:
         print(json.dumps(line), flush=True)

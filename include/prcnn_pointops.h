@@ -10,7 +10,8 @@
  * (pointrcnn_amd/_cabi.py is that binding).
  *
  * Conventions
- *   - every pointer is a DEVICE pointer (HBM) unless the name ends in `_host`;
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in `_host` or the FUNCTION is named
+ *     prcnn_host_* (host pointers only, no HIP call inside: safe in forked dataloader workers);
  *   - tensors are dense row-major fp32 / int32 / int64 exactly as the reference op surface lays
  *     them out; the caller allocates every output (reference: iou3d_utils.py:14,32,68;
  *     roipool3d_utils.py:21-23); callees keep no reference to any buffer after return;
@@ -19,7 +20,9 @@
  *     nms_* blocks on a D2H copy: iou3d.cpp:93-94 -- the sync lives in the Python shim only);
  *   - return value: 0 on success, <0 on error (never exit(): contrast iou3d.cpp:13-21);
  *     prcnn_last_error() returns a thread-local message for the last failing call;
- *   - no global mutable state; every entry point is re-entrant.
+ *   - every entry point is re-entrant and may be called concurrently from several host threads, each on its own
+ *     device (the reference's nn.DataParallel convention).  The only process-wide state is a per-(kernel, device)
+ *     "dynamic-LDS limit already raised" bit, updated atomically (csrc/common.h PrcnnLdsLimit).
  *
  * Arithmetic contract (shared bit-for-bit with oracle/prcnn_oracle.c, trig_mode 1):
  *   squared distances are ((dx*dx + dy*dy) + dz*dz) with individually rounded fp32 operations (no
@@ -43,9 +46,14 @@ typedef void* prcnn_stream_t; /* hipStream_t */
 #define PRCNN_EHIP (-2)         /* HIP runtime / launch failure */
 #define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-int prcnn_abi_version(void);   /* 3: + padding-free grouping (rows_dev / groups_dev, prcnn_group_compact, ...), RoI duplicate
+int prcnn_abi_version(void);   /* 4: + prcnn_host_* (host twins of the reference's *_cpu entry points), prcnn_build_id,
+                                 * prcnn_fps_order (upstream tie order), prcnn_rpn_labels;
+                                 * 3: + padding-free grouping (rows_dev / groups_dev, prcnn_group_compact, ...), RoI duplicate
                                  * elimination (seg_cnt / seg_rows, distinct, valid_n), prcnn_scene_prepare */
 const char* prcnn_last_error(void);
+/* hex digest of the kernel sources + compile flags this library was built from (the Python binding compares it with the
+ * sources it sits next to and refuses / rebuilds a stale library instead of silently loading it) */
+const char* prcnn_build_id(void);
 
 /* ---------------------------------------------------------------------------------------------
  * PointNet++ operators.  Replace pointnet2_cuda.* [UPSTREAM sshaoshuai/Pointnet2.PyTorch, not in
@@ -59,6 +67,16 @@ const char* prcnn_last_error(void);
  *                       bounding-box skip; bit-identical results); NULL = the register-resident kernel;
  *   N <= 2048           ignored. */
 int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, int32_t* idx, prcnn_stream_t stream);
+
+/* Same, with a selectable rule for ties among equal running min-distances (they only occur on clouds with duplicate
+ * points or exact lattices):
+ *   PRCNN_FPS_ORDER_CANONICAL  lowest point index (== prcnn_fps; the contract every other test pins);
+ *   PRCNN_FPS_ORDER_UPSTREAM   the order the upstream CUDA kernel's thread layout produces: argmin (k mod T, k) with
+ *                              T = min(1024, largest power of two <= N) -- for index-by-index
+ *                              comparison against an upstream build; `tmp` (B,N) is required; not a fast path. */
+#define PRCNN_FPS_ORDER_CANONICAL 0
+#define PRCNN_FPS_ORDER_UPSTREAM 1
+int prcnn_fps_order(const float* xyz, int B, int N, int npoint, int order, float* tmp, int32_t* idx, prcnn_stream_t stream);
 
 /* gather_points_wrapper(B,C,N,npoint,feat,idx,out): out[b,c,m] = feat[b,c,idx[b,m]] */
 int prcnn_gather(const float* feat, const int32_t* idx, int B, int C, int N, int M, float* out, prcnn_stream_t stream);
@@ -207,6 +225,24 @@ int prcnn_roipool3d(const float* xyz, const float* boxes3d, const float* feat, i
 
 /* point-in-box flags on the device: flags (M,N) i32 (device twin of roipool3d.cpp:97-125) */
 int prcnn_pts_in_boxes3d(const float* pts, const float* boxes3d, int N, int M, int32_t* flags, prcnn_stream_t stream);
+
+/* RPN training labels for a whole batch on the device (KittiRCNNDataset.generate_rpn_training_labels,
+ * lib/datasets/kitti_rcnn_dataset.py:365-394): pts (B,N,3), gt_boxes3d (B,G,7) [x,y(bottom),z,h,w,l,ry], num_gt (B) i32 or
+ * NULL (all G rows valid) -> cls_label (B,N) i32 in {-1 ignore, 0 background, 1 foreground}, reg_label (B,N,7)
+ * [dx, dy, dz, h, w, l, ry] (zero rows for non-foreground points).  extra_width = 0.2 in the reference.  Boxes are applied in
+ * order, later boxes overwrite earlier ones exactly as the reference's loop does.  G <= 128. */
+int prcnn_rpn_labels(const float* pts, const float* gt_boxes3d, const int32_t* num_gt, int B, int N, int G, float extra_width,
+                     int32_t* cls_label, float* reg_label, prcnn_stream_t stream);
+
+/* HOST twins of the reference's two CPU entry points (roipool3d.cpp:97-125 pts_in_boxes3d_cpu, :127-195 roipool3d_cpu),
+ * which its dataloader calls inside forked worker processes (kitti_rcnn_dataset.py:487,582,625,843,970).  Host pointers,
+ * no HIP call, bit-identical to the reference's CPU arithmetic (double half-extent compares, inclusive bounds).
+ *   pts (N,3), boxes3d (M,7) -> flags (M,N) int64;
+ *   pts (N,3), boxes3d (M,7), feat (N,C) -> pooled_pts (M,S,3), pooled_feat (M,S,C), empty (M) int64; rows of an empty
+ *   box are left untouched (the caller zero-initialises them, roipool3d_utils.py:77-79). */
+int prcnn_host_pts_in_boxes3d(const float* pts, const float* boxes3d, int64_t N, int64_t M, int64_t* flags);
+int prcnn_host_roipool3d(const float* pts, const float* boxes3d, const float* feat, int64_t N, int64_t M, int64_t C, int64_t S,
+                         float* pooled_pts, float* pooled_feat, int64_t* empty);
 
 /* ---------------------------------------------------------------------------------------------
  * iou3d.  Replace iou3d_cuda.{boxes_overlap_bev_gpu,boxes_iou_bev_gpu,nms_gpu,nms_normal_gpu}

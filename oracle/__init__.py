@@ -63,6 +63,24 @@ class _Cpu:
         self.lib.prcnn_cpu_fps(_p(xyz, _F), B, N, npoint, None, _p(idx, _I))
         return idx
 
+    def fps_upstream(self, xyz, npoint):
+        """FPS with the upstream CUDA kernel's tie order: argmin (k mod T, k) among equal maxima"""
+        xyz = _f32(xyz)
+        B, N, _ = xyz.shape
+        idx = np.zeros((B, npoint), np.int32)
+        self.lib.prcnn_cpu_fps_upstream(_p(xyz, _F), B, N, npoint, _p(idx, _I))
+        return idx
+
+    def rpn_labels(self, pts, gt_boxes3d, num_gt=None, extra_width=0.2, trig_mode=1):
+        pts, gt = _f32(pts), _f32(gt_boxes3d)
+        B, N, _ = pts.shape
+        G = gt.shape[1]
+        cls, reg = np.zeros((B, N), np.int32), np.zeros((B, N, 7), np.float32)
+        ng = None if num_gt is None else _i32(num_gt)
+        self.lib.prcnn_cpu_rpn_labels(_p(pts, _F), _p(gt, _F), None if ng is None else _p(ng, _I), B, N, G,
+                                      ctypes.c_float(extra_width), trig_mode, _p(cls, _I), _p(reg, _F))
+        return cls, reg
+
     def gather(self, feat, idx):
         feat, idx = _f32(feat), _i32(idx)
         B, C, N = feat.shape

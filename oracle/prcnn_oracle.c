@@ -86,6 +86,42 @@ PRCNN_EXPORT void prcnn_cpu_fps(const float* xyz, int B, int N, int npoint, floa
     free(own);
 }
 
+/* A.1 with the UPSTREAM tie order: the upstream kernel's T threads (T = min(1024, largest power of
+ * two <= N)) each scan k = t, t+T, ... keeping their first maximum, the tree reduction keeps the lower thread on ties:
+ * among equal maxima the winner is argmin (k mod T, k).  Emulated literally: per-thread best, then threads in order. */
+PRCNN_EXPORT void prcnn_cpu_fps_upstream(const float* xyz, int B, int N, int npoint, int* idx) {
+    int T = 1;
+    while (T * 2 <= N && T < 1024) T <<= 1;
+    float* t = (float*)malloc(sizeof(float) * (size_t)N);
+    for (int b = 0; b < B; b++) {
+        const float* p = xyz + (size_t)b * N * 3;
+        int* o = idx + (size_t)b * npoint;
+        for (int k = 0; k < N; k++) t[k] = 1e10f;
+        if (npoint <= 0) continue;
+        int old = 0;
+        o[0] = 0;
+        for (int j = 1; j < npoint; j++) {
+            float x0 = p[old * 3], y0 = p[old * 3 + 1], z0 = p[old * 3 + 2];
+            float best = -1.0f;
+            int besti = 0;
+            for (int th = 0; th < T; th++) {
+                float tb = -1.0f;
+                int ti = 0;
+                for (int k = th; k < N; k += T) {
+                    float d = sqdist3(p[k * 3], p[k * 3 + 1], p[k * 3 + 2], x0, y0, z0);
+                    float v = d < t[k] ? d : t[k];
+                    t[k] = v;
+                    if (v > tb) { tb = v; ti = k; }
+                }
+                if (tb > best) { best = tb; besti = ti; }
+            }
+            o[j] = besti;
+            old = besti;
+        }
+    }
+    free(t);
+}
+
 /* A.2 gather_operation: out[b,c,m] = feat[b,c,idx[b,m]] */
 PRCNN_EXPORT void prcnn_cpu_gather(const float* feat, const int* idx, int B, int C, int N, int M, float* out) {
     for (int b = 0; b < B; b++)
@@ -267,6 +303,38 @@ PRCNN_EXPORT void prcnn_cpu_pts_in_boxes3d(const float* pts, const float* boxes3
         for (int j = 0; j < N; j++)
             flags[(size_t)i * N + j] =
                 pt_in_box3d(pts[j * 3], pts[j * 3 + 1], pts[j * 3 + 2], bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], ca, sa);
+    }
+}
+
+/* KittiRCNNDataset.generate_rpn_training_labels (lib/datasets/kitti_rcnn_dataset.py:365-394) with the analytic in-box
+ * test above in place of the scipy Delaunay hull test: per frame, GT boxes applied in order; cls (B,N) int32 in {-1,0,1},
+ * reg (B,N,7) [dx, dy, dz, h, w, l, ry].  enlarge_box3d (kitti_utils.py:150-160): h,w,l += 2*extra, y += extra. */
+PRCNN_EXPORT void prcnn_cpu_rpn_labels(const float* pts, const float* gt, const int* num_gt, int B, int N, int G, float extra,
+                                       int trig_mode, int* cls, float* reg) {
+    for (int b = 0; b < B; b++) {
+        const int g = num_gt ? (num_gt[b] < G ? (num_gt[b] < 0 ? 0 : num_gt[b]) : G) : G;
+        for (int n = 0; n < N; n++) {
+            const float* p = pts + ((size_t)b * N + n) * 3;
+            int c = 0;
+            float r[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < g; k++) {
+                const float* bx = gt + ((size_t)b * G + k) * 7;
+                float ca, sa;
+                box_trig(bx[6], trig_mode, &ca, &sa);
+                const float e2 = extra * 2;
+                const int fg = pt_in_box3d(p[0], p[1], p[2], bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], ca, sa);
+                const int en = pt_in_box3d(p[0], p[1], p[2], bx[0], bx[1] + extra, bx[2], bx[3] + e2, bx[4] + e2, bx[5] + e2, ca, sa);
+                if (fg) {
+                    const float cy = bx[1] - bx[3] / 2;
+                    c = 1;
+                    r[0] = bx[0] - p[0]; r[1] = cy - p[1]; r[2] = bx[2] - p[2];
+                    r[3] = bx[3]; r[4] = bx[4]; r[5] = bx[5]; r[6] = bx[6];
+                }
+                if (fg != en) c = -1;
+            }
+            cls[(size_t)b * N + n] = c;
+            memcpy(reg + ((size_t)b * N + n) * 7, r, sizeof(r));
+        }
     }
 }
 

@@ -34,7 +34,19 @@ def extract_rpn_weights(model):
     return spec
 
 
+_TORCH_MLP = False      # cpu_baseline.py sets this: MLP layers through torch's CPU sgemm (multi-threaded BLAS) instead of
+                        # the oracle's scalar double-accumulating loop (which is a CHECKER, not a fair CPU implementation)
+
+
 def _mlp(cpu, rows, layers):
+    if _TORCH_MLP:
+        import torch
+        x = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32))
+        for w, b, relu in layers:
+            x = torch.nn.functional.linear(x, torch.from_numpy(w), None if b is None else torch.from_numpy(b))
+            if relu:
+                x = torch.relu_(x)
+        return x.numpy()
     for w, b, relu in layers:
         rows = cpu.linear_rows(rows, w, b, relu)
     return rows

@@ -20,7 +20,12 @@ _D = ctypes.c_double
 SIGNATURES = {
     "prcnn_abi_version": (_I, []),
     "prcnn_last_error": (ctypes.c_char_p, []),
+    "prcnn_build_id": (ctypes.c_char_p, []),
     "prcnn_fps": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "prcnn_fps_order": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "prcnn_rpn_labels": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "prcnn_host_pts_in_boxes3d": (_I, [_P, _P, _L, _L, _P]),
+    "prcnn_host_roipool3d": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _P]),
     "prcnn_gather": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "prcnn_gather_grad": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "prcnn_gather_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
@@ -90,14 +95,24 @@ def lib():
     import torch  # noqa: F401
     path = _build.LIB
     if not os.path.exists(path):
-        # Build only when the library is MISSING (never silently on a stale check: under torchrun every rank gets
-        # here at once).  `python -m pointrcnn_amd.build` / __graft_entry__.build() is the explicit rebuild.
         try:
             _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001
             raise PointOpsError(
                 "libprcnn_pointops.so is missing and could not be built (%s). The HIP extension is "
                 "mandatory: there is no CPU fallback. Run `python -m pointrcnn_amd.build`." % e)
+    elif not os.environ.get("PRCNN_POINTOPS_LIB") and _build.have_sources() and _build.library_id(path) != _build.source_id():
+        # A library built from OTHER kernel sources than the ones next to this file would load fine (same symbols) and
+        # silently compute with old kernels.  The digest baked into the .so (prcnn_build_id) is compared with the sources:
+        # rebuild when a compiler is here (serialised by a lock file: under torchrun every rank gets here at once),
+        # refuse otherwise.
+        if not os.path.exists(_build.HIPCC):
+            raise PointOpsError("%s is stale (built from %s, sources are %s) and hipcc is not available to rebuild it"
+                                % (path, _build.library_id(path), _build.source_id()))
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            raise PointOpsError("%s is stale and could not be rebuilt (%s)" % (path, e))
     try:
         handle = ctypes.CDLL(path)
     except OSError as e:

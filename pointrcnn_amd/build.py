@@ -8,6 +8,7 @@ so a GPU box never needs to compile.  Flags: -ffp-contract=off is part of the ar
 """
 import fcntl
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -23,21 +24,52 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fh
 
 
 # per-file extra flags.  fps.hip: finite-math-only lets fminf/fmaxf lower to bare v_min_f32/v_max_f32 (no NaN
-# canonicalisation); it permits no reassociation or contraction, so results are unchanged for finite inputs.
-# no-slp-vectorize: packed v_pk_*_f32 have no throughput advantage on gfx950 and cost operand-shuffle movs.
+# canonicalisation); it permits no reassociation or contraction, so results are unchanged for FINITE inputs -- which is the
+# documented domain of prcnn_fps (include/prcnn_pointops.h; a cloud with NaN/Inf coordinates has no farthest point under
+# any rule).  no-slp-vectorize: the distance loops are written on explicit float2 pairs (v_pk_*_f32, the only fp32 VALU
+# form that issues at full rate on gfx950); the SLP vectoriser's own pairings on top of that cost
+# operand-shuffle movs.
 EXTRA_FLAGS = {"fps.hip": ["-ffinite-math-only", "-fno-slp-vectorize"]}
+BUILD_ID_TAG = b"PRCNN_BUILD_ID="
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_id():
+    """hex digest of everything the library is built from: kernel sources, headers, compile flags"""
+    h = hashlib.sha1()
+    deps = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "prcnn_pointops.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    return h.hexdigest()[:20]
+
+
+def library_id(path=None):
+    """the digest baked into a built library (prcnn_build_id()), read from the file without loading it; None if absent"""
+    path = path or LIB
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(BUILD_ID_TAG)
+    return blob[i + len(BUILD_ID_TAG): i + len(BUILD_ID_TAG) + 20].decode("ascii", "replace") if i >= 0 else None
+
+
+def have_sources():
+    return os.path.isdir(CSRC) and bool(sources())
+
+
 def _stale():
+    """the library is missing, or was built from other sources / flags than the ones next to it"""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "prcnn_pointops.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return have_sources() and library_id() != source_id()
 
 
 def build(force=False, verbose=True):
@@ -56,9 +88,13 @@ def build(force=False, verbose=True):
         objdir = os.path.join(LIBDIR, "obj")
         os.makedirs(objdir, exist_ok=True)
         procs = []
+        bid = source_id()
         for src in sources():
             obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
-            procs.append((src, obj, subprocess.Popen([HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj],
+            extra = EXTRA_FLAGS.get(os.path.basename(src), [])
+            if os.path.basename(src) == "cabi_common.hip":
+                extra = extra + ['-DPRCNN_BUILD_ID="%s%s"' % (BUILD_ID_TAG.decode(), bid)]
+            procs.append((src, obj, subprocess.Popen([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj],
                                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs = []
         for src, obj, p in procs:

@@ -13,4 +13,10 @@ int prcnn_fail(int code, const char* fmt, ...) {
 }
 
 PRCNN_API const char* prcnn_last_error(void) { return g_err; }
-PRCNN_API int prcnn_abi_version(void) { return 3; }
+PRCNN_API int prcnn_abi_version(void) { return 4; }
+
+#ifndef PRCNN_BUILD_ID
+#define PRCNN_BUILD_ID "PRCNN_BUILD_ID=unknown"
+#endif
+// the macro carries the "PRCNN_BUILD_ID=" tag so that the digest can also be read from the file without loading it
+PRCNN_API const char* prcnn_build_id(void) { return PRCNN_BUILD_ID + sizeof("PRCNN_BUILD_ID=") - 1; }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/prcnn_pointops.h"
 
 #define PRCNN_API extern "C" __attribute__((visibility("default")))
@@ -21,6 +22,23 @@ int prcnn_fail(int code, const char* fmt, ...);
     } while (0)
 
 static inline int prcnn_divup(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute applies to the function ON THE CURRENT DEVICE only, and one process may drive several devices from
+// several threads (the reference's nn.DataParallel convention, SURVEY 8(b) "Threading").  The "already raised" state is
+// therefore one bit per device, updated atomically; two threads racing on the same device both set the (idempotent)
+// attribute.  Devices beyond 63 set it on every call.
+struct PrcnnLdsLimit {
+    std::atomic<uint64_t> done{0};
+    bool raise(const void* fn, int bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        const uint64_t bit = dev >= 0 && dev < 64 ? (1ull << dev) : 0;
+        if (bit && (done.load(std::memory_order_acquire) & bit)) return true;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+        if (bit) done.fetch_or(bit, std::memory_order_release);
+        return true;
+    }
+};
 
 // ---- wave64 cross-lane reductions on the VALU (DPP), no LDS ---------------------------------
 // row_shr:1,2,4,8 builds an inclusive scan inside each 16-lane row, row_bcast:15 / row_bcast:31

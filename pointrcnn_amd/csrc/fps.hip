@@ -429,21 +429,15 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
         int NP = 1;
         while (NP < N) NP <<= 1;
         int32_t* perm = reinterpret_cast<int32_t*>(tmp);
-        static bool sort_attr = false;
-        if (!sort_attr) {
-            if (hipFuncSetAttribute((const void*)fps_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-                return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the sort kernel");
-            sort_attr = true;
-        }
+        static PrcnnLdsLimit sort_attr;
+        if (!sort_attr.raise((const void*)fps_sort_kernel, 150 * 1024))
+            return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the sort kernel");
         const int sort_threads = NP / 16 < 64 ? 64 : NP / 16;
         hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(sort_threads), lds_sort_bytes(NP), s, xyz, N, NP, perm);
         PRCNN_LAUNCH_CHECK("prcnn_fps(sort)");
-        static bool pruned_attr = false;
-        if (!pruned_attr) {
-            if (hipFuncSetAttribute((const void*)fps_pruned_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 4096) != hipSuccess)
-                return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the pruned kernel");
-            pruned_attr = true;
-        }
+        static PrcnnLdsLimit pruned_attr;
+        if (!pruned_attr.raise((const void*)fps_pruned_kernel<16>, 16 * 4096))
+            return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the pruned kernel");
         if (N <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4>), dim3(B), dim3(1024), 4 * 4096, s, xyz, perm, N, npoint, idx);
         else if (N <= 8192) hipLaunchKernelGGL((fps_pruned_kernel<8>), dim3(B), dim3(1024), 8 * 4096, s, xyz, perm, N, npoint, idx);
         else hipLaunchKernelGGL((fps_pruned_kernel<16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);
@@ -462,5 +456,71 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
         hipLaunchKernelGGL(fps_mem_kernel, dim3(B), dim3(1024), 0, s, xyz, N, npoint, tmp, idx);
     }
     PRCNN_LAUNCH_CHECK("prcnn_fps");
+    return PRCNN_OK;
+}
+
+// =====================================================================================================
+// Upstream tie ORDER (optional mode).  The upstream CUDA kernel runs T = min(1024, largest power of
+// two <= N) threads per frame; thread t scans k = t, t+T, ... keeping its first maximum (strict >), and the tree
+// reduction over threads keeps the lower thread on ties.  Among equal maxima the winner is therefore
+// argmin (k mod T, k) -- not the lowest k of the canonical rule.  This kernel reproduces exactly that order (same
+// distance arithmetic as every other FPS kernel here), so that an upstream build can be compared index for index even
+// on clouds with duplicate points / lattices, the only inputs on which the two rules differ.  Not a fast path: the
+// running min-distances live in `tmp` (HBM/L2).
+// =====================================================================================================
+__global__ __launch_bounds__(1024) void fps_upstream_order_kernel(const float* __restrict__ xyz, int N, int npoint, int T,
+                                                                  float* __restrict__ tmp, int32_t* __restrict__ idx_out) {
+    constexpr int NWMAX = 16;
+    __shared__ int sval[2][NWMAX], stid[2][NWMAX], sidx[2][NWMAX];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    const float* __restrict__ p = xyz + (size_t)b * N * 3;
+    float* __restrict__ t = tmp + (size_t)b * N;
+    int32_t* __restrict__ out = idx_out + (size_t)b * npoint;
+    for (int k = tid; k < N; k += blockDim.x) t[k] = 1e10f;
+    if (tid == 0 && npoint > 0) out[0] = 0;
+    __syncthreads();
+    int old = 0;
+    for (int j = 1; j < npoint; j++) {
+        const float x0 = p[old * 3], y0 = p[old * 3 + 1], z0 = p[old * 3 + 2];
+        float best = -2.0f;
+        int bk = 0x7fffffff;
+        if (tid < T) {
+            for (int k = tid; k < N; k += T) {
+                const float d = sqdist3(p[k * 3], p[k * 3 + 1], p[k * 3 + 2], x0, y0, z0);
+                float v = t[k];
+                v = d < v ? d : v;
+                t[k] = v;
+                if (v > best) { best = v; bk = k; }          // strict: the thread's FIRST maximum
+            }
+        }
+        const int vb = __float_as_int(best);
+        const int wmax = wave_max_i32(vb);
+        const int wtid = wave_min_i32(vb == wmax ? tid : 0x7fffffff);           // ties -> lowest thread
+        const int wk = __shfl(bk, wtid & 63);
+        if (lane == 0) { sval[j & 1][wave] = wmax; stid[j & 1][wave] = wtid; sidx[j & 1][wave] = wk; }
+        __syncthreads();
+        const int v = lane < nw ? sval[j & 1][lane] : (int)0x80000000;
+        const int td = lane < nw ? stid[j & 1][lane] : 0x7fffffff;
+        const int id = lane < nw ? sidx[j & 1][lane] : 0;
+        const int gmax = row0_max_i32(v);
+        const int gtid = row0_min_i32(v == gmax ? td : 0x7fffffff);
+        const int win = __builtin_ctzll(__ballot(v == gmax && td == gtid));
+        old = __builtin_amdgcn_readlane(id, win);
+        if (tid == 0) out[j] = old;
+    }
+}
+
+PRCNN_API int prcnn_fps_order(const float* xyz, int B, int N, int npoint, int order, float* tmp, int32_t* idx, prcnn_stream_t stream) {
+    if (order == PRCNN_FPS_ORDER_CANONICAL) return prcnn_fps(xyz, B, N, npoint, tmp, idx, stream);
+    PRCNN_REQUIRE(order == PRCNN_FPS_ORDER_UPSTREAM, "prcnn_fps_order: unknown order %d", order);
+    PRCNN_REQUIRE(B >= 0 && N > 0 && npoint >= 0 && npoint <= N, "prcnn_fps_order: bad shape B=%d N=%d npoint=%d", B, N, npoint);
+    if (B == 0 || npoint == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(xyz && idx && tmp, "prcnn_fps_order: null pointer (the upstream-order kernel needs the (B,N) tmp buffer)");
+    int T = 1;
+    while (T * 2 <= N && T < 1024) T <<= 1;
+    const int block = T < 64 ? 64 : T;
+    hipLaunchKernelGGL(fps_upstream_order_kernel, dim3(B), dim3(block), 0, (hipStream_t)stream, xyz, N, npoint, T, tmp, idx);
+    PRCNN_LAUNCH_CHECK("prcnn_fps_order");
     return PRCNN_OK;
 }

@@ -187,6 +187,8 @@ __global__ __launch_bounds__(GBQ_THREADS) void grid_ball_query_kernel(const void
     }
 }
 
+template <typename T> struct __attribute__((packed, aligned(4))) Trip { T a, b, c; };
+
 // ---- three_nn over the grid: one thread per query, square rings until the third-best distance is final -------
 #define GNN_THREADS 256
 __global__ __launch_bounds__(GNN_THREADS) void grid_three_nn_kernel(const void* __restrict__ grid, size_t fb,
@@ -204,17 +206,22 @@ __global__ __launch_bounds__(GNN_THREADS) void grid_three_nn_kernel(const void* 
     float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
     int i1 = 0, i2 = 0, i3 = 0;
     const int GD = H.dim;
-    auto visit = [&](int cz, int cxa, int cxb) {          // cells [cxa, cxb] of row cz (all inside the grid)
+    // always_inline: as an out-of-line call the by-reference captures (the running top-3) live in scratch memory
+    auto visit = [&](int cz, int cxa, int cxb) __attribute__((always_inline)) {          // cells [cxa, cxb] of row cz (all inside the grid)
         const int beg = cstart[cz * GD + cxa], end = cstart[cz * GD + cxb + 1];
         for (int t = beg; t < end; t++) {
             const float4 c = pts[t];
             const float dd = sqdist3(ux, uy, uz, c.x, c.y, c.z);
             const int k = __float_as_int(c.w);
             // lexicographic (distance, index): what strict-'<' insertion in index order produces
+            // (written with selects: as an if / else-if ladder the compiler turned the six running values into a
+            //  dynamically indexed array in scratch memory)
             if (dd < b3 || (dd == b3 && k < i3 && dd < INFINITY)) {
-                if (dd < b1 || (dd == b1 && k < i1)) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = dd; i1 = k; }
-                else if (dd < b2 || (dd == b2 && k < i2)) { b3 = b2; i3 = i2; b2 = dd; i2 = k; }
-                else { b3 = dd; i3 = k; }
+                const bool lt1 = dd < b1 || (dd == b1 && k < i1);
+                const bool lt2 = lt1 || dd < b2 || (dd == b2 && k < i2);
+                b3 = lt2 ? b2 : dd; i3 = lt2 ? i2 : k;
+                b2 = lt1 ? b1 : (lt2 ? dd : b2); i2 = lt1 ? i1 : (lt2 ? k : i2);
+                b1 = lt1 ? dd : b1; i1 = lt1 ? k : i1;
             }
         }
     };
@@ -222,7 +229,10 @@ __global__ __launch_bounds__(GNN_THREADS) void grid_three_nn_kernel(const void* 
     if (finite_q) {
         // unclamped cell coordinates of the query (it may lie outside the grid's bounding box)
         const float fx = (ux - H.x0) * H.inv_cs, fz = (uz - H.z0) * H.inv_cs;
-        const int qcx = (int)floorf(fminf(fmaxf(fx, -1.0e6f), 1.0e6f)), qcz = (int)floorf(fminf(fmaxf(fz, -1.0e6f), 1.0e6f));
+        // A query outside the points' bounding box starts from the ring just outside the grid ([-1, GD]) on that side: the
+        // bounds below measure from the query's real coordinates to cell sides, so they stay valid, and a far-away query
+        // costs at most GD rings instead of one ring per cell of its distance.
+        const int qcx = (int)floorf(fminf(fmaxf(fx, -1.0f), (float)GD)), qcz = (int)floorf(fminf(fmaxf(fz, -1.0f), (float)GD));
         for (int R = 0;; R++) {
             const int x0 = qcx - R, x1 = qcx + R, z0 = qcz - R, z1 = qcz + R;
             const int cxa = max(x0, 0), cxb = min(x1, GD - 1);
@@ -250,15 +260,17 @@ __global__ __launch_bounds__(GNN_THREADS) void grid_three_nn_kernel(const void* 
             if (lb > 0.0f && b3 < lb * lb) break;
         }
     }
+    // a query's three values are 12 contiguous bytes of each output: ONE global_store_dwordx3 per array (a wave then writes
+    // 768 contiguous bytes per instruction; nine 4-byte stores at a 12-byte stride measured 10x write amplification)
     const size_t o = ((size_t)b * n + i) * 3;
-    dist2[o] = b1; dist2[o + 1] = b2; dist2[o + 2] = b3;
-    idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+    *reinterpret_cast<Trip<float>*>(dist2 + o) = Trip<float>{b1, b2, b3};
+    *reinterpret_cast<Trip<int32_t>*>(idx + o) = Trip<int32_t>{i1, i2, i3};
     if (weight) {                                 // same expressions as three_nn_kernel (neighbor.hip)
         float r0 = 1.0f / (sqrtf(b1) + 1e-8f);
         float r1 = 1.0f / (sqrtf(b2) + 1e-8f);
         float r2 = 1.0f / (sqrtf(b3) + 1e-8f);
         float s = (r0 + r1) + r2;
-        weight[o] = r0 / s; weight[o + 1] = r1 / s; weight[o + 2] = r2 / s;
+        *reinterpret_cast<Trip<float>*>(weight + o) = Trip<float>{r0 / s, r1 / s, r2 / s};
     }
 }
 
@@ -276,12 +288,9 @@ PRCNN_API int prcnn_grid_build(const float* xyz, int B, int N, float min_cell, i
     PRCNN_REQUIRE(xyz && grid, "prcnn_grid_build: null pointer");
     PRCNN_REQUIRE(((uintptr_t)grid & 15) == 0, "prcnn_grid_build: grid buffer must be 16-byte aligned");
     PRCNN_REQUIRE(grid_bytes >= prcnn_grid_bytes(B, N), "prcnn_grid_build: buffer %zu < %zu bytes", grid_bytes, prcnn_grid_bytes(B, N));
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)grid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GRID_CELLS_MAX * 4) != hipSuccess)
-            return prcnn_fail(PRCNN_EHIP, "prcnn_grid_build: cannot raise the dynamic LDS limit");
-        attr = true;
-    }
+    static PrcnnLdsLimit attr;
+    if (!attr.raise((const void*)grid_build_kernel, GRID_CELLS_MAX * 4))
+        return prcnn_fail(PRCNN_EHIP, "prcnn_grid_build: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(GRID_BUILD_THREADS), (size_t)cells_per_axis * cells_per_axis * 4, (hipStream_t)stream,
                        xyz, N, min_cell, cells_per_axis, grid, grid_frame_bytes(N));
     PRCNN_LAUNCH_CHECK("prcnn_grid_build");

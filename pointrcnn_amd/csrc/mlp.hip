@@ -1467,13 +1467,9 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
 #define PERS_CASE(M, KB0V, A, B, CC)                                                                                         \
         if (mode == M && P.KB == KB0V && n0 == A && n1 == B && n2 == CC) {                                                    \
             constexpr size_t lds = pers_lds_bytes<M, KB0V, A, B, CC>();                                                       \
-            static bool attr = false;                                                                                        \
-            if (!attr) {                                                                                                     \
-                if (hipFuncSetAttribute((const void*)mlp_chain_pers_kernel<M, KB0V, A, B, CC>,                               \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                 \
-                    return prcnn_fail(PRCNN_EHIP, "prcnn_mlp_chain: cannot raise the dynamic LDS limit");                    \
-                attr = true;                                                                                                 \
-            }                                                                                                                \
+            static PrcnnLdsLimit attr;                                                                                       \
+            if (!attr.raise((const void*)mlp_chain_pers_kernel<M, KB0V, A, B, CC>, (int)lds))                                \
+                return prcnn_fail(PRCNN_EHIP, "prcnn_mlp_chain: cannot raise the dynamic LDS limit");                        \
             const int grid = (int)min((long)256, (long)prcnn_divup(P.rows, 32 * PERS_WAVES));                                \
             hipLaunchKernelGGL((mlp_chain_pers_kernel<M, KB0V, A, B, CC>), dim3(grid), dim3(PERS_WAVES * 64), lds, s, C);     \
             PRCNN_LAUNCH_CHECK("prcnn_mlp_chain(persistent)");                                                               \

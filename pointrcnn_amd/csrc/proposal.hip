@@ -637,13 +637,9 @@ static size_t large_sort_bytes(int B, int N) {
 static int launch_sort_split(const char* op, SortParams& P, int B, hipStream_t s, u64* large_ws) {
     if (P.N > PROPOSAL_MAX_SORT) {
         const int Ntot = pow2_at_least(P.N, LARGE_CHUNK), nchunks = Ntot / LARGE_CHUNK;
-        static bool attr_large = false;
-        if (!attr_large) {
-            if (hipFuncSetAttribute((const void*)large_local_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess ||
-                hipFuncSetAttribute((const void*)large_local_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess)
-                return prcnn_fail(PRCNN_EHIP, "%s: cannot raise the dynamic LDS limit", op);
-            attr_large = true;
-        }
+        static PrcnnLdsLimit attr_sort, attr_merge;
+        if (!attr_sort.raise((const void*)large_local_sort_kernel, LDS_BUDGET) || !attr_merge.raise((const void*)large_local_merge_kernel, LDS_BUDGET))
+            return prcnn_fail(PRCNN_EHIP, "%s: cannot raise the dynamic LDS limit", op);
         const size_t lds = lds_sort_bytes(LARGE_CHUNK);
         hipLaunchKernelGGL(large_local_sort_kernel, dim3(nchunks, B), dim3(1024), lds, s, P.scores, P.N, Ntot, large_ws);
         for (int k = 2 * LARGE_CHUNK; k <= Ntot; k <<= 1) {
@@ -658,12 +654,9 @@ static int launch_sort_split(const char* op, SortParams& P, int B, hipStream_t s
     P.Npad = pow2_at_least(P.N, 16);
     const int threads = max(64, ((P.Npad >> 4) + 63) / 64 * 64);
     const size_t lds = lds_sort_bytes(P.Npad) + 40 * sizeof(unsigned);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)sort_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess)
-            return prcnn_fail(PRCNN_EHIP, "%s: cannot raise the dynamic LDS limit", op);
-        attr_set = true;
-    }
+    static PrcnnLdsLimit attr_set;
+    if (!attr_set.raise((const void*)sort_split_kernel, LDS_BUDGET))
+        return prcnn_fail(PRCNN_EHIP, "%s: cannot raise the dynamic LDS limit", op);
     hipLaunchKernelGGL(sort_split_kernel, dim3(B), dim3(threads), lds, s, P);
     PRCNN_LAUNCH_CHECK(op);
     return PRCNN_OK;
@@ -675,12 +668,9 @@ static int launch_greedy_nms_kind(const char* op, const NmsParams& P, int B, hip
     if (lds > LDS_BUDGET)
         return prcnn_fail(PRCNN_EUNSUPPORTED, "%s: keeping up to %d boxes needs %zu B of LDS (> %d); use prcnn_nms", op,
                           max(P.post1, P.post2), lds, LDS_BUDGET);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)greedy_nms_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess)
-            return prcnn_fail(PRCNN_EHIP, "%s: cannot raise the dynamic LDS limit", op);
-        attr_set = true;
-    }
+    static PrcnnLdsLimit attr_set;
+    if (!attr_set.raise((const void*)greedy_nms_kernel<KIND>, LDS_BUDGET))
+        return prcnn_fail(PRCNN_EHIP, "%s: cannot raise the dynamic LDS limit", op);
     hipLaunchKernelGGL(greedy_nms_kernel<KIND>, dim3(P.nseg, B), dim3(NMS_THREADS), lds, s, P);
     PRCNN_LAUNCH_CHECK(op);
     return PRCNN_OK;

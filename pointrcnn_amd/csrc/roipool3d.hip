@@ -290,3 +290,65 @@ PRCNN_API int prcnn_roipool3d_canonical(const float* xyz, const float* pool_boxe
     PRCNN_LAUNCH_CHECK(op);
     return PRCNN_OK;
 }
+
+// =====================================================================================================
+// RPN training labels on the device (second half).  Replaces the per-sample numpy / scipy code of
+// KittiRCNNDataset.generate_rpn_training_labels (lib/datasets/kitti_rcnn_dataset.py:365-394): per GT box a Delaunay
+// hull test of all 16384 points against the box and against the box enlarged by 0.2 m (kitti_utils.enlarge_box3d),
+// foreground = 1, "in the enlarged box only" = -1 (ignored), regression target = (centre - point, h, w, l, ry).
+// Here: one thread per point walks the frame's <= LABEL_MAX_GT boxes (constants in LDS) IN BOX ORDER, so that a point in
+// several boxes ends up with exactly what the reference's sequential overwrites leave.  The in-box test is the
+// analytic one of roipool3d (pt_in_box above) instead of the hull test: identical except for points within rounding
+// distance of a face.
+// =====================================================================================================
+#define LABEL_MAX_GT 128
+__global__ __launch_bounds__(256) void rpn_labels_kernel(const float* __restrict__ pts, const float* __restrict__ gt_boxes3d,
+                                                         const int32_t* __restrict__ num_gt, int N, int G, float extra,
+                                                         int32_t* __restrict__ cls_label, float* __restrict__ reg_label) {
+    __shared__ BoxConst sbox[LABEL_MAX_GT], sbig[LABEL_MAX_GT];
+    __shared__ float sraw[LABEL_MAX_GT][7];
+    const int b = blockIdx.y;
+    const int g = num_gt ? min(max(num_gt[b], 0), G) : G;
+    for (int k = threadIdx.x; k < g; k += 256) {
+        const float* bx = gt_boxes3d + ((size_t)b * G + k) * 7;
+        float big[7];
+#pragma unroll
+        for (int c = 0; c < 7; c++) { sraw[k][c] = bx[c]; big[c] = bx[c]; }
+        big[3] = bx[3] + extra * 2; big[4] = bx[4] + extra * 2; big[5] = bx[5] + extra * 2; big[1] = bx[1] + extra;   // kitti_utils.py:150-160
+        sbox[k] = make_box(bx);
+        sbig[k] = make_box(big);
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float* p = pts + ((size_t)b * N + n) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    int cls = 0;
+    float r[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < g; k++) {
+        const bool fg = pt_in_box(sbox[k], x, y, z), en = pt_in_box(sbig[k], x, y, z);
+        if (fg) {
+            cls = 1;
+            const float cy = sraw[k][1] - sraw[k][3] / 2;          // centre y (float32 arithmetic, as numpy does it)
+            r[0] = sraw[k][0] - x; r[1] = cy - y; r[2] = sraw[k][2] - z;
+            r[3] = sraw[k][3]; r[4] = sraw[k][4]; r[5] = sraw[k][5]; r[6] = sraw[k][6];
+        }
+        if (fg != en) cls = -1;
+    }
+    cls_label[(size_t)b * N + n] = cls;
+    float* o = reg_label + ((size_t)b * N + n) * 7;
+#pragma unroll
+    for (int c = 0; c < 7; c++) o[c] = r[c];
+}
+
+PRCNN_API int prcnn_rpn_labels(const float* pts, const float* gt_boxes3d, const int32_t* num_gt, int B, int N, int G, float extra_width,
+                               int32_t* cls_label, float* reg_label, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(B >= 0 && N >= 0 && G >= 0, "prcnn_rpn_labels: bad shape B=%d N=%d G=%d", B, N, G);
+    PRCNN_REQUIRE(G <= LABEL_MAX_GT, "prcnn_rpn_labels: at most %d GT boxes per frame (got %d)", LABEL_MAX_GT, G);
+    if (B == 0 || N == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(pts && cls_label && reg_label && (G == 0 || gt_boxes3d), "prcnn_rpn_labels: null pointer");
+    hipLaunchKernelGGL(rpn_labels_kernel, dim3(prcnn_divup(N, 256), B), dim3(256), 0, (hipStream_t)stream, pts, gt_boxes3d, num_gt,
+                       N, G, extra_width, cls_label, reg_label);
+    PRCNN_LAUNCH_CHECK("prcnn_rpn_labels");
+    return PRCNN_OK;
+}

@@ -292,12 +292,9 @@ PRCNN_API int prcnn_scene_prepare(const float* raw, const int64_t* offsets, int 
         hipLaunchKernelGGL(scene_flag_kernel, dim3(prcnn_divup(max_points_per_frame, SCENE_THREADS), B), dim3(SCENE_THREADS), 0, s, P);
         PRCNN_LAUNCH_CHECK("prcnn_scene_prepare(flags)");
     }
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)scene_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort_bytes(16384)) != hipSuccess)
-            return prcnn_fail(PRCNN_EHIP, "prcnn_scene_prepare: cannot raise the dynamic LDS limit");
-        attr = true;
-    }
+    static PrcnnLdsLimit attr;
+    if (!attr.raise((const void*)scene_sample_kernel, (int)lds_sort_bytes(16384)))
+        return prcnn_fail(PRCNN_EHIP, "prcnn_scene_prepare: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL(scene_sample_kernel, dim3(B), dim3(SCENE_THREADS), lds_sort_bytes(NP), s, P);
     PRCNN_LAUNCH_CHECK("prcnn_scene_prepare(sample)");
     return PRCNN_OK;

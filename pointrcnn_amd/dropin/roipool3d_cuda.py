@@ -1,9 +1,10 @@
 """`roipool3d_cuda` -- Python stand-in for the reference's pybind module
 (lib/utils/roipool3d/src/roipool3d.cpp:198-203): forward / forward_slow / pts_in_boxes3d_cpu / roipool3d_cpu
 with the reference's argument order and caller-allocated outputs.  All computation is in
-libprcnn_pointops.so; the two *_cpu entry points (whose contract is CPU tensors in, CPU tensors out --
-they serve the dataloader, kitti_rcnn_dataset.py:487,843) stage through the device and run the same HIP
-kernels: there is no CPU implementation in the product."""
+libprcnn_pointops.so: `forward` is the HIP kernel; the two *_cpu entry points (CPU tensors in, CPU tensors out -- the
+reference's dataloader calls them inside forked worker processes, kitti_rcnn_dataset.py:487,582,625,843,970, where no
+HIP context may exist) are the library's prcnn_host_* functions: plain host code, no device, no HIP call, bit-identical
+to the reference's roipool3d.cpp:82-195."""
 import torch
 
 from pointrcnn_amd import _cabi
@@ -30,45 +31,40 @@ def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
     return 1
 
 
-forward_slow = forward   # same contract; the reference's one-thread-per-box variant has no separate meaning here
+# The reference keeps a one-thread-per-box variant of the same computation under this name (roipool3d.cpp:15-46 ->
+# roipool3d_kernel.cu roipool3dLauncher_slow); inputs, outputs and results are those of `forward`, so one kernel serves both.
+forward_slow = forward
 
 
-def _dev():
-    if not torch.cuda.is_available():
-        raise RuntimeError("roipool3d_cuda: no HIP device; the HIP kernels are the only implementation")
-    return torch.device("cuda")
+def _host(t, name, dtype):
+    if t.is_cuda:
+        raise RuntimeError("%s must be a CPU tensor" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous " % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
+    return t.data_ptr()
 
 
 def pts_in_boxes3d_cpu(pts_flag, pts, boxes3d):
     """pts_flag (M,N) int64 CPU out, pts (N,3), boxes3d (M,7) CPU in   [roipool3d.cpp:97-125]"""
-    for t, n in ((pts_flag, "pts_flag"), (pts, "pts"), (boxes3d, "boxes3d")):
-        if not t.is_contiguous():
-            raise RuntimeError("%s must be contiguous " % n)
-    d = _dev()
-    p, b = pts.float().to(d), boxes3d.float().to(d)
-    N, M = p.shape[0], b.shape[0]
-    flags = torch.empty((M, N), dtype=torch.int32, device=d)
-    _cabi.check(_cabi.lib().prcnn_pts_in_boxes3d(_p(p), _p(b), N, M, _p(flags), _stream()), "prcnn_pts_in_boxes3d")
-    pts_flag.copy_(flags.to(torch.int64).cpu())
+    N, M = pts.shape[0], boxes3d.shape[0]
+    if tuple(pts_flag.shape) != (M, N):
+        raise RuntimeError("pts_flag must be (%d, %d)" % (M, N))
+    _cabi.check(_cabi.lib().prcnn_host_pts_in_boxes3d(_host(pts, "pts", torch.float32), _host(boxes3d, "boxes3d", torch.float32),
+                                                      N, M, _host(pts_flag, "pts_flag", torch.int64)), "prcnn_host_pts_in_boxes3d")
     return 1
 
 
 def roipool3d_cpu(pts, boxes3d, pts_feature, pooled_pts, pooled_features, pooled_empty_flag):
     """pts (N,3), boxes3d (M,7), pts_feature (N,C) -> pooled_pts (M,S,3), pooled_features (M,S,C),
     pooled_empty_flag (M) int64   [roipool3d.cpp:127-195]"""
-    for t, n in ((pts, "pts"), (boxes3d, "boxes3d"), (pts_feature, "pts_feature"), (pooled_pts, "pooled_pts"),
-                 (pooled_features, "pooled_features"), (pooled_empty_flag, "pooled_empty_flag")):
-        if not t.is_contiguous():
-            raise RuntimeError("%s must be contiguous " % n)
-    d = _dev()
-    p, b, f = pts.float().to(d), boxes3d.float().to(d), pts_feature.float().to(d)
-    N, M, C, S = p.shape[0], b.shape[0], f.shape[1], pooled_pts.shape[1]
-    out = torch.empty((1, M, S, 3 + C), dtype=torch.float32, device=d)
-    empty = torch.empty((1, M), dtype=torch.int32, device=d)
-    _cabi.check(_cabi.lib().prcnn_roipool3d(_p(p), _p(b), _p(f), 1, N, M, C, S, _p(out), _p(empty), _stream()),
-                "prcnn_roipool3d")
-    out = out[0].cpu()
-    pooled_pts.copy_(out[:, :, :3])
-    pooled_features.copy_(out[:, :, 3:])
-    pooled_empty_flag.copy_(empty[0].to(torch.int64).cpu())
+    N, M, C, S = pts.shape[0], boxes3d.shape[0], pts_feature.shape[1], pooled_pts.shape[1]
+    if tuple(pooled_pts.shape) != (M, S, 3) or tuple(pooled_features.shape) != (M, S, C) or pooled_empty_flag.numel() != M:
+        raise RuntimeError("pooled_pts / pooled_features / pooled_empty_flag must be (M,S,3) / (M,S,C) / (M)")
+    f32 = torch.float32
+    _cabi.check(_cabi.lib().prcnn_host_roipool3d(_host(pts, "pts", f32), _host(boxes3d, "boxes3d", f32),
+                                                 _host(pts_feature, "pts_feature", f32), N, M, C, S,
+                                                 _host(pooled_pts, "pooled_pts", f32), _host(pooled_features, "pooled_features", f32),
+                                                 _host(pooled_empty_flag, "pooled_empty_flag", torch.int64)), "prcnn_host_roipool3d")
     return 1

@@ -42,11 +42,20 @@ def _p(t):
 
 
 # ------------------------------------------------------------------ PointNet++ operators
-def furthest_point_sample(xyz, npoint):
-    """xyz (B,N,3) f32 -> idx (B,npoint) i32   [pointnet2_utils.furthest_point_sample]"""
+def furthest_point_sample(xyz, npoint, order="canonical"):
+    """xyz (B,N,3) f32 -> idx (B,npoint) i32   [pointnet2_utils.furthest_point_sample]
+    order: "canonical" (ties among equal running min-distances -> lowest point index; the tested contract) or "upstream"
+    (the order the upstream CUDA kernel's thread layout produces, SURVEY Appendix A.1: argmin (k mod T, k)) -- they differ
+    only on clouds with duplicate points / exact lattices; "upstream" is a comparison mode, not a fast path."""
     _chk(xyz, "xyz", ndim=3)
     B, N, _ = xyz.shape
     idx = torch.empty((B, npoint), dtype=_INT, device=xyz.device)
+    if order != "canonical":
+        if order != "upstream":
+            raise ValueError("furthest_point_sample: order must be 'canonical' or 'upstream'")
+        tmp = torch.empty((B, N), dtype=_F32, device=xyz.device)
+        _cabi.check(_cabi.lib().prcnn_fps_order(_p(xyz), B, N, npoint, 1, _p(tmp), _p(idx), _stream()), "prcnn_fps_order")
+        return idx
     # (B,N) 4-byte scratch: Morton-order permutation of the spatially pruned kernel (2048 < N <= 16384), or the
     # HBM-resident min-distance array (N > 16384); the small-N kernels need none
     tmp = torch.empty((B, N), dtype=_F32, device=xyz.device) if (N > 16384 or (N > 2048 and FPS_PRUNED)) else None
@@ -239,11 +248,13 @@ def chain_supported(mode, layers, pool_ns=0):
 
 
 class _ChainArgs:
-    """host arrays (wpack*, bias*, nout, relu) describing a stack of PackedLinear layers"""
+    """host arrays (wpack*, bias*, nout, relu) describing a stack of PackedLinear layers.  Holds the layers themselves:
+    the raw pointers below stay valid and the id()s of the cache key cannot be recycled while this object lives."""
 
     def __init__(self, layers):
         n = len(layers)
         self.n = n
+        self.layers = tuple(layers)
         self.wpack = (ctypes.c_void_p * n)(*[l.wpack.data_ptr() for l in layers])
         self.bias = (ctypes.c_void_p * n)(*[(l.bias.data_ptr() if l.bias is not None else None) for l in layers])
         self.nout = (ctypes.c_int * n)(*[l.nout for l in layers])
@@ -452,6 +463,23 @@ def roipool3d_canonical(xyz, pool_boxes3d, rois, extras, feat_cl, sampled_pt_num
         _row_stride(feat_cl), B, N, M, C, S, _p(pts), P, fbuf.data_ptr() + 4 * col, fbuf.stride(0), _p(empty), _p(distinct),
         _stream()), "prcnn_roipool3d_canonical")
     return (pts, fbuf, empty, distinct) if want_distinct else (pts, fbuf, empty)
+
+
+def rpn_labels(pts, gt_boxes3d, num_gt=None, extra_width=0.2):
+    """KittiRCNNDataset.generate_rpn_training_labels (kitti_rcnn_dataset.py:365-394) for a whole batch on the device.
+    pts (B,N,3), gt_boxes3d (B,G,7), num_gt (B) i32 or None -> cls_label (B,N) i32 {-1,0,1}, reg_label (B,N,7)"""
+    _chk(pts, "pts", ndim=3); _chk(gt_boxes3d, "gt_boxes3d", ndim=3)
+    B, N, _ = pts.shape
+    G = gt_boxes3d.shape[1]
+    if gt_boxes3d.shape[0] != B or gt_boxes3d.shape[2] != 7:
+        raise ValueError("rpn_labels: gt_boxes3d must be (%d, G, 7)" % B)
+    if num_gt is not None:
+        _chk(num_gt, "num_gt", _INT, 1)
+    cls = torch.empty((B, N), dtype=_INT, device=pts.device)
+    reg = torch.empty((B, N, 7), dtype=_F32, device=pts.device)
+    _cabi.check(_cabi.lib().prcnn_rpn_labels(_p(pts), _p(gt_boxes3d), _p(num_gt), B, N, G, float(extra_width), _p(cls), _p(reg),
+                                             _stream()), "prcnn_rpn_labels")
+    return cls, reg
 
 
 def pts_in_boxes3d(pts, boxes3d):

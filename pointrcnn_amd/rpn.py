@@ -175,6 +175,18 @@ def lidar_like_clouds(batch, npoints=16384, seed0=100, device="cpu"):
     return out.to(device)
 
 
+def saturated_clouds(batch, npoints=16384, seed0=100, device="cpu"):
+    """16384 points uniform in a 1.6 m cube inside PC_AREA_SCOPE (3 900 points per cubic metre): every ball of every SA level
+    holds at least nsample points, so ball_query never pads -- the cloud model of BASELINE config 1 at the RPN's size, and the
+    worst case for padding-free grouping (nothing to remove, the split is pure overhead)."""
+    out = torch.empty((batch, npoints, 3), dtype=torch.float32)
+    lo = torch.tensor([-0.8, 0.2, 20.0])
+    for f in range(batch):
+        g = torch.Generator().manual_seed(seed0 + f)
+        out[f] = torch.rand((npoints, 3), generator=g) * 1.6 + lo
+    return out.to(device)
+
+
 def rpn_flops_per_frame(cfg=RPNConfig):
     """Algorithmic MLP FLOPs per frame (2*MACs) of the RPN inference graph -- SURVEY.md 8(d): 14.95 GFLOP."""
     macs = 0

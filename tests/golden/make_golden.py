@@ -16,6 +16,12 @@
         reference source is an empty git submodule (parity unpinned: these pin the ORACLE's behaviour across
         refactors, not the reference's).
 
+    net_ref.npz -- outputs of the reference's own unchanged lib/net PointRCNN(mode='TEST') forward (RPN -> proposal layer ->
+        roipool3d -> RCNN) run on the drop-in op surface on CPU (ref_net.py: operators routed to the oracle, graph code = the
+        reference's Python), parameters a pure function of their state-dict names.
+    train_ref.npz -- the reference's own loss code (lib/net/train_functions.py + lib/utils/loss_utils.py) on seeded network
+        outputs, and one whole RPN training forward/backward of the reference's PointRCNN(mode='TRAIN') on the drop-in surface.
+
 Seeds are fixed; re-running reproduces the files byte for byte.
 """
 import os
@@ -149,7 +155,104 @@ def make_canonical_golden(ref):
     np.savez_compressed(os.path.join(HERE, "canonical_ref.npz"), rois=rois, pooled_canonical=pf.numpy(), empty=empty)
 
 
+NET_CASE = dict(B=2, N=16384, seed0=100, wseed=5)
+TRAIN_CASE = dict(B=2, N=8192, seed0=300, wseed=9, G=6)
+
+
+def train_batch(c=TRAIN_CASE):
+    """seeded synthetic RPN training batch: clouds + a few car-sized GT boxes centred on cloud points -> labels via the oracle
+    point-in-box test (shared by make_golden.py and the tests)"""
+    import torch
+    from pointrcnn_amd import rpn as mrpn
+    pts = mrpn.synthetic_clouds(c["B"], c["N"], seed0=c["seed0"]).numpy()
+    cpu = oracle.cpu()
+    gt = np.stack([rand_boxes3d(pts[b], c["G"], seed=c["seed0"] + 50 + b, jitter=0.1) for b in range(c["B"])])
+    gt[..., 3:6] *= 2.5                                   # oversized boxes so that the sparse synthetic cloud yields foreground points
+    cls = np.zeros((c["B"], c["N"]), np.int64)
+    reg = np.zeros((c["B"], c["N"], 7), np.float32)
+    for b in range(c["B"]):
+        inside = cpu.pts_in_boxes3d(pts[b], gt[b]) > 0
+        near = cpu.pts_in_boxes3d(pts[b], enlarge(gt[b], 0.2)) > 0
+        for k in range(c["G"]):
+            fg = inside[k]
+            cls[b][fg] = 1
+            cls[b][near[k] ^ fg] = -1
+            ctr = gt[b, k, 0:3].copy()
+            ctr[1] -= gt[b, k, 3] / 2
+            reg[b, fg, 0:3] = ctr - pts[b][fg]
+            reg[b, fg, 3:7] = gt[b, k, 3:7]
+    return pts, gt, cls, reg
+
+
+def make_net_golden():
+    """outputs of the reference's own unchanged PointRCNN(mode='TEST') (lib/net/*.py) on the drop-in op surface, CPU"""
+    import torch
+    import ref_net
+    from pointrcnn_amd import rpn as mrpn
+    c = NET_CASE
+    model = ref_net.build_reference_model("TEST", seed=c["wseed"])
+    pts = mrpn.synthetic_clouds(c["B"], c["N"], seed0=c["seed0"])
+    out = ref_net.run_reference(model, pts)
+    sd = model.state_dict()
+    g = {"keys": np.array(sorted(sd)), "shapes": np.array([str(tuple(sd[k].shape)) for k in sorted(sd)]), "crc_in": crc(pts.numpy())}
+    g["rpn_cls"] = out["rpn_cls"].numpy()[:, :, 0]
+    g["rpn_reg_s8"] = out["rpn_reg"].numpy()[:, ::8]
+    g["rpn_reg_abs_sum"] = np.abs(out["rpn_reg"].numpy().astype(np.float64)).sum((1, 2))
+    g["feat_s16"] = out["backbone_features"].numpy()[:, :, ::16]
+    for k in ("rois", "roi_scores_raw", "seg_result", "rcnn_cls", "rcnn_reg"):
+        g[k] = out[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "net_ref.npz"), **g)
+    print("net_ref: rois filled", (np.abs(g["rois"]).sum(-1) > 0).sum(1).tolist())
+
+
+def make_train_golden():
+    """(a) the reference's own loss code (train_functions.model_fn + loss_utils) on seeded network outputs: loss, tb_dict,
+    gradients; (b) one RPN training forward/backward of the reference's own PointRCNN(mode='TRAIN') + model_fn on the drop-in
+    op surface (CPU, oracle-backed operators): loss and per-parameter gradient norms + samples"""
+    import torch
+    import ref_net
+    import cpu_ops
+    g = {}
+    for name, (seed, loss_cls) in {"focal": (1, "SigmoidFocalLoss"), "dice": (2, "DiceLoss"), "bce": (3, "BinaryCrossEntropy"),
+                                   "nofg": (4, "SigmoidFocalLoss")}.items():
+        case = ref_net.train_loss_case(seed, nfg=0 if name == "nofg" else 300)
+        if name == "nofg":
+            case[2][:] = 0
+        loss, tb, gc, gr = ref_net.reference_rpn_loss(*case, loss_cls=loss_cls)
+        g[name + "_loss"], g[name + "_gcls"], g[name + "_greg_s4"] = np.float64(loss), gc, gr[:, ::4]
+        g[name + "_tb_keys"], g[name + "_tb_vals"] = np.array(sorted(tb)), np.array([float(tb[k]) for k in sorted(tb)])
+        g[name + "_crc"] = crc(*case)
+    # (b) whole training step
+    c = TRAIN_CASE
+    pts, gt, cls, reg = train_batch(c)
+    ns = ref_net.load()
+    model = ref_net.build_reference_model("TRAIN", seed=c["wseed"], rpn_only=True)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()                                  # CPU and GPU dropout streams differ: the golden step runs without dropout
+    data = {"pts_rect": pts, "pts_features": np.zeros((c["B"], c["N"], 1), np.float32), "pts_input": pts, "gt_boxes3d": gt,
+            "rpn_cls_label": cls, "rpn_reg_label": reg}
+    with cpu_ops.oracle_ops(), cpu_ops.cuda_is_cpu():
+        ret = ns.train_functions.model_joint_fn_decorator()(model, data)
+        ret.loss.backward()
+    names = [n for n, p in sorted(model.named_parameters()) if p.grad is not None]
+    params = dict(model.named_parameters())
+    g["step_loss"] = np.float64(ret.loss.item())
+    g["step_fg"] = np.int64((cls > 0).sum())
+    g["step_names"] = np.array(names)
+    g["step_gnorm"] = np.array([float(params[n].grad.double().norm()) for n in names])
+    g["step_gsample"] = np.stack([np.resize(params[n].grad.reshape(-1)[:8].numpy(), 8) for n in names])
+    g["step_crc"] = crc(pts, gt, cls, reg)
+    np.savez_compressed(os.path.join(HERE, "train_ref.npz"), **g)
+    print("train_ref: step loss", g["step_loss"], "fg", int(g["step_fg"]), "params with grad", len(names))
+
+
 def main():
+    if "--net" in sys.argv:                       # only the network-level fixtures
+        make_net_golden()
+        make_train_golden()
+        return
     cpu, ref = oracle.cpu(), oracle.ref()
     if ref is None:
         raise SystemExit("oracle/_ref is not built (needs /root/reference)")
@@ -182,6 +285,8 @@ def main():
     make_proposal_golden()
     make_canonical_golden(ref)
     make_kitti_eval_golden()
+    make_net_golden()
+    make_train_golden()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 

@@ -1,0 +1,151 @@
+"""BASELINE config 4 on CPU: the RPN training step under DistributedDataParallel over gloo, world size 2.
+
+The step is pointrcnn_amd.train_functions.RPNTrainer (the code bench.py --workload train runs on GPUs over RCCL); the point
+operators underneath are routed to the CPU oracle (tests/cpu_ops.py) because this container has no GPU.  Checked:
+  * the all-reduced gradient of 2 ranks x 1 frame equals the single-process gradient of the 2-frame batch within 1e-5
+    (global loss normalisation makes DDP's average the reference's DataParallel global-batch loss; BatchNorm in eval mode so
+    that batch statistics do not depend on the split),
+  * every rank holds identical parameters after optimizer.step(),
+  * with BatchNorm in training mode the ranks still agree with each other (DDP invariants) and rank 0's buffers are broadcast.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TESTS = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _small_cfg():
+    from pointrcnn_amd import rpn
+    return type("SmallRPN", (rpn.RPNConfig,), {
+        "NUM_POINTS": 1024, "SA_NPOINTS": [256, 64, 16, 8],
+        "SA_RADIUS": [[0.2, 0.5], [0.5, 1.0], [1.0, 2.0], [2.0, 4.0]], "SA_NSAMPLE": [[8, 16], [8, 16], [8, 16], [8, 16]],
+        "SA_MLPS": [[[8, 8, 16], [8, 8, 16]], [[16, 16, 32], [16, 16, 32]], [[32, 32, 64], [32, 32, 64]], [[64, 64, 128], [64, 64, 128]]],
+        "FP_MLPS": [[32, 32], [64, 64], [64, 64], [64, 64]], "CLS_FC": [32], "REG_FC": [32]})
+
+
+def _batch(frames, seed=0):
+    """(pts, cls_label, reg_label) for `frames` frames: 1024 points in a 6 m cube, 3 GT boxes per frame"""
+    sys.path.insert(0, TESTS)
+    import oracle
+    from util import enlarge, rand_boxes3d
+    cpu = oracle.cpu()
+    pts = np.stack([np.random.default_rng(seed + f).uniform([-3, -1, 10], [3, 2, 16], (1024, 3)).astype(np.float32) for f in range(frames)])
+    gt = np.stack([rand_boxes3d(pts[f], 3, seed=seed + 10 + f, jitter=0.05) for f in range(frames)])
+    gt[..., 3:6] *= 1.5
+    cls, reg = cpu.rpn_labels(pts, gt)
+    return torch.from_numpy(pts), torch.from_numpy(cls).long(), torch.from_numpy(reg)
+
+
+def _model(bn_eval):
+    sys.path.insert(0, TESTS)
+    import cpu_ops
+    from pointrcnn_amd import rpn, train_functions as tf
+    m = tf.init_rpn_head_weights(rpn.RPN(cfg=_small_cfg()))
+    cpu_ops.fill_params_by_name(m, seed=3)
+    return m
+
+
+def _freeze_norm_and_dropout(trainer, bn_eval):
+    """RPNTrainer.step puts the model in train(); for the parity check BatchNorm uses running statistics and dropout is off"""
+    orig = trainer.model.train
+
+    def train_then_freeze(mode=True):
+        orig(mode)
+        for mod in trainer.model.modules():
+            if isinstance(mod, torch.nn.Dropout) or (bn_eval and isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))):
+                mod.eval()
+        return trainer.model
+    trainer.model.train = train_then_freeze
+
+
+def _worker(rank, world, port, q, bn_eval):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_ops
+    from pointrcnn_amd import train_functions as tf
+    pts, cls, reg = _batch(world, seed=0)
+    shard = {"pts_input": pts[rank:rank + 1], "rpn_cls_label": cls[rank:rank + 1], "rpn_reg_label": reg[rank:rank + 1]}
+    model = _model(bn_eval)
+    if rank == 1:                                   # DDP must broadcast rank 0's parameters and buffers
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    trainer = tf.RPNTrainer(model, ddp=True, optimizer="sgd")
+    _freeze_norm_and_dropout(trainer, bn_eval)
+    with cpu_ops.oracle_ops():
+        tb = {}
+        loss = trainer.step(shard, tb)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    q.put((rank, float(loss.item()), {n: g.numpy() for n, g in grads.items()}, params.numpy(), tb["rpn_fg_sum"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(bn_eval):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, bn_eval)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_ddp_gradient_equals_single_process_global_batch():
+    res = _run(bn_eval=True)
+    sys.path.insert(0, TESTS)
+    import cpu_ops
+    from pointrcnn_amd import train_functions as tf
+    # single process, the whole 2-frame batch, the reference's (global) loss normalisation
+    pts, cls, reg = _batch(2, seed=0)
+    model = _model(True)
+    trainer = tf.RPNTrainer(model, ddp=False, optimizer="sgd")
+    _freeze_norm_and_dropout(trainer, True)
+    with cpu_ops.oracle_ops():
+        tb = {}
+        loss = trainer.step({"pts_input": pts, "rpn_cls_label": cls, "rpn_reg_label": reg}, tb)
+    assert res[0][4] + res[1][4] == tb["rpn_fg_sum"] and min(res[0][4], res[1][4]) > 0
+    # the global loss is the AVERAGE of the rescaled per-rank losses
+    assert abs(0.5 * (res[0][1] + res[1][1]) - float(loss.item())) <= 1e-5 * max(1.0, abs(float(loss.item())))
+    single = {n: p.grad.numpy() for n, p in model.named_parameters() if p.grad is not None}
+    assert set(single) == set(res[0][2]) == set(res[1][2])
+    worst = 0.0
+    for n, g in single.items():
+        scale = max(1.0, float(np.abs(g).max()))
+        assert np.array_equal(res[0][2][n], res[1][2][n]), "ranks disagree on the all-reduced gradient of %s" % n
+        worst = max(worst, float(np.abs(res[0][2][n] - g).max()) / scale)
+    assert worst <= 1e-5, worst
+    assert np.array_equal(res[0][3], res[1][3])      # identical parameters on both ranks after the step (rank 1 started perturbed)
+    after = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()
+    assert np.abs(after - res[0][3]).max() <= 1e-6   # and equal to the single-process step
+
+
+def test_ddp_with_training_mode_batchnorm_keeps_ranks_in_sync():
+    res = _run(bn_eval=False)
+    assert np.array_equal(res[0][3], res[1][3])
+    for n in res[0][2]:
+        assert np.array_equal(res[0][2][n], res[1][2][n]), n
+    assert np.isfinite(res[0][1]) and np.isfinite(res[1][1])
