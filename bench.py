@@ -86,6 +86,8 @@ def parse(argv=None):
     ap.add_argument("--raw-points", type=int, default=118000, help="raw points per synthetic scan for --input raw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-launches", action="store_true", help="print every library launch of one instrumented step to stderr "
+                    "(name, live rows, executed GFLOP, us, TFLOP/s)")
     args = ap.parse_args(argv)
     train = args.workload == "train"
     if args.steps is None:
@@ -195,7 +197,7 @@ class EventProfiler:
             return rc
         return wrapped
 
-    def summary(self):
+    def summary(self, dump=None):
         torch.cuda.synchronize()
         dev_counts = {}
         for sp in self.splits:
@@ -207,6 +209,10 @@ class EventProfiler:
             d = fam.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0, "rows": 0, "rows_launched": 0})
             ptr = getattr(ptr, "value", ptr)
             live = min(rows, dev_counts[ptr] * unit) if ptr else rows
+            if dump is not None:
+                us = s.elapsed_time(e) * 1e3
+                print("%-28s rows %8d / %8d  flop/row %8.0f  %7.2f GFLOP %8.1f us %6.1f TF/s" %
+                      (name, live, rows, per_row, per_row * live / 1e9, us, per_row * live / us / 1e6 if us > 0 else 0), file=dump)
             d["ms"] += s.elapsed_time(e)
             d["launches"] += 1
             d["flops"] += per_row * live
@@ -227,7 +233,12 @@ def cpu_baseline(model, clouds_cpu, gpu_out):
     cpu = oracle.cpu()
     spec = rpn_cpu.extract_rpn_weights(model)
     cores = os.cpu_count() or 1
-    nframes = int(min(clouds_cpu.shape[0], max(8, cores)))
+    # "oracle ops x nproc frames in parallel processes" -- one single-threaded frame per core (capped at 128
+    # worker processes; above that every worker gets cores // 128 BLAS threads)
+    nframes = int(max(8, min(cores, 128)))
+    if nframes > clouds_cpu.shape[0]:
+        from pointrcnn_amd import rpn as _rpn
+        clouds_cpu = torch.cat([clouds_cpu, _rpn.synthetic_clouds(nframes - clouds_cpu.shape[0], clouds_cpu.shape[1], seed0=90000)])
     res = None
     with tempfile.TemporaryDirectory() as td:
         with open(os.path.join(td, "spec.pkl"), "wb") as f:
@@ -396,7 +407,7 @@ class InferenceBench:
         torch.cuda.empty_cache()
 
 
-def instrumented_pass(args, bench, nprof):
+def instrumented_pass(args, bench, nprof, dump=None):
     """per-op-family GPU time + EXECUTED MLP flops of `nprof` eager steps (HIP events on the launch stream)"""
     from pointrcnn_amd import _cabi, ops as _ops
     prof = EventProfiler(_cabi._lib)
@@ -405,7 +416,7 @@ def instrumented_pass(args, bench, nprof):
     try:
         for _ in range(nprof):
             bench.step(0)
-        return prof.summary()
+        return prof.summary(dump)
     finally:
         _cabi._lib, _ops._split_log = real, None
 
@@ -582,6 +593,8 @@ def main():
     fam = None
     if rank == 0 and not args.no_roofline and args.workload == "rpn":
         nprof = min(3, args.steps)
+        if args.dump_launches:
+            instrumented_pass(args, bench, 1, dump=sys.stderr)
         fam = instrumented_pass(args, bench, nprof)
         mlp = fam.get("mlp", {"ms": 0.0, "launches": 1, "flops": 0.0, "rows": 0, "rows_launched": 0})
         secs = mlp["ms"] * 1e-3

@@ -52,9 +52,13 @@ def _mlp(cpu, rows, layers):
     return rows
 
 
-def rpn_forward_frame(cpu, xyz, spec, timings=None):
-    """xyz (N,3) f32 -> dict(rpn_cls (N,1), rpn_reg (N,R), backbone_features (N,128)); single-threaded."""
+def rpn_forward_frame(cpu, xyz, spec, timings=None, trace=None):
+    """xyz (N,3) f32 -> dict(rpn_cls (N,1), rpn_reg (N,R), backbone_features (N,128)); single-threaded.
+    trace (dict or None): receives every index the graph computes -- "fps" [per SA level (npoint)], "ball" [per level, per
+    scale (M,ns)], "nn_idx" / "nn_w" [per FP level in execution order (n,3)] -- for index-exact parity checks."""
     t = timings if timings is not None else {}
+    tr = trace if trace is not None else {}
+    tr.update({"fps": [], "ball": [], "nn_idx": [], "nn_w": []})
 
     def tick(name, t0):
         t[name] = t.get(name, 0.0) + time.perf_counter() - t0
@@ -68,10 +72,13 @@ def rpn_forward_frame(cpu, xyz, spec, timings=None):
         tick("fps", t0)
         new_xyz = p[fidx]
         outs = []
+        tr["fps"].append(fidx)
+        tr["ball"].append([])
         for sc in level["scales"]:
             t0 = time.perf_counter()
             idx = cpu.ball_query(sc["radius"], sc["nsample"], p[None], new_xyz[None])
             tick("ball_query", t0)
+            tr["ball"][-1].append(idx[0])
             t0 = time.perf_counter()
             gx = cpu.group(p.T[None], idx) - new_xyz.T[None, :, :, None]                  # (1,3,M,ns)
             g = gx if l_feat[-1] is None else np.concatenate([gx, cpu.group(l_feat[-1].T[None], idx)], 1)
@@ -89,6 +96,8 @@ def rpn_forward_frame(cpu, xyz, spec, timings=None):
         d2, idx3 = cpu.three_nn(unknown[None], known[None])
         w3 = cpu.three_weights(d2)
         tick("three_nn", t0)
+        tr["nn_idx"].append(idx3[0])
+        tr["nn_w"].append(w3[0])
         t0 = time.perf_counter()
         interp = cpu.three_interp(l_feat[i].T[None], idx3, w3)[0].T                        # (n, C2)
         rows = interp if l_feat[i - 1] is None else np.concatenate([interp, l_feat[i - 1]], 1)

@@ -6,7 +6,7 @@
 // created.  These functions therefore contain no HIP call at all: plain C++ on host pointers, re-entrant, no allocation
 // beyond one small per-call box table.  (The file carries the .hip suffix only so that the one build rule compiles it.)
 //
-// Arithmetic contract = the reference's CPU code, so results are bit-identical to it (tests: oracle/_ref golden):
+// Arithmetic contract = the reference's CPU code, so results are bit-identical to it (checked in tests/test_host_twins.py):
 //   cy = float(double(bottom_y) - double(h) / 2);   reject when |x-cx| > 10 or |z-cz| > 10 (float compares) or
 //   double(|y-cy|) > double(h)/2;   cos/sin = libm cosf/sinf (the reference's `cos(angle)` on a float argument resolves
 //   to the float overload in C++; the DEVICE kernels use double-evaluated trig rounded once instead);

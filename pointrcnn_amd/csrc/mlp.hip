@@ -78,6 +78,8 @@ struct MlpParams {
     // With xcd_tpf = 128-row tiles per frame (> 0), XCD x works through frames x, x+8, ... one after the other, so the
     // frame's gather source (Z / Y rows, 1-2 MB) stays resident in THAT XCD's L2 instead of every XCD streaming every frame.
     int xcd_tpf;
+    // v2 layer kernel, plain rows: > 0 selects the XCD-aware 1-D tile order with this many column tiles per row tile
+    int wgm_cols;
 };
 
 // With live-row segments the 128-row tile a workgroup works on is NOT blockIdx.x: the live tiles are the first one or two
@@ -278,6 +280,116 @@ __device__ __forceinline__ float interp_gather(const MlpParams& P, long row, int
     return (w[0] * y[(long)id[0] * P.ldY] + w[1] * y[(long)id[1] * P.ldY]) + w[2] * y[(long)id[2] * P.ldY];
 }
 
+// Epilogue shared by the layer kernels: bias + ReLU (+ hoisted-FP interpolated addend, + max-pool over nsample rows) and the
+// stores.  As0 / Bs0: the (now idle) operand LDS, reused to stage the interpolated addend tile (128 x 72 and 128 x 64 floats).
+template <int MODE, int WNB>
+__device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)[2][WNB], float* As0, float* Bs0, int tid, long row0,
+                                               int nb0, bool n_active) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, j = lane & 31;
+    // ---- epilogue -------------------------------------------------------------------------------
+    // Hoisted FP first layer (addY): every output element needs sum_j w_j * Y[idx_j, n].  Fetching that per accumulator
+    // element costs three 4-byte gathers per element; instead the workgroup builds the interpolated 128 x (64*WNB) tile
+    // once -- 16-byte loads, a row's 64 columns = 256 contiguous bytes per neighbour -- into the now idle operand
+    // buffers (As: 128 x 72 floats, Bs: 128 x 64) and the accumulators pick their elements up from LDS.
+    bool staged = false;
+    if (MODE == MODE_PLAIN && P.addY) {
+        staged = (P.Nout % 4 == 0) && (P.ldY % 4 == 0) && aligned16(P.addY);
+        if (staged) {
+#pragma unroll
+            for (int hf = 0; hf < WNB; hf++) {
+                float* T = hf == 0 ? As0 : Bs0;
+                const int ldt = hf == 0 ? 72 : 64;
+                const int ncol0 = (nb0 + hf * 2) * 32;
+                for (int f = tid; f < MLP_BM * 16; f += MLP_THREADS) {
+                    const int r = f >> 4, c = (f & 15) * 4, n = ncol0 + c;
+                    const long g = row0 + r;
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g < P.rows && n < P.Nout) {
+                        const int b = (int)(g / P.n);
+                        const int32_t* id = P.idx3 + g * 3;
+                        const float* w = P.w3 + g * 3;
+                        const float* y = P.addY + (long)b * P.m * P.ldY + n;
+                        const float4 y0 = ld4(y + (long)id[0] * P.ldY), y1 = ld4(y + (long)id[1] * P.ldY), y2 = ld4(y + (long)id[2] * P.ldY);
+                        const float w0 = w[0], w1 = w[1], w2 = w[2];
+                        o.x = (w0 * y0.x + w1 * y1.x) + w2 * y2.x;           // same expression as interp_gather
+                        o.y = (w0 * y0.y + w1 * y1.y) + w2 * y2.y;
+                        o.z = (w0 * y0.z + w1 * y1.z) + w2 * y2.z;
+                        o.w = (w0 * y0.w + w1 * y1.w) + w2 * y2.w;
+                    }
+                    *reinterpret_cast<float4*>(T + r * ldt + c) = o;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!n_active) return;
+    const long wrow0 = row0 + wm * 64;
+#pragma unroll
+    for (int nn = 0; nn < WNB; nn++) {
+        const int nb = nb0 + wn * WNB + nn;
+        if (nb >= P.NB) break;
+        const int n = nb * 32 + j;
+        const bool n_ok = n < P.Nout;
+        const float bias = (P.bias && n_ok) ? P.bias[n] : 0.f;
+        const f32x16& acc0 = acc[0][nn];
+        const f32x16& acc1 = acc[1][nn];
+        if (P.pool_ns == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                long g0 = wrow0 + rin, g1 = wrow0 + 32 + rin;
+                float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
+                if (P.addY && n_ok) {             // hoisted FP first layer: + sum_j w_j * Y[idx_j, n]
+                    if (staged) {
+                        const int blk = wn * WNB + nn;
+                        const float* T = (blk >> 1) == 0 ? As0 : Bs0;
+                        const int ldt = (blk >> 1) == 0 ? 72 : 64, tc = (blk & 1) * 32 + j;
+                        v0 += T[(wm * 64 + rin) * ldt + tc];
+                        v1 += T[(wm * 64 + 32 + rin) * ldt + tc];
+                    } else {
+                        if (g0 < P.rows) v0 += interp_gather(P, g0, n);
+                        if (g1 < P.rows) v1 += interp_gather(P, g1, n);
+                    }
+                }
+                if (P.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                if (n_ok && g0 < P.rows) P.out[g0 * P.ld_out + P.col_off + n] = v0;
+                if (n_ok && g1 < P.rows) P.out[g1 * P.ld_out + P.col_off + n] = v1;
+            }
+        } else {
+            // max over nsample consecutive rows.  max commutes with the (monotone) bias add and ReLU, so
+            // they are applied once per pooled value: bit-identical to pooling the activated rows.
+            float lo0 = acc0[0], hi0 = acc0[8], lo1 = acc1[0], hi1 = acc1[8];
+#pragma unroll
+            for (int r = 1; r < 8; r++) {
+                lo0 = fmaxf(lo0, acc0[r]); hi0 = fmaxf(hi0, acc0[8 + r]);
+                lo1 = fmaxf(lo1, acc1[r]); hi1 = fmaxf(hi1, acc1[8 + r]);
+            }
+            lo0 = fmaxf(lo0, __shfl_xor(lo0, 32)); hi0 = fmaxf(hi0, __shfl_xor(hi0, 32));
+            lo1 = fmaxf(lo1, __shfl_xor(lo1, 32)); hi1 = fmaxf(hi1, __shfl_xor(hi1, 32));
+            const long groups = P.rows / P.pool_ns;
+            float v[4]; long g[4]; int cnt;
+            if (P.pool_ns == 16) {
+                long g0 = wrow0 / 16;
+                v[0] = lo0; v[1] = hi0; v[2] = lo1; v[3] = hi1; g[0] = g0; g[1] = g0 + 1; g[2] = g0 + 2; g[3] = g0 + 3; cnt = 4;
+            } else if (P.pool_ns == 32) {
+                long g0 = wrow0 / 32;
+                v[0] = fmaxf(lo0, hi0); v[1] = fmaxf(lo1, hi1); g[0] = g0; g[1] = g0 + 1; cnt = 2;
+            } else {
+                v[0] = fmaxf(fmaxf(lo0, hi0), fmaxf(lo1, hi1)); g[0] = wrow0 / 64; cnt = 1;
+            }
+            if (h == 0 && n_ok) {
+                for (int t = 0; t < cnt; t++) {
+                    float o = v[t] + bias;
+                    if (P.relu) o = fmaxf(o, 0.f);
+                    if (g[t] < groups) P.out[g[t] * P.ld_out + P.col_off + n] = o;
+                }
+            }
+        }
+    }
+}
+
 // WNB = 32-column blocks per wave: 1 -> workgroup tile 128x64 (narrow layers), 2 -> 128x128 (wide layers: twice
 // the MFMAs per LDS operand read, and a gathered / interpolated A tile is rebuilt for half as many column tiles).
 template <int MODE, int WNB>
@@ -402,106 +514,191 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
         __syncthreads();
     }
 
-    // ---- epilogue -------------------------------------------------------------------------------
-    // Hoisted FP first layer (addY): every output element needs sum_j w_j * Y[idx_j, n].  Fetching that per accumulator
-    // element costs three 4-byte gathers per element; instead the workgroup builds the interpolated 128 x (64*WNB) tile
-    // once -- 16-byte loads, a row's 64 columns = 256 contiguous bytes per neighbour -- into the now idle operand
-    // buffers (As: 128 x 72 floats, Bs: 128 x 64) and the accumulators pick their elements up from LDS.
-    bool staged = false;
-    if (MODE == MODE_PLAIN && P.addY) {
-        staged = (P.Nout % 4 == 0) && (P.ldY % 4 == 0) && aligned16(P.addY);
-        if (staged) {
-#pragma unroll
-            for (int hf = 0; hf < WNB; hf++) {
-                float* T = hf == 0 ? &As[0][0] : &Bs[0][0];
-                const int ldt = hf == 0 ? 72 : 64;
-                const int ncol0 = (nb0 + hf * 2) * 32;
-                for (int f = tid; f < MLP_BM * 16; f += MLP_THREADS) {
-                    const int r = f >> 4, c = (f & 15) * 4, n = ncol0 + c;
-                    const long g = row0 + r;
-                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (g < P.rows && n < P.Nout) {
-                        const int b = (int)(g / P.n);
-                        const int32_t* id = P.idx3 + g * 3;
-                        const float* w = P.w3 + g * 3;
-                        const float* y = P.addY + (long)b * P.m * P.ldY + n;
-                        const float4 y0 = ld4(y + (long)id[0] * P.ldY), y1 = ld4(y + (long)id[1] * P.ldY), y2 = ld4(y + (long)id[2] * P.ldY);
-                        const float w0 = w[0], w1 = w[1], w2 = w[2];
-                        o.x = (w0 * y0.x + w1 * y1.x) + w2 * y2.x;           // same expression as interp_gather
-                        o.y = (w0 * y0.y + w1 * y1.y) + w2 * y2.y;
-                        o.z = (w0 * y0.z + w1 * y1.z) + w2 * y2.z;
-                        o.w = (w0 * y0.w + w1 * y1.w) + w2 * y2.w;
-                    }
-                    *reinterpret_cast<float4*>(T + r * ldt + c) = o;
-                }
-            }
-            __syncthreads();
-        }
+    layer_epilogue<MODE, WNB>(P, acc, &As[0][0], &Bs[0][0], tid, row0, nb0, n_active);
+}
+
+// ---- v2 of the layer kernel: B operand straight from L2 ------------------------------------------------------------------
+// The packed weight image IS the MFMA B-operand layout (lane l of (n-block, k-block) owns 16 contiguous bytes), so a wave can
+// load its own B operands directly into registers; only the A tile (gathered / interpolated / plain rows, shared by the
+// two waves of a column pair) goes through LDS.  What that buys over mlp_layer_kernel:
+//   * LDS per workgroup 69 -> 37 KB and no B staging registers / ds_writes: THREE workgroups per CU instead of two
+//     (registers capped at 168 by the launch bound), so a workgroup that is in its prologue (row metadata, first chunk's
+//     global -> LDS round trip) or its store epilogue leaves two others to feed the MFMA pipe -- the un-overlapped per-tile
+//     fixed costs were what separated the v1 kernel (90-100 TFLOP/s on plain rows) from its own inner loop (150);
+//   * the B stream is a 4-slot register ring requested four k-blocks (4096 MFMA cycles) ahead: its L2 latency never shows.
+// The weights of a layer are <= 1 MB and every workgroup reads all of them: they stay L2 / L1 resident.
+// Plain rows use an XCD-aware 1-D tile order: workgroup b runs on XCD b % 8; the column tiles of one row tile are handed to
+// consecutive slots of ONE XCD, so the A rows they share are fetched from HBM once and hit that XCD's L2 afterwards.
+// waves per SIMD the register allocation is held to: 3 where it fits without spilling (plain rows; the narrow grouped tile),
+// 2 for the gather modes whose row metadata + raw gather registers need the room (they still gain the LDS and the B ring)
+template <int MODE, int WNB, bool FAST> struct LayerBOcc {
+    // plain rows, straight-line form: FOUR workgroups per CU (<= 128 registers).  The plain GEMMs of the graph have power-of-two
+    // tile counts (256 .. 4096): 1024 resident workgroups run them in whole rounds, whereas three per CU (768) leaves a
+    // ragged last round of one workgroup per CU with nothing to hide its latencies behind (measured: 32768 x 512 -> 512 took
+    // 213 us at three per CU against 170 us at two).  With four waves sharing a SIMD's matrix pipe a k-block lasts ~4096
+    // cycles of wall time, so a two-slot B ring (two k-blocks ahead) is ample.
+    static constexpr int W = (MODE == MODE_PLAIN && FAST) ? 4 : ((MODE == MODE_PLAIN || (MODE == MODE_GROUP && WNB == 1)) ? 3 : 2);
+    static constexpr int RING = (MODE == MODE_PLAIN && FAST) ? 2 : 4;
+};
+// FAST: K a multiple of the 32-wide chunk, 16-byte aligned source rows (and, grouped, the hoisted activated-gather form):
+// rows are CLAMPED to the last live row instead of bounds-checked (their results are never stored), so the whole main loop
+// is straight-line code -- no exec-mask branches around the loads, which is what lets the compiler keep the A chunk and the B
+// ring in flight with counted waits instead of draining vmcnt to 0 at every join.
+template <int MODE, int WNB, bool FAST>
+__global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST>::W)) void mlp_layer_b_kernel(const MlpParams Pin) {
+    MlpParams P = Pin;
+    P.rows = effective_rows(Pin);
+    constexpr int QN = 2 * WNB;                          // n-blocks per workgroup
+    long tile_id;
+    int nb0;
+    if (P.wgm_cols > 0) {                                // XCD-aware 1-D order (plain rows)
+        const long bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+        const long rl = slot / P.wgm_cols;
+        tile_id = rl * 8 + xcd;
+        nb0 = (int)(slot - rl * P.wgm_cols) * QN;
+    } else {
+        tile_id = tile_of_block(P, blockIdx.x);
+        nb0 = blockIdx.y * QN;
     }
-    if (!n_active) return;
-    const long wrow0 = row0 + wm * 64;
+    if (tile_id * MLP_BM >= P.rows) return;              // workgroup-uniform (device-side row count / grid padding)
+    if (tile_dead(P, tile_id * MLP_BM)) return;
+    __shared__ __attribute__((aligned(16))) float As[2][MLP_BM * MLP_ALD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index in an SGPR: uniform branches
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, j = lane & 31;
+    const long row0 = tile_id * MLP_BM;
+    const int nchunks = (P.KB + 3) >> 2;
+
+    const int c4 = tid & 7, r0 = tid >> 3;
+    RowMeta<MODE> meta[4];
 #pragma unroll
-    for (int nn = 0; nn < WNB; nn++) {
-        const int nb = nb0 + wn * WNB + nn;
-        if (nb >= P.NB) break;
-        const int n = nb * 32 + j;
-        const bool n_ok = n < P.Nout;
-        const float bias = (P.bias && n_ok) ? P.bias[n] : 0.f;
-        const f32x16& acc0 = acc[0][nn];
-        const f32x16& acc1 = acc[1][nn];
-        if (P.pool_ns == 0) {
+    for (int u = 0; u < 4; u++) {
+        long grow = row0 + r0 + 32 * u;
+        if (FAST && grow >= P.rows) grow = P.rows - 1;
+        make_meta<MODE>(P, grow, meta[u]);
+    }
+
+    Raw<MODE> ra[4];
+    const bool group_act = MODE == MODE_GROUP && P.act != 0;
+    float4 aw0 = make_float4(0.f, 0.f, 0.f, 0.f), aw1 = aw0, aw2 = aw0, ab = aw0;
+    auto load_chunk = [&](int c) {
+        const int k = c * MLP_BK + c4 * 4;
+        if constexpr (FAST) {
+            if constexpr (MODE == MODE_GROUP) {
+                aw0 = ld4(P.act_wx + (long)k * 3); aw1 = ld4(P.act_wx + (long)k * 3 + 4); aw2 = ld4(P.act_wx + (long)k * 3 + 8);
+                ab = ld4(P.act_bias + k);
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
-                long g0 = wrow0 + rin, g1 = wrow0 + 32 + rin;
-                float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
-                if (P.addY && n_ok) {             // hoisted FP first layer: + sum_j w_j * Y[idx_j, n]
-                    if (staged) {
-                        const int blk = wn * WNB + nn;
-                        const float* T = (blk >> 1) == 0 ? &As[0][0] : &Bs[0][0];
-                        const int ldt = (blk >> 1) == 0 ? 72 : 64, tc = (blk & 1) * 32 + j;
-                        v0 += T[(wm * 64 + rin) * ldt + tc];
-                        v1 += T[(wm * 64 + 32 + rin) * ldt + tc];
-                    } else {
-                        if (g0 < P.rows) v0 += interp_gather(P, g0, n);
-                        if (g1 < P.rows) v1 += interp_gather(P, g1, n);
-                    }
-                }
-                if (P.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                if (n_ok && g0 < P.rows) P.out[g0 * P.ld_out + P.col_off + n] = v0;
-                if (n_ok && g1 < P.rows) P.out[g1 * P.ld_out + P.col_off + n] = v1;
+                for (int u = 0; u < 4; u++) ra[u].a = ld4(P.feat + meta[u].off + k);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) ra[u].a = ld4(P.in + meta[u].off + k);
             }
         } else {
-            // max over nsample consecutive rows.  max commutes with the (monotone) bias add and ReLU, so
-            // they are applied once per pooled value: bit-identical to pooling the activated rows.
-            float lo0 = acc0[0], hi0 = acc0[8], lo1 = acc1[0], hi1 = acc1[8];
+            if (group_act && k < P.K) {
+                aw0 = ld4(P.act_wx + (long)k * 3); aw1 = ld4(P.act_wx + (long)k * 3 + 4); aw2 = ld4(P.act_wx + (long)k * 3 + 8);
+                ab = ld4(P.act_bias + k);
+            }
 #pragma unroll
-            for (int r = 1; r < 8; r++) {
-                lo0 = fmaxf(lo0, acc0[r]); hi0 = fmaxf(hi0, acc0[8 + r]);
-                lo1 = fmaxf(lo1, acc1[r]); hi1 = fmaxf(hi1, acc1[8 + r]);
-            }
-            lo0 = fmaxf(lo0, __shfl_xor(lo0, 32)); hi0 = fmaxf(hi0, __shfl_xor(hi0, 32));
-            lo1 = fmaxf(lo1, __shfl_xor(lo1, 32)); hi1 = fmaxf(hi1, __shfl_xor(hi1, 32));
-            const long groups = P.rows / P.pool_ns;
-            float v[4]; long g[4]; int cnt;
-            if (P.pool_ns == 16) {
-                long g0 = wrow0 / 16;
-                v[0] = lo0; v[1] = hi0; v[2] = lo1; v[3] = hi1; g[0] = g0; g[1] = g0 + 1; g[2] = g0 + 2; g[3] = g0 + 3; cnt = 4;
-            } else if (P.pool_ns == 32) {
-                long g0 = wrow0 / 32;
-                v[0] = fmaxf(lo0, hi0); v[1] = fmaxf(lo1, hi1); g[0] = g0; g[1] = g0 + 1; cnt = 2;
-            } else {
-                v[0] = fmaxf(fmaxf(lo0, hi0), fmaxf(lo1, hi1)); g[0] = wrow0 / 64; cnt = 1;
-            }
-            if (h == 0 && n_ok) {
-                for (int t = 0; t < cnt; t++) {
-                    float o = v[t] + bias;
-                    if (P.relu) o = fmaxf(o, 0.f);
-                    if (g[t] < groups) P.out[g[t] * P.ld_out + P.col_off + n] = o;
-                }
-            }
+            for (int u = 0; u < 4; u++) fetch<MODE>(P, meta[u], k, ra[u]);
         }
+    };
+    auto store_chunk = [&](int c, int buf) {
+        const int k = c * MLP_BK + c4 * 4;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float4 v;
+            if constexpr (MODE == MODE_GROUP) {
+                if (FAST || (group_act && meta[u].valid && k < P.K)) {          // == finish<MODE_GROUP> with the prefetched parameters
+                    const float dx = meta[u].dx, dy = meta[u].dy, dz = meta[u].dz;
+                    const float4 z = ra[u].a;
+                    v.x = fmaxf(z.x + (aw0.x * dx + aw0.y * dy + aw0.z * dz) + ab.x, 0.f);
+                    v.y = fmaxf(z.y + (aw0.w * dx + aw1.x * dy + aw1.y * dz) + ab.y, 0.f);
+                    v.z = fmaxf(z.z + (aw1.z * dx + aw1.w * dy + aw2.x * dz) + ab.z, 0.f);
+                    v.w = fmaxf(z.w + (aw2.y * dx + aw2.z * dy + aw2.w * dz) + ab.w, 0.f);
+                    if (!FAST) {
+                        if (k + 1 >= P.K) v.y = 0.f;
+                        if (k + 2 >= P.K) v.z = 0.f;
+                        if (k + 3 >= P.K) v.w = 0.f;
+                    }
+                } else {
+                    v = finish<MODE>(P, meta[u], k, ra[u]);
+                }
+            } else if constexpr (MODE == MODE_PLAIN) {
+                v = ra[u].a;
+            } else {
+                v = finish<MODE>(P, meta[u], k, ra[u]);
+            }
+            *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * u) * MLP_ALD + c4 * 4]) = v;
+        }
+    };
+
+    f32x16 acc[2][WNB];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int n = 0; n < WNB; n++) acc[r][n] = (f32x16){0};
+    const bool n_active = (nb0 + wn * WNB) < P.NB;      // at least this wave's first column block exists (wave-uniform)
+
+    // B ring: slot (g & 3) holds this wave's operands of k-block g, requested four k-blocks ahead.  Loads are unconditional:
+    // column blocks past the layer's width re-read the last block (their results are never stored), k-blocks past K re-read
+    // the last k-block -- the A tile is zero there, so the extra MFMAs of a ragged last chunk add exact zeros.
+    constexpr int RING = LayerBOcc<MODE, WNB, FAST>::RING;      // slots = prefetch distance in k-blocks (4: one chunk, 2: half)
+    float4 bq[RING][WNB];
+    const float* bptr[WNB];
+#pragma unroll
+    for (int n = 0; n < WNB; n++) bptr[n] = P.wpack + ((long)min(nb0 + wn * WNB + n, P.NB - 1) * P.KB) * 256 + lane * 4;
+    const int kb_last = P.KB - 1;
+    auto load_b = [&](int g, int slot) {
+        const long off = (long)min(g, kb_last) * 256;
+#pragma unroll
+        for (int n = 0; n < WNB; n++) bq[slot][n] = ld4(bptr[n] + off);
+    };
+#pragma unroll
+    for (int g = 0; g < RING; g++) load_b(g, g);
+
+    load_chunk(0);
+    store_chunk(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int buf = c & 1;
+        // unconditional (the last iteration re-requests the last chunk and stores it into the idle buffer): a branch around
+        // these loads would make the compiler's wait counts assume the path WITHOUT them, i.e. force them early on the other
+        load_chunk(min(c + 1, nchunks - 1));
+        const float* a_base = &As[buf][(wm * 64 + j) * MLP_ALD + 4 * h];
+#pragma unroll
+        for (int kbl = 0; kbl < 4; kbl++) {
+            if (n_active) {
+                float4 a[2];
+                a[0] = *reinterpret_cast<const float4*>(a_base + kbl * 8);
+                a[1] = *reinterpret_cast<const float4*>(a_base + 32 * MLP_ALD + kbl * 8);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, bq[kbl % RING][n].x, acc[r][n], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].y, bq[kbl % RING][n].y, acc[r][n], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].z, bq[kbl % RING][n].z, acc[r][n], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].w, bq[kbl % RING][n].w, acc[r][n], 0, 0, 0);
+            }
+            // Refill the slot just consumed with k-block g + 4.  Every B operand a chunk uses was therefore requested during
+            // the PREVIOUS chunk, i.e. before this chunk's A loads: vmcnt retires in order, so waiting for a B operand never
+            // drags the younger A loads along -- they have the whole chunk (4096 MFMA cycles) to arrive.
+            load_b(c * 4 + kbl + RING, kbl % RING);
+        }
+        store_chunk(min(c + 1, nchunks - 1), buf ^ 1);
+        __syncthreads();
     }
+    layer_epilogue<MODE, WNB>(P, acc, &As[0][0], nullptr, tid, row0, nb0, n_active);      // (addY launches use the v1 kernel)
 }
 
 // =====================================================================================================
@@ -1252,15 +1449,31 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     static const bool wide_lists = getenv("PRCNN_WIDE_LISTS") != nullptr;
     const bool wide = P.NB >= 4 && (!P.rows_dev || wide_lists) && (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4) >= wide_min;
     dim3 grid(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, wide ? 4 : 2));
+    // v2 (B operand straight from L2, three workgroups per CU): every launch except the hoisted-FP addY epilogue, whose staged
+    // addend tile needs the B half of the v1 kernel's LDS.  PRCNN_LAYER_V1=1 is the A/B switch (same bits).
+    static const bool force_v1 = getenv("PRCNN_LAYER_V1") != nullptr;
+    const bool v2 = !force_v1 && !P.addY;
+    if (v2 && mode == MODE_PLAIN && !P.seg_cnt && P.xcd_tpf == 0 && getenv("PRCNN_NO_WGM") == nullptr) {
+        P.wgm_cols = (int)grid.y;
+        grid = dim3((unsigned)(prcnn_divup(grid.x, 8) * 8 * grid.y), 1);
+    }
+    // straight-line main loop (see mlp_layer_b_kernel): whole 32-wide chunks, 16-byte rows; grouped: the hoisted form only
+    const bool fast = P.K % MLP_BK == 0 && P.vec_a && (mode == MODE_PLAIN || (mode == MODE_GROUP && P.act == 1 && P.C == P.K));
+#define MLP_LAUNCH_B(M, W, F) hipLaunchKernelGGL((mlp_layer_b_kernel<M, W, F>), grid, dim3(MLP_THREADS), 0, s, P)
 #define MLP_LAUNCH(M)                                                                                         \
     do {                                                                                                      \
-        if (wide) hipLaunchKernelGGL((mlp_layer_kernel<M, 2>), grid, dim3(MLP_THREADS), 0, s, P);             \
+        if (v2) {                                                                                             \
+            if (M != MODE_INTERP && fast) { if (wide) MLP_LAUNCH_B(M, 2, (M != MODE_INTERP)); else MLP_LAUNCH_B(M, 1, (M != MODE_INTERP)); } \
+            else if (wide) MLP_LAUNCH_B(M, 2, false);                                                         \
+            else MLP_LAUNCH_B(M, 1, false);                                                                   \
+        } else if (wide) hipLaunchKernelGGL((mlp_layer_kernel<M, 2>), grid, dim3(MLP_THREADS), 0, s, P);      \
         else hipLaunchKernelGGL((mlp_layer_kernel<M, 1>), grid, dim3(MLP_THREADS), 0, s, P);                  \
     } while (0)
     if (mode == MODE_PLAIN) MLP_LAUNCH(MODE_PLAIN);
     else if (mode == MODE_GROUP) MLP_LAUNCH(MODE_GROUP);
     else MLP_LAUNCH(MODE_INTERP);
 #undef MLP_LAUNCH
+#undef MLP_LAUNCH_B
     PRCNN_LAUNCH_CHECK("prcnn_mlp");
     return PRCNN_OK;
 }

@@ -22,6 +22,8 @@
     train_ref.npz -- the reference's own loss code (lib/net/train_functions.py + lib/utils/loss_utils.py) on seeded network
         outputs, and one whole RPN training forward/backward of the reference's PointRCNN(mode='TRAIN') on the drop-in surface.
 
+    labels_ref.npz -- the reference's own generate_rpn_training_labels (numpy + scipy Delaunay) on seeded dense scenes.
+
 Seeds are fixed; re-running reproduces the files byte for byte.
 """
 import os
@@ -248,10 +250,32 @@ def make_train_golden():
     print("train_ref: step loss", g["step_loss"], "fg", int(g["step_fg"]), "params with grad", len(names))
 
 
+def label_scene(seed):
+    """dense synthetic scene for the RPN label fixtures: 16384 points in a 16 x 4 x 20 m volume, 10 car-sized GT boxes centred
+    near cloud points (some overlap each other)"""
+    pts = np.random.default_rng(seed).uniform([-8, -1, 5], [8, 3, 25], (16384, 3)).astype(np.float32)
+    return pts, rand_boxes3d(pts, 10, seed=seed + 50, jitter=0.3)
+
+
+def make_labels_golden():
+    """the reference's own KittiRCNNDataset.generate_rpn_training_labels (kitti_rcnn_dataset.py:365-394, scipy Delaunay hull
+    test) on seeded scenes"""
+    import ref_net
+    ref_net.load()
+    import lib.datasets.kitti_rcnn_dataset as d
+    g = {}
+    for seed in (0, 1, 2):
+        pts, gt = label_scene(seed)
+        cls, reg = d.KittiRCNNDataset.generate_rpn_training_labels(pts, gt)
+        g["cls%d" % seed], g["reg%d" % seed], g["crc%d" % seed] = cls.astype(np.int8), reg, crc(pts, gt)
+    np.savez_compressed(os.path.join(HERE, "labels_ref.npz"), **g)
+
+
 def main():
     if "--net" in sys.argv:                       # only the network-level fixtures
         make_net_golden()
         make_train_golden()
+        make_labels_golden()
         return
     cpu, ref = oracle.cpu(), oracle.ref()
     if ref is None:
@@ -287,6 +311,7 @@ def main():
     make_kitti_eval_golden()
     make_net_golden()
     make_train_golden()
+    make_labels_golden()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 
