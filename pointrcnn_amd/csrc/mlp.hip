@@ -282,7 +282,7 @@ __device__ __forceinline__ float interp_gather(const MlpParams& P, long row, int
 
 // Epilogue shared by the layer kernels: bias + ReLU (+ hoisted-FP interpolated addend, + max-pool over nsample rows) and the
 // stores.  As0 / Bs0: the (now idle) operand LDS, reused to stage the interpolated addend tile (128 x 72 and 128 x 64 floats).
-template <int MODE, int WNB>
+template <int MODE, int WNB, bool ADDY>
 __device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)[2][WNB], float* As0, float* Bs0, int tid, long row0,
                                                int nb0, bool n_active) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -293,43 +293,57 @@ __device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)
     // element costs three 4-byte gathers per element; instead the workgroup builds the interpolated 128 x (64*WNB) tile
     // once -- 16-byte loads, a row's 64 columns = 256 contiguous bytes per neighbour -- into the now idle operand
     // buffers (As: 128 x 72 floats, Bs: 128 x 64) and the accumulators pick their elements up from LDS.
+    // Bs0 == nullptr (v2 kernel: only the A half of the operand LDS exists): the two 64-column halves of a wide tile are staged
+    // one after the other into As0, each followed by the stores of the column blocks that lie in it.
     bool staged = false;
-    if (MODE == MODE_PLAIN && P.addY) {
-        staged = (P.Nout % 4 == 0) && (P.ldY % 4 == 0) && aligned16(P.addY);
-        if (staged) {
-#pragma unroll
-            for (int hf = 0; hf < WNB; hf++) {
-                float* T = hf == 0 ? As0 : Bs0;
-                const int ldt = hf == 0 ? 72 : 64;
-                const int ncol0 = (nb0 + hf * 2) * 32;
-                for (int f = tid; f < MLP_BM * 16; f += MLP_THREADS) {
-                    const int r = f >> 4, c = (f & 15) * 4, n = ncol0 + c;
-                    const long g = row0 + r;
-                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (g < P.rows && n < P.Nout) {
-                        const int b = (int)(g / P.n);
-                        const int32_t* id = P.idx3 + g * 3;
-                        const float* w = P.w3 + g * 3;
-                        const float* y = P.addY + (long)b * P.m * P.ldY + n;
-                        const float4 y0 = ld4(y + (long)id[0] * P.ldY), y1 = ld4(y + (long)id[1] * P.ldY), y2 = ld4(y + (long)id[2] * P.ldY);
-                        const float w0 = w[0], w1 = w[1], w2 = w[2];
-                        o.x = (w0 * y0.x + w1 * y1.x) + w2 * y2.x;           // same expression as interp_gather
-                        o.y = (w0 * y0.y + w1 * y1.y) + w2 * y2.y;
-                        o.z = (w0 * y0.z + w1 * y1.z) + w2 * y2.z;
-                        o.w = (w0 * y0.w + w1 * y1.w) + w2 * y2.w;
-                    }
-                    *reinterpret_cast<float4*>(T + r * ldt + c) = o;
-                }
+    int npass = 1;
+    auto stage_half = [&](int hf, float* T, int ldt) {
+        const int ncol0 = (nb0 + hf * 2) * 32;
+        for (int f = tid; f < MLP_BM * 16; f += MLP_THREADS) {
+            const int r = f >> 4, c = (f & 15) * 4, n = ncol0 + c;
+            const long g = row0 + r;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < P.rows && n < P.Nout) {
+                const int b = (int)(g / P.n);
+                const int32_t* id = P.idx3 + g * 3;
+                const float* w = P.w3 + g * 3;
+                const float* y = P.addY + (long)b * P.m * P.ldY + n;
+                const float4 y0 = ld4(y + (long)id[0] * P.ldY), y1 = ld4(y + (long)id[1] * P.ldY), y2 = ld4(y + (long)id[2] * P.ldY);
+                const float w0 = w[0], w1 = w[1], w2 = w[2];
+                o.x = (w0 * y0.x + w1 * y1.x) + w2 * y2.x;           // same expression as interp_gather
+                o.y = (w0 * y0.y + w1 * y1.y) + w2 * y2.y;
+                o.z = (w0 * y0.z + w1 * y1.z) + w2 * y2.z;
+                o.w = (w0 * y0.w + w1 * y1.w) + w2 * y2.w;
             }
+            *reinterpret_cast<float4*>(T + r * ldt + c) = o;
+        }
+    };
+    if (MODE == MODE_PLAIN && ADDY && P.addY) {
+        staged = (P.Nout % 4 == 0) && (P.ldY % 4 == 0) && aligned16(P.addY);
+        if (staged && Bs0) {
+#pragma unroll
+            for (int hf = 0; hf < WNB; hf++) stage_half(hf, hf == 0 ? As0 : Bs0, hf == 0 ? 72 : 64);
             __syncthreads();
+        } else if (staged) {
+            npass = WNB;
         }
     }
-    if (!n_active) return;
+    if (!n_active && npass == 1) return;              // (with several passes every wave has barriers ahead of it)
     const long wrow0 = row0 + wm * 64;
+#pragma unroll
+    for (int pass = 0; pass < WNB; pass++) {
+    if (pass >= npass) break;
+    if (staged && !Bs0) {
+        if (pass > 0) __syncthreads();                // the previous half has been consumed
+        stage_half(pass, As0, 72);
+        __syncthreads();
+    }
+    if (!n_active) continue;
 #pragma unroll
     for (int nn = 0; nn < WNB; nn++) {
         const int nb = nb0 + wn * WNB + nn;
-        if (nb >= P.NB) break;
+        if (nb >= P.NB) continue;
+        if (staged && !Bs0 && ((wn * WNB + nn) >> 1) != pass) continue;
         const int n = nb * 32 + j;
         const bool n_ok = n < P.Nout;
         const float bias = (P.bias && n_ok) ? P.bias[n] : 0.f;
@@ -341,11 +355,11 @@ __device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)
                 int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
                 long g0 = wrow0 + rin, g1 = wrow0 + 32 + rin;
                 float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
-                if (P.addY && n_ok) {             // hoisted FP first layer: + sum_j w_j * Y[idx_j, n]
+                if (ADDY && P.addY && n_ok) {     // hoisted FP first layer: + sum_j w_j * Y[idx_j, n]
                     if (staged) {
                         const int blk = wn * WNB + nn;
-                        const float* T = (blk >> 1) == 0 ? As0 : Bs0;
-                        const int ldt = (blk >> 1) == 0 ? 72 : 64, tc = (blk & 1) * 32 + j;
+                        const float* T = ((blk >> 1) == 0 || !Bs0) ? As0 : Bs0;
+                        const int ldt = ((blk >> 1) == 0 || !Bs0) ? 72 : 64, tc = (blk & 1) * 32 + j;
                         v0 += T[(wm * 64 + rin) * ldt + tc];
                         v1 += T[(wm * 64 + 32 + rin) * ldt + tc];
                     } else {
@@ -387,6 +401,7 @@ __device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)
                 }
             }
         }
+    }
     }
 }
 
@@ -514,38 +529,43 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
         __syncthreads();
     }
 
-    layer_epilogue<MODE, WNB>(P, acc, &As[0][0], &Bs[0][0], tid, row0, nb0, n_active);
+    layer_epilogue<MODE, WNB, true>(P, acc, &As[0][0], &Bs[0][0], tid, row0, nb0, n_active);
 }
 
 // ---- v2 of the layer kernel: B operand straight from L2 ------------------------------------------------------------------
 // The packed weight image IS the MFMA B-operand layout (lane l of (n-block, k-block) owns 16 contiguous bytes), so a wave can
 // load its own B operands directly into registers; only the A tile (gathered / interpolated / plain rows, shared by the
 // two waves of a column pair) goes through LDS.  What that buys over mlp_layer_kernel:
-//   * LDS per workgroup 69 -> 37 KB and no B staging registers / ds_writes: THREE workgroups per CU instead of two
-//     (registers capped at 168 by the launch bound), so a workgroup that is in its prologue (row metadata, first chunk's
-//     global -> LDS round trip) or its store epilogue leaves two others to feed the MFMA pipe -- the un-overlapped per-tile
-//     fixed costs were what separated the v1 kernel (90-100 TFLOP/s on plain rows) from its own inner loop (150);
+//   * LDS per workgroup 69 -> 37 KB and no B staging registers / ds_writes: three or four workgroups per CU instead of two
+//     (LayerBOcc below), so a workgroup that is in its prologue (row metadata, first chunk's global -> LDS round trip) or
+//     its store epilogue leaves the others to feed the MFMA pipe -- the un-overlapped per-tile fixed costs were what
+//     separated the v1 kernel (90-100 TFLOP/s on plain rows) from its own inner loop (150);
 //   * the B stream is a 4-slot register ring requested four k-blocks (4096 MFMA cycles) ahead: its L2 latency never shows.
 // The weights of a layer are <= 1 MB and every workgroup reads all of them: they stay L2 / L1 resident.
 // Plain rows use an XCD-aware 1-D tile order: workgroup b runs on XCD b % 8; the column tiles of one row tile are handed to
 // consecutive slots of ONE XCD, so the A rows they share are fetched from HBM once and hit that XCD's L2 afterwards.
 // waves per SIMD the register allocation is held to: 3 where it fits without spilling (plain rows; the narrow grouped tile),
 // 2 for the gather modes whose row metadata + raw gather registers need the room (they still gain the LDS and the B ring)
-template <int MODE, int WNB, bool FAST> struct LayerBOcc {
+#ifndef PRCNN_ABL
+#define PRCNN_ABL 0            // ablation builds of mlp_layer_b_kernel (tools/build_ablation.py): bit 0 no epilogue, 1 no A loads in
+#endif                         // the loop, 2 no B loads in the loop, 3 no LDS refill + barrier in the loop -- never set in the product
+template <int MODE, int WNB, bool FAST, bool ADDY> struct LayerBOcc {
     // plain rows, straight-line form: FOUR workgroups per CU (<= 128 registers).  The plain GEMMs of the graph have power-of-two
     // tile counts (256 .. 4096): 1024 resident workgroups run them in whole rounds, whereas three per CU (768) leaves a
     // ragged last round of one workgroup per CU with nothing to hide its latencies behind (measured: 32768 x 512 -> 512 took
     // 213 us at three per CU against 170 us at two).  With four waves sharing a SIMD's matrix pipe a k-block lasts ~4096
     // cycles of wall time, so a two-slot B ring (two k-blocks ahead) is ample.
-    static constexpr int W = (MODE == MODE_PLAIN && FAST) ? 4 : ((MODE == MODE_PLAIN || (MODE == MODE_GROUP && WNB == 1)) ? 3 : 2);
-    static constexpr int RING = (MODE == MODE_PLAIN && FAST) ? 2 : 4;
+    // ADDY (hoisted-FP first layer: the epilogue stages the interpolated addend tile through LDS while the accumulators are
+    // live): three per CU -- at 128 registers that epilogue spills
+    static constexpr int W = ADDY ? (WNB == 1 ? 4 : 3) : (MODE == MODE_PLAIN && FAST) ? 4 : ((MODE == MODE_PLAIN || (MODE == MODE_GROUP && WNB == 1)) ? 3 : 2);
+    static constexpr int RING = (MODE == MODE_PLAIN && FAST && W == 4) ? 2 : 4;
 };
 // FAST: K a multiple of the 32-wide chunk, 16-byte aligned source rows (and, grouped, the hoisted activated-gather form):
 // rows are CLAMPED to the last live row instead of bounds-checked (their results are never stored), so the whole main loop
 // is straight-line code -- no exec-mask branches around the loads, which is what lets the compiler keep the A chunk and the B
 // ring in flight with counted waits instead of draining vmcnt to 0 at every join.
-template <int MODE, int WNB, bool FAST>
-__global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST>::W)) void mlp_layer_b_kernel(const MlpParams Pin) {
+template <int MODE, int WNB, bool FAST, bool ADDY>
+__global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST, ADDY>::W)) void mlp_layer_b_kernel(const MlpParams Pin) {
     MlpParams P = Pin;
     P.rows = effective_rows(Pin);
     constexpr int QN = 2 * WNB;                          // n-blocks per workgroup
@@ -644,7 +664,7 @@ __global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST>::W)) void 
     // B ring: slot (g & 3) holds this wave's operands of k-block g, requested four k-blocks ahead.  Loads are unconditional:
     // column blocks past the layer's width re-read the last block (their results are never stored), k-blocks past K re-read
     // the last k-block -- the A tile is zero there, so the extra MFMAs of a ragged last chunk add exact zeros.
-    constexpr int RING = LayerBOcc<MODE, WNB, FAST>::RING;      // slots = prefetch distance in k-blocks (4: one chunk, 2: half)
+    constexpr int RING = LayerBOcc<MODE, WNB, FAST, ADDY>::RING;      // slots = prefetch distance in k-blocks (4: one chunk, 2: half)
     float4 bq[RING][WNB];
     const float* bptr[WNB];
 #pragma unroll
@@ -665,8 +685,8 @@ __global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST>::W)) void 
         const int buf = c & 1;
         // unconditional (the last iteration re-requests the last chunk and stores it into the idle buffer): a branch around
         // these loads would make the compiler's wait counts assume the path WITHOUT them, i.e. force them early on the other
-        load_chunk(min(c + 1, nchunks - 1));
-        const float* a_base = &As[buf][(wm * 64 + j) * MLP_ALD + 4 * h];
+        if (!(PRCNN_ABL & 2)) load_chunk(min(c + 1, nchunks - 1));
+        const float* a_base = &As[(PRCNN_ABL & 8) ? 0 : buf][(wm * 64 + j) * MLP_ALD + 4 * h];
 #pragma unroll
         for (int kbl = 0; kbl < 4; kbl++) {
             if (n_active) {
@@ -693,12 +713,25 @@ __global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST>::W)) void 
             // Refill the slot just consumed with k-block g + 4.  Every B operand a chunk uses was therefore requested during
             // the PREVIOUS chunk, i.e. before this chunk's A loads: vmcnt retires in order, so waiting for a B operand never
             // drags the younger A loads along -- they have the whole chunk (4096 MFMA cycles) to arrive.
-            load_b(c * 4 + kbl + RING, kbl % RING);
+            if (!(PRCNN_ABL & 4)) load_b(c * 4 + kbl + RING, kbl % RING);
         }
-        store_chunk(min(c + 1, nchunks - 1), buf ^ 1);
-        __syncthreads();
+        if (!(PRCNN_ABL & 8)) {
+            store_chunk(min(c + 1, nchunks - 1), buf ^ 1);
+            __syncthreads();
+        }
     }
-    layer_epilogue<MODE, WNB>(P, acc, &As[0][0], nullptr, tid, row0, nb0, n_active);      // (addY launches use the v1 kernel)
+    if (PRCNN_ABL & 1) {        // keep the accumulators alive with a store that (practically) never happens
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int n = 0; n < WNB; n++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) sum += acc[r][n][e];
+        if (sum == 123.456f) P.out[tid] = sum;
+        return;
+    }
+    layer_epilogue<MODE, WNB, ADDY>(P, acc, &As[0][0], nullptr, tid, row0, nb0, n_active);
 }
 
 // =====================================================================================================
@@ -1447,19 +1480,31 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     // (a device-side row count means a compacted list: P.rows is its worst case, the live part is expected to be small)
     static const long wide_min = getenv("PRCNN_WIDE_MIN_TILES") ? atol(getenv("PRCNN_WIDE_MIN_TILES")) : 192;
     static const bool wide_lists = getenv("PRCNN_WIDE_LISTS") != nullptr;
-    const bool wide = P.NB >= 4 && (!P.rows_dev || wide_lists) && (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4) >= wide_min;
+    bool wide = P.NB >= 4 && (!P.rows_dev || wide_lists) && (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4) >= wide_min;
     dim3 grid(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, wide ? 4 : 2));
-    // v2 (B operand straight from L2, three workgroups per CU): every launch except the hoisted-FP addY epilogue, whose staged
-    // addend tile needs the B half of the v1 kernel's LDS.  PRCNN_LAYER_V1=1 is the A/B switch (same bits).
+    // v2 (B operand straight from L2, up to four workgroups per CU) is the default; PRCNN_LAYER_V1=1 is the A/B switch (same bits).
     static const bool force_v1 = getenv("PRCNN_LAYER_V1") != nullptr;
-    const bool v2 = !force_v1 && !P.addY;
+    const bool v2 = !force_v1;
+    const bool fast = P.K % MLP_BK == 0 && P.vec_a && (mode == MODE_PLAIN || (mode == MODE_GROUP && P.act == 1 && P.C == P.K));
+    if (v2 && fast && mode == MODE_PLAIN && wide && getenv("PRCNN_WIDE_MIN_TILES") == nullptr) {
+        // four workgroups per CU = 1024 resident tiles: with >= 1024 wide tiles the narrow tile (twice as many, half as long)
+        // runs in more, staggered rounds, so one round's store epilogue overlaps the next one's main loop (measured: 32768 x
+        // 512 -> 512 171 -> 160 us, 131072 x 256 -> 256 173 -> 167 us); between 384 and 1023 wide tiles the wide tile's better
+        // MFMA : LDS-read ratio wins (32768 x 512 -> 256: 74 vs 81 us)
+        const long tiles_wide = (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4);
+        wide = tiles_wide >= 384 && tiles_wide < 1024;
+    }
+    grid = dim3(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, wide ? 4 : 2));
     if (v2 && mode == MODE_PLAIN && !P.seg_cnt && P.xcd_tpf == 0 && getenv("PRCNN_NO_WGM") == nullptr) {
         P.wgm_cols = (int)grid.y;
         grid = dim3((unsigned)(prcnn_divup(grid.x, 8) * 8 * grid.y), 1);
     }
-    // straight-line main loop (see mlp_layer_b_kernel): whole 32-wide chunks, 16-byte rows; grouped: the hoisted form only
-    const bool fast = P.K % MLP_BK == 0 && P.vec_a && (mode == MODE_PLAIN || (mode == MODE_GROUP && P.act == 1 && P.C == P.K));
-#define MLP_LAUNCH_B(M, W, F) hipLaunchKernelGGL((mlp_layer_b_kernel<M, W, F>), grid, dim3(MLP_THREADS), 0, s, P)
+    // (fast = straight-line main loop, see mlp_layer_b_kernel: whole 32-wide chunks, 16-byte rows; grouped: the hoisted form only)
+#define MLP_LAUNCH_B(M, W, F)                                                                                            \
+    do {                                                                                                                 \
+        if (M == MODE_PLAIN && P.addY) hipLaunchKernelGGL((mlp_layer_b_kernel<M, W, F, (M == MODE_PLAIN)>), grid, dim3(MLP_THREADS), 0, s, P); \
+        else hipLaunchKernelGGL((mlp_layer_b_kernel<M, W, F, false>), grid, dim3(MLP_THREADS), 0, s, P);              \
+    } while (0)
 #define MLP_LAUNCH(M)                                                                                         \
     do {                                                                                                      \
         if (v2) {                                                                                             \
