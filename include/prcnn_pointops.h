@@ -47,7 +47,8 @@ typedef void* prcnn_stream_t; /* hipStream_t */
 #define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
 int prcnn_abi_version(void);   /* 4: + prcnn_host_* (host twins of the reference's *_cpu entry points), prcnn_build_id,
-                                 * prcnn_fps_order (upstream tie order), prcnn_rpn_labels;
+                                 * prcnn_fps_order (upstream tie order), prcnn_rpn_labels,
+                                 * prcnn_ball_query2_grid takes xyz (dense-frame scan fallback);
                                  * 3: + padding-free grouping (rows_dev / groups_dev, prcnn_group_compact, ...), RoI duplicate
                                  * elimination (seg_cnt / seg_rows, distinct, valid_n), prcnn_scene_prepare */
 const char* prcnn_last_error(void);
@@ -338,9 +339,13 @@ size_t prcnn_grid_bytes(int B, int N);
  * crowded near-sensor regions cheap for the ball query; ~1 point per cell suits the three_nn ring search). */
 int prcnn_grid_build(const float* xyz, int B, int N, float min_cell, int cells_per_axis, void* grid, size_t grid_bytes,
                      prcnn_stream_t stream);
-/* == prcnn_ball_query2 on the binned points (N = points per frame the grid was built with); nsample_b = 0: one radius */
-int prcnn_ball_query2_grid(const void* grid, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a,
-                           int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, prcnn_stream_t stream);
+/* == prcnn_ball_query2 on the binned points (N = points per frame the grid was built with); nsample_b = 0: one radius.
+ * xyz (B,N,3), the points the grid was built from, or NULL.  With xyz given, DENSE frames -- prcnn_grid_build estimates the
+ * candidates a ball visits from the cell occupancy; above N/32 the grid kernel's per-candidate cost exceeds a scan's -- are
+ * answered by the index-order scan of prcnn_ball_query2 instead (launched behind the grid kernel; each kernel exits at once on
+ * the other's frames, so the launch sequence is static).  Results are identical either way. */
+int prcnn_ball_query2_grid(const void* grid, const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a,
+                           int nsample_a, int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, prcnn_stream_t stream);
 /* == prcnn_three_nn with `known` given as a grid of m points per frame */
 int prcnn_three_nn_grid(const void* grid, const float* unknown, int B, int n, int m, float* dist2, int32_t* idx, float* weight,
                         prcnn_stream_t stream);

@@ -60,7 +60,7 @@ SIGNATURES = {
     "prcnn_roipool3d_canonical": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
     "prcnn_grid_bytes": (_Z, [_I, _I]),
     "prcnn_grid_build": (_I, [_P, _I, _I, _F, _I, _P, _Z, _P]),
-    "prcnn_ball_query2_grid": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _F, _I, _P, _P]),
+    "prcnn_ball_query2_grid": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _P, _F, _I, _P, _P]),
     "prcnn_three_nn_grid": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "prcnn_rotate_iou_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "prcnn_kitti_overlaps": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P]),

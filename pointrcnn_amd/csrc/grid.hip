@@ -15,23 +15,10 @@
 //               the hits, ascending, padded with the smallest;
 //   three_nn  : strict-'<' insertion in index order == the three smallest (d2, index) pairs, lexicographically
 // -- so the output is bit-identical to the scan regardless of the (arbitrary) order of points inside a cell.
-#include "common.h"
+#include "grid_layout.h"
 
-#define GRID_DIM_MAX 128                         // cells per axis: 64 (three_nn: ~1 known point per cell) or 128 (ball query:
-#define GRID_CELLS_MAX (GRID_DIM_MAX * GRID_DIM_MAX)   //  crowded near-sensor cells stay small); buffers are sized for 128
 #define GRID_BUILD_THREADS 1024
 
-struct GridHeader {
-    float x0, z0, inv_cs, cs;
-    int dim, pad0, pad1, pad2;                    // dim = cells per axis of THIS grid
-};
-// per-frame block inside the caller's buffer: header | cell_start[128*128 + 1] | sorted[N] float4
-static inline size_t grid_frame_bytes(int N) {
-    size_t b = sizeof(GridHeader) + (size_t)(GRID_CELLS_MAX + 1) * 4;
-    b = (b + 15) & ~(size_t)15;
-    return b + (size_t)N * 16;
-}
-__device__ __forceinline__ const GridHeader* grid_header(const void* g, size_t fb, int b) { return (const GridHeader*)((const char*)g + fb * b); }
 __device__ __forceinline__ const int32_t* grid_cells(const void* g, size_t fb, int b) { return (const int32_t*)((const char*)g + fb * b + sizeof(GridHeader)); }
 __device__ __forceinline__ const float4* grid_points(const void* g, size_t fb, int b) {
     size_t off = (sizeof(GridHeader) + (size_t)(GRID_CELLS_MAX + 1) * 4 + 15) & ~(size_t)15;
@@ -57,6 +44,19 @@ __device__ __forceinline__ float block_reduce(float v, bool is_min, float* scrat
     __syncthreads();
     float r = scratch[0];
     for (int w = 1; w < nw; w++) r = is_min ? fminf(r, scratch[w]) : fmaxf(r, scratch[w]);
+    return r;
+}
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < nw; w++) r += scratch[w];
+    __syncthreads();
     return r;
 }
 
@@ -92,8 +92,13 @@ __global__ __launch_bounds__(GRID_BUILD_THREADS) void grid_build_kernel(const fl
     }
     __syncthreads();
     // exclusive scan of the counts: per_thread consecutive cells per thread, wave scan, wave offsets
-    int ssum = 0;
-    for (int u = 0; u < per_thread; u++) ssum += cnt[tid * per_thread + u];
+    int ssum = 0, occ = 0;
+    for (int u = 0; u < per_thread; u++) {
+        const int c = cnt[tid * per_thread + u];
+        ssum += c;
+        occ += c > 0;
+    }
+    const float occupied = block_reduce_sum((float)occ, red);
     int inc = ssum;
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -113,7 +118,12 @@ __global__ __launch_bounds__(GRID_BUILD_THREADS) void grid_build_kernel(const fl
         run += c;
     }
     if (tid == GRID_BUILD_THREADS - 1) cstart[ncell] = run;
-    if (tid == 0) { H->x0 = mnx; H->z0 = mnz; H->inv_cs = inv; H->cs = cs; H->dim = dim; }
+    if (tid == 0) {
+        H->x0 = mnx; H->z0 = mnz; H->inv_cs = inv; H->cs = cs; H->dim = dim;
+        const float side = 2.0f * min_cell * inv + 1.0f;                       // cells a ball of radius min_cell spans per axis
+        H->cand = (float)N / fmaxf(occupied, 1.0f) * side * side;
+        H->pad1 = H->pad2 = 0;
+    }
     __syncthreads();
     for (int i = tid; i < N; i += GRID_BUILD_THREADS) {
         float x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
@@ -142,12 +152,14 @@ template <bool DUAL>
 __global__ __launch_bounds__(GBQ_THREADS) void grid_ball_query_kernel(const void* __restrict__ grid, size_t fb,
                                                                      const float* __restrict__ new_xyz, int M, float ra,
                                                                      float r2a, int nsa, int32_t* __restrict__ idxa, float rb,
-                                                                     float r2b, int nsb, int32_t* __restrict__ idxb) {
+                                                                     float r2b, int nsb, int32_t* __restrict__ idxb, int N,
+                                                                     int skip_dense) {
     extern __shared__ int lists[];               // [nsa + nsb][GBQ_THREADS]
     const int b = blockIdx.y, tid = threadIdx.x;
     const int m = blockIdx.x * GBQ_THREADS + tid;
     if (m >= M) return;
     const GridHeader H = *grid_header(grid, fb, b);
+    if (skip_dense && grid_frame_dense(H, N)) return;          // the scan kernel takes this frame (same results)
     const int32_t* __restrict__ cstart = grid_cells(grid, fb, b);
     const float4* __restrict__ pts = grid_points(grid, fb, b);
     const float* q = new_xyz + ((size_t)b * M + m) * 3;
@@ -297,8 +309,8 @@ PRCNN_API int prcnn_grid_build(const float* xyz, int B, int N, float min_cell, i
     return PRCNN_OK;
 }
 
-PRCNN_API int prcnn_ball_query2_grid(const void* grid, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a,
-                                     int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, prcnn_stream_t stream) {
+PRCNN_API int prcnn_ball_query2_grid(const void* grid, const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a,
+                                     int nsample_a, int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, prcnn_stream_t stream) {
     const bool dual = nsample_b > 0;
     PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && nsample_a > 0 && nsample_b >= 0, "prcnn_ball_query2_grid: bad shape");
     if (B == 0 || M == 0) return PRCNN_OK;
@@ -309,11 +321,14 @@ PRCNN_API int prcnn_ball_query2_grid(const void* grid, const float* new_xyz, int
     const float r2a = radius_a * radius_a, r2b = radius_b * radius_b;      // fp32 products, as the oracle
     if (dual)
         hipLaunchKernelGGL(grid_ball_query_kernel<true>, g, dim3(GBQ_THREADS), lds, (hipStream_t)stream, grid, grid_frame_bytes(N),
-                           new_xyz, M, radius_a, r2a, nsample_a, idx_a, radius_b, r2b, nsample_b, idx_b);
+                           new_xyz, M, radius_a, r2a, nsample_a, idx_a, radius_b, r2b, nsample_b, idx_b, N, xyz ? 1 : 0);
     else
         hipLaunchKernelGGL(grid_ball_query_kernel<false>, g, dim3(GBQ_THREADS), lds, (hipStream_t)stream, grid, grid_frame_bytes(N),
-                           new_xyz, M, radius_a, r2a, nsample_a, idx_a, 0.f, 0.f, 0, (int32_t*)nullptr);
+                           new_xyz, M, radius_a, r2a, nsample_a, idx_a, 0.f, 0.f, 0, (int32_t*)nullptr, N, xyz ? 1 : 0);
     PRCNN_LAUNCH_CHECK("prcnn_ball_query2_grid");
+    // dense frames (GridHeader::cand): the index-order scan, restricted to exactly the frames the grid kernel skipped
+    if (xyz) return prcnn_launch_ball_query_scan(xyz, new_xyz, B, N, M, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, grid,
+                                                 (hipStream_t)stream);
     return PRCNN_OK;
 }
 

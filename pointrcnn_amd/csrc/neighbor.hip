@@ -10,7 +10,7 @@
 // candidates in ascending index order makes the "first nsample hits in index order" contract fall
 // out by construction -- no sort, no compaction pass.  The MSG levels query two radii around the
 // same centroids: ball_query2 evaluates both in the same pass (half the scans).
-#include "common.h"
+#include "grid_layout.h"
 
 #define BQ_THREADS 64       // ball query: ONE wave per workgroup -> wave-local staging, 4x more workgroups than 256-thread
                             // blocks (the op only has B*M threads in total), no cross-wave barrier in the scan
@@ -36,9 +36,12 @@ template <bool DUAL>
 __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float* __restrict__ xyz,
                                                                 const float* __restrict__ new_xyz, int N, int M,
                                                                 float r2a, int nsa, int32_t* __restrict__ idxa,
-                                                                float r2b, int nsb, int32_t* __restrict__ idxb) {
+                                                                float r2b, int nsb, int32_t* __restrict__ idxb,
+                                                                const void* __restrict__ grid, size_t grid_fb) {
     __shared__ __attribute__((aligned(16))) float spts[NB_CHUNK * 4];
     const int b = blockIdx.y, tid = threadIdx.x;
+    // launched behind the grid kernel (prcnn_ball_query2_grid): only the frames that kernel left to the scan
+    if (grid && !grid_frame_dense(*grid_header(grid, grid_fb, b), N)) return;
     const int m = blockIdx.x * BQ_THREADS + tid;
     const bool valid = m < M;
     const float* __restrict__ p = xyz + (size_t)b * N * 3;
@@ -200,21 +203,27 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float* __res
 }
 
 static int ball_query_impl(const float* xyz, const float* new_xyz, int B, int N, int M, float ra, int nsa, int32_t* ia,
-                           float rb, int nsb, int32_t* ib, bool dual, hipStream_t s) {
+                           float rb, int nsb, int32_t* ib, bool dual, hipStream_t s, const void* dense_grid = nullptr) {
     PRCNN_REQUIRE(B >= 0 && N > 0 && M >= 0 && nsa > 0 && (!dual || nsb > 0),
                   "prcnn_ball_query: bad shape B=%d N=%d M=%d nsample=%d/%d", B, N, M, nsa, nsb);
     if (B == 0 || M == 0) return PRCNN_OK;
     PRCNN_REQUIRE(xyz && new_xyz && ia && (!dual || ib), "prcnn_ball_query: null pointer");
     dim3 grid(prcnn_divup(M, BQ_THREADS), B);
     float r2a = ra * ra, r2b = rb * rb;        // fp32 product, as the oracle
+    const size_t gfb = grid_frame_bytes(N);
     if (dual)
         hipLaunchKernelGGL(ball_query_kernel<true>, grid, dim3(BQ_THREADS), 0, s, xyz, new_xyz, N, M, r2a, nsa, ia, r2b,
-                           nsb, ib);
+                           nsb, ib, dense_grid, gfb);
     else
         hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(BQ_THREADS), 0, s, xyz, new_xyz, N, M, r2a, nsa, ia,
-                           0.f, 0, (int32_t*)nullptr);
+                           0.f, 0, (int32_t*)nullptr, dense_grid, gfb);
     PRCNN_LAUNCH_CHECK("prcnn_ball_query");
     return PRCNN_OK;
+}
+
+int prcnn_launch_ball_query_scan(const float* xyz, const float* new_xyz, int B, int N, int M, float radius_a, int nsample_a,
+                                 int32_t* idx_a, float radius_b, int nsample_b, int32_t* idx_b, const void* grid, hipStream_t s) {
+    return ball_query_impl(xyz, new_xyz, B, N, M, radius_a, nsample_a, idx_a, radius_b, nsample_b, idx_b, nsample_b > 0, s, grid);
 }
 
 PRCNN_API int prcnn_ball_query(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample,

@@ -96,6 +96,7 @@ def gather_rows(in_cl, idx):
 # Frames with at least this many points are searched through a per-frame grid (csrc/grid.hip) instead of a full scan:
 # identical results, ~N/30 of the distance evaluations.  PRCNN_GRID_SEARCH=0 forces the scans (A/B, debugging).
 GRID_MIN_POINTS = 2048 if os.environ.get("PRCNN_GRID_SEARCH", "1") != "0" else 1 << 62
+DENSE_SCAN = os.environ.get("PRCNN_DENSE_SCAN", "1") != "0"      # dense frames fall back to the scan (A/B switch, same results)
 BQ_GRID_CELLS = int(os.environ.get("PRCNN_BQ_GRID_CELLS", "128"))       # cells per axis of the ball-query grid (64 | 128)
 
 
@@ -112,15 +113,16 @@ class Grid:
                     "prcnn_grid_build")
 
 
-def ball_query_grid(grid, new_xyz, radius_a, nsample_a, radius_b=0.0, nsample_b=0):
-    """== ball_query / ball_query2 on a Grid of the source points"""
+def ball_query_grid(grid, new_xyz, radius_a, nsample_a, radius_b=0.0, nsample_b=0, xyz=None):
+    """== ball_query / ball_query2 on a Grid of the source points.  xyz: the points the grid was built from -- frames the grid
+    build flags as dense are then answered by the index-order scan (same results, see prcnn_ball_query2_grid)"""
     _chk(new_xyz, "new_xyz", ndim=3)
     B, M = new_xyz.shape[0], new_xyz.shape[1]
     if B != grid.B:
         raise ValueError("ball_query_grid: %d frames of centroids vs %d frames in the grid" % (B, grid.B))
     ia = torch.empty((B, M, nsample_a), dtype=_INT, device=new_xyz.device)
     ib = torch.empty((B, M, nsample_b), dtype=_INT, device=new_xyz.device) if nsample_b else None
-    _cabi.check(_cabi.lib().prcnn_ball_query2_grid(_p(grid.buf), _p(new_xyz), B, grid.N, M, float(radius_a), nsample_a, _p(ia),
+    _cabi.check(_cabi.lib().prcnn_ball_query2_grid(_p(grid.buf), _p(xyz), _p(new_xyz), B, grid.N, M, float(radius_a), nsample_a, _p(ia),
                                                    float(radius_b), nsample_b, _p(ib), _stream()), "prcnn_ball_query2_grid")
     return (ia, ib) if nsample_b else ia
 
@@ -131,7 +133,7 @@ def ball_query(radius, nsample, xyz, new_xyz):
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
     if N >= GRID_MIN_POINTS and B > 0 and M > 0:
-        return ball_query_grid(Grid(xyz, radius, BQ_GRID_CELLS), new_xyz, radius, nsample)
+        return ball_query_grid(Grid(xyz, radius, BQ_GRID_CELLS), new_xyz, radius, nsample, xyz=xyz if DENSE_SCAN else None)
     idx = torch.empty((B, M, nsample), dtype=_INT, device=xyz.device)
     _cabi.check(_cabi.lib().prcnn_ball_query(_p(xyz), _p(new_xyz), B, N, M, float(radius), nsample, _p(idx), _stream()),
                 "prcnn_ball_query")
@@ -144,7 +146,8 @@ def ball_query2(radius_a, nsample_a, radius_b, nsample_b, xyz, new_xyz):
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
     if N >= GRID_MIN_POINTS and B > 0 and M > 0:
-        return ball_query_grid(Grid(xyz, max(radius_a, radius_b), BQ_GRID_CELLS), new_xyz, radius_a, nsample_a, radius_b, nsample_b)
+        return ball_query_grid(Grid(xyz, max(radius_a, radius_b), BQ_GRID_CELLS), new_xyz, radius_a, nsample_a, radius_b, nsample_b,
+                               xyz=xyz if DENSE_SCAN else None)
     ia = torch.empty((B, M, nsample_a), dtype=_INT, device=xyz.device)
     ib = torch.empty((B, M, nsample_b), dtype=_INT, device=xyz.device)
     _cabi.check(_cabi.lib().prcnn_ball_query2(_p(xyz), _p(new_xyz), B, N, M, float(radius_a), nsample_a, _p(ia),

@@ -89,3 +89,35 @@ def test_grid_is_used_above_the_threshold_and_matches_full_size(dev, cpu):
     sd, si, sw = torch.empty_like(d2), torch.empty_like(i3), torch.empty_like(w3)
     ops._cabi.check(lib.prcnn_three_nn(x.data_ptr(), new.data_ptr(), 2, 16384, 4096, sd.data_ptr(), si.data_ptr(), sw.data_ptr(), st), "scan")
     assert torch.equal(i3, si) and torch.equal(d2, sd) and torch.equal(w3, sw)
+
+
+def test_dense_frames_fall_back_to_the_scan_with_identical_results(dev, cpu):
+    """prcnn_grid_build estimates the candidates a ball visits from the cell occupancy; frames above N/32 are answered by the
+    index-order scan launched behind the grid kernel (prcnn_ball_query2_grid with xyz).  A batch mixing a sparse KITTI-like
+    frame, a saturated 1.6 m cube (every ball full) and a frame on the threshold's other side must come out identical to the
+    scan / the oracle whichever kernel took which frame -- and identical to the grid kernel alone (xyz=None)."""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(3)
+    N, M = 16384, 4096
+    sparse = kitti_cloud(1, N, seed=21)[0]
+    cube = (r.random((N, 3), dtype=np.float32) * 1.6 + np.array([-0.8, 0.2, 20.0], np.float32)).astype(np.float32)
+    medium = (r.random((N, 3), dtype=np.float32) * np.array([12, 3, 12], np.float32)).astype(np.float32)
+    pts = np.stack([sparse, cube, medium, cube[::-1].copy()])
+    x = torch.from_numpy(pts).to(dev)
+    q_np = np.ascontiguousarray(pts[:, ::N // M][:, :M])
+    q = torch.from_numpy(q_np).to(dev)
+    ra, nsa, rb, nsb = 0.1, 16, 0.5, 32
+    g = ops.Grid(x, rb, 128)
+    ga, gb = ops.ball_query_grid(g, q, ra, nsa, rb, nsb, xyz=x)                 # grid + scan fallback
+    ha, hb = ops.ball_query_grid(g, q, ra, nsa, rb, nsb)                        # grid kernel on every frame
+    assert torch.equal(ga, ha) and torch.equal(gb, hb)
+    for f in range(4):
+        assert np.array_equal(ga[f].cpu().numpy(), cpu.ball_query(ra, nsa, pts[f:f + 1], q_np[f:f + 1])[0]), f
+        assert np.array_equal(gb[f].cpu().numpy(), cpu.ball_query(rb, nsb, pts[f:f + 1], q_np[f:f + 1])[0]), f
+    # the density estimate itself: the cube is flagged, the KITTI-like frame is not
+    fb = ops._cabi.lib().prcnn_grid_bytes(1, N)
+    cand = [float(g.buf[f * fb: f * fb + 32].view(torch.float32)[5].item()) for f in range(4)]
+    assert cand[0] < N / 32 < cand[1] and cand[3] > N / 32, cand
+    one = ops.ball_query_grid(g, q, rb, nsb, xyz=x)                              # single radius through the same path
+    assert torch.equal(one, gb)
+    assert torch.equal(ops.ball_query2(ra, nsa, rb, nsb, x, q)[1], gb)           # what the modules call
