@@ -60,7 +60,7 @@ def parse(argv=None):
     ap.add_argument("--npoints", type=int, default=16384)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto", help="replay the step from a hipGraph")
     ap.add_argument("--streams", type=int, default=None,
-                    help="batches in flight per GPU, default 16 (rpn) / 10 (rcnn) (each on its own HIP stream AND hardware queue, see GPU_MAX_HW_QUEUES "
+                    help="batches in flight per GPU, default 20 (rpn) / 10 (rcnn) (each on its own HIP stream AND hardware queue, see GPU_MAX_HW_QUEUES "
                          "above): step k runs on HIP stream k %% streams, so one batch's FPS "
                          "(1 workgroup per frame = 32 of 256 CUs) overlaps another batch's MLP / neighbour kernels")
     ap.add_argument("--proposals", choices=["off", "normal", "rotate"], default="normal",
@@ -410,6 +410,8 @@ class InferenceBench:
 def instrumented_pass(args, bench, nprof, dump=None):
     """per-op-family GPU time + EXECUTED MLP flops of `nprof` eager steps (HIP events on the launch stream)"""
     from pointrcnn_amd import _cabi, ops as _ops
+    bench.step(0)                           # one unprofiled eager step first (allocator / lazy state after the graph replays)
+    torch.cuda.synchronize()
     prof = EventProfiler(_cabi._lib)
     real = _cabi._lib
     _cabi._lib, _ops._split_log = prof, prof.splits
@@ -534,7 +536,7 @@ def main():
     else:
         model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
     if args.streams is None:      # rcnn: each in-flight batch holds several GB of worst-case-sized RoI-stage buffers
-        args.streams = 16 if args.workload == "rpn" else 10
+        args.streams = 20 if args.workload == "rpn" else 10
     nstreams = max(1, args.streams)
 
     raw = None

@@ -377,6 +377,133 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
     }
 }
 
+// =====================================================================================================
+// N > 16384 (BASELINE config 5: 65 536 points per frame): the frame does not fit one workgroup's registers (1024 threads x
+// 16 points), and re-reading it from L2 every iteration (fps_mem_kernel below) costs ~12 us per sample.  Here a frame is
+// owned by S = ceil(N / 16384) workgroups, each keeping its 16384-point slice and running min-distances in VGPRs exactly
+// as fps_reg_kernel does; per sample the S workgroups exchange their local candidates through L2:
+//   * every workgroup publishes {value, global index, x, y, z} as five naturally aligned 8-byte {data, tag} granules,
+//     each written by ONE device-scope (sc1) store, tag = the sample number -- a granule is either the old or the new
+//     pair, never torn, so no separate flag / release fence is needed (MI355X_MICROARCH.md, hand-off price list);
+//   * wave 0 of every workgroup polls the 5 S granules of its frame (one lane each, L1-bypassing loads) until all carry
+//     the current tag, reduces them (max value, ties -> lowest slice == lowest point index) and broadcasts the winner
+//     through LDS.  Slots are double-buffered by sample parity: a workgroup can run at most one sample ahead of the
+//     slowest one of its frame (it needs that one's NEXT publication to proceed).
+// The launcher clears the slots (hipMemsetAsync, tag 0xFFFFFFFF is never a sample number).  All workgroups of a frame
+// must become resident for the frame to progress; they are consecutive in the grid, so at most the last dispatched frame
+// waits for a CU, and it gets one when any other frame finishes.  The poll is bounded: a workgroup that does not see its
+// partners within ~2^20 polls (about a second) gives up and fills the rest of its output with -1 (a hang would take the GPU down with it).
+// Results are bit-identical to the single-workgroup kernels (same distance arithmetic, same tie rule).
+// =====================================================================================================
+#define FPS_MULTI_SLICE 16384
+#define FPS_MULTI_MAX_SPLIT 12          // 5 * S polling lanes must fit one wave
+#define FPS_MULTI_SPIN_LIMIT (1 << 20)
+
+__global__ __launch_bounds__(1024) void fps_multi_kernel(const float* __restrict__ xyz, int N, int npoint, int S,
+                                                         unsigned long long* __restrict__ slots, int32_t* __restrict__ idx_out) {
+    constexpr int BLOCK = 1024, PPT = 16, NW = BLOCK / 64;
+    typedef typename fvec_t<PPT>::type fvec;
+    __shared__ float slot[2][NW][8];
+    __shared__ float win[2][4];            // idx(bits), x, y, z of the frame-wide winner
+    const int b = blockIdx.x / S, sl = blockIdx.x - b * S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ pf = xyz + (size_t)b * N * 3;
+    const int base = sl * FPS_MULTI_SLICE;
+    const float* __restrict__ p = pf + (size_t)base * 3;
+    const int n_loc = min(FPS_MULTI_SLICE, N - base);
+    int32_t* __restrict__ out = idx_out + (size_t)b * npoint;
+    unsigned long long* __restrict__ fslots = slots + (size_t)b * 2 * S * 5;          // [parity][slice][5]
+
+    fvec px, py, pz, pt;
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        int k = tid * PPT + i;
+        bool ok = k < n_loc;
+        px[i] = ok ? p[k * 3 + 0] : 0.f;
+        py[i] = ok ? p[k * 3 + 1] : 0.f;
+        pz[i] = ok ? p[k * 3 + 2] : 0.f;
+        pt[i] = ok ? 1e10f : -1.0f;
+    }
+    if (sl == 0 && tid == 0 && npoint > 0) out[0] = 0;
+    float x0 = pf[0], y0 = pf[1], z0 = pf[2];
+    bool dead = false;
+
+    for (int j = 1; j < npoint; j++) {
+        float best = -2.0f;
+        const f32x2 qx = {x0, x0}, qy = {y0, y0}, qz = {z0, z0};
+#pragma unroll
+        for (int i = 0; i + 1 < PPT; i += 2) {
+            f32x2 dx = (f32x2){px[i], px[i + 1]} - qx;
+            f32x2 dy = (f32x2){py[i], py[i + 1]} - qy;
+            f32x2 dz = (f32x2){pz[i], pz[i + 1]} - qz;
+            f32x2 d = (dx * dx + dy * dy) + dz * dz;
+            float t0 = __builtin_fminf(pt[i], d.x), t1 = __builtin_fminf(pt[i + 1], d.y);
+            pt[i] = t0; pt[i + 1] = t1;
+            best = __builtin_fmaxf(best, __builtin_fmaxf(t0, t1));
+        }
+        const int wmax = wave_max_i32_fused(__float_as_int(best));
+        const float wmaxf = __int_as_float(wmax);
+        const int owner = __builtin_ctzll(__ballot(best == wmaxf));
+        int istar = PPT - 1;
+#pragma unroll
+        for (int i = PPT - 2; i >= 0; i--)
+            if ((__ballot(pt[i] == wmaxf) >> owner) & 1ULL) istar = i;
+        istar = __builtin_amdgcn_readfirstlane(istar);
+        const int widx = (wave * 64 + owner) * PPT + istar;
+        float sx = px[istar], sy = py[istar], sz = pz[istar];
+        float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), owner));
+        float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), owner));
+        float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), owner));
+        float* s = slot[j & 1][wave];
+        if (lane == 0) { s[0] = wmaxf; s[1] = __int_as_float(widx); s[2] = wx; s[3] = wy; s[4] = wz; }
+        __syncthreads();
+        if (wave == 0) {
+            // workgroup-level candidate (as fps_reg_kernel), then the exchange with the frame's other slices
+            const float* r = slot[j & 1][lane < NW ? lane : 0];
+            int v = lane < NW ? __float_as_int(r[0]) : (int)0x80000000;
+            const int gmax = row0_max_i32_fused(v);
+            const int wwin = __builtin_ctzll(__ballot(v == gmax));
+            const float* rw = slot[j & 1][wwin];
+            unsigned long long* mine = fslots + ((size_t)(j & 1) * S + sl) * 5;
+            if (lane < 5) {
+                unsigned data = lane == 0 ? (unsigned)gmax : lane == 1 ? (unsigned)(base + __float_as_int(rw[1])) : __float_as_uint(rw[lane]);
+                __hip_atomic_store(mine + lane, ((unsigned long long)(unsigned)j << 32) | data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int ng = 5 * S;
+            const unsigned long long* src = fslots + (size_t)(j & 1) * S * 5 + (lane < ng ? lane : 0);
+            unsigned long long g = 0;
+            int spins = 0;
+            while (!dead) {
+                g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = lane >= ng || (unsigned)(g >> 32) == (unsigned)j;
+                if (__all(ok)) break;
+                if (++spins > FPS_MULTI_SPIN_LIMIT) dead = true;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            // lane 5 t holds slice t's value: frame-wide max, ties -> lowest slice (= lowest point index)
+            const int val = (lane < ng && lane % 5 == 0) ? (int)(unsigned)g : (int)0x80000000;
+            const int fmax = wave_max_i32(val);
+            const int wl = __builtin_ctzll(__ballot(val == fmax));                // lane 5 * winning slice
+            const unsigned lo = (unsigned)g;
+            if (lane == 0) {
+                win[j & 1][0] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)lo, wl + 1));
+                win[j & 1][1] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)lo, wl + 2));
+                win[j & 1][2] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)lo, wl + 3));
+                win[j & 1][3] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)lo, wl + 4));
+                if (dead) win[j & 1][0] = __int_as_float(-1);
+            }
+        }
+        __syncthreads();
+        const int gidx = __float_as_int(win[j & 1][0]);
+        x0 = win[j & 1][1]; y0 = win[j & 1][2]; z0 = win[j & 1][3];
+        if (gidx < 0) {                              // a partner never showed up: give up loudly (-1 indices), do not hang
+            for (int k = j + tid; k < npoint; k += BLOCK) if (sl == 0) out[k] = -1;
+            return;
+        }
+        if (sl == 0 && tid == 0) out[j] = gidx;
+    }
+}
+
 // HBM/L2-resident fallback for N > 16384: points and temp are re-read every iteration.
 __global__ __launch_bounds__(1024) void fps_mem_kernel(const float* __restrict__ xyz, int N, int npoint,
                                                        float* __restrict__ tmp, int32_t* __restrict__ idx_out) {
@@ -453,7 +580,17 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
     else if (N <= 16384) launch_fps<1024, 16>(xyz, B, N, npoint, idx, s);
     else {
         PRCNN_REQUIRE(tmp, "prcnn_fps: N=%d > 16384 needs the (B,N) tmp buffer", N);
-        hipLaunchKernelGGL(fps_mem_kernel, dim3(B), dim3(1024), 0, s, xyz, N, npoint, tmp, idx);
+        const int S = prcnn_divup(N, FPS_MULTI_SLICE);
+        // multi-workgroup register-resident kernel: the exchange slots (B * 2 * S * 5 granules of 8 bytes) live at the start
+        // of tmp, which is 4 N bytes per frame >= 80 S bytes.  Needs every slice of a frame resident at once: up to 256 CUs.
+        static const bool use_mem = getenv("PRCNN_FPS_MEM") != nullptr;       // A/B switch: the L2 re-read kernel (same bits)
+        if (!use_mem && S <= FPS_MULTI_MAX_SPLIT && ((uintptr_t)tmp & 7) == 0) {
+            const size_t slot_bytes = (size_t)B * 2 * S * 5 * sizeof(unsigned long long);
+            if (hipMemsetAsync(tmp, 0xFF, slot_bytes, s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot clear the exchange slots");
+            hipLaunchKernelGGL(fps_multi_kernel, dim3(B * S), dim3(1024), 0, s, xyz, N, npoint, S, reinterpret_cast<unsigned long long*>(tmp), idx);
+        } else {
+            hipLaunchKernelGGL(fps_mem_kernel, dim3(B), dim3(1024), 0, s, xyz, N, npoint, tmp, idx);
+        }
     }
     PRCNN_LAUNCH_CHECK("prcnn_fps");
     return PRCNN_OK;

@@ -221,6 +221,20 @@ def test_config5_point_ops_at_65536_points(dev, cpu):
     assert np.array_equal(w3.cpu().numpy(), cpu.three_weights(rd2))
 
 
+def test_fps_multi_workgroup_kernel_ties_and_ragged_sizes(dev, cpu):
+    """N > 16384: a frame is split over ceil(N / 16384) workgroups that exchange candidates through L2 every sample; the tie
+    rule (lowest point index) has to hold ACROSS the slices, for slice counts 2..4, ragged last slices and several frames"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(5)
+    lat = np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(32), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)   # 32768 pts, ties everywhere
+    rag = r.random((3, 40000, 3), dtype=np.float32) * np.array([80, 4, 70], np.float32)
+    dup = np.concatenate([rag[:1, :20000], rag[:1, :20000]], 1)                   # the second slice-and-a-half repeats the first
+    for pts, npoint in ((lat, 700), (rag, 1500), (dup, 900), (r.random((2, 16385, 3), dtype=np.float32), 300)):
+        got = ops.furthest_point_sample(T(pts, dev), npoint).cpu().numpy()
+        assert (got >= 0).all(), "a workgroup gave up waiting for its partners"
+        assert np.array_equal(got, cpu.fps(pts, npoint))
+
+
 def test_config5_rpn_graph_runs_at_65536_points(dev, cpu):
     """the whole RPN graph on one 65 536-point frame (fused path) vs the oracle graph"""
     from oracle import rpn_cpu

@@ -1,15 +1,20 @@
 #!/bin/bash
-# copy the summaries produced by tools/refresh_profiles.sh (gpurun_out/refresh) into profiles/
+# copy the summaries produced by tools/refresh_profiles.sh (gpurun_out/refresh) into profiles/ (round tag = $1, default r02)
 set -e
 R=gpurun_out/refresh
-cp $R/bench_default.json profiles/r01_final_bench.json
-cp $R/bench_streams1.json profiles/r01_final_bench_streams1.json
-cp $R/bench_lidar.json profiles/r01_final_bench_lidar.json
-cp $R/bench_raw_input.json profiles/r01_final_bench_raw_input.json
-cp $R/bench_rcnn.json profiles/r01_final_bench_rcnn.json
-cp $R/kernel_stats.txt profiles/r01_final_kernel_stats.txt
-cp $R/kernel_stats_streams1.txt profiles/r01_final_kernel_stats_streams1.txt
-cp $R/hbm_traffic.json profiles/r01_hbm_traffic.json
-cp $R/mfma_util.txt profiles/r01_mfma_util.txt
-cp $R/opbench.jsonl profiles/r01_opbench.jsonl
+T=${1:-r02}
+cp $R/bench_default.json profiles/${T}_final_bench.json
+cp $R/bench_driver_flags.json profiles/${T}_final_bench_steps20.json
+cp $R/bench_streams1.json profiles/${T}_final_bench_streams1.json
+cp $R/bench_lidar.json profiles/${T}_final_bench_lidar.json
+cp $R/bench_raw_input.json profiles/${T}_final_bench_raw_input.json
+cp $R/bench_rcnn.json profiles/${T}_final_bench_rcnn.json
+cp $R/bench_train.json profiles/${T}_final_bench_train.json
+cp $R/bench_config5_rpn.json profiles/${T}_final_bench_config5_rpn.json
+cp $R/kernel_stats.txt profiles/${T}_final_kernel_stats.txt
+cp $R/kernel_stats_streams1.txt profiles/${T}_final_kernel_stats_streams1.txt
+cp $R/kernel_stats_train.txt profiles/${T}_final_kernel_stats_train.txt
+cp $R/hbm_traffic.json profiles/${T}_hbm_traffic.json
+cp $R/mfma_util.txt profiles/${T}_mfma_util.txt
+cp $R/opbench.jsonl profiles/${T}_opbench.jsonl
 ls -la profiles
