@@ -115,8 +115,12 @@ int prcnn_three_nn(const float* unknown, const float* known, int B, int n, int m
 /* three_interpolate_wrapper(B,C,m,n,feat,idx,weight,out): out[b,c,i] = (w0*f[i0] + w1*f[i1]) + w2*f[i2] */
 int prcnn_three_interp(const float* feat, const int32_t* idx, const float* weight, int B, int C, int m, int n,
                        float* out, prcnn_stream_t stream);
+/* three_interpolate_grad_wrapper: grad_feat (B,C,m) += scatter(grad_out (B,C,n) * weight); grad_feat pre-zeroed by the caller.
+ * workspace: (B*m*C) floats of scratch or NULL.  With a workspace the scatter runs through a channels-last accumulator (the 64
+ * lanes of a wave add to 64 consecutive channels of one known point: one or two cache lines per atomic instruction instead of
+ * 64) and is transposed into grad_feat afterwards; NULL selects the direct kernel. */
 int prcnn_three_interp_grad(const float* grad_out, const int32_t* idx, const float* weight, int B, int C, int n,
-                            int m, float* grad_feat, prcnn_stream_t stream);
+                            int m, float* grad_feat, float* workspace, prcnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused per-point MLP layers (new; replaces the SharedMLP = Conv2d1x1+BN+ReLU (+max_pool2d) chain

@@ -35,7 +35,7 @@ SIGNATURES = {
     "prcnn_group_grad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "prcnn_three_nn": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "prcnn_three_interp": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
-    "prcnn_three_interp_grad": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "prcnn_three_interp_grad": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "prcnn_wpack_floats": (_Z, [_I, _I]),
     "prcnn_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
     "prcnn_mlp_rows": (_I, [_P, _I, _L, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P]),

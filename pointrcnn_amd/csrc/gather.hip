@@ -79,6 +79,112 @@ __global__ __launch_bounds__(G_THREADS) void three_interp_grad_kernel(const floa
     }
 }
 
+// ---- backward of grouping_operation, padding-aware ----------------------------------------------------------------
+// ball_query pads a group with copies of its first hit, so most of a group's nsample gradient entries scatter to the SAME
+// source point: the one-atomic-per-entry kernel above serialises them (16-32 lanes of a wave on one address; it was 20 % of
+// the RPN training step).  Here a lane owns one group: the entries that map to the group's first index are summed in
+// registers (one atomic for all of them), the remaining distinct hits get one atomic each.  Correct for ANY index tensor
+// (entries are classified by comparing with the group's first index, not by assuming the padding pattern).
+template <int NS>
+__global__ __launch_bounds__(G_THREADS) void group_grad_kernel(const float* __restrict__ grad_out, const int32_t* __restrict__ idx,
+                                                               int C, int N, int M, float* __restrict__ grad_feat) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + lane;
+    const bool live = m < M;
+    int id[NS];
+    const int32_t* ip = idx + ((size_t)b * M + (live ? m : 0)) * NS;
+#pragma unroll
+    for (int q = 0; q < NS / 4; q++) {
+        const int4 v = *reinterpret_cast<const int4*>(ip + 4 * q);
+        id[4 * q] = v.x; id[4 * q + 1] = v.y; id[4 * q + 2] = v.z; id[4 * q + 3] = v.w;
+    }
+    unsigned long long other = 0;                    // bit s: entry s does NOT map to the group's first index
+#pragma unroll
+    for (int s = 1; s < NS; s++) other |= (unsigned long long)(id[s] != id[0]) << s;
+    if (!live) other = 0;
+    // wave-uniform bound of the positions that need their own atomic (ball query: the real hits are a short prefix)
+    const unsigned long long any = __ballot(other != 0) ? 1 : 0;
+    int last = 0;
+    if (any) {
+        int mine = other ? 64 - __builtin_clzll(other) : 0;
+        last = wave_max_i32(mine);
+    }
+    float* gf = grad_feat + (size_t)b * C * N;
+    for (int c = wave; c < C; c += G_THREADS / 64) {
+        const float* g = grad_out + (((size_t)b * C + c) * M + (live ? m : 0)) * NS;
+        float v[NS];
+#pragma unroll
+        for (int q = 0; q < NS / 4; q++) {
+            const float4 t = *reinterpret_cast<const float4*>(g + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        float first = v[0];
+#pragma unroll
+        for (int s = 1; s < NS; s++) first += ((other >> s) & 1ULL) ? 0.f : v[s];
+        if (live) atomicAdd(gf + (size_t)c * N + id[0], first);
+#pragma unroll
+        for (int s = 1; s < NS; s++) {
+            if (s >= last) break;                    // wave-uniform
+            if ((other >> s) & 1ULL) atomicAdd(gf + (size_t)c * N + id[s], v[s]);
+        }
+    }
+}
+
+// ---- backward of three_interpolate through a channels-last accumulator --------------------------------------------
+// grad_feat[b, c, idx[b,i,k]] += grad_out[b, c, i] * w[b,i,k].  In the (B,C,m) layout of the op surface the 64 lanes of a wave
+// (64 unknown points) hit 64 unrelated cache lines per atomic instruction -- 18 % of the RPN training step.  With the
+// accumulator channels-last, (B,m,C), the lanes are 64 consecutive CHANNELS of one known point: one or two cache lines per
+// instruction.  grad_out tiles (64 channels x 64 points) are transposed through LDS on the way in, a second kernel
+// transposes the accumulator back into the caller's (B,C,m) tensor.
+__global__ __launch_bounds__(G_THREADS) void three_interp_grad_cl_kernel(const float* __restrict__ grad_out, const int32_t* __restrict__ idx,
+                                                                         const float* __restrict__ w, int C, int n, int m,
+                                                                         float* __restrict__ acc_cl) {
+    __shared__ float tile[64][65];
+    __shared__ int sid[64][3];
+    __shared__ float sw[64][3];
+    const int b = blockIdx.y, i0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 192) {
+        const int i = threadIdx.x / 3, k = threadIdx.x - i * 3;
+        const bool ok = i0 + i < n;
+        sid[i][k] = ok ? idx[((size_t)b * n + i0 + i) * 3 + k] : 0;
+        sw[i][k] = ok ? w[((size_t)b * n + i0 + i) * 3 + k] : 0.f;
+    }
+    float* acc = acc_cl + (size_t)b * m * C;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        __syncthreads();
+        // coalesced over the points (lanes), 16 channels per wave
+        for (int cc = wave; cc < 64; cc += 4) {
+            const int c = c0 + cc;
+            tile[cc][lane] = (c < C && i0 + lane < n) ? grad_out[((size_t)b * C + c) * n + i0 + lane] : 0.f;
+        }
+        __syncthreads();
+        const int c = c0 + lane;
+        if (c < C) {
+            for (int ii = wave; ii < 64; ii += 4) {
+                if (i0 + ii >= n) break;
+                const float gv = tile[lane][ii];
+                atomicAdd(acc + (size_t)sid[ii][0] * C + c, gv * sw[ii][0]);
+                atomicAdd(acc + (size_t)sid[ii][1] * C + c, gv * sw[ii][1]);
+                atomicAdd(acc + (size_t)sid[ii][2] * C + c, gv * sw[ii][2]);
+            }
+        }
+    }
+}
+
+// (B, m, C) -> += into (B, C, m), 64 x 64 tiles through LDS
+__global__ __launch_bounds__(G_THREADS) void transpose_add_kernel(const float* __restrict__ in_cl, int C, int m, float* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int kk = wave; kk < 64; kk += 4)
+        tile[kk][lane] = (k0 + kk < m && c0 + lane < C) ? in_cl[((size_t)b * m + k0 + kk) * C + c0 + lane] : 0.f;
+    __syncthreads();
+    for (int cc = wave; cc < 64; cc += 4)
+        if (c0 + cc < C && k0 + lane < m) out[((size_t)b * C + c0 + cc) * m + k0 + lane] += tile[lane][cc];
+}
+
 __global__ __launch_bounds__(G_THREADS) void gather_rows_kernel(const float* __restrict__ in, int ld_in,
                                                                 const int32_t* __restrict__ idx, int N, int M, int C,
                                                                 float* __restrict__ out) {
@@ -136,8 +242,16 @@ PRCNN_API int prcnn_group_grad(const float* grad_out, const int32_t* idx, int B,
     int rc = check_bcn("prcnn_group_grad", grad_out, idx, grad_feat, B, C, N, J);
     if (rc) return rc;
     if (B == 0 || C == 0 || J == 0) return PRCNN_OK;
-    hipLaunchKernelGGL(gather_grad_kernel, dim3(prcnn_divup(J, G_THREADS), B), dim3(G_THREADS), 0, (hipStream_t)stream,
-                       grad_out, idx, C, N, (int)J, grad_feat);
+    const bool vec = ((uintptr_t)grad_out & 15) == 0 && ((uintptr_t)idx & 15) == 0;
+    if (vec && (nsample == 16 || nsample == 32 || nsample == 64)) {          // padding-aware kernel (one lane per group)
+        dim3 grid(prcnn_divup(M, 64), B);
+        if (nsample == 16) hipLaunchKernelGGL(group_grad_kernel<16>, grid, dim3(G_THREADS), 0, (hipStream_t)stream, grad_out, idx, C, N, M, grad_feat);
+        else if (nsample == 32) hipLaunchKernelGGL(group_grad_kernel<32>, grid, dim3(G_THREADS), 0, (hipStream_t)stream, grad_out, idx, C, N, M, grad_feat);
+        else hipLaunchKernelGGL(group_grad_kernel<64>, grid, dim3(G_THREADS), 0, (hipStream_t)stream, grad_out, idx, C, N, M, grad_feat);
+    } else {
+        hipLaunchKernelGGL(gather_grad_kernel, dim3(prcnn_divup(J, G_THREADS), B), dim3(G_THREADS), 0, (hipStream_t)stream,
+                           grad_out, idx, C, N, (int)J, grad_feat);
+    }
     PRCNN_LAUNCH_CHECK("prcnn_group_grad");
     return PRCNN_OK;
 }
@@ -154,10 +268,19 @@ PRCNN_API int prcnn_three_interp(const float* feat, const int32_t* idx, const fl
 }
 
 PRCNN_API int prcnn_three_interp_grad(const float* grad_out, const int32_t* idx, const float* weight, int B, int C,
-                                      int n, int m, float* grad_feat, prcnn_stream_t stream) {
+                                      int n, int m, float* grad_feat, float* workspace, prcnn_stream_t stream) {
     PRCNN_REQUIRE(B >= 0 && C >= 0 && m > 0 && n >= 0, "prcnn_three_interp_grad: bad shape");
     if (B == 0 || C == 0 || n == 0) return PRCNN_OK;
     PRCNN_REQUIRE(grad_out && idx && weight && grad_feat, "prcnn_three_interp_grad: null pointer");
+    if (workspace) {            // channels-last accumulator (B, m, C), zeroed here, transposed into grad_feat afterwards
+        hipStream_t s = (hipStream_t)stream;
+        if (hipMemsetAsync(workspace, 0, (size_t)B * m * C * sizeof(float), s) != hipSuccess)
+            return prcnn_fail(PRCNN_EHIP, "prcnn_three_interp_grad: cannot clear the workspace");
+        hipLaunchKernelGGL(three_interp_grad_cl_kernel, dim3(prcnn_divup(n, 64), B), dim3(G_THREADS), 0, s, grad_out, idx, weight, C, n, m, workspace);
+        hipLaunchKernelGGL(transpose_add_kernel, dim3(prcnn_divup(m, 64), prcnn_divup(C, 64), B), dim3(G_THREADS), 0, s, workspace, C, m, grad_feat);
+        PRCNN_LAUNCH_CHECK("prcnn_three_interp_grad");
+        return PRCNN_OK;
+    }
     hipLaunchKernelGGL(three_interp_grad_kernel, dim3(prcnn_divup(n, G_THREADS), B), dim3(G_THREADS), 0,
                        (hipStream_t)stream, grad_out, idx, weight, C, n, m, grad_feat);
     PRCNN_LAUNCH_CHECK("prcnn_three_interp_grad");

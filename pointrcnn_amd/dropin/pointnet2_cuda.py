@@ -66,5 +66,5 @@ def three_interpolate_wrapper(B, C, m, n, features, idx, weight, out):
 def three_interpolate_grad_wrapper(B, C, n, m, grad_out, idx, weight, grad_features):
     _chk(grad_out, "grad_out"); _chk(idx, "idx", _I32); _chk(weight, "weight"); _chk(grad_features, "grad_features")
     _cabi.check(_cabi.lib().prcnn_three_interp_grad(_p(grad_out), _p(idx), _p(weight), B, C, n, m, _p(grad_features),
-                                                    _stream()), "prcnn_three_interp_grad")
+                                                    None, _stream()), "prcnn_three_interp_grad")     # no scratch in this API shape: direct kernel
     return 1

@@ -206,7 +206,8 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     _chk(grad_out, "grad_out", ndim=3); _chk(idx, "idx", _INT, 3); _chk(weight, "weight", ndim=3)
     B, C, n = grad_out.shape
     g = torch.zeros((B, C, m), dtype=_F32, device=grad_out.device)
-    _cabi.check(_cabi.lib().prcnn_three_interp_grad(_p(grad_out), _p(idx), _p(weight), B, C, n, m, _p(g), _stream()),
+    ws = torch.empty((B, m, C), dtype=_F32, device=grad_out.device)        # channels-last accumulator (see the header)
+    _cabi.check(_cabi.lib().prcnn_three_interp_grad(_p(grad_out), _p(idx), _p(weight), B, C, n, m, _p(g), _p(ws), _stream()),
                 "prcnn_three_interp_grad")
     return g
 

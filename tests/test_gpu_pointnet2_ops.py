@@ -195,3 +195,30 @@ def test_fps_pruned_and_plain_variants_are_bit_identical(dev, cpu, B, N, npoint,
             assert np.array_equal(got, cpu.fps(xyz, npoint))
     finally:
         ops.FPS_PRUNED = old
+
+
+def test_backward_kernels_at_training_shapes(dev, cpu):
+    """group_grad: the padding-aware kernel (nsample 16 / 32 / 64, one lane per group) on real ball-query index tensors (first
+    hit repeated), on arbitrary indices and on ragged M / C; three_interpolate_grad: the channels-last accumulator path
+    (n, m, C not multiples of 64).  Scatter-adds in another order: 1e-5 of the result's scale."""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(9)
+    B, N = 2, 3000
+    xyz = r.random((B, N, 3), dtype=np.float32) * np.array([8, 2, 8], np.float32)
+    for ns, M, C, radius in ((16, 333, 37, 0.25), (32, 256, 96, 0.4), (64, 130, 5, 0.6)):
+        new_xyz = np.ascontiguousarray(xyz[:, :M])
+        bq = cpu.ball_query(radius, ns, xyz, new_xyz)                       # padded with the first hit
+        rnd = r.integers(0, N, (B, M, ns)).astype(np.int32)                 # arbitrary indices: no padding structure at all
+        same = np.repeat(r.integers(0, N, (B, M, 1)).astype(np.int32), ns, 2)     # every entry the same point
+        for gidx in (bq, rnd, same):
+            ggo = r.normal(size=(B, C, M, ns)).astype(np.float32)
+            want = cpu.group_grad(ggo, gidx, N)
+            got = ops.group_grad(T(ggo, dev), T(gidx, dev), N).cpu().numpy()
+            assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    for n, m, C in ((1000, 257, 70), (4096, 1024, 128), (65, 64, 3)):
+        i3 = r.integers(0, m, (B, n, 3)).astype(np.int32)
+        w3 = r.random((B, n, 3)).astype(np.float32)
+        go = r.normal(size=(B, C, n)).astype(np.float32)
+        want = cpu.three_interp_grad(go, i3, w3, m)
+        got = ops.three_interpolate_grad(T(go, dev), T(i3, dev), T(w3, dev), m).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
