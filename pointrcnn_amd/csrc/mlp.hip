@@ -1675,6 +1675,174 @@ static bool chain_fast_ok(int mode, const ChainParams& C, int n0, int n1, int n2
 
 static int nb32(int n) { return (n + 31) / 32; }
 
+// =====================================================================================================
+// Two-layer STACK for short row lists (round 2): the wide SA levels (SA3 / SA4: 128 -> 196 -> 256, 256 -> 256|384 -> 512) run
+// on padding-free flat lists of only a few thousand rows, where the layer kernel's 128-row tiles leave most CUs idle and every
+// launch is a chain of exposed latencies (two launches of 20-45 us per scale for < 1.3 GFLOP).  Here a workgroup owns
+// 32 rows and carries them through BOTH layers: the activated-gather rows are built once into LDS, the four waves split each
+// layer's output columns (32-column blocks), layer A's result goes bias + ReLU into a second LDS tile and is layer B's A
+// operand; the weights stream from L2 straight into the MFMA B registers (4-slot ring, as mlp_layer_b_kernel).  With few
+// row tiles the layer-B column blocks are additionally split over gridDim.y workgroups (each recomputes the cheap layer A),
+// so that ~256 workgroups exist whatever the list length.
+// Arithmetic per output element is the layer kernels': k ascending in the same MFMA steps, bias then ReLU -- bit-identical.
+// =====================================================================================================
+#define ST_ROWS 32
+#define ST_MAX_K0 256
+#define ST_MAX_NB0 12
+template <int NBW0, int NBW1>
+__global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Cin) {
+    MlpParams P = Cin.a;
+    P.rows = effective_rows(Cin.a);
+    const long row0 = (long)blockIdx.x * ST_ROWS;
+    if (row0 >= P.rows) return;
+    extern __shared__ __attribute__((aligned(16))) float st_lds[];
+    const int lda = P.K + 4;                               // row strides (floats): +4 keeps the ds_read_b128 of 16 rows conflict-free
+    const int n0pad = P.NB * 32, ldb = n0pad + 4;
+    float* actA = st_lds;                                  // [32][K0 + 4]
+    float* actB = st_lds + ST_ROWS * lda;                  // [32][NB0 * 32 + 4]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+
+    // ---- activated-gather rows -> actA: thread = (row tid / 8, 16-byte column piece tid % 8 of every 32-channel chunk)
+    {
+        const int r = tid >> 3, c4 = tid & 7;
+        long grow = row0 + r;
+        if (grow >= P.rows) grow = P.rows - 1;             // clamped: never stored
+        RowMeta<MODE_GROUP> meta;
+        make_meta<MODE_GROUP>(P, grow, meta);
+        const float dx = meta.dx, dy = meta.dy, dz = meta.dz;
+        // all of the row's gathered pieces first (independent L2 / HBM round trips in flight together), then the arithmetic
+        float4 zr[ST_MAX_K0 / 32];
+#pragma unroll
+        for (int u = 0; u < ST_MAX_K0 / 32; u++) {
+            const int k = c4 * 4 + 32 * u;
+            zr[u] = (k < P.K && !(PRCNN_ABL & 16)) ? ld4(P.feat + meta.off + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < ST_MAX_K0 / 32; u++) {
+            const int k = c4 * 4 + 32 * u;
+            if (k >= P.K) break;
+            const float4 z = zr[u];
+            const float4 aw0 = ld4(P.act_wx + (long)k * 3), aw1 = ld4(P.act_wx + (long)k * 3 + 4), aw2 = ld4(P.act_wx + (long)k * 3 + 8);
+            const float4 ab = ld4(P.act_bias + k);
+            float4 v;                                       // == the layer kernels' activated gather, same expression
+            v.x = fmaxf(z.x + (aw0.x * dx + aw0.y * dy + aw0.z * dz) + ab.x, 0.f);
+            v.y = fmaxf(z.y + (aw0.w * dx + aw1.x * dy + aw1.y * dz) + ab.y, 0.f);
+            v.z = fmaxf(z.z + (aw1.z * dx + aw1.w * dy + aw2.x * dz) + ab.z, 0.f);
+            v.w = fmaxf(z.w + (aw2.y * dx + aw2.z * dy + aw2.w * dz) + ab.w, 0.f);
+            *reinterpret_cast<float4*>(actA + r * lda + k) = v;
+        }
+    }
+
+    // one layer: this wave's NBW column blocks (nbs[q] < NBtot) over KB k-blocks of the A tile `act` (stride ld)
+    auto run_layer = [&](auto& acc, const int (&nbs)[4], int nbw, int NBtot, const float* wpack, int KB, const float* act, int ld) {
+        const float* bptr[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) bptr[q] = wpack + ((long)min(nbs[q], NBtot - 1) * KB) * 256 + lane * 4;
+        float4 bq[4][4];
+        auto load_b = [&](int g, int slot) {
+            const long off = (long)min(g, KB - 1) * 256;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (q < nbw) bq[slot][q] = ld4(bptr[q] + off);
+        };
+#pragma unroll
+        for (int g = 0; g < 4; g++) load_b(g, g);
+        const float* a_base = act + j * ld + 4 * h;
+        float4 a_next = *reinterpret_cast<const float4*>(a_base);
+        for (int kb0 = 0; kb0 < KB; kb0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int kb = kb0 + u;
+                if (kb < KB) {
+                    // one wave per SIMD here: the next k-block's A operand is requested before this one's MFMAs, or its LDS
+                    // latency would show between every 8-16 MFMAs (the tile has spare columns: the read past KB is harmless)
+                    const float4 a = a_next;
+                    a_next = *reinterpret_cast<const float4*>(a_base + min(kb + 1, KB - 1) * 8);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (q < nbw) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[u][q].x, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (q < nbw) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[u][q].y, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (q < nbw) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[u][q].z, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (q < nbw) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[u][q].w, acc[q], 0, 0, 0);
+                }
+                if (!(PRCNN_ABL & 128)) load_b(kb + 4, u);
+            }
+        }
+    };
+
+    __syncthreads();
+    // ---- layer A: column blocks wave, wave + 4, ... of N0
+    {
+        f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = (f32x16){0};
+        int nbs[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) nbs[q] = wave + 4 * q;
+        run_layer(acc, nbs, NBW0, P.NB, P.wpack, (PRCNN_ABL & 32) ? 1 : P.KB, actA, lda);
+#pragma unroll
+        for (int q = 0; q < NBW0; q++) {
+            const int nb = nbs[q];
+            if (nb >= P.NB) continue;                       // (wave-uniform)
+            const int n = nb * 32 + j;
+            const float bias = (P.bias && n < P.Nout) ? P.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc[q][r] + bias;
+                if (P.relu) v = fmaxf(v, 0.f);
+                actB[rin * ldb + n] = n < P.Nout ? v : 0.f;  // columns past N0 are exact zeros (layer B's K padding)
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer B: this workgroup's slice of the N1 column blocks (gridDim.y slices), split over the waves
+    {
+        f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = (f32x16){0};
+        const int NB1 = (Cin.N1 + 31) / 32;
+        int nbs[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) nbs[q] = blockIdx.y * (4 * NBW1) + wave + 4 * q;
+        run_layer(acc, nbs, NBW1, NB1, Cin.wpack1, (PRCNN_ABL & 64) ? 1 : Cin.KB1, actB, ldb);
+#pragma unroll
+        for (int q = 0; q < NBW1; q++) {
+            const int nb = nbs[q];
+            if (nb >= NB1) continue;
+            const int n = nb * 32 + j;
+            const bool n_ok = n < Cin.N1;
+            const float bias = (Cin.bias1 && n_ok) ? Cin.bias1[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const long g = row0 + rin;
+                float v = acc[q][r] + bias;
+                if (Cin.relu1) v = fmaxf(v, 0.f);
+                if (n_ok && g < P.rows) P.out[g * P.ld_out + P.col_off + n] = v;
+            }
+        }
+    }
+}
+
+// shapes the stack kernel takes (hoisted grouped form on flat row lists, no pooling)
+static bool stack2_ok(int mode, const ChainParams& C) {
+    const MlpParams& P = C.a;
+    return mode == MODE_GROUP && C.nlayers == 2 && P.act == 1 && P.pool_ns == 0 && P.ns == 1 && P.C == P.K && P.K % 8 == 0 &&
+           P.K <= ST_MAX_K0 && P.vec_a && (P.Nout > 128 || C.N1 > 128) && nb32(P.Nout) <= ST_MAX_NB0 && nb32(C.N1) <= 16;
+}
+
+template <int NBW0, int NBW1>
+static void launch_stack2(const ChainParams& C, int cs, hipStream_t s) {
+    const size_t lds = (size_t)ST_ROWS * ((C.a.K + 4) + (nb32(C.a.Nout) * 32 + 4)) * sizeof(float);
+    hipLaunchKernelGGL((mlp_stack2_kernel<NBW0, NBW1>), dim3(prcnn_divup(C.a.rows, ST_ROWS), cs), dim3(256), lds, s, C);
+}
+
+
 static bool chain_instance_exists(int mode, int n0, int n1, int n2) {
     struct { int m, a, b, c; } T[] = {{MODE_GROUP, 1, 1, 1}, {MODE_GROUP, 1, 1, 2}, {MODE_GROUP, 2, 2, 4}, {MODE_GROUP, 2, 3, 4},
                                       {MODE_GROUP, 2, 4, 0}, {MODE_GROUP, 3, 4, 0},          // hoisted SA2 stacks
@@ -1688,6 +1856,10 @@ static bool chain_instance_exists(int mode, int n0, int n1, int n2) {
 PRCNN_API int prcnn_mlp_chain_supported(int mode, int nlayers, const int* nout, int pool_ns) {
     if (!nout || nlayers < 1 || nlayers > 3) return 0;
     if (!(pool_ns == 0 || pool_ns == 16 || pool_ns == 32)) return 0;
+    // two wide layers on an un-pooled grouped list: the stack kernel (hoisted form, nsample 1 -- checked again at dispatch)
+    if (mode == MODE_GROUP && nlayers == 2 && pool_ns == 0 && nout[0] > 0 && nout[1] > 0 && (nout[0] > 128 || nout[1] > 128) &&
+        nb32(nout[0]) <= ST_MAX_NB0 && nb32(nout[1]) <= 16 && getenv("PRCNN_NO_STACK") == nullptr)
+        return 1;
     for (int l = 0; l < nlayers; l++)
         if (nout[l] <= 0 || nout[l] > 128) return 0;
     return chain_instance_exists(mode, nb32(nout[0]), nlayers > 1 ? nb32(nout[1]) : 0, nlayers > 2 ? nb32(nout[2]) : 0) ? 1 : 0;
@@ -1702,6 +1874,25 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
     if (C.nlayers > 1) C.KB1 = (P.Nout + 7) / 8;
     if (C.nlayers > 2) C.KB2 = (C.N1 + 7) / 8;
     if (P.rows == 0) return PRCNN_OK;
+    if (stack2_ok(mode, C)) {
+        // layer-B column blocks per workgroup: all of them when the list is long enough to fill the chip with row tiles,
+        // four (one per wave) otherwise -- the column slices then go to gridDim.y workgroups
+        const int tiles = prcnn_divup(P.rows, ST_ROWS), nbw0 = prcnn_divup(n0, 4);
+        const int nbw1 = tiles >= 256 ? prcnn_divup(n1, 4) : 1, cs = prcnn_divup(n1, 4 * nbw1);
+        static PrcnnLdsLimit attr[3][4];
+#define STACK_CASE(A, B)                                                                                                 \
+        if (nbw0 == A && nbw1 == B) {                                                                                    \
+            if (!attr[A - 1][B - 1].raise((const void*)mlp_stack2_kernel<A, B>, 96 * 1024))                              \
+                return prcnn_fail(PRCNN_EHIP, "prcnn_mlp_chain(stack): cannot raise the dynamic LDS limit");             \
+            launch_stack2<A, B>(C, cs, s);                                                                               \
+            PRCNN_LAUNCH_CHECK("prcnn_mlp_chain(stack)");                                                                \
+            return PRCNN_OK;                                                                                             \
+        }
+        STACK_CASE(1, 1) STACK_CASE(1, 2) STACK_CASE(1, 3) STACK_CASE(1, 4)
+        STACK_CASE(2, 1) STACK_CASE(2, 2) STACK_CASE(2, 3) STACK_CASE(2, 4)
+        STACK_CASE(3, 1) STACK_CASE(3, 2) STACK_CASE(3, 3) STACK_CASE(3, 4)
+#undef STACK_CASE
+    }
     // SA level 0: xyz-only rows, three narrow layers, pooled -- persistent register-weight kernel
     if (mode == MODE_GROUP && P.C == 0 && !P.act && P.K == 3 && C.nlayers == 3 && P.new_xyz && P.pool_ns == P.ns && C.N2 % 4 == 0 &&
         getenv("PRCNN_NO_SA0") == nullptr) {              // (A/B switch; the generic chain kernel gives the same bits)
@@ -1773,7 +1964,7 @@ static int fill_chain(ChainParams& C, int nlayers, const float* const* wpack, co
     for (int l = 0; l < nlayers; l++) {
         PRCNN_REQUIRE(wpack[l] && aligned16(wpack[l]), "prcnn_mlp_chain: layer %d wpack null/unaligned", l);
         PRCNN_REQUIRE(bias[l] == nullptr || aligned16(bias[l]), "prcnn_mlp_chain: layer %d bias must be 16-byte aligned and padded to a multiple of 32", l);
-        PRCNN_REQUIRE(nout[l] > 0 && nout[l] <= 128, "prcnn_mlp_chain: layer %d width %d (1..128)", l, nout[l]);
+        PRCNN_REQUIRE(nout[l] > 0 && nout[l] <= 512, "prcnn_mlp_chain: layer %d width %d (1..512)", l, nout[l]);
     }
     PRCNN_REQUIRE(pool_ns == 0 || pool_ns == 16 || pool_ns == 32, "prcnn_mlp_chain: pool_ns=%d (0/16/32)", pool_ns);
     PRCNN_REQUIRE(ld_out >= col_off + nout[nlayers - 1], "prcnn_mlp_chain: ld_out too small");

@@ -55,7 +55,10 @@ def _run_scale(xyz, ctr, idx, src, layers, act, out, ns, pool, groups_dev):
     """One grouping scale: gather + SharedMLP (+ max-pool over the nsample rows when `pool`), the register-resident chain
     kernel where an instance exists, LDS-tiled layer kernels otherwise.  groups_dev: device-side group count (dedup)."""
     pool_ns = ns if pool else 0
-    if (ns == 1 or (pool and ns in (16, 32))) and ops.chain_supported(1, layers, pool_ns):
+    # layers wider than 128 channels: only the two-layer stack kernel takes them (hoisted form on a flat, un-pooled row list)
+    wide = any(l.nout > 128 for l in layers)
+    if (ns == 1 or (pool and ns in (16, 32))) and (not wide or (act is not None and ns == 1 and src is not None)) \
+            and ops.chain_supported(1, layers, pool_ns):
         return ops.mlp_chain_group(xyz, ctr, idx, src, layers, out=out, pool_ns=pool_ns, act=act, groups_dev=groups_dev)
     if len(layers) == 1:
         return ops.mlp_group(xyz, ctr, idx, src, layers[0], out=out, pool_ns=pool_ns, act=act, groups_dev=groups_dev)

@@ -6,10 +6,12 @@ sys.path.insert(0, ".")
 from pointrcnn_amd import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-line = [os.path.basename(os.environ.get("PRCNN_POINTOPS_LIB", "product"))]
+fill = os.environ.get("ABL_FILL", "randn")          # randn | zeros | ones: operand data changes the power draw, hence the clock
+line = [os.path.basename(os.environ.get("PRCNN_POINTOPS_LIB", "product")) + " fill=" + fill]
 for rows, K, N in ((32768, 512, 512), (131072, 256, 256), (8192, 512, 512), (524288, 128, 128)):
-    x = torch.randn(rows, K, device=dev)
-    lin = ops.PackedLinear(torch.randn(N, K, device=dev) * 0.05, torch.randn(N, device=dev), relu=True)
+    mk = {"randn": torch.randn, "zeros": torch.zeros, "ones": torch.ones}[fill]
+    x = mk(rows, K, device=dev)
+    lin = ops.PackedLinear(mk(N, K, device=dev) * 0.05, torch.randn(N, device=dev), relu=True)
     out = torch.empty(rows, N, device=dev)
     for _ in range(3):
         ops.mlp_rows(x, lin, out=(out, 0))
