@@ -753,6 +753,7 @@ struct ChainParams {
     const float* wpack1; const float* bias1; int KB1, N1, relu1;
     const float* wpack2; const float* bias2; int KB2, N2, relu2;
     int nlayers;
+    int stack_split;           // mlp_stack2_kernel: most workgroups per row tile (set by dispatch_chain)
 };
 
 #define CH_DPP_FMAX(v, ctrl) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
@@ -1689,12 +1690,20 @@ static int nb32(int n) { return (n + 31) / 32; }
 #define ST_ROWS 32
 #define ST_MAX_K0 256
 #define ST_MAX_NB0 12
-template <int NBW0, int NBW1>
+#define ST_RING 8                // k-blocks of weights in flight per wave (one wave per SIMD: registers are plentiful)
+template <int NBW0>
 __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Cin) {
     MlpParams P = Cin.a;
     P.rows = effective_rows(Cin.a);
-    const long row0 = (long)blockIdx.x * ST_ROWS;
-    if (row0 >= P.rows) return;
+    // layer-B column groups (4 blocks, one per wave) are dealt to `ysplit` workgroups per row tile: 1 when the list alone
+    // fills the chip, up to Cin.stack_split when it is short -- decided HERE from the device-side row count (the host only
+    // knows the padded bound: 8192 rows for the 2048 that SA4 really has).  The live workgroups are the FIRST tiles * ysplit
+    // of the 1-D grid, so that the dispatcher spreads them over XCDs and CUs like any dense launch; the rest leave.
+    const int tiles_eff = (int)((P.rows + ST_ROWS - 1) / ST_ROWS);
+    const int ysplit = min(Cin.stack_split, max(1, (256 + tiles_eff - 1) / max(tiles_eff, 1)));
+    if ((long)blockIdx.x >= (long)tiles_eff * ysplit) return;
+    const int tile = blockIdx.x / ysplit, ysl = blockIdx.x - tile * ysplit;
+    const long row0 = (long)tile * ST_ROWS;
     extern __shared__ __attribute__((aligned(16))) float st_lds[];
     const int lda = P.K + 4;                               // row strides (floats): +4 keeps the ds_read_b128 of 16 rows conflict-free
     const int n0pad = P.NB * 32, ldb = n0pad + 4;
@@ -1703,6 +1712,32 @@ __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Ci
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
+
+    // ---- weight rings: layer A's and the first layer-B column group's, requested first
+    const int NB1 = (Cin.N1 + 31) / 32, NCG = (NB1 + 3) / 4;
+    const int KBa = (PRCNN_ABL & 32) ? 1 : P.KB, KBb = (PRCNN_ABL & 64) ? 1 : Cin.KB1;
+    int nbsA[4];
+    const float* bpA[4];
+    float4 bqA[ST_RING][4], bqB[ST_RING][4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        nbsA[q] = wave + 4 * q;
+        bpA[q] = P.wpack + ((long)min(nbsA[q], P.NB - 1) * P.KB) * 256 + lane * 4;
+    }
+    const float* bpB[4];
+    auto prime_b = [&](int cg) {
+        bpB[0] = Cin.wpack1 + ((long)min(cg * 4 + wave, NB1 - 1) * Cin.KB1) * 256 + lane * 4;
+#pragma unroll
+        for (int g = 0; g < ST_RING; g++) bqB[g][0] = ld4(bpB[0] + (long)min(g, KBb - 1) * 256);
+    };
+#pragma unroll
+    for (int g = 0; g < ST_RING; g++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q < NBW0) bqA[g][q] = ld4(bpA[q] + (long)min(g, KBa - 1) * 256);
+    }
+    bpB[1] = bpB[2] = bpB[3] = Cin.wpack1;
+    prime_b(ysl);
 
     // ---- activated-gather rows -> actA: thread = (row tid / 8, 16-byte column piece tid % 8 of every 32-channel chunk)
     {
@@ -1735,29 +1770,25 @@ __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Ci
         }
     }
 
-    // one layer: this wave's NBW column blocks (nbs[q] < NBtot) over KB k-blocks of the A tile `act` (stride ld)
-    auto run_layer = [&](auto& acc, const int (&nbs)[4], int nbw, int NBtot, const float* wpack, int KB, const float* act, int ld) {
-        const float* bptr[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) bptr[q] = wpack + ((long)min(nbs[q], NBtot - 1) * KB) * 256 + lane * 4;
-        float4 bq[4][4];
+    // one layer: this wave's NBW column blocks over KB k-blocks of the A tile `act` (stride ld); the weight ring `bq` was
+    // primed by ring_fill -- at kernel entry for BOTH layers, so that the cold-weight round trips (these launches run once per
+    // step, between kernels that sweep the L2) overlap the row gather instead of heading each layer
+    auto run_layer = [&](auto& acc, float4 (&bq)[ST_RING][4], const float* const (&bptr)[4], int nbw, int KB, const float* act, int ld) {
         auto load_b = [&](int g, int slot) {
             const long off = (long)min(g, KB - 1) * 256;
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (q < nbw) bq[slot][q] = ld4(bptr[q] + off);
         };
-#pragma unroll
-        for (int g = 0; g < 4; g++) load_b(g, g);
         const float* a_base = act + j * ld + 4 * h;
         float4 a_next = *reinterpret_cast<const float4*>(a_base);
-        for (int kb0 = 0; kb0 < KB; kb0 += 4) {
+        for (int kb0 = 0; kb0 < KB; kb0 += ST_RING) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < ST_RING; u++) {
                 const int kb = kb0 + u;
                 if (kb < KB) {
                     // one wave per SIMD here: the next k-block's A operand is requested before this one's MFMAs, or its LDS
-                    // latency would show between every 8-16 MFMAs (the tile has spare columns: the read past KB is harmless)
+                    // latency would show between every 4-16 MFMAs
                     const float4 a = a_next;
                     a_next = *reinterpret_cast<const float4*>(a_base + min(kb + 1, KB - 1) * 8);
 #pragma unroll
@@ -1769,7 +1800,7 @@ __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Ci
 #pragma unroll
                     for (int q = 0; q < 4; q++) if (q < nbw) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[u][q].w, acc[q], 0, 0, 0);
                 }
-                if (!(PRCNN_ABL & 128)) load_b(kb + 4, u);
+                if (!(PRCNN_ABL & 128)) load_b(kb + ST_RING, u);
             }
         }
     };
@@ -1780,13 +1811,10 @@ __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Ci
         f32x16 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) acc[q] = (f32x16){0};
-        int nbs[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) nbs[q] = wave + 4 * q;
-        run_layer(acc, nbs, NBW0, P.NB, P.wpack, (PRCNN_ABL & 32) ? 1 : P.KB, actA, lda);
+        run_layer(acc, bqA, bpA, NBW0, KBa, actA, lda);
 #pragma unroll
         for (int q = 0; q < NBW0; q++) {
-            const int nb = nbs[q];
+            const int nb = nbsA[q];
             if (nb >= P.NB) continue;                       // (wave-uniform)
             const int n = nb * 32 + j;
             const float bias = (P.bias && n < P.Nout) ? P.bias[n] : 0.f;
@@ -1800,31 +1828,24 @@ __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Ci
         }
     }
     __syncthreads();
-    // ---- layer B: this workgroup's slice of the N1 column blocks (gridDim.y slices), split over the waves
-    {
+    // ---- layer B: column groups ysl, ysl + ysplit, ...; one 32-column block per wave and pass
+    for (int cg = ysl; cg < NCG; cg += ysplit) {
+        if (cg != ysl) prime_b(cg);
         f32x16 acc[4];
+        acc[0] = (f32x16){0};
+        run_layer(acc, bqB, bpB, 1, KBb, actB, ldb);
+        const int nb = cg * 4 + wave;
+        if (nb >= NB1) continue;                            // (wave-uniform)
+        const int n = nb * 32 + j;
+        const bool n_ok = n < Cin.N1;
+        const float bias = (Cin.bias1 && n_ok) ? Cin.bias1[n] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc[q] = (f32x16){0};
-        const int NB1 = (Cin.N1 + 31) / 32;
-        int nbs[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) nbs[q] = blockIdx.y * (4 * NBW1) + wave + 4 * q;
-        run_layer(acc, nbs, NBW1, NB1, Cin.wpack1, (PRCNN_ABL & 64) ? 1 : Cin.KB1, actB, ldb);
-#pragma unroll
-        for (int q = 0; q < NBW1; q++) {
-            const int nb = nbs[q];
-            if (nb >= NB1) continue;
-            const int n = nb * 32 + j;
-            const bool n_ok = n < Cin.N1;
-            const float bias = (Cin.bias1 && n_ok) ? Cin.bias1[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const long g = row0 + rin;
-                float v = acc[q][r] + bias;
-                if (Cin.relu1) v = fmaxf(v, 0.f);
-                if (n_ok && g < P.rows) P.out[g * P.ld_out + P.col_off + n] = v;
-            }
+        for (int r = 0; r < 16; r++) {
+            const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const long g = row0 + rin;
+            float v = acc[0][r] + bias;
+            if (Cin.relu1) v = fmaxf(v, 0.f);
+            if (n_ok && g < P.rows) P.out[g * P.ld_out + P.col_off + n] = v;
         }
     }
 }
@@ -1836,12 +1857,11 @@ static bool stack2_ok(int mode, const ChainParams& C) {
            P.K <= ST_MAX_K0 && P.vec_a && (P.Nout > 128 || C.N1 > 128) && nb32(P.Nout) <= ST_MAX_NB0 && nb32(C.N1) <= 16;
 }
 
-template <int NBW0, int NBW1>
-static void launch_stack2(const ChainParams& C, int cs, hipStream_t s) {
+template <int NBW0>
+static void launch_stack2(const ChainParams& C, hipStream_t s) {
     const size_t lds = (size_t)ST_ROWS * ((C.a.K + 4) + (nb32(C.a.Nout) * 32 + 4)) * sizeof(float);
-    hipLaunchKernelGGL((mlp_stack2_kernel<NBW0, NBW1>), dim3(prcnn_divup(C.a.rows, ST_ROWS), cs), dim3(256), lds, s, C);
+    hipLaunchKernelGGL((mlp_stack2_kernel<NBW0>), dim3((unsigned)(prcnn_divup(C.a.rows, ST_ROWS) * C.stack_split)), dim3(256), lds, s, C);
 }
-
 
 static bool chain_instance_exists(int mode, int n0, int n1, int n2) {
     struct { int m, a, b, c; } T[] = {{MODE_GROUP, 1, 1, 1}, {MODE_GROUP, 1, 1, 2}, {MODE_GROUP, 2, 2, 4}, {MODE_GROUP, 2, 3, 4},
@@ -1875,22 +1895,20 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
     if (C.nlayers > 2) C.KB2 = (C.N1 + 7) / 8;
     if (P.rows == 0) return PRCNN_OK;
     if (stack2_ok(mode, C)) {
-        // layer-B column blocks per workgroup: all of them when the list is long enough to fill the chip with row tiles,
-        // four (one per wave) otherwise -- the column slices then go to gridDim.y workgroups
-        const int tiles = prcnn_divup(P.rows, ST_ROWS), nbw0 = prcnn_divup(n0, 4);
-        const int nbw1 = tiles >= 256 ? prcnn_divup(n1, 4) : 1, cs = prcnn_divup(n1, 4 * nbw1);
-        static PrcnnLdsLimit attr[3][4];
-#define STACK_CASE(A, B)                                                                                                 \
-        if (nbw0 == A && nbw1 == B) {                                                                                    \
-            if (!attr[A - 1][B - 1].raise((const void*)mlp_stack2_kernel<A, B>, 96 * 1024))                              \
+        // stack_split = the most workgroups a row tile's layer-B column groups may be dealt to; the kernel picks the split
+        // from the device-side row count
+        const int nbw0 = prcnn_divup(n0, 4);
+        C.stack_split = prcnn_divup(n1, 4);
+        static PrcnnLdsLimit attr[3];
+#define STACK_CASE(A)                                                                                                    \
+        if (nbw0 == A) {                                                                                                 \
+            if (!attr[A - 1].raise((const void*)mlp_stack2_kernel<A>, 96 * 1024))                                        \
                 return prcnn_fail(PRCNN_EHIP, "prcnn_mlp_chain(stack): cannot raise the dynamic LDS limit");             \
-            launch_stack2<A, B>(C, cs, s);                                                                               \
+            launch_stack2<A>(C, s);                                                                                      \
             PRCNN_LAUNCH_CHECK("prcnn_mlp_chain(stack)");                                                                \
             return PRCNN_OK;                                                                                             \
         }
-        STACK_CASE(1, 1) STACK_CASE(1, 2) STACK_CASE(1, 3) STACK_CASE(1, 4)
-        STACK_CASE(2, 1) STACK_CASE(2, 2) STACK_CASE(2, 3) STACK_CASE(2, 4)
-        STACK_CASE(3, 1) STACK_CASE(3, 2) STACK_CASE(3, 3) STACK_CASE(3, 4)
+        STACK_CASE(1) STACK_CASE(2) STACK_CASE(3)
 #undef STACK_CASE
     }
     // SA level 0: xyz-only rows, three narrow layers, pooled -- persistent register-weight kernel
