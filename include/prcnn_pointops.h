@@ -239,6 +239,20 @@ int prcnn_pts_in_boxes3d(const float* pts, const float* boxes3d, int N, int M, i
 int prcnn_rpn_labels(const float* pts, const float* gt_boxes3d, const int32_t* num_gt, int B, int N, int G, float extra_width,
                      int32_t* cls_label, float* reg_label, prcnn_stream_t stream);
 
+/* GT-augmentation scene edit for a batch of scenes on the device -- the point work of
+ * KittiRCNNDataset.apply_gt_aug_to_one_scene (lib/datasets/kitti_rcnn_dataset.py:484-489 one pts_in_boxes3d_cpu scan of the
+ * scene per accepted object, :501-507 boolean-mask copy + concatenate).  pts (B,N,3), intensity (B,N) or NULL, boxes3d (B,K,7)
+ * = the accepted objects' boxes [x,y(bottom),z,h,w,l,ry] (K <= 64), tested with h + extra_h (2.0 in the reference);
+ * new_pts (B,P,3) / new_intensity (B,P) = the pasted objects' points, already concatenated in paste order.  num_pts / num_boxes /
+ * num_new: (B) i32 live counts or NULL (all rows live).  Output: out_pts (B,N+P,3), out_intensity (B,N+P) or NULL: the scene
+ * points outside every box IN THEIR ORIGINAL ORDER, then the new points; rows >= out_count[b] are zero.  out_count (B) i32;
+ * removed (B,N) i32 or NULL: 1 where a scene point was dropped (the complement of the reference's src_pts_flag).
+ * In-box test == prcnn_pts_in_boxes3d.  The sampling loop (database lookup, road plane, collision test) stays with the caller. */
+int prcnn_gt_aug_edit(const float* pts, const float* intensity, const int32_t* num_pts, const float* boxes3d,
+                      const int32_t* num_boxes, float extra_h, const float* new_pts, const float* new_intensity,
+                      const int32_t* num_new, int B, int N, int K, int P, float* out_pts, float* out_intensity,
+                      int32_t* out_count, int32_t* removed, prcnn_stream_t stream);
+
 /* HOST twins of the reference's two CPU entry points (roipool3d.cpp:97-125 pts_in_boxes3d_cpu, :127-195 roipool3d_cpu),
  * which its dataloader calls inside forked worker processes (kitti_rcnn_dataset.py:487,582,625,843,970).  Host pointers,
  * no HIP call, bit-identical to the reference's CPU arithmetic (double half-extent compares, inclusive bounds).

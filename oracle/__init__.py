@@ -71,6 +71,24 @@ class _Cpu:
         self.lib.prcnn_cpu_fps_upstream(_p(xyz, _F), B, N, npoint, _p(idx, _I))
         return idx
 
+    def gt_aug_edit(self, pts, intensity, boxes3d, new_pts, new_intensity, num_pts=None, num_boxes=None, num_new=None,
+                    extra_h=2.0, trig_mode=1):
+        """-> out_pts (B,N+P,3), out_intensity (B,N+P), count (B) i32, removed (B,N) i32"""
+        pts, boxes3d, new_pts = _f32(pts), _f32(boxes3d), _f32(new_pts)
+        intensity, new_intensity = _f32(intensity), _f32(new_intensity)
+        B, N, _ = pts.shape
+        K, P = boxes3d.shape[1], new_pts.shape[1]
+        cnt = [None if c is None else np.ascontiguousarray(c, np.int32) for c in (num_pts, num_boxes, num_new)]
+        out_pts = np.zeros((B, N + P, 3), np.float32)
+        out_int = np.zeros((B, N + P), np.float32)
+        count = np.zeros((B,), np.int32)
+        removed = np.zeros((B, N), np.int32)
+        self.lib.prcnn_cpu_gt_aug_edit(_p(pts, _F), _p(intensity, _F), None if cnt[0] is None else _p(cnt[0], _I), _p(boxes3d, _F),
+                                       None if cnt[1] is None else _p(cnt[1], _I), ctypes.c_float(extra_h), _p(new_pts, _F),
+                                       _p(new_intensity, _F), None if cnt[2] is None else _p(cnt[2], _I), B, N, K, P, trig_mode,
+                                       _p(out_pts, _F), _p(out_int, _F), _p(count, _I), _p(removed, _I))
+        return out_pts, out_int, count, removed
+
     def rpn_labels(self, pts, gt_boxes3d, num_gt=None, extra_width=0.2, trig_mode=1):
         pts, gt = _f32(pts), _f32(gt_boxes3d)
         B, N, _ = pts.shape

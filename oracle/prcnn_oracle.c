@@ -306,6 +306,51 @@ PRCNN_EXPORT void prcnn_cpu_pts_in_boxes3d(const float* pts, const float* boxes3
     }
 }
 
+/* The point work of KittiRCNNDataset.apply_gt_aug_to_one_scene (lib/datasets/kitti_rcnn_dataset.py:484-489: one
+ * pts_in_boxes3d_cpu scan per accepted object with h += 2, keep flag cleared; :501-507: pts_rect[src_pts_flag == 1] then
+ * np.concatenate with the pasted points), per scene of a batch.  Rows past out_count are zero. */
+PRCNN_EXPORT void prcnn_cpu_gt_aug_edit(const float* pts, const float* inten, const int* num_pts, const float* boxes, const int* num_boxes,
+                                        float extra_h, const float* new_pts, const float* new_inten, const int* num_new, int B, int N,
+                                        int K, int P, int trig_mode, float* out_pts, float* out_inten, int* out_count, int* removed) {
+    for (int b = 0; b < B; b++) {
+        const int n = num_pts ? (num_pts[b] < 0 ? 0 : (num_pts[b] < N ? num_pts[b] : N)) : N;
+        const int k = num_boxes ? (num_boxes[b] < 0 ? 0 : (num_boxes[b] < K ? num_boxes[b] : K)) : K;
+        const int np = num_new ? (num_new[b] < 0 ? 0 : (num_new[b] < P ? num_new[b] : P)) : P;
+        float* op = out_pts + (size_t)b * (N + P) * 3;
+        float* oi = out_inten ? out_inten + (size_t)b * (N + P) : 0;
+        int kept = 0;
+        for (int i = 0; i < N; i++)
+            if (removed) removed[(size_t)b * N + i] = 0;
+        for (int i = 0; i < n; i++) {
+            const float* p = pts + ((size_t)b * N + i) * 3;
+            int inside = 0;
+            for (int q = 0; q < k; q++) {
+                const float* bx = boxes + ((size_t)b * K + q) * 7;
+                float ca, sa;
+                const float h = bx[3] + extra_h;
+                box_trig(bx[6], trig_mode, &ca, &sa);
+                inside |= pt_in_box3d(p[0], p[1], p[2], bx[0], bx[1], bx[2], h, bx[4], bx[5], ca, sa);
+            }
+            if (removed) removed[(size_t)b * N + i] = inside;
+            if (!inside) {
+                op[kept * 3] = p[0]; op[kept * 3 + 1] = p[1]; op[kept * 3 + 2] = p[2];
+                if (oi) oi[kept] = inten[(size_t)b * N + i];
+                kept++;
+            }
+        }
+        for (int i = 0; i < np; i++) {
+            const float* q = new_pts + ((size_t)b * P + i) * 3;
+            op[(kept + i) * 3] = q[0]; op[(kept + i) * 3 + 1] = q[1]; op[(kept + i) * 3 + 2] = q[2];
+            if (oi) oi[kept + i] = new_inten[(size_t)b * P + i];
+        }
+        for (int i = kept + np; i < N + P; i++) {
+            op[i * 3] = op[i * 3 + 1] = op[i * 3 + 2] = 0.f;
+            if (oi) oi[i] = 0.f;
+        }
+        out_count[b] = kept + np;
+    }
+}
+
 /* KittiRCNNDataset.generate_rpn_training_labels (lib/datasets/kitti_rcnn_dataset.py:365-394) with the analytic in-box
  * test above in place of the scipy Delaunay hull test: per frame, GT boxes applied in order; cls (B,N) int32 in {-1,0,1},
  * reg (B,N,7) [dx, dy, dz, h, w, l, ry].  enlarge_box3d (kitti_utils.py:150-160): h,w,l += 2*extra, y += extra. */

@@ -24,6 +24,7 @@ SIGNATURES = {
     "prcnn_fps": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "prcnn_fps_order": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "prcnn_rpn_labels": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "prcnn_gt_aug_edit": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "prcnn_host_pts_in_boxes3d": (_I, [_P, _P, _L, _L, _P]),
     "prcnn_host_roipool3d": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _P]),
     "prcnn_gather": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),

@@ -352,3 +352,110 @@ PRCNN_API int prcnn_rpn_labels(const float* pts, const float* gt_boxes3d, const 
     PRCNN_LAUNCH_CHECK("prcnn_rpn_labels");
     return PRCNN_OK;
 }
+
+
+// =====================================================================================================
+// GT-augmentation scene edit (second half).  KittiRCNNDataset.apply_gt_aug_to_one_scene
+// (lib/datasets/kitti_rcnn_dataset.py:408-511) pastes database objects into a scene: for every ACCEPTED object it calls
+// pts_in_boxes3d_cpu on the whole scene against the object's box with h += 2 (:484-489), clears those points' keep flag, and
+// after the loop keeps `pts_rect[src_pts_flag == 1]` and concatenates the pasted objects' points (:501-507) -- one full-scene
+// scan per object plus two boolean-mask copies on the host.  Here the whole edit is one launch for a batch of scenes: a
+// workgroup per scene holds the accepted boxes' constants in LDS, tests each point against all of them once, compacts the
+// survivors IN INDEX ORDER (ballot + prefix popcount per wave, the 16 wave counts through a double-buffered LDS row: one
+// barrier per 1024 points) and appends the new points; the tail of the (N + P)-row output is zero-filled.
+// The sampling loop around it (database lookup, road plane, the shapely collision test) stays host code and out of scope.
+// In-box test: pt_in_box above (== prcnn_pts_in_boxes3d).
+// =====================================================================================================
+#define AUG_MAX_BOXES 64
+#define AUG_THREADS 1024
+__global__ __launch_bounds__(AUG_THREADS) void gt_aug_edit_kernel(
+    const float* __restrict__ pts, const float* __restrict__ inten, const int32_t* __restrict__ num_pts,
+    const float* __restrict__ boxes, const int32_t* __restrict__ num_boxes, float extra_h, const float* __restrict__ new_pts,
+    const float* __restrict__ new_inten, const int32_t* __restrict__ num_new, int N, int K, int P, float* __restrict__ out_pts,
+    float* __restrict__ out_inten, int32_t* __restrict__ out_count, int32_t* __restrict__ removed) {
+    __shared__ BoxConst sbox[AUG_MAX_BOXES];
+    __shared__ int wsum[2][AUG_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = num_pts ? min(max(num_pts[b], 0), N) : N;
+    const int k = num_boxes ? min(max(num_boxes[b], 0), K) : K;
+    const int np = num_new ? min(max(num_new[b], 0), P) : P;
+    for (int i = tid; i < k; i += AUG_THREADS) {
+        const float* bx = boxes + ((size_t)b * K + i) * 7;
+        float big[7];
+#pragma unroll
+        for (int c = 0; c < 7; c++) big[c] = bx[c];
+        big[3] = bx[3] + extra_h;                              // kitti_rcnn_dataset.py:484-485 (float32 add, as numpy does it)
+        sbox[i] = make_box(big);
+    }
+    __syncthreads();
+    const float* __restrict__ p = pts + (size_t)b * N * 3;
+    const float* __restrict__ it = inten ? inten + (size_t)b * N : nullptr;
+    float* __restrict__ op = out_pts + (size_t)b * (N + P) * 3;
+    float* __restrict__ oi = out_inten ? out_inten + (size_t)b * (N + P) : nullptr;
+    int kept = 0;                                              // workgroup-uniform running count
+    int trip = 0;
+    // the next trip's point is requested before this trip's test / barrier (the loop is one load round trip per trip otherwise)
+    float nx = 0.f, ny = 0.f, nz = 0.f, nw = 0.f;
+    if (tid < n) { nx = p[tid * 3]; ny = p[tid * 3 + 1]; nz = p[tid * 3 + 2]; if (it) nw = it[tid]; }
+    for (int base = 0; base < n; base += AUG_THREADS, trip ^= 1) {
+        const int i = base + tid;
+        const float x = nx, y = ny, z = nz, w = nw;
+        const int i2 = i + AUG_THREADS;
+        if (i2 < n) { nx = p[i2 * 3]; ny = p[i2 * 3 + 1]; nz = p[i2 * 3 + 2]; if (it) nw = it[i2]; }
+        bool keep = i < n;
+        if (keep) {
+            bool inside = false;
+            for (int q = 0; q < k; q++) inside |= pt_in_box(sbox[q], x, y, z);
+            keep = !inside;
+            if (removed) removed[(size_t)b * N + i] = inside ? 1 : 0;
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) wsum[trip][wave] = __popcll(mask);
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int v = 0; v < AUG_THREADS / 64; v++) {
+            const int c = wsum[trip][v];
+            off += v < wave ? c : 0;
+            total += c;
+        }
+        if (keep) {
+            const int pos = kept + off + __popcll(mask & ((1ULL << lane) - 1ULL));
+            op[pos * 3] = x; op[pos * 3 + 1] = y; op[pos * 3 + 2] = z;
+            if (oi) oi[pos] = w;
+        }
+        kept += total;
+    }
+    const float* __restrict__ q3 = new_pts + (size_t)b * P * 3;
+    for (int i = tid; i < np * 3; i += AUG_THREADS) op[kept * 3 + i] = q3[i];
+    if (oi) {
+        const float* __restrict__ qi = new_inten + (size_t)b * P;
+        for (int i = tid; i < np; i += AUG_THREADS) oi[kept + i] = qi[i];
+    }
+    const int cnt = kept + np;
+    for (int i = cnt * 3 + tid; i < (N + P) * 3; i += AUG_THREADS) op[i] = 0.f;
+    if (oi)
+        for (int i = cnt + tid; i < N + P; i += AUG_THREADS) oi[i] = 0.f;
+    if (removed)
+        for (int i = n + tid; i < N; i += AUG_THREADS) removed[(size_t)b * N + i] = 0;
+    if (tid == 0) out_count[b] = cnt;
+}
+
+PRCNN_API int prcnn_gt_aug_edit(const float* pts, const float* intensity, const int32_t* num_pts, const float* boxes3d,
+                                const int32_t* num_boxes, float extra_h, const float* new_pts, const float* new_intensity,
+                                const int32_t* num_new, int B, int N, int K, int P, float* out_pts, float* out_intensity,
+                                int32_t* out_count, int32_t* removed, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(B >= 0 && N >= 0 && K >= 0 && P >= 0, "prcnn_gt_aug_edit: bad shape");
+    PRCNN_REQUIRE(K <= AUG_MAX_BOXES, "prcnn_gt_aug_edit: more than 64 boxes per scene");
+    PRCNN_REQUIRE((long)N + P < (1L << 29), "prcnn_gt_aug_edit: scene too large");
+    if (B == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(out_count && (N + P == 0 || out_pts), "prcnn_gt_aug_edit: null output");
+    PRCNN_REQUIRE((N == 0 || pts) && (K == 0 || boxes3d) && (P == 0 || new_pts), "prcnn_gt_aug_edit: null input");
+    PRCNN_REQUIRE(!out_intensity || ((N == 0 || intensity) && (P == 0 || new_intensity)),
+                  "prcnn_gt_aug_edit: out_intensity needs intensity and new_intensity");
+    hipLaunchKernelGGL(gt_aug_edit_kernel, dim3(B), dim3(AUG_THREADS), 0, (hipStream_t)stream, pts, out_intensity ? intensity : nullptr,
+                       num_pts, boxes3d, num_boxes, extra_h, new_pts, new_intensity, num_new, N, K, P, out_pts, out_intensity, out_count,
+                       removed);
+    PRCNN_LAUNCH_CHECK("prcnn_gt_aug_edit");
+    return PRCNN_OK;
+}

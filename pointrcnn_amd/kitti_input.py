@@ -116,3 +116,19 @@ class ScenePreparer:
         raw, off, calib, hw = (packed[k].to(dev, non_blocking=True) for k in ("raw", "offsets", "calib", "img_hw"))
         xyz, inten, src, nvalid, status = ops.scene_prepare(raw, off, packed["max_points"], calib, hw, self.scope, self.npoints, seed)
         return {"pts_input": xyz, "pts_rect": xyz, "pts_features": inten.unsqueeze(-1), "src": src, "nvalid": nvalid, "status": status}
+
+
+def gt_aug_edit_scene(pts_rect, pts_intensity, accepted_boxes3d, new_pts_list, new_intensity_list, device="cuda"):
+    """The point work of KittiRCNNDataset.apply_gt_aug_to_one_scene (lib/datasets/kitti_rcnn_dataset.py:484-507) for one
+    scene, on the device: drop every scene point inside an accepted object's box (h + 2, :484-489), keep the rest in order and
+    append the pasted objects' points (:501-507).  numpy in, numpy out (pts_rect (n', 3), pts_intensity (n',)) -- what the
+    reference's function returns as its second and third value.  Batches of scenes: ops.gt_aug_edit."""
+    pts = torch.as_tensor(np.ascontiguousarray(pts_rect, np.float32), device=device)[None]
+    inten = torch.as_tensor(np.ascontiguousarray(pts_intensity, np.float32), device=device)[None]
+    boxes = torch.as_tensor(np.ascontiguousarray(accepted_boxes3d, np.float32).reshape(-1, 7), device=device)[None]
+    new_pts = np.concatenate(new_pts_list, axis=0).astype(np.float32) if len(new_pts_list) else np.zeros((0, 3), np.float32)
+    new_int = np.concatenate(new_intensity_list, axis=0).astype(np.float32) if len(new_intensity_list) else np.zeros((0,), np.float32)
+    out_pts, out_int, count = ops.gt_aug_edit(pts, inten, boxes, torch.as_tensor(new_pts, device=device)[None],
+                                              torch.as_tensor(new_int, device=device)[None])
+    n = int(count[0])
+    return out_pts[0, :n].cpu().numpy(), out_int[0, :n].cpu().numpy()

@@ -101,6 +101,13 @@ def main():
              timeit(lambda: ops.roipool3d(xd, rd, pfd, 512), 5, 1), bytes=Bd * 2 * Md * 512 * 133 * 4)
         del xd, pfd, rd
 
+    # ---- GT-augmentation scene edit (kitti_rcnn_dataset.py:484-507): 15 accepted objects per scene, ~4000 pasted points
+    ab = rois_for(xyz, 15, 3)
+    npts, nint = torch.randn(B, 4000, 3, device=dev), torch.rand(B, 4000, device=dev)
+    inten = torch.rand(B, N, device=dev)
+    emit("gt_aug_edit", "B%d N%d K15 P4000" % (B, N), timeit(lambda: ops.gt_aug_edit(xyz, inten, ab, npts, nint)),
+         bytes=B * (2 * N * 16 + 2 * 4000 * 16))
+
     # ---- NMS (default RPN path: normal, 6300 boxes, thr 0.8) and rotated
     c = torch.rand(6300, 2, generator=g) * torch.tensor([80.0, 70.0])
     s = torch.rand(6300, 2, generator=g) * torch.tensor([0.5, 1.5]) + torch.tensor([0.8, 1.7])

@@ -486,6 +486,40 @@ def rpn_labels(pts, gt_boxes3d, num_gt=None, extra_width=0.2):
     return cls, reg
 
 
+def gt_aug_edit(pts, intensity, boxes3d, new_pts, new_intensity, num_pts=None, num_boxes=None, num_new=None, extra_h=2.0,
+                want_removed=False):
+    """The point work of KittiRCNNDataset.apply_gt_aug_to_one_scene (kitti_rcnn_dataset.py:484-507) for a batch of scenes.
+    pts (B,N,3), intensity (B,N) or None, boxes3d (B,K,7) accepted objects (tested with h + extra_h), new_pts (B,P,3),
+    new_intensity (B,P) or None; num_* (B) i32 live counts or None.
+    -> out_pts (B,N+P,3), out_intensity (B,N+P) or None, count (B) i32 [, removed (B,N) i32]: surviving scene points in their
+    original order, then the new points; rows past count are zero."""
+    _chk(pts, "pts", ndim=3); _chk(boxes3d, "boxes3d", ndim=3); _chk(new_pts, "new_pts", ndim=3)
+    B, N, _ = pts.shape
+    K, P = boxes3d.shape[1], new_pts.shape[1]
+    if boxes3d.shape[0] != B or boxes3d.shape[2] != 7 or new_pts.shape[0] != B or new_pts.shape[2] != 3:
+        raise ValueError("gt_aug_edit: boxes3d must be (%d, K, 7), new_pts (%d, P, 3)" % (B, B))
+    if (intensity is None) != (new_intensity is None):
+        raise ValueError("gt_aug_edit: intensity and new_intensity go together")
+    if intensity is not None:
+        _chk(intensity, "intensity", ndim=2); _chk(new_intensity, "new_intensity", ndim=2)
+        if tuple(intensity.shape) != (B, N) or tuple(new_intensity.shape) != (B, P):
+            raise ValueError("gt_aug_edit: intensity must be (B, N), new_intensity (B, P)")
+    for name, t in (("num_pts", num_pts), ("num_boxes", num_boxes), ("num_new", num_new)):
+        if t is not None:
+            _chk(t, name, _INT, 1)
+            if t.shape[0] != B:
+                raise ValueError("gt_aug_edit: %s must be (%d,)" % (name, B))
+    dev = pts.device
+    out_pts = torch.empty((B, N + P, 3), dtype=_F32, device=dev)
+    out_int = torch.empty((B, N + P), dtype=_F32, device=dev) if intensity is not None else None
+    count = torch.empty((B,), dtype=_INT, device=dev)
+    removed = torch.empty((B, N), dtype=_INT, device=dev) if want_removed else None
+    _cabi.check(_cabi.lib().prcnn_gt_aug_edit(_p(pts), _p(intensity), _p(num_pts), _p(boxes3d), _p(num_boxes), float(extra_h),
+                                              _p(new_pts), _p(new_intensity), _p(num_new), B, N, K, P, _p(out_pts), _p(out_int),
+                                              _p(count), _p(removed), _stream()), "prcnn_gt_aug_edit")
+    return (out_pts, out_int, count, removed) if want_removed else (out_pts, out_int, count)
+
+
 def pts_in_boxes3d(pts, boxes3d):
     """pts (N,3), boxes3d (M,7) -> flags (M,N) i32"""
     _chk(pts, "pts", ndim=2); _chk(boxes3d, "boxes3d", ndim=2)
