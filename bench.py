@@ -200,10 +200,14 @@ class EventProfiler:
 
     def summary(self, dump=None):
         torch.cuda.synchronize()
-        dev_counts = {}
+        dev_counts, undedup = {}, {}
         for sp in self.splits:
-            for k, v in enumerate(sp.counts.cpu().tolist()):
+            c = sp.counts.cpu().tolist()
+            for k, v in enumerate(c):
                 dev_counts[sp.counts.data_ptr() + 4 * k] = v
+            # rows the list's launch stands for in the graph without padding-free grouping: all G * nsample rows of the
+            # scale, minus what the dense list (its own launches) carries
+            undedup[sp.counts.data_ptr()] = sp.G * sp.ns - c[1] * sp.ns
         fam = {}
         for name, s, e, (per_row, rows, ptr, unit) in self.records:
             key = "mlp" if name.startswith("prcnn_mlp_") else name[len("prcnn_"):]
@@ -219,6 +223,7 @@ class EventProfiler:
             d["flops"] += per_row * live
             d["rows"] += live
             d["rows_launched"] += rows
+            d["rows_undedup"] = d.get("rows_undedup", 0) + (undedup[ptr] if ptr in undedup else live)
         return fam
 
 
@@ -640,7 +645,7 @@ def main():
                             "launches_per_step": mlp["launches"] // nprof,
                             "avg_launch_us": round(1e3 * mlp["ms"] / max(1, mlp["launches"]), 2),
                             "flops_per_step": mlp["flops"] / nprof, "rows_per_step": mlp["rows"] // nprof,
-                            "rows_per_step_without_dedup": mlp["rows_launched"] // nprof,
+                            "rows_per_step_without_dedup": mlp.get("rows_undedup", mlp["rows_launched"]) // nprof,
                             "reference_graph_flops_per_step": ref_flops / nprof if ref_flops else None,
                             "reference_graph_TFLOPs": round(ref_flops / secs / 1e12, 3) if ref_flops and secs > 0 else None,
                             "note": "achieved/frac = executed flops (after exact first-layer hoisting and padding-free grouping) / "

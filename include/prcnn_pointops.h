@@ -46,7 +46,8 @@ typedef void* prcnn_stream_t; /* hipStream_t */
 #define PRCNN_EHIP (-2)         /* HIP runtime / launch failure */
 #define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-int prcnn_abi_version(void);   /* 4: + prcnn_host_* (host twins of the reference's *_cpu entry points), prcnn_build_id,
+int prcnn_abi_version(void);   /* 5: + prcnn_gt_aug_edit;
+                                 * 4: + prcnn_host_* (host twins of the reference's *_cpu entry points), prcnn_build_id,
                                  * prcnn_fps_order (upstream tie order), prcnn_rpn_labels,
                                  * prcnn_ball_query2_grid takes xyz (dense-frame scan fallback);
                                  * 3: + padding-free grouping (rows_dev / groups_dev, prcnn_group_compact, ...), RoI duplicate
@@ -66,7 +67,11 @@ const char* prcnn_build_id(void);
  *   N > 16384           required: HBM-resident running min-distances;
  *   2048 < N <= 16384   optional: when given, selects the spatially pruned kernel (Morton pre-sort into `tmp`, exact
  *                       bounding-box skip; bit-identical results); NULL = the register-resident kernel;
- *   N <= 2048           ignored. */
+ *   N <= 2048           ignored.
+ * Domain: FINITE coordinates.  The kernels order distances through integer compares of their bit patterns and bare
+ * v_min/v_max (the file is built with -ffinite-math-only); a cloud holding NaN / Inf has no farthest point under any rule
+ * and the indices returned for it are unspecified (always within [0, N)).  Callers with unvalidated input filter first
+ * (prcnn_scene_prepare drops non-finite raw points). */
 int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, int32_t* idx, prcnn_stream_t stream);
 
 /* Same, with a selectable rule for ties among equal running min-distances (they only occur on clouds with duplicate

@@ -1701,10 +1701,12 @@ __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Ci
     // of the 1-D grid, so that the dispatcher spreads them over XCDs and CUs like any dense launch; the rest leave.
     const int tiles_eff = (int)((P.rows + ST_ROWS - 1) / ST_ROWS);
     const int ysplit = min(Cin.stack_split, max(1, (256 + tiles_eff - 1) / max(tiles_eff, 1)));
-    if ((long)blockIdx.x >= (long)tiles_eff * ysplit) return;
-    const int tile = blockIdx.x / ysplit, ysl = blockIdx.x - tile * ysplit;
-    const long row0 = (long)tile * ST_ROWS;
     extern __shared__ __attribute__((aligned(16))) float st_lds[];
+    // (the grid is capped: the padded bound can be 16 x the live list, and thousands of workgroups that only leave cost more than
+    //  the loop does)
+    for (long unit = blockIdx.x; unit < (long)tiles_eff * ysplit; unit += gridDim.x) {
+    const int tile = (int)(unit / ysplit), ysl = (int)(unit - (long)tile * ysplit);
+    const long row0 = (long)tile * ST_ROWS;
     const int lda = P.K + 4;                               // row strides (floats): +4 keeps the ds_read_b128 of 16 rows conflict-free
     const int n0pad = P.NB * 32, ldb = n0pad + 4;
     float* actA = st_lds;                                  // [32][K0 + 4]
@@ -1848,6 +1850,8 @@ __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Ci
             if (n_ok && g < P.rows) P.out[g * P.ld_out + P.col_off + n] = v;
         }
     }
+    __syncthreads();                                        // the LDS tiles are rebuilt by the next unit
+    }
 }
 
 // shapes the stack kernel takes (hoisted grouped form on flat row lists, no pooling)
@@ -1860,7 +1864,7 @@ static bool stack2_ok(int mode, const ChainParams& C) {
 template <int NBW0>
 static void launch_stack2(const ChainParams& C, hipStream_t s) {
     const size_t lds = (size_t)ST_ROWS * ((C.a.K + 4) + (nb32(C.a.Nout) * 32 + 4)) * sizeof(float);
-    hipLaunchKernelGGL((mlp_stack2_kernel<NBW0>), dim3((unsigned)(prcnn_divup(C.a.rows, ST_ROWS) * C.stack_split)), dim3(256), lds, s, C);
+    hipLaunchKernelGGL((mlp_stack2_kernel<NBW0>), dim3((unsigned)min((long)prcnn_divup(C.a.rows, ST_ROWS) * C.stack_split, 2048L)), dim3(256), lds, s, C);
 }
 
 static bool chain_instance_exists(int mode, int n0, int n1, int n2) {

@@ -26,6 +26,7 @@ _POOL_FUSED = (16, 32, 64)
 HOIST_FIRST_LAYER = True
 GROUP_DEDUP = os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"       # padding-free grouping (csrc/dedup.hip); 0 = A/B switch, same bits
 DEDUP_SPARSE_DIV = int(os.environ.get("PRCNN_DEDUP_SPARSE_DIV", "4"))  # groups with <= nsample/DIV hits run as flat rows
+STACK_ALL_FLAT = os.environ.get("PRCNN_STACK_ALL_FLAT", "1") != "0"      # A/B switch: stack-kernel scales keep a dense list when off
 
 
 def _channels_last(features):
@@ -51,13 +52,19 @@ def _flatten_frames(x):
     return x.as_strided((1, B * N, C), (B * N * x.stride(1), x.stride(1), 1), x.storage_offset())
 
 
+def _stack_scale(layers, act, src):
+    """True when the flat (nsample 1, un-pooled) row list of this scale runs on the two-layer stack kernel"""
+    return (any(l.nout > 128 for l in layers) and act is not None and src is not None and src.shape[-1] <= 256
+            and src.shape[-1] % 8 == 0 and ops.chain_supported(1, layers, 0))
+
+
 def _run_scale(xyz, ctr, idx, src, layers, act, out, ns, pool, groups_dev):
     """One grouping scale: gather + SharedMLP (+ max-pool over the nsample rows when `pool`), the register-resident chain
     kernel where an instance exists, LDS-tiled layer kernels otherwise.  groups_dev: device-side group count (dedup)."""
     pool_ns = ns if pool else 0
     # layers wider than 128 channels: only the two-layer stack kernel takes them (hoisted form on a flat, un-pooled row list)
     wide = any(l.nout > 128 for l in layers)
-    if (ns == 1 or (pool and ns in (16, 32))) and (not wide or (act is not None and ns == 1 and src is not None)) \
+    if (ns == 1 or (pool and ns in (16, 32))) and (not wide or (ns == 1 and _stack_scale(layers, act, src))) \
             and ops.chain_supported(1, layers, pool_ns):
         return ops.mlp_chain_group(xyz, ctr, idx, src, layers, out=out, pool_ns=pool_ns, act=act, groups_dev=groups_dev)
     if len(layers) == 1:
@@ -177,15 +184,21 @@ class _PointnetSAModuleBase(nn.Module):
                 # over copies of a row is the row -- sparse groups contribute only their real rows to one flat row list
                 # (segmented max afterwards), dense groups run as they are, each list with a device-side length.
                 # Same bits, far fewer rows.
-                sp = ops.GroupSplit(idxs[i], new_xyz, N, max(1, ns // DEDUP_SPARSE_DIV), valid_n=valid_n)
+                # Scales the two-layer stack kernel takes (wide SA3 / SA4 stacks in hoisted form) send EVERY group through the
+                # flat list: the stack kernel carries a row through both layers whatever the list length, so the dense list
+                # would buy nothing there and its three launches per scale (two layer kernels, one scatter) would run empty on
+                # most clouds.
+                all_flat = STACK_ALL_FLAT and _stack_scale(layers, act, src)
+                sp = ops.GroupSplit(idxs[i], new_xyz, N, ns if all_flat else max(1, ns // DEDUP_SPARSE_DIV), valid_n=valid_n)
                 xyz_f = xyz.view(1, B * N, 3)
                 src_f = None if src is None else _flatten_frames(src)
                 t1 = torch.empty((sp.max_rows, c_outs[i]), dtype=torch.float32, device=xyz.device)
-                tn = torch.empty((sp.G, c_outs[i]), dtype=torch.float32, device=xyz.device)
                 _run_scale(xyz_f, sp.rnx, sp.ridx, src_f, layers, act, (t1, 0), 1, False, sp.rows)
-                _run_scale(xyz_f, sp.nxn, sp.idxn, src_f, layers, act, (tn, 0), ns, True, sp.count_dense)
                 ops.segmax_scatter(t1, sp, dst[0], col)
-                ops.scatter_rows(tn, sp.listn, sp.count_dense, dst[0], col)
+                if not all_flat:
+                    tn = torch.empty((sp.G, c_outs[i]), dtype=torch.float32, device=xyz.device)
+                    _run_scale(xyz_f, sp.nxn, sp.idxn, src_f, layers, act, (tn, 0), ns, True, sp.count_dense)
+                    ops.scatter_rows(tn, sp.listn, sp.count_dense, dst[0], col)
             else:
                 x = _run_scale(xyz, ctr, idxs[i], src, layers, act, dst if fused_pool else None, ns, fused_pool, None)
                 if not fused_pool:
