@@ -1466,6 +1466,9 @@ __global__ void maxpool_rows_kernel(const float* __restrict__ in, int ld_in, lon
 }
 
 
+static bool rows32_ok(int mode, const MlpParams& P);
+static int launch_rows32(MlpParams& P, hipStream_t s);
+
 static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     PRCNN_REQUIRE(P.wpack && P.out, "prcnn_mlp: null weight/output pointer");
     PRCNN_REQUIRE(P.rows >= 0 && P.K > 0 && P.Nout > 0, "prcnn_mlp: bad shape rows=%ld K=%d Nout=%d", P.rows, P.K, P.Nout);
@@ -1476,6 +1479,7 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     if (P.rows == 0) return PRCNN_OK;
     P.KB = (P.K + 7) / 8;
     P.NB = (P.Nout + 31) / 32;
+    if (rows32_ok(mode, P)) return launch_rows32(P, s);
     // >= 97 output channels: 128x128 workgroup tile -- unless that leaves most of the 256 CUs without a workgroup
     // (few rows, e.g. FP3's 2048 known points): then the 128x64 tile doubles the number of workgroups
     // (a device-side row count means a compacted list: P.rows is its worst case, the live part is expected to be small)
@@ -1831,6 +1835,8 @@ __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Ci
     }
     __syncthreads();
     // ---- layer B: column groups ysl, ysl + ysplit, ...; one 32-column block per wave and pass
+    // (two groups per pass -- a second accumulator chain -- was tried: the registers it takes cost the second resident
+    //  workgroup, 37 -> 47 us on a 16384-row list)
     for (int cg = ysl; cg < NCG; cg += ysplit) {
         if (cg != ysl) prime_b(cg);
         f32x16 acc[4];
@@ -1852,6 +1858,110 @@ __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Ci
     }
     __syncthreads();                                        // the LDS tiles are rebuilt by the next unit
     }
+}
+
+// =====================================================================================================
+// SHORT plain layers (round 2): a long-K layer on a few thousand rows (FP3's hoisted 2048 x 1024 -> 512 product) gives the
+// 128-row layer kernel 128 workgroups of 32 chunks each -- half the chip, a chain of exposed latencies (53 us for 2.1 GFLOP).
+// Same shape of solution as the stack kernel: a workgroup owns 32 rows, holds them whole in LDS (K <= 1024: 131 KB), its
+// four waves take one 32-column block each per pass with the weights streamed from L2 into the register ring, and the column
+// groups of a row tile are dealt to up to Nout/128 workgroups.  k ascends from a zero accumulator in the layer kernels' MFMA
+// steps, bias then ReLU: the same bits.
+// =====================================================================================================
+#define R32_MAX_K 1024
+__global__ __launch_bounds__(256, 1) void mlp_rows32_kernel(const MlpParams Pin, int split_max) {
+    MlpParams P = Pin;
+    P.rows = effective_rows(Pin);
+    const int tiles_eff = (int)((P.rows + ST_ROWS - 1) / ST_ROWS);
+    const int ysplit = min(split_max, max(1, (256 + tiles_eff - 1) / max(tiles_eff, 1)));
+    extern __shared__ __attribute__((aligned(16))) float st_lds[];
+    const int lda = P.K + 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int NCG = (P.NB + 3) / 4;
+    for (long unit = blockIdx.x; unit < (long)tiles_eff * ysplit; unit += gridDim.x) {
+        const int tile = (int)(unit / ysplit), ysl = (int)(unit - (long)tile * ysplit);
+        const long row0 = (long)tile * ST_ROWS;
+        const float* bp;
+        float4 bq[ST_RING];
+        auto prime = [&](int cg) {
+            bp = P.wpack + ((long)min(cg * 4 + wave, P.NB - 1) * P.KB) * 256 + lane * 4;
+#pragma unroll
+            for (int g = 0; g < ST_RING; g++) bq[g] = ld4(bp + (long)min(g, P.KB - 1) * 256);
+        };
+        prime(ysl);
+        // the 32 rows -> LDS: thread = (row tid / 8, 16-byte piece tid % 8 of every 32-float chunk), sixteen pieces in flight
+        {
+            const int r = tid >> 3, c4 = tid & 7;
+            long grow = row0 + r;
+            if (grow >= P.rows) grow = P.rows - 1;          // clamped: never stored
+            const float* src = P.in + grow * (long)P.ld_in + c4 * 4;
+            float* dst = st_lds + r * lda + c4 * 4;
+            for (int k0 = 0; k0 < P.K; k0 += 512) {
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = (k0 + 32 * u + c4 * 4 < P.K) ? ld4(src + k0 + 32 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 16; u++)
+                    if (k0 + 32 * u + c4 * 4 < P.K) *reinterpret_cast<float4*>(dst + k0 + 32 * u) = v[u];
+            }
+        }
+        __syncthreads();
+        const float* a_base = st_lds + j * lda + 4 * h;
+        for (int cg = ysl; cg < NCG; cg += ysplit) {
+            if (cg != ysl) prime(cg);
+            f32x16 acc = (f32x16){0};
+            float4 a_next = *reinterpret_cast<const float4*>(a_base);
+            for (int kb0 = 0; kb0 < P.KB; kb0 += ST_RING) {
+#pragma unroll
+                for (int u = 0; u < ST_RING; u++) {
+                    const int kb = kb0 + u;
+                    if (kb < P.KB) {
+                        const float4 a = a_next;
+                        a_next = *reinterpret_cast<const float4*>(a_base + min(kb + 1, P.KB - 1) * 8);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[u].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[u].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[u].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[u].w, acc, 0, 0, 0);
+                    }
+                    bq[u] = ld4(bp + (long)min(kb + ST_RING, P.KB - 1) * 256);
+                }
+            }
+            const int nb = cg * 4 + wave;
+            if (nb >= P.NB) continue;                       // (wave-uniform)
+            const int n = nb * 32 + j;
+            const bool n_ok = n < P.Nout;
+            const float bias = (P.bias && n_ok) ? P.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const long g = row0 + rin;
+                float v = acc[r] + bias;
+                if (P.relu) v = fmaxf(v, 0.f);
+                if (n_ok && g < P.rows) P.out[g * P.ld_out + P.col_off + n] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static bool rows32_ok(int mode, const MlpParams& P) {
+    static const bool off = getenv("PRCNN_NO_ROWS32") != nullptr;    // A/B switch (the layer kernel gives the same bits)
+    return !off && mode == MODE_PLAIN && !P.addY && P.pool_ns == 0 && !P.seg_cnt && P.vec_a && P.K % 8 == 0 && P.K >= 256 &&
+           P.K <= R32_MAX_K && P.Nout >= 128 && P.rows <= 4096;
+}
+
+static int launch_rows32(MlpParams& P, hipStream_t s) {
+    static PrcnnLdsLimit attr;
+    if (!attr.raise((const void*)mlp_rows32_kernel, 144 * 1024))
+        return prcnn_fail(PRCNN_EHIP, "prcnn_mlp(rows32): cannot raise the dynamic LDS limit");
+    const int split_max = prcnn_divup(P.NB, 4);
+    const size_t lds = (size_t)ST_ROWS * (P.K + 4) * sizeof(float);
+    hipLaunchKernelGGL(mlp_rows32_kernel, dim3((unsigned)min((long)prcnn_divup(P.rows, ST_ROWS) * split_max, 2048L)), dim3(256), lds, s,
+                       P, split_max);
+    PRCNN_LAUNCH_CHECK("prcnn_mlp(rows32)");
+    return PRCNN_OK;
 }
 
 // shapes the stack kernel takes (hoisted grouped form on flat row lists, no pooling)

@@ -321,3 +321,30 @@ def test_concurrent_threads_and_streams_are_reentrant(dev, cpu):
         for a, b in zip(par[i], serial[i]):
             assert np.array_equal(a, b)
         assert np.array_equal(serial[i][0], cpu.fps(clouds[i], 4096))
+
+
+@pytest.mark.gpu
+def test_short_plain_layers_rows32_kernel(dev, cpu):
+    """mlp_rows32_kernel (plain layers on <= 4096 rows, 256 <= K <= 1024): equal to the oracle at the MLP tolerance and BIT-identical
+    to the 128-row layer kernel (the same rows inside a longer launch), ragged row counts, column tails, wider output buffers"""
+    from pointrcnn_amd import ops
+    rng = np.random.default_rng(3)
+    for rows, K, N in ((2048, 1024, 512), (1, 256, 128), (33, 264, 200), (4096, 512, 512), (31, 1024, 130)):
+        x = rng.normal(size=(8192, K)).astype(np.float32)
+        w = (rng.normal(size=(N, K)) * 0.05).astype(np.float32)
+        b = rng.normal(size=(N,)).astype(np.float32)
+        xt = torch.from_numpy(x).to(dev)
+        lin = ops.PackedLinear(torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), relu=True)
+        long_run = ops.mlp_rows(xt, lin)                                  # 8192 rows: the layer kernel
+        out = torch.full((rows, N + 7), -7.0, device=dev)
+        ops.mlp_rows(xt[:rows], lin, out=(out, 3))                        # <= 4096 rows: the 32-row kernel, into a wider buffer
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:, 3:3 + N], long_run[:rows].cpu().numpy())
+        assert (got[:, :3] == -7.0).all() and (got[:, 3 + N:] == -7.0).all()
+        ref = cpu.linear_rows(x[:rows], w, b, relu=True)
+        assert np.abs(got[:, 3:3 + N] - ref).max() <= mlp_tol(ref)
+    # device-side row count
+    cnt = torch.tensor([100], dtype=torch.int32, device=dev)
+    out = torch.zeros((4096, N), device=dev)
+    ops.mlp_rows(xt[:4096], lin, out=(out, 0), rows_dev=cnt)
+    assert np.array_equal(out[:100].cpu().numpy(), long_run[:100].cpu().numpy()) and not out[100:].any()
