@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python bench.p
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-cpu-baseline --no-roofline --no-variants --streams 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python bench.py --workload train --steps 10 > /dev/null 2>&1
 python -m pointrcnn_amd.opbench > $O/opbench.jsonl 2> $O/opbench.err
-python profiles/summarize_rocprof.py $O/kt3 "default: python bench.py (16 batches in flight, hipGraph replay)" > $O/kernel_stats.txt
+python profiles/summarize_rocprof.py $O/kt3 "default: python bench.py (20 batches in flight, hipGraph replay)" > $O/kernel_stats.txt
 python profiles/summarize_rocprof.py $O/kt1 "python bench.py --streams 1 (one batch in flight)" > $O/kernel_stats_streams1.txt
 python profiles/summarize_rocprof.py $O/ktt "python bench.py --workload train --steps 10 (RPN training step, bs16, eager)" > $O/kernel_stats_train.txt
 # keep the merge small: only summaries travel back
