@@ -27,6 +27,7 @@ HOIST_FIRST_LAYER = True
 GROUP_DEDUP = os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"       # padding-free grouping (csrc/dedup.hip); 0 = A/B switch, same bits
 DEDUP_SPARSE_DIV = int(os.environ.get("PRCNN_DEDUP_SPARSE_DIV", "4"))  # groups with <= nsample/DIV hits run as flat rows
 STACK_ALL_FLAT = os.environ.get("PRCNN_STACK_ALL_FLAT", "1") != "0"      # A/B switch: stack-kernel scales keep a dense list when off
+STACK_ALL_FLAT_MAX_ROWS = 1 << 20
 
 
 def _channels_last(features):
@@ -187,8 +188,10 @@ class _PointnetSAModuleBase(nn.Module):
                 # Scales the two-layer stack kernel takes (wide SA3 / SA4 stacks in hoisted form) send EVERY group through the
                 # flat list: the stack kernel carries a row through both layers whatever the list length, so the dense list
                 # would buy nothing there and its three launches per scale (two layer kernels, one scatter) would run empty on
-                # most clouds.
-                all_flat = STACK_ALL_FLAT and _stack_scale(layers, act, src)
+                # most clouds.  Only for short levels (the RPN's SA3 / SA4): where the padded bound runs into millions of rows
+                # (the RCNN stage's 64-sample groups over 100 RoIs per frame) many groups ARE dense, and pooling them in the
+                # layer kernel's epilogue beats a round trip of their rows through HBM (two-stage detector 5.1 k vs 4.4 k frames/s).
+                all_flat = STACK_ALL_FLAT and B * M * ns <= STACK_ALL_FLAT_MAX_ROWS and _stack_scale(layers, act, src)
                 sp = ops.GroupSplit(idxs[i], new_xyz, N, ns if all_flat else max(1, ns // DEDUP_SPARSE_DIV), valid_n=valid_n)
                 xyz_f = xyz.view(1, B * N, 3)
                 src_f = None if src is None else _flatten_frames(src)
