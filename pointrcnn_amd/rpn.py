@@ -9,6 +9,8 @@ proposal layer lives in pointrcnn_amd/proposal_layer.py and is attached by point
 This is what bench.py times; the reference's own unchanged lib/net/rpn.py builds the same graph through
 `pointrcnn_amd.install()` (INTEGRATION.md).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,6 +19,16 @@ import pointrcnn_amd
 pointrcnn_amd.install()
 from pointnet2_lib.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG  # noqa: E402
 import pointnet2_lib.pointnet2.pytorch_utils as pt_utils  # noqa: E402
+
+
+from . import ops  # noqa: E402
+
+# sampling chain of all SA levels ahead of the set-abstraction work, on a side stream (see Pointnet2MSG._sample_ahead):
+# "auto" = in the training step only.  Measured on MI355X: training step 51.0 -> 48.8 ms; one inference batch in flight
+# 8.82 -> 8.52 ms per bs32 step (PRCNN_FPS_AHEAD=1); but 20 captured batches in flight 12.4 k -> 8.9 k frames/s -- every
+# graph's fork asks for a second hardware queue, and more than ~20 busy queues collide (bench.py, stream-count sweep).
+FPS_AHEAD = os.environ.get("PRCNN_FPS_AHEAD", "auto")
+_SIDE_STREAMS = {}
 
 
 class RPNConfig:
@@ -69,13 +81,42 @@ class Pointnet2MSG(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
+    def _sample_ahead(self, xyz):
+        """The furthest-point-sampling chain of ALL levels on a side stream.  Level k's sample set depends on level k-1's
+        and on nothing else (no features), and FPS is a serial chain on one workgroup per frame (4.8 ms at level 0, 5.7 ms
+        for the four levels, 32 of 256 CUs): with a single batch in flight -- latency mode, the training step -- the other
+        levels' samples can be drawn underneath the set-abstraction work of the levels before them.
+        -> per level (new_xyz, ready-event); the tensors are held by the caller until the end of the forward pass."""
+        cur = torch.cuda.current_stream()
+        side = _SIDE_STREAMS.get(cur.cuda_stream)
+        if side is None:
+            side = _SIDE_STREAMS[cur.cuda_stream] = torch.cuda.Stream()
+        side.wait_stream(cur)
+        ahead, x = [], xyz
+        with torch.cuda.stream(side):
+            for m in self.SA_modules:
+                idx = ops.furthest_point_sample(x, m.npoint)
+                x = ops.gather_rows(x, idx)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                ahead.append((x, ev, idx))
+        return side, ahead
+
     def forward(self, pointcloud):
         xyz, features = self._break_up_pc(pointcloud)
         l_xyz, l_features = [xyz], [features]
+        want = FPS_AHEAD == "1" or (FPS_AHEAD == "auto" and torch.is_grad_enabled())
+        side, ahead = self._sample_ahead(xyz) if (want and xyz.is_cuda) else (None, None)
         for i in range(len(self.SA_modules)):
-            li_xyz, li_features = self.SA_modules[i](l_xyz[i], l_features[i])
+            if ahead is not None:
+                torch.cuda.current_stream().wait_event(ahead[i][1])
+                li_xyz, li_features = self.SA_modules[i](l_xyz[i], l_features[i], ahead[i][0])
+            else:
+                li_xyz, li_features = self.SA_modules[i](l_xyz[i], l_features[i])
             l_xyz.append(li_xyz)
             l_features.append(li_features)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)      # (joins the fork: required inside a graph capture)
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
             l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
         return l_xyz[0], l_features[0]
