@@ -102,11 +102,13 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict_
         const int wmax = wave_max_i32_fused(__float_as_int(best));       // >= 0, or -1/-2: int order == float order
         const float wmaxf = __int_as_float(wmax);
         const int owner = __builtin_ctzll(__ballot(best == wmaxf));      // lowest lane holding the maximum
-        int istar = PPT - 1;
+        // lowest slot holding the maximum: every lane finds the lowest slot holding ITS maximum (2 VALU per slot), the owner's
+        // answer is read out -- a ballot + scalar shift / test / select per slot cost 5 instructions each, and a lone
+        // latency-bound wave pays ~4 cycles per instruction whatever unit runs it (tools/fps_timing.py)
+        int myslot = PPT - 1;
 #pragma unroll
-        for (int i = PPT - 2; i >= 0; i--)                               // lowest matching slot of that lane
-            if ((__ballot(pt[i] == wmaxf) >> owner) & 1ULL) istar = i;
-        istar = __builtin_amdgcn_readfirstlane(istar);
+        for (int i = PPT - 2; i >= 0; i--) myslot = (pt[i] == best) ? i : myslot;
+        const int istar = __builtin_amdgcn_readlane(myslot, owner);
         const int widx = (wave * 64 + owner) * PPT + istar;
         float sx = px[istar], sy = py[istar], sz = pz[istar];
         float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), owner));
@@ -246,6 +248,16 @@ __device__ __forceinline__ int row0_min_i32_fused(int v) {
     return __builtin_amdgcn_readlane(v, 15);
 }
 
+#ifdef PRCNN_FPS_TIMING            // dev build (tools/fps_timing.py): per-wave cycle sums of the loop's phases, frame 0
+__device__ unsigned long long prcnn_fps_dbg[16 * 8 + 16];
+PRCNN_API int prcnn_fps_timing_read(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(prcnn_fps_dbg), sizeof(prcnn_fps_dbg)) == hipSuccess ? 0 : -1;
+}
+#define FPS_T(...) __VA_ARGS__
+#else
+#define FPS_T(...)
+#endif
+
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ perm,
                                                           int N, int npoint, int32_t* __restrict__ idx_out) {
@@ -292,6 +304,8 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
     float cval = 1e10f; int corig = 0x7fffffff; float cx = 0.f, cy = 0.f, cz = 0.f;
     bool first = true;
 
+    FPS_T(unsigned long long t_upd = 0, t_wait = 0, t_red = 0, n_upd = 0, t_u1 = 0, t_u2 = 0, t_u3 = 0, t_u4 = 0; unsigned long long t0 = __builtin_readcyclecounter();)
+    FPS_T(const unsigned long long t_begin = t0;)
     for (int j = 1; j < npoint; j++) {
         // lower bound of the distance from the new sample to anything in this wave's box
         float gx = fmaxf(fmaxf(lox - x0, x0 - hix), 0.f);
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
         // (L and cval are >= 0 or cval = -1 for an all-padding wave: the int compare is the float compare; L < cval
         //  means some point MAY change.  L >= cval => provably nothing changes.)
         if (update) {
+            FPS_T(unsigned long long u0 = __builtin_readcyclecounter();)
             float best = -2.0f;
             if (PPT >= 2) {
                 const f32x2 qx = {x0, x0}, qy = {y0, y0}, qz = {z0, z0};
@@ -320,23 +335,30 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
                 float t = __builtin_fminf(pt[0], d);
                 pt[0] = t; best = t;
             }
+            FPS_T(unsigned long long u1 = __builtin_readcyclecounter(); t_u1 += u1 - u0;)
             const int wmax = wave_max_i32_fused(__float_as_int(best));
             const float wmaxf = __int_as_float(wmax);
+            FPS_T(unsigned long long u2 = __builtin_readcyclecounter(); t_u2 += u2 - u1;)
             // candidates = (lane, slot) with t == wmax; the one with the LOWEST ORIGINAL index wins.  Fast path (a
-            // unique maximum, the overwhelmingly common case): the slot masks live in SGPRs and the search runs on
-            // the scalar unit -- an updating wave is usually ALONE on its SIMD and latency-bound, so its VALU
-            // instruction count is what matters.
-            unsigned long long anym = 0ULL;
-            int total = 0, istar = 0;
+            // unique maximum, the overwhelmingly common case).  An updating wave is usually ALONE on its SIMD and issues one
+            // instruction every ~4-5 cycles, so its instruction count is the latency of the whole sample (measured with
+            // tools/fps_timing.py: ~1450 cycles per update, of which a per-slot ballot + scalar select chain took ~600).
+            // Here every lane finds the lowest slot holding ITS maximum and how many slots do (3 VALU per slot, no scalar
+            // chain); one ballot finds the lanes holding the wave maximum; unique lane with a unique slot = fast path.
+            int myslot = 0, mycnt = 0;
 #pragma unroll
             for (int i = PPT - 1; i >= 0; i--) {
-                unsigned long long m = __ballot(pt[i] == wmaxf);
-                total += __popcll(m);
-                if (m) { istar = i; anym = m; }
+                const bool e = pt[i] == best;
+                myslot = e ? i : myslot;
+                mycnt += e ? 1 : 0;
             }
+            const unsigned long long anym = __ballot(best == wmaxf);
+            const int owner0 = __builtin_ctzll(anym);
+            const int total = (__popcll(anym) == 1 && __builtin_amdgcn_readlane(mycnt, owner0) == 1) ? 1 : 2;
+            int istar = __builtin_amdgcn_readlane(myslot, owner0);
+            FPS_T(unsigned long long u3 = __builtin_readcyclecounter(); t_u3 += u3 - u2;)
             if (total == 1) {
-                istar = __builtin_amdgcn_readfirstlane(istar);
-                const int owner = __builtin_ctzll(anym);
+                const int owner = owner0;
                 corig = s_po[istar * BLOCK + (wave << 6) + owner];          // own wave's entries: no barrier needed
                 float sx = px[istar], sy = py[istar], sz = pz[istar];
                 cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), owner));
@@ -359,10 +381,13 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
             }
             cval = wmaxf;
             first = false;
+            FPS_T(t_u4 += __builtin_readcyclecounter() - u3;)
         }
+        FPS_T(unsigned long long t1 = __builtin_readcyclecounter(); t_upd += t1 - t0; n_upd += update ? 1 : 0;)
         float* s = slot[j & 1][wave];
         if (lane == 0) { s[0] = cval; s[1] = __int_as_float(corig); s[2] = cx; s[3] = cy; s[4] = cz; }
         __syncthreads();
+        FPS_T(unsigned long long t2 = __builtin_readcyclecounter(); t_wait += t2 - t1;)
         const float* r = slot[j & 1][lane < NW ? lane : 0];
         int v = lane < NW ? __float_as_int(r[0]) : (int)0x80000000;
         int id = __float_as_int(r[1]);
@@ -374,7 +399,10 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
         y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry), wwin));
         z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rz), wwin));
         if (tid == 0) out[j] = gorig;
+        FPS_T(t0 = __builtin_readcyclecounter(); t_red += t0 - t2;)
     }
+    FPS_T(if (b == 0 && lane == 0) { unsigned long long* d = prcnn_fps_dbg + wave * 8; d[0] = t_upd; d[1] = t_wait; d[2] = t_red; d[3] = n_upd;
+                                     d[4] = __builtin_readcyclecounter() - t_begin; d[5] = t_u1; d[6] = t_u2; d[7] = t_u3; prcnn_fps_dbg[128 + wave] = t_u4; })
 }
 
 // =====================================================================================================
@@ -444,11 +472,10 @@ __global__ __launch_bounds__(1024) void fps_multi_kernel(const float* __restrict
         const int wmax = wave_max_i32_fused(__float_as_int(best));
         const float wmaxf = __int_as_float(wmax);
         const int owner = __builtin_ctzll(__ballot(best == wmaxf));
-        int istar = PPT - 1;
+        int myslot = PPT - 1;                                             // (as fps_reg_kernel: per-lane lowest slot, owner's read out)
 #pragma unroll
-        for (int i = PPT - 2; i >= 0; i--)
-            if ((__ballot(pt[i] == wmaxf) >> owner) & 1ULL) istar = i;
-        istar = __builtin_amdgcn_readfirstlane(istar);
+        for (int i = PPT - 2; i >= 0; i--) myslot = (pt[i] == best) ? i : myslot;
+        const int istar = __builtin_amdgcn_readlane(myslot, owner);
         const int widx = (wave * 64 + owner) * PPT + istar;
         float sx = px[istar], sy = py[istar], sz = pz[istar];
         float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), owner));
