@@ -264,12 +264,13 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
     constexpr int BLOCK = 1024, NW = 16;
     typedef typename fvec_t<PPT>::type fvec;
     typedef int ivec __attribute__((ext_vector_type(PPT >= 2 ? PPT : 2)));
-    __shared__ float slot[2][NW][8];   // val, orig(bits), x, y, z
+    __shared__ float slot[2][NW][4];   // x, y, z of every wave's candidate
+    __shared__ unsigned long long cell[3];
     // original indices of the points a lane holds: only the winner's is ever needed, so they live in LDS (slot-major:
     // s_po[i * 1024 + tid]) instead of PPT more VGPRs per lane -- at 96 VGPRs the four FPS waves of a SIMD left 128
     // registers, too few for ANY of the MLP kernels (160-216), i.e. a CU hosting an FPS workgroup was lost to them
     extern __shared__ int s_po[];
-    __builtin_amdgcn_s_setprio(3);     // the serial chain every batch waits for: its few instructions go first
+    __builtin_amdgcn_s_setprio(2);     // the serial chain every batch waits for: its few instructions go first (3 while a wave updates)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ p = xyz + (size_t)b * N * 3;
@@ -299,6 +300,8 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
     hix = wave_max_f32_fused(hix); hiy = wave_max_f32_fused(hiy); hiz = wave_max_f32_fused(hiz);
 
     if (tid == 0 && npoint > 0) out[0] = 0;
+    if (tid < 3) cell[tid] = 0ULL;
+    __syncthreads();
     float x0 = p[0], y0 = p[1], z0 = p[2];
     // cached candidate of this wave (uniform): value, original index, coordinates
     float cval = 1e10f; int corig = 0x7fffffff; float cx = 0.f, cy = 0.f, cz = 0.f;
@@ -306,6 +309,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
 
     FPS_T(unsigned long long t_upd = 0, t_wait = 0, t_red = 0, n_upd = 0, t_u1 = 0, t_u2 = 0, t_u3 = 0, t_u4 = 0; unsigned long long t0 = __builtin_readcyclecounter();)
     FPS_T(const unsigned long long t_begin = t0;)
+    int cb = 1;                                // exchange cell of sample j: j % 3
     for (int j = 1; j < npoint; j++) {
         // lower bound of the distance from the new sample to anything in this wave's box
         float gx = fmaxf(fmaxf(lox - x0, x0 - hix), 0.f);
@@ -316,6 +320,10 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
         // (L and cval are >= 0 or cval = -1 for an all-padding wave: the int compare is the float compare; L < cval
         //  means some point MAY change.  L >= cval => provably nothing changes.)
         if (update) {
+            // the sample waits for the updating wave(s): ahead of the three waves that share the SIMD and are still
+            // working through their own bound test / exchange read (oldest-first arbitration otherwise: tools/fps_timing.py
+            // shows the fourth wave of a SIMD taking 2-3x as long for the same instructions)
+            __builtin_amdgcn_s_setprio(3);
             FPS_T(unsigned long long u0 = __builtin_readcyclecounter();)
             float best = -2.0f;
             if (PPT >= 2) {
@@ -381,23 +389,37 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
             }
             cval = wmaxf;
             first = false;
+            __builtin_amdgcn_s_setprio(2);
             FPS_T(t_u4 += __builtin_readcyclecounter() - u3;)
         }
         FPS_T(unsigned long long t1 = __builtin_readcyclecounter(); t_upd += t1 - t0; n_upd += update ? 1 : 0;)
-        float* s = slot[j & 1][wave];
-        if (lane == 0) { s[0] = cval; s[1] = __int_as_float(corig); s[2] = cx; s[3] = cy; s[4] = cz; }
+        // Exchange: every wave folds its candidate into ONE 64-bit LDS cell with an atomic max and parks the coordinates in
+        // its slot; after the barrier a wave reads the cell and the winner's slot -- two dependent LDS reads and ~20
+        // instructions, where reading all 16 candidates and reducing them twice by DPP (maximum, then lowest index among
+        // equals) was ~60 instructions per wave and sample.  key = [value, order-preserving | 2^28-1 - original index | wave]:
+        // the largest key is the largest value, ties -> lowest original index.  Cells rotate over three (the next one is
+        // cleared by wave 0 while nobody can still be reading it: its readers passed the previous barrier).
+        if (lane == 0) {
+            float* s = slot[j & 1][wave];
+            s[0] = cx; s[1] = cy; s[2] = cz;
+            const unsigned hi = (unsigned)__float_as_int(cval) ^ 0x80000000u;
+            const unsigned lo = ((0xFFFFFFFu - (unsigned)min(corig, 0xFFFFFFF)) << 4) | (unsigned)wave;
+            // (one lane, one instruction: atomicMax() would be wrapped in the compiler's wave-aggregation loop, ~25 more
+            //  instructions per wave and sample on the critical path)
+            const unsigned long long key = ((unsigned long long)hi << 32) | lo;
+            asm volatile("ds_max_u64 %0, %1" : : "v"((unsigned)(size_t)&cell[cb]), "v"(key) : "memory");
+            if (wave == 0) cell[cb == 2 ? 0 : cb + 1] = 0ULL;
+        }
         __syncthreads();
         FPS_T(unsigned long long t2 = __builtin_readcyclecounter(); t_wait += t2 - t1;)
-        const float* r = slot[j & 1][lane < NW ? lane : 0];
-        int v = lane < NW ? __float_as_int(r[0]) : (int)0x80000000;
-        int id = __float_as_int(r[1]);
-        float rx = r[2], ry = r[3], rz = r[4];
-        const int gmax = row0_max_i32_fused(v);
-        const int gorig = row0_min_i32_fused((v == gmax && lane < NW) ? id : 0x7fffffff);
-        const int wwin = __builtin_ctzll(__ballot(v == gmax && id == gorig && lane < NW));
-        x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx), wwin));
-        y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry), wwin));
-        z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rz), wwin));
+        const unsigned long long kwin = cell[cb];
+        const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)kwin);
+        const int gorig = (int)(0xFFFFFFFu - (klo >> 4));
+        const float* r = slot[j & 1][klo & 15u];
+        x0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r[0])));
+        y0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r[1])));
+        z0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r[2])));
+        cb = cb == 2 ? 0 : cb + 1;
         if (tid == 0) out[j] = gorig;
         FPS_T(t0 = __builtin_readcyclecounter(); t_red += t0 - t2;)
     }
