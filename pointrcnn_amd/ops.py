@@ -96,6 +96,7 @@ def gather_rows(in_cl, idx):
 # Frames with at least this many points are searched through a per-frame grid (csrc/grid.hip) instead of a full scan:
 # identical results, ~N/30 of the distance evaluations.  PRCNN_GRID_SEARCH=0 forces the scans (A/B, debugging).
 GRID_MIN_POINTS = 2048 if os.environ.get("PRCNN_GRID_SEARCH", "1") != "0" else 1 << 62
+THREE_NN_GRID_MIN = int(os.environ.get("PRCNN_THREE_NN_GRID_MIN", "1024")) if GRID_MIN_POINTS < (1 << 62) else 1 << 62   # known points
 DENSE_SCAN = os.environ.get("PRCNN_DENSE_SCAN", "1") != "0"      # dense frames fall back to the scan (A/B switch, same results)
 BQ_GRID_CELLS = int(os.environ.get("PRCNN_BQ_GRID_CELLS", "128"))       # cells per axis of the ball-query grid (64 | 128)
 
@@ -181,7 +182,7 @@ def three_nn(unknown, known, want_weight=False):
     d2 = torch.empty((B, n, 3), dtype=_F32, device=unknown.device)
     idx = torch.empty((B, n, 3), dtype=_INT, device=unknown.device)
     w = torch.empty((B, n, 3), dtype=_F32, device=unknown.device) if want_weight else None
-    if m >= GRID_MIN_POINTS and B > 0 and n > 0:
+    if m >= THREE_NN_GRID_MIN and B > 0 and n > 0:
         g = Grid(known, 0.0)
         _cabi.check(_cabi.lib().prcnn_three_nn_grid(_p(g.buf), _p(unknown), B, n, m, _p(d2), _p(idx), _p(w), _stream()),
                     "prcnn_three_nn_grid")

@@ -121,3 +121,28 @@ def test_dense_frames_fall_back_to_the_scan_with_identical_results(dev, cpu):
     one = ops.ball_query_grid(g, q, rb, nsb, xyz=x)                              # single radius through the same path
     assert torch.equal(one, gb)
     assert torch.equal(ops.ball_query2(ra, nsa, rb, nsb, x, q)[1], gb)           # what the modules call
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [1024, 256, 67])
+def test_grid_three_nn_on_small_known_sets_equals_scan(dev, cpu, m):
+    """ops.three_nn takes the grid from 1024 known points on (round 2: FP1's 4096 x 1024 search, 88 -> 47 us incl. the grid
+    build): sparse grids (well under one point per cell, many empty rings) must still give the scan's bits -- incl. duplicates"""
+    from pointrcnn_amd import ops
+    lib = ops._cabi.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for seed, dup in ((3, False), (4, True)):
+        known_np = kitti_cloud(3, m, seed=seed)
+        if dup:
+            known_np[:, m // 2:] = known_np[:, :m - m // 2]
+        unk_np = kitti_cloud(3, 4096, seed=seed + 10)
+        known, unk = torch.from_numpy(known_np).to(dev), torch.from_numpy(unk_np).to(dev)
+        g = ops.Grid(known, 0.0)
+        d2, i3, w3 = (torch.empty((3, 4096, 3), device=dev), torch.empty((3, 4096, 3), dtype=torch.int32, device=dev),
+                      torch.empty((3, 4096, 3), device=dev))
+        sd, si, sw = torch.empty_like(d2), torch.empty_like(i3), torch.empty_like(w3)
+        ops._cabi.check(lib.prcnn_three_nn_grid(g.buf.data_ptr(), unk.data_ptr(), 3, 4096, m, d2.data_ptr(), i3.data_ptr(), w3.data_ptr(), st), "grid")
+        ops._cabi.check(lib.prcnn_three_nn(unk.data_ptr(), known.data_ptr(), 3, 4096, m, sd.data_ptr(), si.data_ptr(), sw.data_ptr(), st), "scan")
+        assert torch.equal(i3, si) and torch.equal(d2, sd) and torch.equal(w3, sw)
+        od, oi = cpu.three_nn(unk_np, known_np)
+        assert np.array_equal(i3.cpu().numpy(), oi)
