@@ -1097,7 +1097,10 @@ __device__ __forceinline__ void fchain_layer(const f32x16 (&in)[NBI], f32x16 (&o
 #endif
 template <int MODE> struct FAST_RING { static constexpr int D = MODE == MODE_PLAIN ? FAST_RING_PLAIN : (MODE == MODE_GROUP ? FAST_RING_GROUP : FAST_RING_INTERP); };
 template <int MODE, int NB0, int NB1, int NB2>
-__global__ __launch_bounds__(256) void mlp_chain_fast_kernel(const ChainParams Cin) {
+// (the plain-row instances with a narrow second layer -- the heads -- are asked for three waves per SIMD: 164 registers without a spill where the compiler
+//  settles at 180 unprompted, -3 % per launch, and a wave still fits next to a resident FPS workgroup; the interpolating
+//  instance spills at that budget, 235 -> 277 us, and keeps two)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == MODE_PLAIN && NB1 <= 3) ? 3 : 2, 8))) void mlp_chain_fast_kernel(const ChainParams Cin) {
     ChainParams C = Cin;
     C.a.rows = effective_rows(Cin.a);
     const MlpParams& P = C.a;
