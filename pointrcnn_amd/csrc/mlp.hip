@@ -297,25 +297,52 @@ __device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)
     // one after the other into As0, each followed by the stores of the column blocks that lie in it.
     bool staged = false;
     int npass = 1;
+    // A thread stages the 16-byte column piece (tid % 16) of rows tid / 16 + 16 u, u = 0..7.  Four rows at a time: their index /
+    // weight triples first, then their twelve gathers, then the arithmetic -- two dependent round trips per four rows.  (Row by
+    // row, with a 64-bit division for the frame of each, the loop was eight times two exposed round trips: ~10 of the ~30 us a
+    // workgroup of FP1's layer stays resident, whatever the locality of the gathers -- tools/interp_volume_probe.py.)
     auto stage_half = [&](int hf, float* T, int ldt) {
         const int ncol0 = (nb0 + hf * 2) * 32;
-        for (int f = tid; f < MLP_BM * 16; f += MLP_THREADS) {
-            const int r = f >> 4, c = (f & 15) * 4, n = ncol0 + c;
-            const long g = row0 + r;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g < P.rows && n < P.Nout) {
-                const int b = (int)(g / P.n);
-                const int32_t* id = P.idx3 + g * 3;
-                const float* w = P.w3 + g * 3;
-                const float* y = P.addY + (long)b * P.m * P.ldY + n;
-                const float4 y0 = ld4(y + (long)id[0] * P.ldY), y1 = ld4(y + (long)id[1] * P.ldY), y2 = ld4(y + (long)id[2] * P.ldY);
-                const float w0 = w[0], w1 = w[1], w2 = w[2];
-                o.x = (w0 * y0.x + w1 * y1.x) + w2 * y2.x;           // same expression as interp_gather
-                o.y = (w0 * y0.y + w1 * y1.y) + w2 * y2.y;
-                o.z = (w0 * y0.z + w1 * y1.z) + w2 * y2.z;
-                o.w = (w0 * y0.w + w1 * y1.w) + w2 * y2.w;
+        const int c = (tid & 15) * 4, n = ncol0 + c, rbase = tid >> 4;
+        const bool col_ok = n < P.Nout;
+        // frame of a row: a 128-row tile spans at most two frames when a frame has at least 128 rows
+        const long bfirst = row0 / P.n;                       // (workgroup-uniform: one scalar division)
+        const long next_frame_row = (bfirst + 1) * (long)P.n;
+        const bool two_frames_at_most = P.n >= MLP_BM;
+#pragma unroll
+        for (int q = 0; q < MLP_BM / 64; q++) {
+            int32_t id[4][3];
+            float w[4][3];
+            const float* ybase[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const long g = row0 + rbase + 16 * (q * 4 + u);
+                ok[u] = g < P.rows && col_ok;
+                const long gg = ok[u] ? g : row0;               // (row0 < P.rows: the tile exists)
+                const int32_t* ip = P.idx3 + gg * 3;
+                const float* wp = P.w3 + gg * 3;
+                id[u][0] = ip[0]; id[u][1] = ip[1]; id[u][2] = ip[2];
+                w[u][0] = wp[0]; w[u][1] = wp[1]; w[u][2] = wp[2];
+                const long b = two_frames_at_most ? bfirst + (gg >= next_frame_row ? 1 : 0) : gg / P.n;
+                ybase[u] = P.addY + b * P.m * P.ldY + (col_ok ? n : 0);
             }
-            *reinterpret_cast<float4*>(T + r * ldt + c) = o;
+            float4 y[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) y[u][k] = ld4(ybase[u] + (long)id[u][k] * P.ldY);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[u]) {
+                    o.x = (w[u][0] * y[u][0].x + w[u][1] * y[u][1].x) + w[u][2] * y[u][2].x;   // same expression as interp_gather
+                    o.y = (w[u][0] * y[u][0].y + w[u][1] * y[u][1].y) + w[u][2] * y[u][2].y;
+                    o.z = (w[u][0] * y[u][0].z + w[u][1] * y[u][1].z) + w[u][2] * y[u][2].z;
+                    o.w = (w[u][0] * y[u][0].w + w[u][1] * y[u][1].w) + w[u][2] * y[u][2].w;
+                }
+                *reinterpret_cast<float4*>(T + (rbase + 16 * (q * 4 + u)) * ldt + c) = o;
+            }
         }
     };
     if (MODE == MODE_PLAIN && ADDY && P.addY) {
