@@ -204,7 +204,11 @@ int prcnn_mlp_rows_addinterp(const float* in, int ld_in, int K, const float* wpa
  * pool_ns == nsample or 0).  Only a fixed set of width combinations is instantiated: ask
  * prcnn_mlp_chain_supported first, or handle PRCNN_EUNSUPPORTED by issuing the per-layer calls.
  * mode: 0 = rows, 1 = group, 2 = interp.  act_wx / act_bias: hoisted first layer, as for prcnn_mlp_group /
- * prcnn_mlp_interp (the chain then starts at the second layer). */
+ * prcnn_mlp_interp (the chain then starts at the second layer).
+ * One more shape (round 2): mode 1, TWO layers wider than 128 (nout[l] <= 384 / 512), un-pooled, nsample 1, hoisted first
+ * layer with C <= 256 -- the flat row lists of the wide set-abstraction levels -- runs as a 32-row two-layer stack through
+ * LDS (same bits as the per-layer calls); prcnn_mlp_chain_supported answers 1 for it from the widths alone, the call itself
+ * returns PRCNN_EUNSUPPORTED if the other conditions are not met. */
 int prcnn_mlp_chain_supported(int mode, int nlayers, const int* nout, int pool_ns);
 int prcnn_mlp_chain_rows(const float* in, int ld_in, int64_t rows, int K, int nlayers, const float* const* wpack,
                          const float* const* bias, const int* nout, const int* relu, float* out, int ld_out,
