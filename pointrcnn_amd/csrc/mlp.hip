@@ -2056,7 +2056,9 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
 #undef STACK_CASE
     }
     // SA level 0: xyz-only rows, three narrow layers, pooled -- persistent register-weight kernel
-    if (mode == MODE_GROUP && P.C == 0 && !P.act && P.K == 3 && C.nlayers == 3 && P.new_xyz && P.pool_ns == P.ns && C.N2 % 4 == 0 &&
+    // (pooled groups, or -- nsample 1, no pooling -- the flat row list of the padding-free path: the same kernel writes rows)
+    if (mode == MODE_GROUP && P.C == 0 && !P.act && P.K == 3 && C.nlayers == 3 && P.new_xyz &&
+        (P.pool_ns == P.ns || (P.pool_ns == 0 && P.ns == 1)) && C.N2 % 4 == 0 &&
         getenv("PRCNN_NO_SA0") == nullptr) {              // (A/B switch; the generic chain kernel gives the same bits)
         // persistent: one resident workgroup per occupancy slot (256 CUs x 3 or 2 workgroups at 115 / 243 registers)
 #define SA0_CASE(W0, W1, NBL, NSV)                                                                                        \
@@ -2068,6 +2070,8 @@ static int dispatch_chain(int mode, ChainParams& C, hipStream_t s) {
         }
         SA0_CASE(16, 16, 1, 16)
         SA0_CASE(32, 32, 2, 32)
+        SA0_CASE(16, 16, 1, 1)
+        SA0_CASE(32, 32, 2, 1)
 #undef SA0_CASE
     }
     // Opt-in (PRCNN_PERSISTENT_CHAIN=1): 6-12 % faster per launch with ONE batch in flight, but a persistent workgroup
