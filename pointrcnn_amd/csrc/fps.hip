@@ -263,7 +263,6 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
                                                           int N, int npoint, int32_t* __restrict__ idx_out) {
     constexpr int BLOCK = 1024, NW = 16;
     typedef typename fvec_t<PPT>::type fvec;
-    typedef int ivec __attribute__((ext_vector_type(PPT >= 2 ? PPT : 2)));
     __shared__ float slot[2][NW][4];   // x, y, z of every wave's candidate
     __shared__ unsigned long long cell[3];
     // original indices of the points a lane holds: only the winner's is ever needed, so they live in LDS (slot-major:
