@@ -19,4 +19,4 @@ PRCNN_API int prcnn_abi_version(void) { return 5; }
 #define PRCNN_BUILD_ID "PRCNN_BUILD_ID=unknown"
 #endif
 // the macro carries the "PRCNN_BUILD_ID=" tag so that the digest can also be read from the file without loading it
-PRCNN_API const char* prcnn_build_id(void) { return PRCNN_BUILD_ID + sizeof("PRCNN_BUILD_ID=") - 1; }
+PRCNN_API const char* prcnn_build_id(void) { return &PRCNN_BUILD_ID[sizeof("PRCNN_BUILD_ID=") - 1]; }
