@@ -11,11 +11,15 @@ kernel), neither of which exists for ROCm; here the two heavy pieces are HIP ker
   * the greedy gt<->detection matching (`compute_statistics_jit`) for every (frame, score threshold) pair at once:
     3769 frames x 41 thresholds = 154 k independent sequential problems, one thread each.
 
-Everything else (label parsing, `clean_data`, threshold selection, PR / mAP assembly, printing) is cheap bookkeeping
-and stays in numpy, restated from eval.py line by line.  The compute backend is injected (`backend=`) so that the tests
-can run the same host code on the CPU oracle; the default backend is the HIP library and nothing else.
+Everything else (label parsing, the per-object ignore classification, threshold selection, PR / mAP assembly, printing)
+is host bookkeeping, written as whole-array numpy over ONE concatenated table of all frames' objects (`_Table`): the
+reference walks objects and frames in Python loops (eval.py:29-84, 400-440, 496-544), which dominates its run time once
+the IoU and matching are kernels.  The protocol (class aliases, the height / occlusion / truncation limits, the
+41-point recall sampling, the running maximum over recall, 11-point interpolation) fixes the numbers; the summation
+orders that decide the last bit (frame order for the similarity sums, left-to-right for the 11-point sum) are kept by
+construction (`np.cumsum`, which accumulates sequentially, where `np.sum` would add pairwise).  The compute backend is
+injected (`backend=`) so that the tests can run the same host code on the CPU oracle; the default backend is the HIP library and nothing else.
 """
-import io as sysio
 import pathlib
 import re
 
@@ -23,50 +27,42 @@ import numpy as np
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# kitti_common.py subset
+# label files -> annotation dictionaries (the dictionaries are the reference's interchange format, kitti_common.py:292-346)
 # ----------------------------------------------------------------------------------------------------------------
+_FIELDS = 15            # type, truncated, occluded, alpha, bbox(4), h w l, x y z, ry [, score]
+
+
 def get_image_index_str(img_idx):
-    return "{:06d}".format(img_idx)
+    return "%06d" % img_idx
 
 
 def get_label_anno(label_path):
-    """kitti_common.py:292-329 -- one label / detection txt file -> annotation dict (dimensions reordered to l,h,w)"""
+    """one KITTI label / detection txt file -> annotation dict; `dimensions` reordered from the file's (h, w, l) to (l, h, w)
+    as kitti_common.py:292-329 delivers them"""
     with open(label_path, "r") as f:
-        content = [line.strip().split(" ") for line in f.readlines()]
-    a = {}
-    a["name"] = np.array([x[0] for x in content])
-    a["truncated"] = np.array([float(x[1]) for x in content])
-    a["occluded"] = np.array([int(x[2]) for x in content])
-    a["alpha"] = np.array([float(x[3]) for x in content])
-    a["bbox"] = np.array([[float(v) for v in x[4:8]] for x in content]).reshape(-1, 4)
-    a["dimensions"] = np.array([[float(v) for v in x[8:11]] for x in content]).reshape(-1, 3)[:, [2, 0, 1]]
-    a["location"] = np.array([[float(v) for v in x[11:14]] for x in content]).reshape(-1, 3)
-    a["rotation_y"] = np.array([float(x[14]) for x in content]).reshape(-1)
-    if len(content) != 0 and len(content[0]) == 16:
-        a["score"] = np.array([float(x[15]) for x in content])
-    else:
-        a["score"] = np.zeros([len(a["bbox"])])
-    return a
+        rows = [ln.split() for ln in f.read().splitlines() if ln.strip()]
+    n = len(rows)
+    ncol = len(rows[0]) if n else _FIELDS
+    names = np.array([r[0] for r in rows]) if n else np.array([])
+    num = np.array([r[1:] for r in rows], dtype=np.float64).reshape(n, ncol - 1)
+    return {"name": names, "truncated": num[:, 0], "occluded": num[:, 1].astype(np.int64), "alpha": num[:, 2],
+            "bbox": num[:, 3:7], "dimensions": num[:, [9, 7, 8]], "location": num[:, 10:13], "rotation_y": num[:, 13],
+            "score": num[:, 14] if ncol == _FIELDS + 1 else np.zeros(n)}
 
 
 def get_label_annos(label_folder, image_ids=None):
-    """kitti_common.py:331-346"""
-    if image_ids is None:
-        prog = re.compile(r"^\d{6}.txt$")
-        image_ids = sorted(int(p.stem) for p in pathlib.Path(label_folder).glob("*.txt") if prog.match(p.name))
-    if not isinstance(image_ids, list):
-        image_ids = list(range(image_ids))
+    """all (or the listed) frames of a folder, in index order (kitti_common.py:331-346)"""
     folder = pathlib.Path(label_folder)
+    if image_ids is None:
+        image_ids = sorted(int(p.stem) for p in folder.glob("*.txt") if re.fullmatch(r"\d{6}\.txt", p.name))
+    elif not isinstance(image_ids, list):
+        image_ids = list(range(image_ids))
     return [get_label_anno(folder / (get_image_index_str(i) + ".txt")) for i in image_ids]
 
 
 def filter_annos_low_score(image_annos, thresh):
-    """kitti_common.py:215-227"""
-    out = []
-    for anno in image_annos:
-        keep = [i for i, s in enumerate(anno["score"]) if s >= thresh]
-        out.append({k: anno[k][keep] for k in anno.keys()})
-    return out
+    """drop detections scoring below `thresh` (kitti_common.py:215-227)"""
+    return [{k: v[np.flatnonzero(np.asarray(a["score"]) >= thresh)] for k, v in a.items()} for a in image_annos]
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -100,65 +96,16 @@ class HipBackend:
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# eval.py
+# the evaluation protocol, on one concatenated object table
 # ----------------------------------------------------------------------------------------------------------------
-def get_thresholds(scores, num_gt, num_sample_pts=41):
-    """eval.py:7-26"""
-    scores = np.sort(scores)[::-1]
-    current_recall = 0
-    thresholds = []
-    for i, score in enumerate(scores):
-        l_recall = (i + 1) / num_gt
-        r_recall = (i + 2) / num_gt if i < (len(scores) - 1) else l_recall
-        if ((r_recall - current_recall) < (current_recall - l_recall)) and (i < (len(scores) - 1)):
-            continue
-        thresholds.append(score)
-        current_recall += 1 / (num_sample_pts - 1.0)
-    return thresholds
-
-
-def clean_data(gt_anno, dt_anno, current_class, difficulty):
-    """eval.py:29-84"""
-    CLASS_NAMES = ["car", "pedestrian", "cyclist"]
-    MIN_HEIGHT = [40, 25, 25]
-    MAX_OCCLUSION = [0, 1, 2]
-    MAX_TRUNCATION = [0.15, 0.3, 0.5]
-    dc_bboxes, ignored_gt, ignored_dt = [], [], []
-    current_cls_name = CLASS_NAMES[current_class].lower()
-    num_valid_gt = 0
-    for i in range(len(gt_anno["name"])):
-        bbox = gt_anno["bbox"][i]
-        gt_name = gt_anno["name"][i].lower()
-        height = bbox[3] - bbox[1]
-        if gt_name == current_cls_name:
-            valid_class = 1
-        elif current_cls_name == "pedestrian" and gt_name == "person_sitting":
-            valid_class = 0
-        elif current_cls_name == "car" and gt_name == "van":
-            valid_class = 0
-        else:
-            valid_class = -1
-        ignore = (gt_anno["occluded"][i] > MAX_OCCLUSION[difficulty]) or (gt_anno["truncated"][i] > MAX_TRUNCATION[difficulty]) \
-            or (height <= MIN_HEIGHT[difficulty])
-        if valid_class == 1 and not ignore:
-            ignored_gt.append(0)
-            num_valid_gt += 1
-        elif valid_class == 0 or (ignore and valid_class == 1):
-            ignored_gt.append(1)
-        else:
-            ignored_gt.append(-1)
-        if gt_anno["name"][i] == "DontCare":
-            dc_bboxes.append(gt_anno["bbox"][i])
-    for i in range(len(dt_anno["name"])):
-        valid_class = 1 if dt_anno["name"][i].lower() == current_cls_name else -1
-        height = abs(dt_anno["bbox"][i, 3] - dt_anno["bbox"][i, 1])
-        if height < MIN_HEIGHT[difficulty]:
-            ignored_dt.append(1)
-        elif valid_class == 1:
-            ignored_dt.append(0)
-        else:
-            ignored_dt.append(-1)
-    return num_valid_gt, ignored_gt, ignored_dt, dc_bboxes
+_CLASS_TO_NAME = {0: "Car", 1: "Pedestrian", 2: "Cyclist", 3: "Van", 4: "Person_sitting"}
+_EVAL_CLASSES = ("car", "pedestrian", "cyclist")             # eval.py:30
+_NEIGHBOUR_CLASS = {"car": "van", "pedestrian": "person_sitting"}   # evaluated as "ignored", not as misses (eval.py:45-50)
+# per difficulty (easy, moderate, hard): minimum 2-D box height [px], maximum occlusion level, maximum truncation (eval.py:31-33)
+_MIN_HEIGHT = np.array([40.0, 25.0, 25.0])
+_MAX_OCCLUSION = np.array([0, 1, 2])
+_MAX_TRUNCATION = np.array([0.15, 0.3, 0.5])
+N_SAMPLE_PTS = 41
 
 
 def _offsets(counts):
@@ -167,198 +114,238 @@ def _offsets(counts):
     return off
 
 
+def _cat(annos, key, width=None, dtype=np.float64):
+    parts = [np.asarray(a[key]).reshape(-1, width) if width else np.asarray(a[key]).reshape(-1) for a in annos]
+    if not parts:
+        return np.zeros((0, width) if width else (0,), dtype)
+    return np.concatenate(parts, 0).astype(dtype, copy=False)
+
+
+class _Table:
+    """every object of every frame of one annotation list in flat arrays + frame offsets; built once per eval_class call and
+    shared by all (class, difficulty) settings"""
+
+    def __init__(self, annos, is_dt):
+        self.count = np.array([len(a["name"]) for a in annos], np.int64)
+        self.off = _offsets(self.count)
+        names = [np.asarray(a["name"], dtype=str).reshape(-1) for a in annos]
+        self.name = np.concatenate(names) if names else np.array([], dtype=str)
+        self.lname = np.char.lower(self.name) if self.name.size else self.name
+        self.bbox = _cat(annos, "bbox", 4)
+        self.alpha = _cat(annos, "alpha")
+        if is_dt:
+            self.score = _cat(annos, "score")
+            self.data = np.concatenate([self.bbox, self.alpha[:, None], self.score[:, None]], 1)     # eval.py:432-435
+        else:
+            self.occluded = _cat(annos, "occluded")
+            self.truncated = _cat(annos, "truncated")
+            self.data = np.concatenate([self.bbox, self.alpha[:, None]], 1)                          # eval.py:430-431
+        self.frame = np.repeat(np.arange(len(annos)), self.count)
+
+
+def _classify(gt, dt, current_class, difficulty):
+    """The per-object ignore codes of eval.py:29-84 for all frames at once.
+    ground truth: 0 = counts, 1 = matched without reward or penalty (neighbour class, or too hard for this difficulty),
+    -1 = other class; detections: 0 = counts, 1 = too small, -1 = other class; DontCare regions per frame."""
+    cls = _EVAL_CLASSES[current_class]
+    same = gt.lname == cls
+    neighbour = gt.lname == _NEIGHBOUR_CLASS.get(cls, "\0")
+    height = gt.bbox[:, 3] - gt.bbox[:, 1]
+    too_hard = (gt.occluded > _MAX_OCCLUSION[difficulty]) | (gt.truncated > _MAX_TRUNCATION[difficulty]) \
+        | (height <= _MIN_HEIGHT[difficulty])
+    ign_gt = np.full(gt.name.shape, -1, np.int32)
+    ign_gt[neighbour | (same & too_hard)] = 1
+    ign_gt[same & ~too_hard] = 0
+    is_dc = gt.name == "DontCare"
+    ign_det = np.where(dt.lname == cls, 0, -1).astype(np.int32)
+    ign_det[np.abs(dt.bbox[:, 3] - dt.bbox[:, 1]) < _MIN_HEIGHT[difficulty]] = 1
+    n_frames = len(gt.count)
+    return dict(ign_gt=ign_gt, ign_det=ign_det, dc=gt.bbox[is_dc],
+                dc_off=_offsets(np.bincount(gt.frame[is_dc], minlength=n_frames)),
+                total_num_valid_gt=int(np.count_nonzero(ign_gt == 0)))
+
+
+def clean_data(gt_anno, dt_anno, current_class, difficulty):
+    """single-frame form with the reference's return convention (eval.py:29): (num_valid_gt, ignored_gt, ignored_dt, dc_bboxes)"""
+    c = _classify(_Table([gt_anno], False), _Table([dt_anno], True), current_class, difficulty)
+    return c["total_num_valid_gt"], c["ign_gt"].tolist(), c["ign_det"].tolist(), list(c["dc"])
+
+
+def get_thresholds(scores, num_gt, num_sample_pts=N_SAMPLE_PTS):
+    """Score thresholds at which recall crosses the sample levels 0, 1/40, 2/40, ... (eval.py:7-26).
+    With the matched scores in descending order, detection i stands for the recall interval [(i+1)/num_gt, (i+2)/num_gt];
+    a level takes the first not yet used detection whose interval's far end is at least as close to the level as its near
+    end (the last detection always qualifies).  Both distances are monotone in i, so per level the first qualifying
+    detection is the first False of one whole-array comparison; <= 41 levels are ever consumed below full recall."""
+    s = np.sort(np.asarray(scores, dtype=np.float64))[::-1]
+    n = len(s)
+    if n == 0:
+        return []
+    rank = np.arange(n)
+    near = (rank + 1) / num_gt
+    far = np.where(rank < n - 1, (rank + 2) / num_gt, near)
+    step = 1 / (num_sample_pts - 1.0)
+    picked, level, start = [], 0, 0
+    while start < n:
+        passed_over = (far[start:] - level) < (level - near[start:])
+        passed_over[-1] = False
+        start += int(np.argmin(passed_over))
+        picked.append(start)
+        start += 1
+        level += step                    # accumulated, not t * step: the reference's levels carry this rounding
+    return s[picked].tolist()
+
+
 def _boxes7(annos):
-    """(x, y, z, l, h, w, ry) rows of a list of annotation dicts (eval.py:372-384)"""
-    parts = [np.concatenate([a["location"].reshape(-1, 3), a["dimensions"].reshape(-1, 3), a["rotation_y"].reshape(-1, 1)], 1)
-             for a in annos]
-    return np.concatenate(parts, 0) if parts else np.zeros((0, 7))
+    """(x, y, z, l, h, w, ry) rows (the operand layout of eval.py:372-384)"""
+    return np.concatenate([_cat(annos, "location", 3), _cat(annos, "dimensions", 3), _cat(annos, "rotation_y")[:, None]], 1)
 
 
 def calculate_iou_partly(gt_annos, dt_annos, metric, backend):
     """eval.py:326-397, per-frame blocks only.  Called like the reference's eval_class does -- with (dt_annos, gt_annos) --
     so the FIRST argument indexes the rows.  -> (list of per-frame (n_first, n_second) float64 arrays, flat, ov_off)"""
-    assert len(gt_annos) == len(dt_annos)
+    if len(gt_annos) != len(dt_annos):
+        raise ValueError("frame lists differ in length")
+    if metric not in (0, 1, 2):
+        raise ValueError("unknown metric")
     n_first = np.array([len(a["name"]) for a in gt_annos], np.int64)
     n_second = np.array([len(a["name"]) for a in dt_annos], np.int64)
-    off1, off2 = _offsets(n_first), _offsets(n_second)
     ov_off = _offsets(n_first * n_second)
-    if metric == 0:
-        b1 = np.concatenate([a["bbox"].reshape(-1, 4) for a in gt_annos], 0) if len(gt_annos) else np.zeros((0, 4))
-        b2 = np.concatenate([a["bbox"].reshape(-1, 4) for a in dt_annos], 0) if len(dt_annos) else np.zeros((0, 4))
-    elif metric in (1, 2):
-        b1, b2 = _boxes7(gt_annos), _boxes7(dt_annos)
-    else:
-        raise ValueError("unknown metric")
-    flat = backend.overlaps(metric, b1, off1, b2, off2, ov_off)
-    blocks = [flat[ov_off[i]:ov_off[i + 1]].reshape(n_first[i], n_second[i]) for i in range(len(gt_annos))]
+    rows = (lambda an: _cat(an, "bbox", 4)) if metric == 0 else _boxes7
+    flat = backend.overlaps(metric, rows(gt_annos), _offsets(n_first), rows(dt_annos), _offsets(n_second), ov_off)
+    blocks = [flat[ov_off[i]:ov_off[i + 1]].reshape(n_first[i], n_second[i]) for i in range(len(n_first))]
     return blocks, flat, ov_off
 
 
-def _prepare_data(gt_annos, dt_annos, current_class, difficulty):
-    """eval.py:400-440, concatenated over frames with offsets"""
-    ign_gt, ign_det, dcs, gt_datas, dt_datas, dc_counts = [], [], [], [], [], []
-    total_num_valid_gt = 0
-    for g, d in zip(gt_annos, dt_annos):
-        num_valid_gt, ig, idt, dc = clean_data(g, d, current_class, difficulty)
-        ign_gt.append(np.array(ig, dtype=np.int32).reshape(-1))
-        ign_det.append(np.array(idt, dtype=np.int32).reshape(-1))
-        dc = np.stack(dc, 0).astype(np.float64) if len(dc) else np.zeros((0, 4))
-        dcs.append(dc)
-        dc_counts.append(dc.shape[0])
-        total_num_valid_gt += num_valid_gt
-        gt_datas.append(np.concatenate([g["bbox"].reshape(-1, 4), g["alpha"].reshape(-1, 1)], 1))
-        dt_datas.append(np.concatenate([d["bbox"].reshape(-1, 4), d["alpha"].reshape(-1, 1), d["score"].reshape(-1, 1)], 1))
-    cat = lambda xs, w: np.concatenate(xs, 0) if xs else np.zeros((0, w))      # noqa: E731
-    return dict(gt_datas=cat(gt_datas, 5), dt_datas=cat(dt_datas, 6), ign_gt=np.concatenate(ign_gt) if ign_gt else np.zeros(0, np.int32),
-                ign_det=np.concatenate(ign_det) if ign_det else np.zeros(0, np.int32), dc=cat(dcs, 4),
-                dc_off=_offsets(dc_counts), total_num_valid_gt=total_num_valid_gt)
+def _pr_curves(res, compute_aos):
+    """(frames, thresholds, 4) per-frame [tp, fp, fn, similarity] -> recall, precision, aos per threshold with the running
+    maximum towards higher recall (eval.py:514-544).  cumsum adds the frames in order, one at a time -- the order in which
+    the reference accumulates them, which fixes the last bit of the similarity sum."""
+    sim = np.where(res[..., 3] != -1, res[..., 3], 0.0)
+    tp, fp, fn = (res[..., c].sum(0) for c in range(3))               # integer-valued: any order is exact
+    sim = np.cumsum(sim, axis=0)[-1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        curves = [tp / (tp + fn), tp / (tp + fp), sim / (tp + fp) if compute_aos else None]
+    return [None if c is None else np.maximum.accumulate(c[::-1])[::-1] for c in curves]
 
 
 def eval_class(gt_annos, dt_annos, current_classes, difficultys, metric, min_overlaps, compute_aos=False, backend=None):
     """eval.py:443-544.  -> dict(recall, precision, orientation), each [num_class, num_difficulty, num_minoverlap, 41]"""
     backend = backend or HipBackend()
-    assert len(gt_annos) == len(dt_annos)
     _, flat, ov_off = calculate_iou_partly(dt_annos, gt_annos, metric, backend)          # rows = detections (:468)
-    gt_off = _offsets([len(a["name"]) for a in gt_annos])
-    dt_off = _offsets([len(a["name"]) for a in dt_annos])
-    N_SAMPLE_PTS = 41
+    gt, dt = _Table(gt_annos, False), _Table(dt_annos, True)
     shape = [len(current_classes), len(difficultys), len(min_overlaps), N_SAMPLE_PTS]
     precision, recall, aos = np.zeros(shape), np.zeros(shape), np.zeros(shape)
     for m, current_class in enumerate(current_classes):
         for l, difficulty in enumerate(difficultys):
-            P = _prepare_data(gt_annos, dt_annos, current_class, difficulty)
-            args = (flat, ov_off, P["gt_datas"], gt_off, P["dt_datas"], dt_off, P["ign_gt"], P["ign_det"], P["dc"], P["dc_off"], metric)
+            P = _classify(gt, dt, current_class, difficulty)
+            args = (flat, ov_off, gt.data, gt.off, dt.data, dt.off, P["ign_gt"], P["ign_det"], P["dc"], P["dc_off"], metric)
             for k, min_overlap in enumerate(min_overlaps[:, metric, m]):
-                # pass 1 (:479-494): scores of the detections that match a valid gt at this overlap
+                # pass 1 (:479-494): scores of the detections that match a counted gt at this overlap
                 _, matched = backend.statistics(*args, min_overlap, np.zeros(1), False, False)
-                scores = matched[~np.isnan(matched)]
-                thresholds = np.array(get_thresholds(scores, P["total_num_valid_gt"]))
+                thresholds = np.array(get_thresholds(matched[~np.isnan(matched)], P["total_num_valid_gt"]))
                 if len(thresholds) == 0:
                     continue
-                # pass 2 (:496-524): tp / fp / fn / similarity per (frame, threshold), summed over frames in frame order
+                # pass 2 (:496-524): tp / fp / fn / similarity per (frame, threshold)
                 res, _ = backend.statistics(*args, min_overlap, thresholds, True, compute_aos)
-                res = res.reshape(len(gt_annos), len(thresholds), 4)
-                pr = np.zeros([len(thresholds), 4])
-                for f in range(res.shape[0]):
-                    pr[:, :3] += res[f, :, :3]
-                    sim = res[f, :, 3]
-                    pr[:, 3] += np.where(sim != -1, sim, 0.0)
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    for i in range(len(thresholds)):
-                        recall[m, l, k, i] = pr[i, 0] / (pr[i, 0] + pr[i, 2])
-                        precision[m, l, k, i] = pr[i, 0] / (pr[i, 0] + pr[i, 1])
-                        if compute_aos:
-                            aos[m, l, k, i] = pr[i, 3] / (pr[i, 0] + pr[i, 1])
-                for i in range(len(thresholds)):
-                    precision[m, l, k, i] = np.max(precision[m, l, k, i:], axis=-1)
-                    recall[m, l, k, i] = np.max(recall[m, l, k, i:], axis=-1)
-                    if compute_aos:
-                        aos[m, l, k, i] = np.max(aos[m, l, k, i:], axis=-1)
+                r, p, a = _pr_curves(res.reshape(len(gt_annos), len(thresholds), 4), compute_aos)
+                T = len(thresholds)
+                recall[m, l, k, :T], precision[m, l, k, :T] = r, p
+                if compute_aos:
+                    aos[m, l, k, :T] = a
     return {"recall": recall, "precision": precision, "orientation": aos}
 
 
 def get_mAP(prec):
-    """eval.py:547-551 (11-point interpolation over the 41 sample points)"""
-    sums = 0
-    for i in range(0, prec.shape[-1], 4):
-        sums = sums + prec[..., i]
-    return sums / 11 * 100
+    """11-point interpolated AP [%] from the 41 sample points: every fourth point, added left to right (eval.py:547-551)"""
+    return np.cumsum(prec[..., ::4], axis=-1)[..., -1] / 11 * 100
 
 
 def do_eval(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos=False, backend=None):
-    """eval.py:563-583"""
+    """eval.py:563-583 -> (mAP_bbox, mAP_bev, mAP_3d, mAP_aos), each [class, difficulty, min_overlap]"""
     backend = backend or HipBackend()
     difficultys = [0, 1, 2]
-    ret = eval_class(gt_annos, dt_annos, current_classes, difficultys, 0, min_overlaps, compute_aos, backend)
-    mAP_bbox = get_mAP(ret["precision"])
-    mAP_aos = get_mAP(ret["orientation"]) if compute_aos else None
-    mAP_bev = get_mAP(eval_class(gt_annos, dt_annos, current_classes, difficultys, 1, min_overlaps, backend=backend)["precision"])
-    mAP_3d = get_mAP(eval_class(gt_annos, dt_annos, current_classes, difficultys, 2, min_overlaps, backend=backend)["precision"])
-    return mAP_bbox, mAP_bev, mAP_3d, mAP_aos
+    by_metric = [eval_class(gt_annos, dt_annos, current_classes, difficultys, metric, min_overlaps,
+                            compute_aos and metric == 0, backend) for metric in (0, 1, 2)]
+    maps = [get_mAP(r["precision"]) for r in by_metric]
+    return maps[0], maps[1], maps[2], (get_mAP(by_metric[0]["orientation"]) if compute_aos else None)
 
 
 def do_coco_style_eval(gt_annos, dt_annos, current_classes, overlap_ranges, compute_aos, backend=None):
-    """eval.py:586-602"""
-    min_overlaps = np.zeros([10, *overlap_ranges.shape[1:]])
-    for i in range(overlap_ranges.shape[1]):
-        for j in range(overlap_ranges.shape[2]):
-            min_overlaps[:, i, j] = np.linspace(overlap_ranges[0, i, j], overlap_ranges[1, i, j], int(overlap_ranges[2, i, j]))
-    mAP_bbox, mAP_bev, mAP_3d, mAP_aos = do_eval(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos, backend)
-    mAP_bbox, mAP_bev, mAP_3d = mAP_bbox.mean(-1), mAP_bev.mean(-1), mAP_3d.mean(-1)
-    if mAP_aos is not None:
-        mAP_aos = mAP_aos.mean(-1)
-    return mAP_bbox, mAP_bev, mAP_3d, mAP_aos
+    """eval.py:586-602: overlap_ranges[(start, stop, count), metric, class] -> APs averaged over the overlap grid"""
+    lo, hi, num = overlap_ranges
+    min_overlaps = np.zeros((10,) + lo.shape)
+    for ij in np.ndindex(lo.shape):
+        min_overlaps[(slice(None),) + ij] = np.linspace(lo[ij], hi[ij], int(num[ij]))
+    return tuple(None if v is None else v.mean(-1)
+                 for v in do_eval(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos, backend))
 
 
 def print_str(value, *arg, sstream=None):
-    if sstream is None:
-        sstream = sysio.StringIO()
-    sstream.truncate(0)
-    sstream.seek(0)
-    print(value, *arg, file=sstream)
-    return sstream.getvalue()
-
-
-_CLASS_TO_NAME = {0: "Car", 1: "Pedestrian", 2: "Cyclist", 3: "Van", 4: "Person_sitting"}
+    """what print() would write for the arguments, as a string (eval.py:554-560)"""
+    text = " ".join(str(v) for v in (value,) + arg) + "\n"
+    if sstream is not None:
+        sstream.truncate(0)
+        sstream.seek(0)
+        sstream.write(text)
+    return text
 
 
 def _classes_int(current_classes):
-    name_to_class = {v: n for n, v in _CLASS_TO_NAME.items()}
+    by_name = {v: n for n, v in _CLASS_TO_NAME.items()}
     if not isinstance(current_classes, (list, tuple)):
         current_classes = [current_classes]
-    return [name_to_class[c] if isinstance(c, str) else c for c in current_classes]
+    return [by_name[c] if isinstance(c, str) else c for c in current_classes]
 
 
 def _has_alpha(dt_annos):
-    for anno in dt_annos:
-        if anno["alpha"].shape[0] != 0:
-            return bool(anno["alpha"][0] != -10)
-    return False
+    """AOS is evaluated when the first non-empty detection frame carries a real alpha (-10 marks "none"; eval.py:633-640)"""
+    first = next((a["alpha"] for a in dt_annos if a["alpha"].shape[0] != 0), None)
+    return first is not None and bool(first[0] != -10)
+
+
+def _ap_lines(title, rows):
+    """one result block: the title line, then `<label> AP:easy, moderate, hard` per (label, values, number format) row"""
+    return title + "\n" + "".join("%s AP:%s\n" % (label, ", ".join(format(v, fmt) for v in vals)) for label, vals, fmt in rows)
 
 
 def get_official_eval_result(gt_annos, dt_annos, current_classes, backend=None):
     """eval.py:605-675: -> (result string, dict of the nine Car AP numbers)"""
-    overlap_0_7 = np.array([[0.7, 0.5, 0.5, 0.7, 0.5], [0.7, 0.5, 0.5, 0.7, 0.5], [0.7, 0.5, 0.5, 0.7, 0.5]])
-    overlap_0_5 = np.array([[0.7, 0.5, 0.5, 0.7, 0.5], [0.5, 0.25, 0.25, 0.5, 0.25], [0.5, 0.25, 0.25, 0.5, 0.25]])
-    min_overlaps = np.stack([overlap_0_7, overlap_0_5], axis=0)
+    # [overlap set, metric (bbox, bev, 3d), class]: the official thresholds and the relaxed set
+    per_class, per_class_relaxed = np.array([0.7, 0.5, 0.5, 0.7, 0.5]), np.array([0.5, 0.25, 0.25, 0.5, 0.25])
+    strict = np.stack([per_class, per_class, per_class])                       # bbox, bev, 3d
+    relaxed = np.stack([per_class, per_class_relaxed, per_class_relaxed])      # the 2-D box threshold is not relaxed
     current_classes = _classes_int(current_classes)
-    min_overlaps = min_overlaps[:, :, current_classes]
+    min_overlaps = np.stack([strict, relaxed], axis=0)[:, :, current_classes]
     compute_aos = _has_alpha(dt_annos)
     mAPbbox, mAPbev, mAP3d, mAPaos = do_eval(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos, backend)
     result = ""
     for j, curcls in enumerate(current_classes):
         for i in range(min_overlaps.shape[0]):
-            result += print_str((f"{_CLASS_TO_NAME[curcls]} " "AP@{:.2f}, {:.2f}, {:.2f}:".format(*min_overlaps[i, :, j])))
-            result += print_str((f"bbox AP:{mAPbbox[j, 0, i]:.4f}, " f"{mAPbbox[j, 1, i]:.4f}, " f"{mAPbbox[j, 2, i]:.4f}"))
-            result += print_str((f"bev  AP:{mAPbev[j, 0, i]:.4f}, " f"{mAPbev[j, 1, i]:.4f}, " f"{mAPbev[j, 2, i]:.4f}"))
-            result += print_str((f"3d   AP:{mAP3d[j, 0, i]:.4f}, " f"{mAP3d[j, 1, i]:.4f}, " f"{mAP3d[j, 2, i]:.4f}"))
+            rows = [("bbox", mAPbbox[j, :, i], ".4f"), ("bev ", mAPbev[j, :, i], ".4f"), ("3d  ", mAP3d[j, :, i], ".4f")]
             if compute_aos:
-                result += print_str((f"aos  AP:{mAPaos[j, 0, i]:.2f}, " f"{mAPaos[j, 1, i]:.2f}, " f"{mAPaos[j, 2, i]:.2f}"))
-    ret_dict = {"Car_3d_easy": mAP3d[0, 0, 0], "Car_3d_moderate": mAP3d[0, 1, 0], "Car_3d_hard": mAP3d[0, 2, 0],
-                "Car_bev_easy": mAPbev[0, 0, 0], "Car_bev_moderate": mAPbev[0, 1, 0], "Car_bev_hard": mAPbev[0, 2, 0],
-                "Car_image_easy": mAPbbox[0, 0, 0], "Car_image_moderate": mAPbbox[0, 1, 0], "Car_image_hard": mAPbbox[0, 2, 0]}
+                rows.append(("aos ", mAPaos[j, :, i], ".2f"))
+            result += _ap_lines("%s AP@%.2f, %.2f, %.2f:" % ((_CLASS_TO_NAME[curcls],) + tuple(min_overlaps[i, :, j])), rows)
+    ret_dict = {"Car_%s_%s" % (mname, dname): table[0, d, 0]
+                for mname, table in (("3d", mAP3d), ("bev", mAPbev), ("image", mAPbbox))
+                for d, dname in enumerate(("easy", "moderate", "hard"))}
     return result, ret_dict
 
 
 def get_coco_eval_result(gt_annos, dt_annos, current_classes, backend=None):
-    """eval.py:678-740"""
-    class_to_range = {0: [0.5, 0.95, 10], 1: [0.25, 0.7, 10], 2: [0.25, 0.7, 10], 3: [0.5, 0.95, 10], 4: [0.25, 0.7, 10]}
+    """eval.py:678-740: APs averaged over ten overlap thresholds per class"""
+    class_to_range = {0: (0.5, 0.95, 10), 1: (0.25, 0.7, 10), 2: (0.25, 0.7, 10), 3: (0.5, 0.95, 10), 4: (0.25, 0.7, 10)}
     current_classes = _classes_int(current_classes)
-    overlap_ranges = np.zeros([3, 3, len(current_classes)])
-    for i, curcls in enumerate(current_classes):
-        overlap_ranges[:, :, i] = np.array(class_to_range[curcls])[:, np.newaxis]
+    overlap_ranges = np.stack([np.tile(np.array(class_to_range[c])[:, None], (1, 3)) for c in current_classes], axis=-1)
     compute_aos = _has_alpha(dt_annos)
     mAPbbox, mAPbev, mAP3d, mAPaos = do_coco_style_eval(gt_annos, dt_annos, current_classes, overlap_ranges, compute_aos, backend)
     result = ""
     for j, curcls in enumerate(current_classes):
-        o_range = np.array(class_to_range[curcls])[[0, 2, 1]]
-        o_range[1] = (o_range[2] - o_range[0]) / (o_range[1] - 1)
-        result += print_str((f"{_CLASS_TO_NAME[curcls]} " "coco AP@{:.2f}:{:.2f}:{:.2f}:".format(*o_range)))
-        result += print_str((f"bbox AP:{mAPbbox[j, 0]:.2f}, " f"{mAPbbox[j, 1]:.2f}, " f"{mAPbbox[j, 2]:.2f}"))
-        result += print_str((f"bev  AP:{mAPbev[j, 0]:.2f}, " f"{mAPbev[j, 1]:.2f}, " f"{mAPbev[j, 2]:.2f}"))
-        result += print_str((f"3d   AP:{mAP3d[j, 0]:.2f}, " f"{mAP3d[j, 1]:.2f}, " f"{mAP3d[j, 2]:.2f}"))
+        start, stop, count = class_to_range[curcls]
+        rows = [("bbox", mAPbbox[j], ".2f"), ("bev ", mAPbev[j], ".2f"), ("3d  ", mAP3d[j], ".2f")]
         if compute_aos:
-            result += print_str((f"aos  AP:{mAPaos[j, 0]:.2f}, " f"{mAPaos[j, 1]:.2f}, " f"{mAPaos[j, 2]:.2f}"))
+            rows.append(("aos ", mAPaos[j], ".2f"))
+        result += _ap_lines("%s coco AP@%.2f:%.2f:%.2f:" % (_CLASS_TO_NAME[curcls], start, (stop - start) / (count - 1), stop), rows)
     return result
 
 
@@ -368,7 +355,7 @@ def evaluate(label_path, result_path, label_split_file, current_class=0, coco=Fa
     if score_thresh > 0:
         dt_annos = filter_annos_low_score(dt_annos, score_thresh)
     with open(label_split_file, "r") as f:
-        val_image_ids = [int(line) for line in f.readlines()]
+        val_image_ids = [int(tok) for tok in f.read().split()]
     gt_annos = get_label_annos(label_path, val_image_ids)
     if coco:
         return get_coco_eval_result(gt_annos, dt_annos, current_class, backend)
