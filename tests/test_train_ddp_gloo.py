@@ -73,7 +73,15 @@ def _freeze_norm_and_dropout(trainer, bn_eval):
     trainer.model.train = train_then_freeze
 
 
-def _worker(rank, world, port, q, bn_eval):
+def _drop_foreground(cls, reg, frame):
+    """frame `frame` of the batch gets no foreground point at all (an empty scene: every label background)"""
+    cls, reg = cls.clone(), reg.clone()
+    cls[frame] = 0
+    reg[frame] = 0
+    return cls, reg
+
+
+def _worker(rank, world, port, q, bn_eval, empty_frame=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -82,6 +90,8 @@ def _worker(rank, world, port, q, bn_eval):
     import cpu_ops
     from pointrcnn_amd import train_functions as tf
     pts, cls, reg = _batch(world, seed=0)
+    if empty_frame is not None:
+        cls, reg = _drop_foreground(cls, reg, empty_frame)
     shard = {"pts_input": pts[rank:rank + 1], "rpn_cls_label": cls[rank:rank + 1], "rpn_reg_label": reg[rank:rank + 1]}
     model = _model(bn_eval)
     if rank == 1:                                   # DDP must broadcast rank 0's parameters and buffers
@@ -100,11 +110,11 @@ def _worker(rank, world, port, q, bn_eval):
     dist.destroy_process_group()
 
 
-def _run(bn_eval):
+def _run(bn_eval, empty_frame=None, target=None, extra=()):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, bn_eval)) for r in range(world)]
+    procs = [ctx.Process(target=target or _worker, args=(r, world, port, q, bn_eval, empty_frame) + tuple(extra)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
@@ -114,20 +124,22 @@ def _run(bn_eval):
     return res
 
 
-def test_ddp_gradient_equals_single_process_global_batch():
-    res = _run(bn_eval=True)
+def _check_against_single_process(res, empty_frame=None):
     sys.path.insert(0, TESTS)
     import cpu_ops
     from pointrcnn_amd import train_functions as tf
     # single process, the whole 2-frame batch, the reference's (global) loss normalisation
     pts, cls, reg = _batch(2, seed=0)
+    if empty_frame is not None:
+        cls, reg = _drop_foreground(cls, reg, empty_frame)
     model = _model(True)
     trainer = tf.RPNTrainer(model, ddp=False, optimizer="sgd")
     _freeze_norm_and_dropout(trainer, True)
     with cpu_ops.oracle_ops():
         tb = {}
         loss = trainer.step({"pts_input": pts, "rpn_cls_label": cls, "rpn_reg_label": reg}, tb)
-    assert res[0][4] + res[1][4] == tb["rpn_fg_sum"] and min(res[0][4], res[1][4]) > 0
+    assert res[0][4] + res[1][4] == tb["rpn_fg_sum"]
+    assert (min(res[0][4], res[1][4]) > 0) if empty_frame is None else (res[empty_frame][4] == 0 and tb["rpn_fg_sum"] > 0)
     # the global loss is the AVERAGE of the rescaled per-rank losses
     assert abs(0.5 * (res[0][1] + res[1][1]) - float(loss.item())) <= 1e-5 * max(1.0, abs(float(loss.item())))
     single = {n: p.grad.numpy() for n, p in model.named_parameters() if p.grad is not None}
@@ -141,6 +153,64 @@ def test_ddp_gradient_equals_single_process_global_batch():
     assert np.array_equal(res[0][3], res[1][3])      # identical parameters on both ranks after the step (rank 1 started perturbed)
     after = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()
     assert np.abs(after - res[0][3]).max() <= 1e-6   # and equal to the single-process step
+
+
+def test_ddp_gradient_equals_single_process_global_batch():
+    _check_against_single_process(_run(bn_eval=True))
+
+
+def test_ddp_rank_without_foreground_neither_hangs_nor_changes_the_gradient():
+    """One rank's shard is an empty scene (fg_sum == 0 branch, train_functions.py:117-118 of the reference).  Its regression
+    head must still take part in the bucketed all-reduce -- with the reg outputs out of the autograd graph DDP would wait for
+    that bucket forever on the peers and raise on this rank's next forward -- and the averaged gradient is still the
+    single-process gradient of the 2-frame batch (the reference's DataParallel handles this case by construction)."""
+    _check_against_single_process(_run(bn_eval=True, empty_frame=1), empty_frame=1)
+
+
+def _loss_worker(rank, world, port, q, bn_eval, empty_frame, loss_cls):
+    """loss-level check for the LOSS_CLS settings: grads w.r.t. this rank's own logits under `dist`"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pointrcnn_amd import train_functions as tf
+    cls_o, reg_o, cls_l, reg_l = _loss_case(world)
+    cfg = type("C", (tf.RPNLossConfig,), {"LOSS_CLS": loss_cls})
+    a = cls_o[rank:rank + 1].clone().requires_grad_(True)
+    b = reg_o[rank:rank + 1].clone().requires_grad_(True)
+    loss = tf.get_rpn_loss(a, b, cls_l[rank:rank + 1], reg_l[rank:rank + 1], cfg, dist=dist)
+    loss.backward()
+    q.put((rank, float(loss.item()), a.grad.numpy(), b.grad.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _loss_case(frames, n=512, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    cls_o = torch.randn(frames, n, 1, generator=g)
+    reg_o = torch.randn(frames, n, 76, generator=g) * 0.3
+    cls_l = (torch.rand(frames, n, generator=g) < 0.2).long() - (torch.rand(frames, n, generator=g) < 0.05).long()
+    cls_l[1, : n // 2] = cls_l[1, : n // 2].clamp(max=0)             # ragged foreground counts across the ranks
+    reg_l = torch.randn(frames, n, 7, generator=g)
+    reg_l[..., 3:6] = reg_l[..., 3:6].abs() + 1.0
+    return cls_o, reg_o, cls_l, reg_l
+
+
+def test_every_cls_loss_is_the_global_batch_loss_under_data_parallel():
+    """focal, dice and BCE: world x the DDP-averaged gradient (= the mean of the ranks' gradients w.r.t. their own outputs, here
+    compared output by output) is the gradient of the ONE loss the reference computes over the gathered batch"""
+    from pointrcnn_amd import train_functions as tf
+    for loss_cls in ("SigmoidFocalLoss", "DiceLoss", "BinaryCrossEntropy"):
+        res = _run(True, None, target=_loss_worker, extra=(loss_cls,))
+        cls_o, reg_o, cls_l, reg_l = _loss_case(2)
+        cfg = type("C", (tf.RPNLossConfig,), {"LOSS_CLS": loss_cls})
+        a, b = cls_o.clone().requires_grad_(True), reg_o.clone().requires_grad_(True)
+        loss = tf.get_rpn_loss(a, b, cls_l, reg_l, cfg)
+        loss.backward()
+        assert abs(0.5 * (res[0][1] + res[1][1]) - float(loss.item())) <= 1e-5 * max(1.0, abs(float(loss.item()))), loss_cls
+        for r in range(2):
+            for got, want in ((res[r][2], a.grad[r:r + 1].numpy()), (res[r][3], b.grad[r:r + 1].numpy())):
+                assert np.abs(got / 2 - want).max() <= 1e-6 * max(1.0, float(np.abs(want).max())), (loss_cls, r)
 
 
 def test_ddp_with_training_mode_batchnorm_keeps_ranks_in_sync():
