@@ -46,7 +46,7 @@ typedef void* prcnn_stream_t; /* hipStream_t */
 #define PRCNN_EHIP (-2)         /* HIP runtime / launch failure */
 #define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-int prcnn_abi_version(void);   /* 5: + prcnn_gt_aug_edit;
+int prcnn_abi_version(void);   /* 6: + prcnn_fps_status; 5: + prcnn_gt_aug_edit;
                                  * 4: + prcnn_host_* (host twins of the reference's *_cpu entry points), prcnn_build_id,
                                  * prcnn_fps_order (upstream tie order), prcnn_rpn_labels,
                                  * prcnn_ball_query2_grid takes xyz (dense-frame scan fallback);
@@ -73,6 +73,12 @@ const char* prcnn_build_id(void);
  * and the indices returned for it are unspecified (always within [0, N)).  Callers with unvalidated input filter first
  * (prcnn_scene_prepare drops non-finite raw points). */
 int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, int32_t* idx, prcnn_stream_t stream);
+
+/* N > 16384 runs one frame on several cooperating workgroups whose wait for each other is bounded (a hang would take the
+ * GPU down); a workgroup that gave up fills the rest of its frame's output with -1 and marks a host-visible word.
+ * prcnn_fps_status() returns PRCNN_EHIP (and clears the mark) if that happened since the last check, PRCNN_OK otherwise;
+ * it does not synchronise -- call it after the stream has.  prcnn_fps itself checks the mark before every such launch. */
+int prcnn_fps_status(void);
 
 /* Same, with a selectable rule for ties among equal running min-distances (they only occur on clouds with duplicate
  * points or exact lattices):
@@ -244,7 +250,9 @@ int prcnn_pts_in_boxes3d(const float* pts, const float* boxes3d, int N, int M, i
  * lib/datasets/kitti_rcnn_dataset.py:365-394): pts (B,N,3), gt_boxes3d (B,G,7) [x,y(bottom),z,h,w,l,ry], num_gt (B) i32 or
  * NULL (all G rows valid) -> cls_label (B,N) i32 in {-1 ignore, 0 background, 1 foreground}, reg_label (B,N,7)
  * [dx, dy, dz, h, w, l, ry] (zero rows for non-foreground points).  extra_width = 0.2 in the reference.  Boxes are applied in
- * order, later boxes overwrite earlier ones exactly as the reference's loop does.  G <= 128. */
+ * order, later boxes overwrite earlier ones exactly as the reference's loop does.  G <= 128.  The in-box test is the analytic
+ * one of roipool3d WITHOUT its 10 m centre-distance gate (the reference's hull test has none: a box with a half extent over
+ * 10 m keeps all its points); it can differ from the hull test only for points within rounding distance of a face. */
 int prcnn_rpn_labels(const float* pts, const float* gt_boxes3d, const int32_t* num_gt, int B, int N, int G, float extra_width,
                      int32_t* cls_label, float* reg_label, prcnn_stream_t stream);
 

@@ -277,9 +277,9 @@ static void box_trig(float angle, int trig_mode, float* cosa, float* sina) {
 }
 
 /* roipool3d.cpp:82-95 pt_in_box3d_cpu */
-static int pt_in_box3d(float x, float y, float z, float cx, float bottom_y, float cz, float h, float w, float l,
-                       float cosa, float sina) {
-    float max_dis = 10.0f, x_rot, z_rot, cy;
+static int pt_in_box3d_gate(float x, float y, float z, float cx, float bottom_y, float cz, float h, float w, float l,
+                            float cosa, float sina, float max_dis) {
+    float x_rot, z_rot, cy;
     cy = (float)((double)bottom_y - (double)h / 2.0);
     if ((fabsf(x - cx) > max_dis) || ((double)fabsf(y - cy) > (double)h / 2.0) || (fabsf(z - cz) > max_dis)) return 0;
     {
@@ -291,6 +291,11 @@ static int pt_in_box3d(float x, float y, float z, float cx, float bottom_y, floa
     }
     return ((double)x_rot >= -(double)l / 2.0) & ((double)x_rot <= (double)l / 2.0) &
            ((double)z_rot >= -(double)w / 2.0) & ((double)z_rot <= (double)w / 2.0);
+}
+
+static int pt_in_box3d(float x, float y, float z, float cx, float bottom_y, float cz, float h, float w, float l,
+                       float cosa, float sina) {
+    return pt_in_box3d_gate(x, y, z, cx, bottom_y, cz, h, w, l, cosa, sina, 10.0f);
 }
 
 /* roipool3d.cpp:97-125 pts_in_boxes3d_cpu: flags (M,N) int64 */
@@ -367,8 +372,9 @@ PRCNN_EXPORT void prcnn_cpu_rpn_labels(const float* pts, const float* gt, const 
                 float ca, sa;
                 box_trig(bx[6], trig_mode, &ca, &sa);
                 const float e2 = extra * 2;
-                const int fg = pt_in_box3d(p[0], p[1], p[2], bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], ca, sa);
-                const int en = pt_in_box3d(p[0], p[1], p[2], bx[0], bx[1] + extra, bx[2], bx[3] + e2, bx[4] + e2, bx[5] + e2, ca, sa);
+                /* the reference tests against the box's convex hull (kitti_utils.in_hull): no 10 m centre-distance gate */
+                const int fg = pt_in_box3d_gate(p[0], p[1], p[2], bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], ca, sa, INFINITY);
+                const int en = pt_in_box3d_gate(p[0], p[1], p[2], bx[0], bx[1] + extra, bx[2], bx[3] + e2, bx[4] + e2, bx[5] + e2, ca, sa, INFINITY);
                 if (fg) {
                     const float cy = bx[1] - bx[3] / 2;
                     c = 1;

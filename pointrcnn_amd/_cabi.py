@@ -22,6 +22,7 @@ SIGNATURES = {
     "prcnn_last_error": (ctypes.c_char_p, []),
     "prcnn_build_id": (ctypes.c_char_p, []),
     "prcnn_fps": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "prcnn_fps_status": (_I, []),
     "prcnn_fps_order": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "prcnn_rpn_labels": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "prcnn_gt_aug_edit": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -449,7 +449,8 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
 #define FPS_MULTI_SPIN_LIMIT (1 << 20)
 
 __global__ __launch_bounds__(1024) void fps_multi_kernel(const float* __restrict__ xyz, int N, int npoint, int S,
-                                                         unsigned long long* __restrict__ slots, int32_t* __restrict__ idx_out) {
+                                                         unsigned long long* __restrict__ slots, int32_t* __restrict__ idx_out,
+                                                         int* __restrict__ timed_out) {
     constexpr int BLOCK = 1024, PPT = 16, NW = BLOCK / 64;
     typedef typename fvec_t<PPT>::type fvec;
     __shared__ float slot[2][NW][8];
@@ -546,6 +547,8 @@ __global__ __launch_bounds__(1024) void fps_multi_kernel(const float* __restrict
         x0 = win[j & 1][1]; y0 = win[j & 1][2]; z0 = win[j & 1][3];
         if (gidx < 0) {                              // a partner never showed up: give up loudly (-1 indices), do not hang
             for (int k = j + tid; k < npoint; k += BLOCK) if (sl == 0) out[k] = -1;
+            // sticky, host-visible (pinned, device-mapped word): the NEXT prcnn_fps / prcnn_fps_status call reports it
+            if (tid == 0 && timed_out) __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
         if (sl == 0 && tid == 0) out[j] = gidx;
@@ -593,6 +596,27 @@ static void launch_fps(const float* xyz, int B, int N, int npoint, int32_t* idx,
     hipLaunchKernelGGL((fps_reg_kernel<BLOCK, PPT>), dim3(B), dim3(BLOCK), 0, s, xyz, N, npoint, idx);
 }
 
+// The multi-slice kernel's poll is bounded; a slice that gave up marks this pinned host word (device-mapped, written with a
+// system-scope store), which the host can read without synchronising with the stream.  -1 indices are never consumed
+// silently: the next prcnn_fps call and prcnn_fps_status() return PRCNN_EHIP once the mark is set.
+static int* fps_timeout_word() {
+    static int* word = [] {
+        int* w = nullptr;
+        if (hipHostMalloc((void**)&w, sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return (int*)nullptr; }
+        *w = 0;
+        return w;
+    }();
+    return word;
+}
+
+PRCNN_API int prcnn_fps_status(void) {
+    int* w = fps_timeout_word();
+    if (w && __atomic_exchange_n(w, 0, __ATOMIC_RELAXED) != 0)
+        return prcnn_fail(PRCNN_EHIP, "prcnn_fps: a multi-workgroup launch (N > 16384) gave up waiting for a partner slice; "
+                                      "its output holds -1 indices (were all ceil(N/16384) workgroups of a frame able to become resident?)");
+    return PRCNN_OK;
+}
+
 PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, int32_t* idx, prcnn_stream_t stream) {
     PRCNN_REQUIRE(B >= 0 && N > 0 && npoint >= 0, "prcnn_fps: bad shape B=%d N=%d npoint=%d", B, N, npoint);
     PRCNN_REQUIRE(npoint <= N, "prcnn_fps: npoint %d > N %d", npoint, N);
@@ -635,7 +659,9 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
         if (!use_mem && S <= FPS_MULTI_MAX_SPLIT && ((uintptr_t)tmp & 7) == 0) {
             const size_t slot_bytes = (size_t)B * 2 * S * 5 * sizeof(unsigned long long);
             if (hipMemsetAsync(tmp, 0xFF, slot_bytes, s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot clear the exchange slots");
-            hipLaunchKernelGGL(fps_multi_kernel, dim3(B * S), dim3(1024), 0, s, xyz, N, npoint, S, reinterpret_cast<unsigned long long*>(tmp), idx);
+            if (int st = prcnn_fps_status()) return st;               // an earlier launch of this kind timed out: say so now
+            hipLaunchKernelGGL(fps_multi_kernel, dim3(B * S), dim3(1024), 0, s, xyz, N, npoint, S, reinterpret_cast<unsigned long long*>(tmp), idx,
+                               fps_timeout_word());
         } else {
             hipLaunchKernelGGL(fps_mem_kernel, dim3(B), dim3(1024), 0, s, xyz, N, npoint, tmp, idx);
         }

@@ -30,8 +30,13 @@ __device__ __forceinline__ BoxConst make_box(const float* bx) {
     return b;
 }
 
+// GATE: the reference's pt_in_box3d rejects any point further than max_dis = 10 m from the centre in x or z before it rotates
+// (roipool3d.cpp:87-89, roipool3d_kernel.cu:19-21) -- part of roipool3d / pts_in_boxes3d semantics.  The label generator is a
+// hull test on the box corners with no such limit (kitti_rcnn_dataset.py:365-394): GATE = false.
+template <bool GATE = true>
 __device__ __forceinline__ bool pt_in_box(const BoxConst& b, float x, float y, float z) {
-    if (fabsf(x - b.cx) > 10.0f || fabsf(y - b.cy) > b.hh || fabsf(z - b.cz) > 10.0f) return false;
+    if (fabsf(y - b.cy) > b.hh) return false;
+    if (GATE && (fabsf(x - b.cx) > 10.0f || fabsf(z - b.cz) > 10.0f)) return false;
     float dx = x - b.cx, dz = z - b.cz;
     float x_rot = __fadd_rn(__fmul_rn(dx, b.cosa), __fmul_rn(dz, -b.sina));
     float z_rot = __fadd_rn(__fmul_rn(dx, b.sina), __fmul_rn(dz, b.cosa));
@@ -298,7 +303,8 @@ PRCNN_API int prcnn_roipool3d_canonical(const float* xyz, const float* pool_boxe
 // foreground = 1, "in the enlarged box only" = -1 (ignored), regression target = (centre - point, h, w, l, ry).
 // Here: one thread per point walks the frame's <= LABEL_MAX_GT boxes (constants in LDS) IN BOX ORDER, so that a point in
 // several boxes ends up with exactly what the reference's sequential overwrites leave.  The in-box test is the
-// analytic one of roipool3d (pt_in_box above) instead of the hull test: identical except for points within rounding
+// analytic one of roipool3d (pt_in_box above, WITHOUT its 10 m centre-distance gate: the hull test has none, so a GT box
+// with a half extent over 10 m keeps all its points) instead of the hull test: identical except for points within rounding
 // distance of a face.
 // =====================================================================================================
 #define LABEL_MAX_GT 128
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256) void rpn_labels_kernel(const float* __restrict
     int cls = 0;
     float r[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < g; k++) {
-        const bool fg = pt_in_box(sbox[k], x, y, z), en = pt_in_box(sbig[k], x, y, z);
+        const bool fg = pt_in_box<false>(sbox[k], x, y, z), en = pt_in_box<false>(sbig[k], x, y, z);
         if (fg) {
             cls = 1;
             const float cy = sraw[k][1] - sraw[k][3] / 2;          // centre y (float32 arithmetic, as numpy does it)

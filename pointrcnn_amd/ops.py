@@ -64,6 +64,12 @@ def furthest_point_sample(xyz, npoint, order="canonical"):
     return idx
 
 
+def fps_status():
+    """Raise if a multi-workgroup furthest_point_sample launch (N > 16384) timed out waiting for a partner slice since the
+    last check (its output then holds -1 indices).  Does not synchronise: call after the stream has (end of a step / test)."""
+    _cabi.check(_cabi.lib().prcnn_fps_status(), "prcnn_fps_status")
+
+
 def gather(features, idx):
     """features (B,C,N), idx (B,M) i32 -> (B,C,M)   [gather_operation]"""
     _chk(features, "features", ndim=3); _chk(idx, "idx", _INT, 2)

@@ -10,6 +10,7 @@ This is what bench.py times; the reference's own unchanged lib/net/rpn.py builds
 `pointrcnn_amd.install()` (INTEGRATION.md).
 """
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -29,6 +30,7 @@ from . import ops  # noqa: E402
 # graph's fork asks for a second hardware queue, and more than ~20 busy queues collide (bench.py, stream-count sweep).
 FPS_AHEAD = os.environ.get("PRCNN_FPS_AHEAD", "auto")
 _SIDE_STREAMS = {}
+_SIDE_LOCK = threading.Lock()
 
 
 class RPNConfig:
@@ -87,10 +89,12 @@ class Pointnet2MSG(nn.Module):
         for the four levels, 32 of 256 CUs): with a single batch in flight -- latency mode, the training step -- the other
         levels' samples can be drawn underneath the set-abstraction work of the levels before them.
         -> per level (new_xyz, ready-event); the tensors are held by the caller until the end of the forward pass."""
-        cur = torch.cuda.current_stream()
-        side = _SIDE_STREAMS.get(cur.cuda_stream)
-        if side is None:
-            side = _SIDE_STREAMS[cur.cuda_stream] = torch.cuda.Stream()
+        cur = torch.cuda.current_stream(xyz.device)
+        key = (xyz.device.index, cur.cuda_stream)      # the default stream's handle is 0 on EVERY device
+        with _SIDE_LOCK:                               # DataParallel-style callers run one thread per device
+            side = _SIDE_STREAMS.get(key)
+            if side is None:
+                side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=xyz.device)
         side.wait_stream(cur)
         ahead, x = [], xyz
         with torch.cuda.stream(side):
