@@ -46,7 +46,7 @@ typedef void* prcnn_stream_t; /* hipStream_t */
 #define PRCNN_EHIP (-2)         /* HIP runtime / launch failure */
 #define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-int prcnn_abi_version(void);   /* 6: + prcnn_fps_status; 5: + prcnn_gt_aug_edit;
+int prcnn_abi_version(void);   /* 6: + prcnn_fps_status, training-mode SharedMLP (prcnn_train_*); 5: + prcnn_gt_aug_edit;
                                  * 4: + prcnn_host_* (host twins of the reference's *_cpu entry points), prcnn_build_id,
                                  * prcnn_fps_order (upstream tie order), prcnn_rpn_labels,
                                  * prcnn_ball_query2_grid takes xyz (dense-frame scan fallback);
@@ -460,6 +460,69 @@ int prcnn_scene_prepare(const float* raw, const int64_t* offsets, int B, int64_t
                         const float* calib, const int32_t* img_hw, const double* scope, int npoints, uint32_t seed,
                         float* out_xyz, float* out_intensity, int32_t* out_src, int32_t* nvalid, int32_t* status,
                         void* workspace, size_t workspace_bytes, prcnn_stream_t stream);
+
+/* ======================================================================================================
+ * Training-mode SharedMLP (csrc/mlp_train.h) -- BASELINE config 4, `train_rcnn.py --train_mode rpn`.
+ * Replaces, for one SharedMLP layer, nn.Conv2d(1x1, bias=False) -> nn.BatchNorm2d (batch statistics, running-stat update) ->
+ * ReLU and its autograd (cuDNN / ATen in the reference: lib/net/pointnet2_msg.py:20-45 via the upstream pytorch_utils.SharedMLP,
+ * tools/train_rcnn.py:198-199), with F.max_pool2d(kernel=[1, nsample]) after the last layer.  All tensors are channels-last rows.
+ * The layer's ONLY saved activation is its pre-normalisation output y; consumers apply relu(y * scale + shift) on load.
+ *
+ * prcnn_train_src_t says how the rows entering a layer's convolution are produced (mode = 0 plain rows `in`, optionally with
+ * the previous layer's normalisation `pro_scale / pro_shift` (K entries zero-padded to a multiple of 32 floats) applied;
+ * 1 = grouped rows [feat[idx] | xyz[idx] - new_xyz] (the weight is packed with k_rot = 3), rows = B * M * ns, K = C + 3;
+ * 2 = interpolated rows [sum_j w3 known[idx3] | skip], rows = B * n, K = C2 + C1).
+ * prcnn_train_grad_t is the gradient arriving at a layer: G w.r.t. the layer's ACTIVATED output -- (rows, N) rows, or, for a
+ * max-pooled layer (pool_ns > 0), (rows / pool_ns, N) pooled rows + the arg-max byte per (group, channel) -- together with the
+ * saved y and the layer's constant table cst (6 rows of ld_c floats: scale, shift, mean, invstd from prcnn_train_bn_finalize;
+ * mean(dyhat), mean(dyhat * xhat) from prcnn_train_bn_backward).  N, ldG, ld_y, ld_c multiples of 4; 16-byte aligned bases.
+ * ====================================================================================================== */
+typedef struct prcnn_train_src {
+    int mode;
+    int64_t rows;
+    int K;
+    const float* in; int ld_in; const float* pro_scale; const float* pro_shift;
+    const float* xyz; const float* new_xyz; const int32_t* idx; const float* feat; int ld_feat; int B, N, M, ns, C;
+    const float* known; const int32_t* idx3; const float* w3; const float* skip; int ld_known, ld_skip, n, m, C2, C1;
+} prcnn_train_src_t;
+typedef struct prcnn_train_grad {
+    int64_t rows;
+    int N;
+    const float* G; int ldG;
+    const uint8_t* arg; int pool_ns;
+    const float* y; int ld_y;
+    float* cst; int ld_c;
+} prcnn_train_grad_t;
+
+/* y (rows, Nout) = A . W^T, wpack = prcnn_pack_weight(W (Nout, K)); a_dump (rows, ld_dump) optional copy of the assembled A rows
+ * (gathered sources; what prcnn_train_wgrad consumes); part (prcnn_train_part_floats): per-64-row column (mean, M2) partials */
+size_t prcnn_train_part_floats(int64_t rows, int ld_part);
+int prcnn_train_fwd(const prcnn_train_src_t* src, const float* wpack, int Nout, float* y, int ld_y, float* a_dump, int ld_dump,
+                    float* part, int ld_part, prcnn_stream_t stream);
+/* batch mean / biased variance (double, fixed summation order) -> cst rows 0..3; running_mean / running_var (may be NULL)
+ * updated as nn.BatchNorm does: (1 - momentum) * old + momentum * new, unbiased variance */
+int prcnn_train_bn_finalize(const float* part, int ld_part, int64_t rows, int N, const float* gamma, const float* beta, float eps,
+                            float momentum, float* running_mean, float* running_var, float* cst, int ld_c, prcnn_stream_t stream);
+/* out[g, col_off + n] = max over the ns rows of group g of relu(y * scale + shift); arg (groups, N) u8 = FIRST maximal row
+ * (torch.max / max_pool2d route the gradient there); ns = 1, arg NULL: plain normalise + ReLU */
+int prcnn_train_pool(const float* y, int ld_y, int64_t groups, int ns, int N, const float* cst, int ld_c, float* out, int ld_out,
+                     int col_off, uint8_t* arg, prcnn_stream_t stream);
+/* dgamma, dbeta (N) and cst rows 4, 5; part: prcnn_train_bwd_part_floats floats of scratch */
+size_t prcnn_train_bwd_part_floats(int64_t rows, int ld_part);
+int prcnn_train_bn_backward(const prcnn_train_grad_t* g, float* part, int ld_part, float* dgamma, float* dbeta, prcnn_stream_t stream);
+/* out (rows, Kin) = dy . W: gradient w.r.t. the rows that entered the convolution; wpack_t = prcnn_pack_weight(W^T (Kin, N)) */
+int prcnn_train_dgrad(const prcnn_train_grad_t* g, const float* wpack_t, int Kin, float* out, int ld_out, prcnn_stream_t stream);
+/* dW (N, K) = dy^T . a, a (rows, lda) = the rows that entered the convolution (y of the previous layer with pro_scale / pro_shift,
+ * padded to a multiple of 128 floats; or an a_dump); part: splits * N * K floats, splits from prcnn_train_wgrad_splits */
+int prcnn_train_wgrad_splits(int64_t rows, int N, int K);
+int prcnn_train_wgrad(const prcnn_train_grad_t* g, const float* a, int lda, int K, const float* pro_scale, const float* pro_shift,
+                      float* part, int splits, float* dW, prcnn_stream_t stream);
+/* backward of the gathers on channels-last rows: dfeat (B, N, ld_d) += scatter of G ((B, M, ns) rows, C channels) through idx;
+ * dknown (B, m, ld_d) += w3-weighted scatter of G ((B, n) rows) through idx3.  Outputs pre-zeroed by the caller. */
+int prcnn_group_rows_grad(const float* G, int ldG, const int32_t* idx, int B, int M, int ns, int C, int N, float* dfeat, int ld_d,
+                          prcnn_stream_t stream);
+int prcnn_interp_rows_grad(const float* G, int ldG, const int32_t* idx3, const float* w3, int B, int n, int m, int C, float* dknown,
+                           int ld_d, prcnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,24 @@ _L = ctypes.c_int64
 _Z = ctypes.c_size_t
 _D = ctypes.c_double
 
+
+
+class TrainSrc(ctypes.Structure):
+    """prcnn_train_src_t (include/prcnn_pointops.h)"""
+    _fields_ = [("mode", _I), ("rows", _L), ("K", _I),
+                ("in_", _P), ("ld_in", _I), ("pro_scale", _P), ("pro_shift", _P),
+                ("xyz", _P), ("new_xyz", _P), ("idx", _P), ("feat", _P), ("ld_feat", _I),
+                ("B", _I), ("N", _I), ("M", _I), ("ns", _I), ("C", _I),
+                ("known", _P), ("idx3", _P), ("w3", _P), ("skip", _P), ("ld_known", _I), ("ld_skip", _I),
+                ("n", _I), ("m", _I), ("C2", _I), ("C1", _I)]
+
+
+class TrainGrad(ctypes.Structure):
+    """prcnn_train_grad_t (include/prcnn_pointops.h)"""
+    _fields_ = [("rows", _L), ("N", _I), ("G", _P), ("ldG", _I), ("arg", _P), ("pool_ns", _I), ("y", _P), ("ld_y", _I),
+                ("cst", _P), ("ld_c", _I)]
+
+
 # name -> (restype, argtypes); mirrors include/prcnn_pointops.h one for one
 SIGNATURES = {
     "prcnn_abi_version": (_I, []),
@@ -73,6 +91,17 @@ SIGNATURES = {
     "prcnn_scene_workspace_bytes": (_Z, [_L, _I]),
     "prcnn_scene_prepare": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _I, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "prcnn_nms_batched": (_I, [_P, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
+    "prcnn_train_part_floats": (_Z, [_L, _I]),
+    "prcnn_train_fwd": (_I, [ctypes.POINTER(TrainSrc), _P, _I, _P, _I, _P, _I, _P, _I, _P]),
+    "prcnn_train_bn_finalize": (_I, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P]),
+    "prcnn_train_pool": (_I, [_P, _I, _L, _I, _I, _P, _I, _P, _I, _I, _P, _P]),
+    "prcnn_train_bwd_part_floats": (_Z, [_L, _I]),
+    "prcnn_train_bn_backward": (_I, [ctypes.POINTER(TrainGrad), _P, _I, _P, _P, _P]),
+    "prcnn_train_dgrad": (_I, [ctypes.POINTER(TrainGrad), _P, _I, _P, _I, _P]),
+    "prcnn_train_wgrad_splits": (_I, [_L, _I, _I]),
+    "prcnn_train_wgrad": (_I, [ctypes.POINTER(TrainGrad), _P, _I, _I, _P, _P, _P, _I, _P, _P]),
+    "prcnn_group_rows_grad": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "prcnn_interp_rows_grad": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
 }
 
 _lib = None

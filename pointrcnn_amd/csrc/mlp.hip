@@ -2201,3 +2201,6 @@ PRCNN_API int prcnn_mlp_chain_interp(const float* known_cl, int ld_known, const 
     if (B % 8 == 0 && n % 128 == 0 && getenv("PRCNN_NO_XCD_ORDER") == nullptr) C.a.xcd_tpf = n / 128;
     return dispatch_chain(MODE_INTERP, C, (hipStream_t)stream);
 }
+
+// training-mode SharedMLP (forward with batch statistics, dgrad, wgrad): shares the row fetchers and weight image above
+#include "mlp_train.h"

@@ -2,9 +2,13 @@
 the constructor and forward signatures the reference uses (lib/net/pointnet2_msg.py:27-34,44,61,66-68;
 lib/net/rcnn_net.py:33-41,180) [UPSTREAM module, absent from the tree; semantics per SURVEY.md Appendix A].
 
-Two execution paths with identical results:
-  * composed path (training / autograd): FPS -> gather -> ball_query -> grouping -> SharedMLP -> max_pool,
-    every point op a HIP kernel behind an autograd Function (pointnet2_utils);
+Three execution paths with identical results:
+  * composed path (autograd, anything the kernels do not cover): FPS -> gather -> ball_query -> grouping -> SharedMLP ->
+    max_pool, every point op a HIP kernel behind an autograd Function (pointnet2_utils), convolutions / BatchNorm in torch;
+  * fused TRAINING path (autograd on, BatchNorm in training mode; pointrcnn_amd/train_mlp.py, csrc/mlp_train.h): the whole
+    SharedMLP of a scale -- gather, 1x1 convs on the MFMA pipe, batch statistics, ReLU, max-pool with arg-max -- and its
+    backward (BatchNorm reduction, dgrad, wgrad, scatter through the gather) are hand-written kernels on channels-last
+    rows; only each layer's pre-normalisation output is kept for backward.  PRCNN_TRAIN_FUSED=0 is the A/B switch;
   * fused inference path (no autograd, BN in eval mode): features stay channels-last, the two radii of an MSG
     level are queried in one scan, grouping / 3-NN interpolation is folded into the first MLP layer's MFMA
     A-tile, max-pool into the last layer's epilogue, and both scales write straight into the concatenated
@@ -17,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from pointrcnn_amd import ops
+from pointrcnn_amd import ops, train_mlp
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
 
@@ -28,6 +32,7 @@ GROUP_DEDUP = os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"       # padding-fr
 DEDUP_SPARSE_DIV = int(os.environ.get("PRCNN_DEDUP_SPARSE_DIV", "4"))  # groups with <= nsample/DIV hits run as flat rows
 STACK_ALL_FLAT = os.environ.get("PRCNN_STACK_ALL_FLAT", "1") != "0"      # A/B switch: stack-kernel scales keep a dense list when off
 STACK_ALL_FLAT_MAX_ROWS = 1 << 20
+TRAIN_FUSED = os.environ.get("PRCNN_TRAIN_FUSED", "1") != "0"          # hand-written training-mode SharedMLP (train_mlp.py)
 
 
 def _channels_last(features):
@@ -100,6 +105,8 @@ class _PointnetSAModuleBase(nn.Module):
         """xyz (B,N,3), features (B,C,N) or None -> new_xyz (B,npoint,3) or None, new_features (B,sum C_out,npoint)"""
         if self._fused_ok(xyz, features):
             return self._forward_fused(xyz, features, new_xyz)
+        if self._train_ok(xyz, features):
+            return self._forward_train(xyz, features, new_xyz)
         new_features_list = []
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         if new_xyz is None:
@@ -121,6 +128,38 @@ class _PointnetSAModuleBase(nn.Module):
                 raise NotImplementedError
             new_features_list.append(new_features.squeeze(-1))
         return new_xyz, torch.cat(new_features_list, dim=1)
+
+    # ---- fused training path ------------------------------------------------------------------
+    def _train_ok(self, xyz, features):
+        if not TRAIN_FUSED or not train_mlp.usable(xyz, features) or self.pool_method != "max_pool" or self.npoint is None:
+            return False
+        for g, m in zip(self.groupers, self.mlps):
+            if not isinstance(g, pointnet2_utils.QueryAndGroup) or not g.use_xyz or g.nsample > 255 or not train_mlp.stack_ok(m.layers()):
+                return False
+        return True
+
+    def _forward_train(self, xyz, features, new_xyz):
+        """sampling and neighbour search carry no gradient; the grouped SharedMLP + max-pool of every scale is ONE autograd
+        node over the channels-last features (train_mlp.SharedMLPTrain)"""
+        xyz = xyz.contiguous()
+        B = xyz.shape[0]
+        with torch.no_grad():
+            if new_xyz is None:
+                new_xyz = ops.gather_rows(xyz, ops.furthest_point_sample(xyz, self.npoint))
+            new_xyz = new_xyz.contiguous()
+            if len(self.groupers) == 2:
+                a, b = self.groupers
+                idxs = list(ops.ball_query2(a.radius, a.nsample, b.radius, b.nsample, xyz, new_xyz))
+            else:
+                idxs = [ops.ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
+        feat_cl = _channels_last(features)
+        M = new_xyz.shape[1]
+        outs = []
+        for g, mlp, idx in zip(self.groupers, self.mlps, idxs):
+            src = train_mlp.Source("group", xyz=xyz, new_xyz=new_xyz, idx=idx)
+            outs.append(train_mlp.run_stack(mlp.layers(), src, feat_cl, None, pool_ns=g.nsample).view(B, M, -1))
+        out_cl = outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
+        return new_xyz, out_cl.transpose(1, 2)
 
     # ---- fused inference path -----------------------------------------------------------------
     def _forward_fused(self, xyz, features, new_xyz):
@@ -256,6 +295,16 @@ class PointnetFPModule(nn.Module):
         if (not torch.is_grad_enabled()) and known is not None and unknown.is_cuda and self.mlp.fusable() \
                 and known_feats.dtype == torch.float32:
             return self._forward_fused(unknown, known, unknow_feats, known_feats)
+        if TRAIN_FUSED and known is not None and train_mlp.usable(unknown, known_feats, unknow_feats) \
+                and train_mlp.stack_ok(self.mlp.layers()):
+            # fused training path: 3-NN search without gradient, interpolation + concat + SharedMLP as one autograd node
+            unknown, known = unknown.contiguous(), known.contiguous()
+            B, n, _ = unknown.shape
+            with torch.no_grad():
+                _, idx3, w3 = ops.three_nn(unknown, known, want_weight=True)
+            src = train_mlp.Source("interp", idx3=idx3, w3=w3)
+            x = train_mlp.run_stack(self.mlp.layers(), src, _channels_last(known_feats), _channels_last(unknow_feats))
+            return x.view(B, n, -1).transpose(1, 2)
         if known is not None:
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)

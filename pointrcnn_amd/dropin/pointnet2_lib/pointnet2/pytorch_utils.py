@@ -226,6 +226,15 @@ class _ConvBase(nn.Sequential):
         return self._cached(("hoist_interp", c2), build)
 
     def forward(self, x):
+        if torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3:
+            # training: Conv1d -> BatchNorm1d -> ReLU on (B, C, L) as one hand-written autograd node (train_mlp.py)
+            from pointrcnn_amd import train_mlp
+            from . import pointnet2_modules
+            if pointnet2_modules.TRAIN_FUSED and train_mlp.stack_ok([self]):
+                B, C, L = x.shape
+                rows = _rows_view(x.permute(0, 2, 1))
+                y = train_mlp.run_stack([self], train_mlp.Source("plain"), rows.reshape(B * L, C))
+                return y.view(B, L, -1).permute(0, 2, 1)
         if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or not self.fusable():
             return super().forward(x)
         return run_conv_stack([self], x)

@@ -1,0 +1,219 @@
+"""Training-mode SharedMLP kernels (csrc/mlp_train.h, pointrcnn_amd/train_mlp.py) against plain PyTorch fp32: the reference
+runs these layers as nn.Conv2d(1x1) -> nn.BatchNorm2d (batch statistics) -> ReLU -> max over nsample through torch
+(upstream pytorch_utils.SharedMLP; lib/net/pointnet2_msg.py:20-45), so torch's own modules + autograd ARE the reference here.
+
+Tolerances (written where used): forward 1e-5 * scale (fp32 MFMA sums in a different k order than torch's GEMM);
+parameter / input gradients 1e-4 relative to the tensor's largest entry where no arg-max is involved; with max-pooling a
+near-tie between two rows can route one gradient entry differently in the two implementations (both are valid sub-gradients),
+so pooled cases are held to 1e-5 in the median and 5e-3 in norm."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rel, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= rel * scale, "%s: max abs err %.3e > %.1e * %.3e" % (what, err, rel, scale)
+
+
+def _close_pooled(a, b, what):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    scale = max(1e-12, float(b.abs().max()))
+    assert float((a - b).abs().median()) <= 1e-5 * scale, what
+    assert float((a - b).norm()) <= 5e-3 * max(1e-12, float(b.norm())), what
+
+
+class _TorchStack(nn.Module):
+    """Conv(1x1, no bias) -> BN -> ReLU layers on (R, K) rows, the torch reference"""
+
+    def __init__(self, chans, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.lin = nn.ModuleList([nn.Linear(a, b, bias=False) for a, b in zip(chans[:-1], chans[1:])])
+        self.bn = nn.ModuleList([nn.BatchNorm1d(b) for b in chans[1:]])
+        with torch.no_grad():
+            for l, b in zip(self.lin, self.bn):
+                l.weight.copy_(torch.randn(l.weight.shape, generator=g) * (1.0 / np.sqrt(l.weight.shape[1])))
+                b.weight.copy_(torch.rand(b.weight.shape, generator=g) + 0.5)
+                b.bias.copy_(torch.randn(b.bias.shape, generator=g) * 0.2)
+                b.running_mean.copy_(torch.randn(b.bias.shape, generator=g) * 0.1)
+
+    def forward(self, x):
+        for l, b in zip(self.lin, self.bn):
+            x = torch.relu(b(l(x)))
+        return x
+
+
+def _run_ours(ref, src, x0, x1, pool_ns):
+    from pointrcnn_amd import train_mlp
+    bns = [copy.deepcopy(b) for b in ref.bn]
+    params = []
+    for l, b in zip(ref.lin, bns):
+        params += [l.weight.detach().clone().requires_grad_(True), b.weight.detach().clone().requires_grad_(True),
+                   b.bias.detach().clone().requires_grad_(True)]
+    out = train_mlp.SharedMLPTrain.apply(src, bns, pool_ns, x0, x1, *params)
+    return out, params, bns
+
+
+@pytest.mark.parametrize("rows,chans", [(1000, [128, 128]), (4099, [99, 64, 96, 128]), (300, [3, 16, 16, 32]), (2048, [259, 128, 196, 256]),
+                                        (777, [515, 256, 384, 512])])
+def test_plain_stack_forward_backward_equal_torch(dev, rows, chans):
+    from pointrcnn_amd import train_mlp
+    g = torch.Generator().manual_seed(rows)
+    ref = _TorchStack(chans, seed=rows).to(dev).train()
+    x = (torch.randn(rows, chans[0], generator=g) * 1.5 + 0.3).to(dev)
+    xr = x.clone().requires_grad_(True)
+    want = ref(xr)
+    gout = torch.randn(want.shape, generator=g).to(dev)
+    want.backward(gout)
+    xo = x.clone().requires_grad_(True)
+    got, params, bns = _run_ours(ref, train_mlp.Source("plain"), xo, None, 0)
+    got.backward(gout)
+    _close(got, want, 1e-5, "forward")
+    _close(xo.grad, xr.grad, 1e-4, "input gradient")
+    for l, (lin, bn) in enumerate(zip(ref.lin, ref.bn)):
+        _close(params[3 * l].grad, lin.weight.grad, 1e-4, "dW layer %d" % l)
+        _close(params[3 * l + 1].grad, bn.weight.grad, 1e-4, "dgamma layer %d" % l)
+        _close(params[3 * l + 2].grad, bn.bias.grad, 1e-4, "dbeta layer %d" % l)
+        _close(bns[l].running_mean, bn.running_mean, 1e-5, "running_mean layer %d" % l)
+        _close(bns[l].running_var, bn.running_var, 1e-5, "running_var layer %d" % l)
+        assert int(bns[l].num_batches_tracked) == int(bn.num_batches_tracked) == 1
+
+
+def test_statistics_survive_a_large_mean(dev):
+    """batch variance from (mean, M2) slab partials: no E[y^2] - mean^2 cancellation when |mean| >> std"""
+    from pointrcnn_amd import train_mlp
+    ref = _TorchStack([64, 64], seed=3).to(dev).train()
+    with torch.no_grad():
+        ref.lin[0].weight.copy_(torch.eye(64, device=dev))
+    x = (torch.randn(70000, 64, generator=torch.Generator().manual_seed(1)) * 0.05 + 30.0).to(dev)
+    want = ref(x)
+    got, _, bns = _run_ours(ref, train_mlp.Source("plain"), x.clone().requires_grad_(True), None, 0)
+    _close(bns[0].running_var, ref.bn[0].running_var, 1e-4, "running_var")
+    _close(got, want, 2e-4, "normalised output")        # xhat = (y - 30) / 0.05: input rounding is amplified 600 x
+
+
+def _modules(kind, dev, seed, **kw):
+    import pointrcnn_amd
+    pointrcnn_amd.install()
+    from pointnet2_lib.pointnet2 import pointnet2_modules as pm
+    torch.manual_seed(seed)
+    m = (pm.PointnetSAModuleMSG(**kw) if kind == "sa" else pm.PointnetFPModule(**kw)).to(dev).train()
+    with torch.no_grad():
+        for p in m.modules():
+            if isinstance(p, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                p.weight.uniform_(0.5, 1.5)
+                p.bias.normal_(0, 0.2)
+    return pm, m, copy.deepcopy(m)
+
+
+def _compare_modules(ma, mb, pooled):
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    assert set(pa) == set(pb)
+    for n in pa:
+        assert pa[n].grad is not None and pb[n].grad is not None, n
+        (_close_pooled if pooled else (lambda a, b, w: _close(a, b, 1e-4, w)))(pa[n].grad, pb[n].grad, n)
+    for (na, ba), (nb, bb) in zip(ma.named_buffers(), mb.named_buffers()):
+        if ba.dtype.is_floating_point:
+            _close(ba, bb, 1e-5, na)
+        else:
+            assert int(ba) == int(bb)
+
+
+@pytest.mark.parametrize("C", [0, 8, 96])
+def test_sa_module_fused_training_equals_composed_torch_path(dev, C):
+    """PointnetSAModuleMSG in training mode: hand-written path == the composed path (HIP grouping ops + torch Conv2d /
+    BatchNorm2d / ReLU / max, the reference's own structure): outputs, feature gradient, every parameter gradient and
+    BatchNorm buffer.  Clouds dense enough that groups are partly padded, partly full."""
+    B, N = 3, 1500
+    pm, fused, comp = _modules("sa", dev, 5 + C, npoint=200, radii=[0.15, 0.3], nsamples=[16, 32],
+                               mlps=[[C, 16, 16, 32], [C, 32, 48, 64]], use_xyz=True, bn=True)
+    g = torch.Generator().manual_seed(C)
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    feat = None if C == 0 else torch.randn(B, C, N, generator=g).to(dev)
+    fa = None if feat is None else feat.clone().requires_grad_(True)
+    fb = None if feat is None else feat.clone().requires_grad_(True)
+    assert fused._train_ok(xyz, fa)
+    nx_a, out_a = fused(xyz, fa)
+    pm.TRAIN_FUSED = False
+    try:
+        nx_b, out_b = comp(xyz, fb)
+    finally:
+        pm.TRAIN_FUSED = True
+    assert torch.equal(nx_a, nx_b)
+    _close(out_a, out_b, 1e-5, "pooled features")
+    gout = torch.randn(out_b.shape, generator=g).to(dev)
+    out_a.backward(gout)
+    out_b.backward(gout)
+    if feat is not None:
+        _close_pooled(fa.grad, fb.grad, "feature gradient")
+    _compare_modules(fused, comp, pooled=True)
+
+
+@pytest.mark.parametrize("C1", [0, 32])
+def test_fp_module_fused_training_equals_composed_torch_path(dev, C1):
+    B, n, m, C2 = 2, 900, 250, 64
+    pm, fused, comp = _modules("fp", dev, 11 + C1, mlp=[C2 + C1, 128, 64])
+    g = torch.Generator().manual_seed(C1 + 1)
+    unknown, known = torch.rand(B, n, 3, generator=g).to(dev), torch.rand(B, m, 3, generator=g).to(dev)
+    kf = torch.randn(B, C2, m, generator=g).to(dev)
+    uf = None if C1 == 0 else torch.randn(B, C1, n, generator=g).to(dev)
+    ka, kb = kf.clone().requires_grad_(True), kf.clone().requires_grad_(True)
+    ua = None if uf is None else uf.clone().requires_grad_(True)
+    ub = None if uf is None else uf.clone().requires_grad_(True)
+    out_a = fused(unknown, known, ua, ka)
+    pm.TRAIN_FUSED = False
+    try:
+        out_b = comp(unknown, known, ub, kb)
+    finally:
+        pm.TRAIN_FUSED = True
+    _close(out_a, out_b, 1e-5, "propagated features")
+    gout = torch.randn(out_b.shape, generator=g).to(dev)
+    out_a.backward(gout)
+    out_b.backward(gout)
+    _close(ka.grad, kb.grad, 1e-4, "known-feature gradient")
+    if uf is not None:
+        _close(ua.grad, ub.grad, 1e-4, "skip-feature gradient")
+    _compare_modules(fused, comp, pooled=False)
+
+
+def test_conv1d_head_layer_fused_training_equals_torch(dev):
+    import pointrcnn_amd
+    pointrcnn_amd.install()
+    from pointnet2_lib.pointnet2 import pointnet2_modules as pm, pytorch_utils as pt
+    torch.manual_seed(0)
+    a = pt.Conv1d(128, 128, bn=True).to(dev).train()
+    b = copy.deepcopy(a)
+    x = torch.randn(2, 128, 3000, device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = a(xa)
+    pm.TRAIN_FUSED = False
+    try:
+        yb = b(xb)
+    finally:
+        pm.TRAIN_FUSED = True
+    _close(ya, yb, 1e-5, "head layer")
+    gout = torch.randn_like(yb)
+    ya.backward(gout)
+    yb.backward(gout)
+    _close(xa.grad, xb.grad, 1e-4, "input gradient")
+    _compare_modules(a, b, pooled=False)
+
+
+def test_eval_mode_and_unsupported_layers_keep_their_paths(dev):
+    """BatchNorm in eval mode / a layer without BatchNorm is not this path's business: stack_ok says no, modules fall back"""
+    import pointrcnn_amd
+    pointrcnn_amd.install()
+    from pointrcnn_amd import train_mlp
+    from pointnet2_lib.pointnet2 import pytorch_utils as pt
+    a = pt.Conv1d(16, 16, bn=True).to(dev)
+    assert train_mlp.stack_ok([a.train()]) and not train_mlp.stack_ok([a.eval()])
+    assert not train_mlp.stack_ok([pt.Conv1d(16, 16, bn=False).to(dev).train()])
+    assert not train_mlp.stack_ok([pt.Conv1d(16, 1, bn=True).to(dev).train()])            # channel count not a multiple of 4
