@@ -69,12 +69,12 @@ def test_plain_stack_forward_backward_equal_torch(dev, rows, chans):
     g = torch.Generator().manual_seed(rows)
     ref = _TorchStack(chans, seed=rows).to(dev).train()
     x = (torch.randn(rows, chans[0], generator=g) * 1.5 + 0.3).to(dev)
+    xo = x.clone().requires_grad_(True)
+    got, params, bns = _run_ours(ref, train_mlp.Source("plain"), xo, None, 0)      # (copies the BatchNorm buffers BEFORE the reference runs)
     xr = x.clone().requires_grad_(True)
     want = ref(xr)
     gout = torch.randn(want.shape, generator=g).to(dev)
     want.backward(gout)
-    xo = x.clone().requires_grad_(True)
-    got, params, bns = _run_ours(ref, train_mlp.Source("plain"), xo, None, 0)
     got.backward(gout)
     _close(got, want, 1e-5, "forward")
     _close(xo.grad, xr.grad, 1e-4, "input gradient")
@@ -94,8 +94,8 @@ def test_statistics_survive_a_large_mean(dev):
     with torch.no_grad():
         ref.lin[0].weight.copy_(torch.eye(64, device=dev))
     x = (torch.randn(70000, 64, generator=torch.Generator().manual_seed(1)) * 0.05 + 30.0).to(dev)
-    want = ref(x)
     got, _, bns = _run_ours(ref, train_mlp.Source("plain"), x.clone().requires_grad_(True), None, 0)
+    want = ref(x)
     _close(bns[0].running_var, ref.bn[0].running_var, 1e-4, "running_var")
     _close(got, want, 2e-4, "normalised output")        # xhat = (y - 30) / 0.05: input rounding is amplified 600 x
 
