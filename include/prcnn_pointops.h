@@ -472,10 +472,8 @@ int prcnn_scene_prepare(const float* raw, const int64_t* offsets, int B, int64_t
  * the previous layer's normalisation `pro_scale / pro_shift` (K entries zero-padded to a multiple of 32 floats) applied;
  * 1 = grouped rows [feat[idx] | xyz[idx] - new_xyz] (the weight is packed with k_rot = 3), rows = B * M * ns, K = C + 3;
  * 2 = interpolated rows [sum_j w3 known[idx3] | skip], rows = B * n, K = C2 + C1).
- * prcnn_train_grad_t is the gradient arriving at a layer: G w.r.t. the layer's ACTIVATED output -- (rows, N) rows, or, for a
- * max-pooled layer (pool_ns > 0), (rows / pool_ns, N) pooled rows + the arg-max byte per (group, channel) -- together with the
- * saved y and the layer's constant table cst (6 rows of ld_c floats: scale, shift, mean, invstd from prcnn_train_bn_finalize;
- * mean(dyhat), mean(dyhat * xhat) from prcnn_train_bn_backward).  N, ldG, ld_y, ld_c multiples of 4; 16-byte aligned bases.
+ * A layer's constant table cst holds 6 rows of ld_c floats: scale = gamma * invstd, shift = beta - mean * scale, mean, invstd
+ * (forward), mean(dyhat), mean(dyhat * xhat) (backward).  One call runs a whole stack; the host side is C++ (no per-layer Python).
  * ====================================================================================================== */
 typedef struct prcnn_train_src {
     int mode;
@@ -485,38 +483,42 @@ typedef struct prcnn_train_src {
     const float* xyz; const float* new_xyz; const int32_t* idx; const float* feat; int ld_feat; int B, N, M, ns, C;
     const float* known; const int32_t* idx3; const float* w3; const float* skip; int ld_known, ld_skip, n, m, C2, C1;
 } prcnn_train_src_t;
-typedef struct prcnn_train_grad {
-    int64_t rows;
-    int N;
-    const float* G; int ldG;
-    const uint8_t* arg; int pool_ns;
-    const float* y; int ld_y;
-    float* cst; int ld_c;
-} prcnn_train_grad_t;
 
-/* y (rows, Nout) = A . W^T, wpack = prcnn_pack_weight(W (Nout, K)); a_dump (rows, ld_dump) optional copy of the assembled A rows
- * (gathered sources; what prcnn_train_wgrad consumes); part (prcnn_train_part_floats): per-64-row column (mean, M2) partials */
-size_t prcnn_train_part_floats(int64_t rows, int ld_part);
-int prcnn_train_fwd(const prcnn_train_src_t* src, const float* wpack, int Nout, float* y, int ld_y, float* a_dump, int ld_dump,
-                    float* part, int ld_part, prcnn_stream_t stream);
-/* batch mean / biased variance (double, fixed summation order) -> cst rows 0..3; running_mean / running_var (may be NULL)
- * updated as nn.BatchNorm does: (1 - momentum) * old + momentum * new, unbiased variance */
-int prcnn_train_bn_finalize(const float* part, int ld_part, int64_t rows, int N, const float* gamma, const float* beta, float eps,
-                            float momentum, float* running_mean, float* running_var, float* cst, int ld_c, prcnn_stream_t stream);
-/* out[g, col_off + n] = max over the ns rows of group g of relu(y * scale + shift); arg (groups, N) u8 = FIRST maximal row
- * (torch.max / max_pool2d route the gradient there); ns = 1, arg NULL: plain normalise + ReLU */
-int prcnn_train_pool(const float* y, int ld_y, int64_t groups, int ns, int N, const float* cst, int ld_c, float* out, int ld_out,
-                     int col_off, uint8_t* arg, prcnn_stream_t stream);
-/* dgamma, dbeta (N) and cst rows 4, 5; part: prcnn_train_bwd_part_floats floats of scratch */
-size_t prcnn_train_bwd_part_floats(int64_t rows, int ld_part);
-int prcnn_train_bn_backward(const prcnn_train_grad_t* g, float* part, int ld_part, float* dgamma, float* dbeta, prcnn_stream_t stream);
-/* out (rows, Kin) = dy . W: gradient w.r.t. the rows that entered the convolution; wpack_t = prcnn_pack_weight(W^T (Kin, N)) */
-int prcnn_train_dgrad(const prcnn_train_grad_t* g, const float* wpack_t, int Kin, float* out, int ld_out, prcnn_stream_t stream);
-/* dW (N, K) = dy^T . a, a (rows, lda) = the rows that entered the convolution (y of the previous layer with pro_scale / pro_shift,
- * padded to a multiple of 128 floats; or an a_dump); part: splits * N * K floats, splits from prcnn_train_wgrad_splits */
-int prcnn_train_wgrad_splits(int64_t rows, int N, int K);
-int prcnn_train_wgrad(const prcnn_train_grad_t* g, const float* a, int lda, int K, const float* pro_scale, const float* pro_shift,
-                      float* part, int splits, float* dW, prcnn_stream_t stream);
+/* One layer of a stack.  The caller owns every buffer (nothing is allocated inside):
+ *   W (Nout, K) conv weight in torch layout (K = the source's K for layer 0, the previous layer's Nout after that); gamma, beta,
+ *   running_mean, running_var (Nout) and eps, momentum of its BatchNorm;
+ *   y (rows, Nout)  the layer's saved pre-normalisation output (written by forward, read by backward);
+ *   cst (6, ld_c)   constant table, ZERO-INITIALISED by the caller before forward; ld_c a multiple of 128, >= Nout;
+ *   wpack           prcnn_wpack_floats(Nout, K) floats: the forward weight image (written by forward);
+ *   wpack_t         prcnn_wpack_floats(Kin, Nout) floats: the dgrad weight image, Kin = K (K - 3 for a grouped layer 0, whose
+ *                   xyz columns carry no gradient); NULL when the layer's input takes no gradient (layer 0 only);
+ *   dW (Nout, K) in torch's channel order, dgamma, dbeta (Nout): written by backward. */
+typedef struct prcnn_train_layer {
+    int Nout;
+    const float* W; const float* gamma; const float* beta;
+    float eps, momentum;
+    float* running_mean; float* running_var;
+    float* y;
+    float* cst; int ld_c;
+    float* wpack; float* wpack_t;
+    float* dW; float* dgamma; float* dbeta;
+} prcnn_train_layer_t;
+
+/* scratch both passes need (partials of the statistics, wgrad partial tiles, the inter-layer gradient ping-pong); 256-byte aligned */
+size_t prcnn_train_stack_work_bytes(int64_t rows, const prcnn_train_layer_t* layers, int nl, int K0, int backward);
+/* forward of the whole stack: per layer pack weights -> y = A . W^T on the MFMA pipe with per-64-row (mean, M2) partials -> batch
+ * statistics in double, fixed order -> cst rows 0..3 and the running statistics ((1 - momentum) * old + momentum * new, unbiased
+ * variance); then out[g, col_off + n] = max over the pool_ns rows of group g of relu(y * scale + shift), arg (groups, Nout) u8 = the
+ * FIRST maximal row (torch.max / max_pool2d route the gradient there); pool_ns <= 1: plain normalise + ReLU, arg unused.
+ * a_dump (rows, ld_dump): copy of the assembled first-layer rows of a gathered source (backward's wgrad reads it); NULL for plain. */
+int prcnn_train_stack_fwd(const prcnn_train_src_t* src, const prcnn_train_layer_t* layers, int nl, int pool_ns, float* a_dump, int ld_dump,
+                          float* out, int ld_out, int col_off, uint8_t* arg, void* work, size_t work_bytes, prcnn_stream_t stream);
+/* backward of the whole stack from gout = d loss / d out ((rows / pool_ns, N_last) rows): per layer BatchNorm reductions (dgamma,
+ * dbeta), wgrad (dW), dgrad into the previous layer.  gin (rows, ld_gin), may be NULL: gradient w.r.t. the rows that entered layer 0
+ * (grouped source: the C feature columns only) -- scatter it with prcnn_group_rows_grad / prcnn_interp_rows_grad. */
+int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_train_layer_t* layers, int nl, int pool_ns, const float* a_dump,
+                          int ld_dump, const float* gout, int ld_gout, const uint8_t* arg, float* gin, int ld_gin, void* work,
+                          size_t work_bytes, prcnn_stream_t stream);
 /* backward of the gathers on channels-last rows: dfeat (B, N, ld_d) += scatter of G ((B, M, ns) rows, C channels) through idx;
  * dknown (B, m, ld_d) += w3-weighted scatter of G ((B, n) rows) through idx3.  Outputs pre-zeroed by the caller. */
 int prcnn_group_rows_grad(const float* G, int ldG, const int32_t* idx, int B, int M, int ns, int C, int N, float* dfeat, int ld_d,

@@ -28,10 +28,11 @@ class TrainSrc(ctypes.Structure):
                 ("n", _I), ("m", _I), ("C2", _I), ("C1", _I)]
 
 
-class TrainGrad(ctypes.Structure):
-    """prcnn_train_grad_t (include/prcnn_pointops.h)"""
-    _fields_ = [("rows", _L), ("N", _I), ("G", _P), ("ldG", _I), ("arg", _P), ("pool_ns", _I), ("y", _P), ("ld_y", _I),
-                ("cst", _P), ("ld_c", _I)]
+class TrainLayer(ctypes.Structure):
+    """prcnn_train_layer_t (include/prcnn_pointops.h)"""
+    _fields_ = [("Nout", _I), ("W", _P), ("gamma", _P), ("beta", _P), ("eps", _F), ("momentum", _F),
+                ("running_mean", _P), ("running_var", _P), ("y", _P), ("cst", _P), ("ld_c", _I), ("wpack", _P), ("wpack_t", _P),
+                ("dW", _P), ("dgamma", _P), ("dbeta", _P)]
 
 
 # name -> (restype, argtypes); mirrors include/prcnn_pointops.h one for one
@@ -91,15 +92,9 @@ SIGNATURES = {
     "prcnn_scene_workspace_bytes": (_Z, [_L, _I]),
     "prcnn_scene_prepare": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _I, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "prcnn_nms_batched": (_I, [_P, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
-    "prcnn_train_part_floats": (_Z, [_L, _I]),
-    "prcnn_train_fwd": (_I, [ctypes.POINTER(TrainSrc), _P, _I, _P, _I, _P, _I, _P, _I, _P]),
-    "prcnn_train_bn_finalize": (_I, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P]),
-    "prcnn_train_pool": (_I, [_P, _I, _L, _I, _I, _P, _I, _P, _I, _I, _P, _P]),
-    "prcnn_train_bwd_part_floats": (_Z, [_L, _I]),
-    "prcnn_train_bn_backward": (_I, [ctypes.POINTER(TrainGrad), _P, _I, _P, _P, _P]),
-    "prcnn_train_dgrad": (_I, [ctypes.POINTER(TrainGrad), _P, _I, _P, _I, _P]),
-    "prcnn_train_wgrad_splits": (_I, [_L, _I, _I]),
-    "prcnn_train_wgrad": (_I, [ctypes.POINTER(TrainGrad), _P, _I, _I, _P, _P, _P, _I, _P, _P]),
+    "prcnn_train_stack_work_bytes": (_Z, [_L, ctypes.POINTER(TrainLayer), _I, _I, _I]),
+    "prcnn_train_stack_fwd": (_I, [ctypes.POINTER(TrainSrc), ctypes.POINTER(TrainLayer), _I, _I, _P, _I, _P, _I, _I, _P, _P, _Z, _P]),
+    "prcnn_train_stack_bwd": (_I, [ctypes.POINTER(TrainSrc), ctypes.POINTER(TrainLayer), _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _Z, _P]),
     "prcnn_group_rows_grad": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "prcnn_interp_rows_grad": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
 }

@@ -177,19 +177,23 @@ __global__ __launch_bounds__(MLP_THREADS, ((WNB == 1 && MODE != MODE_INTERP) ? 3
     }
 }
 
-// Batch statistics from the slab partials.  Block = 64 columns x 16 slab lanes (1024 threads); everything in double, combined in a
-// fixed order.  cst rows (ld_c floats each): 0 scale = gamma * invstd, 1 shift = beta - mean * scale, 2 mean, 3 invstd.
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int ld_part, long rows, int N,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                           float momentum, float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var, float* __restrict__ cst, int ld_c) {
-    __shared__ double s1[16][64], s2[16][64];
+// Batch statistics from the slab partials, in two deterministic stages (everything in double, fixed summation order):
+//   bn_chunk_kernel     grid (N / 64, chunks): block (64 columns x 4 lanes) sums its range of slabs -> (sum y, sum y^2-equivalent)
+//   bn_finalize_kernel  grid (N / 64): combines the <= 64 chunk sums -> cst rows (ld_c floats each): 0 scale = gamma * invstd,
+//                       1 shift = beta - mean * scale, 2 mean, 3 invstd; running statistics as nn.BatchNorm updates them.
+// A single block walking all 32 k slabs of a 2 M-row layer took 150 us -- per layer, forty layers a step.
+#define BN_CHUNKS 64
+__global__ __launch_bounds__(256) void bn_chunk_kernel(const float* __restrict__ part, int ld_part, long rows, int N, double* __restrict__ chunk) {
+    __shared__ double s1[4][64], s2[4][64];
     const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
     const long nslab = (rows + 63) >> 6;
+    const long per = (nslab + BN_CHUNKS - 1) / BN_CHUNKS;
+    const long sl0 = (long)blockIdx.y * per;
+    const long sl1 = sl0 + per < nslab ? sl0 + per : nslab;
     double a = 0.0, b = 0.0;
     if (n < N) {
-        for (long sl = q; sl < nslab; sl += 16) {
+        for (long sl = sl0 + q; sl < sl1; sl += 4) {
             const double cn = (double)(sl == nslab - 1 ? rows - sl * 64 : 64);
             const double m = (double)part[(sl * 2 + 0) * ld_part + n], m2 = (double)part[(sl * 2 + 1) * ld_part + n];
             a += cn * m;
@@ -199,23 +203,32 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     s1[q][c] = a; s2[q][c] = b;
     __syncthreads();
     if (q == 0 && n < N) {
-        double A = 0.0, Bq = 0.0;
-        for (int t = 0; t < 16; t++) { A += s1[t][c]; Bq += s2[t][c]; }
-        const double mean = A / (double)rows;
-        double var = Bq / (double)rows - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[n] : 1.f, be = beta ? beta[n] : 0.f;
-        const float scale = g * invstd;
-        cst[0 * ld_c + n] = scale;
-        cst[1 * ld_c + n] = be - (float)mean * scale;
-        cst[2 * ld_c + n] = (float)mean;
-        cst[3 * ld_c + n] = invstd;
-        if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
-        if (running_var) {
-            const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
-            running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
-        }
+        chunk[((long)blockIdx.y * 2 + 0) * N + n] = (s1[0][c] + s1[1][c]) + (s1[2][c] + s1[3][c]);
+        chunk[((long)blockIdx.y * 2 + 1) * N + n] = (s2[0][c] + s2[1][c]) + (s2[2][c] + s2[3][c]);
+    }
+}
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ chunk, long rows, int N,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         float momentum, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var, float* __restrict__ cst, int ld_c) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    double A = 0.0, Bq = 0.0;
+    for (int t = 0; t < BN_CHUNKS; t++) { A += chunk[((long)t * 2 + 0) * N + n]; Bq += chunk[((long)t * 2 + 1) * N + n]; }
+    const double mean = A / (double)rows;
+    double var = Bq / (double)rows - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[n] : 1.f, be = beta ? beta[n] : 0.f;
+    const float scale = g * invstd;
+    cst[0 * ld_c + n] = scale;
+    cst[1 * ld_c + n] = be - (float)mean * scale;
+    cst[2 * ld_c + n] = (float)mean;
+    cst[3 * ld_c + n] = invstd;
+    if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
     }
 }
 
@@ -303,26 +316,35 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const TrainBwd T, fl
     }
 }
 
-// tile partials -> dbeta = sum dyhat, dgamma = sum dyhat * xhat (double, fixed order); cst rows 4, 5 = their means over the rows
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int ld_part, long tiles, long rows, int N,
-                                                               float* __restrict__ cst, int ld_c, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta) {
-    __shared__ double s1[16][64], s2[16][64];
+// tile partials -> dbeta = sum dyhat, dgamma = sum dyhat * xhat (double, fixed order, the same two stages as the forward
+// statistics); cst rows 4, 5 = their means over the rows
+__global__ __launch_bounds__(256) void bn_bwd_chunk_kernel(const float* __restrict__ part, int ld_part, long tiles, int N, double* __restrict__ chunk) {
+    __shared__ double s1[4][64], s2[4][64];
     const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
+    const long per = (tiles + BN_CHUNKS - 1) / BN_CHUNKS;
+    const long t0 = (long)blockIdx.y * per;
+    const long t1 = t0 + per < tiles ? t0 + per : tiles;
     double a = 0.0, b = 0.0;
     if (n < N)
-        for (long t = q; t < tiles; t += 16) { a += (double)part[(t * 2 + 0) * ld_part + n]; b += (double)part[(t * 2 + 1) * ld_part + n]; }
+        for (long t = t0 + q; t < t1; t += 4) { a += (double)part[(t * 2 + 0) * ld_part + n]; b += (double)part[(t * 2 + 1) * ld_part + n]; }
     s1[q][c] = a; s2[q][c] = b;
     __syncthreads();
     if (q == 0 && n < N) {
-        double A = 0.0, Bq = 0.0;
-        for (int t = 0; t < 16; t++) { A += s1[t][c]; Bq += s2[t][c]; }
-        if (dbeta) dbeta[n] = (float)A;
-        if (dgamma) dgamma[n] = (float)Bq;
-        cst[4 * ld_c + n] = (float)(A / (double)rows);
-        cst[5 * ld_c + n] = (float)(Bq / (double)rows);
+        chunk[((long)blockIdx.y * 2 + 0) * N + n] = (s1[0][c] + s1[1][c]) + (s1[2][c] + s1[3][c]);
+        chunk[((long)blockIdx.y * 2 + 1) * N + n] = (s2[0][c] + s2[1][c]) + (s2[2][c] + s2[3][c]);
     }
+}
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ chunk, long rows, int N, float* __restrict__ cst,
+                                                             int ld_c, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    double A = 0.0, Bq = 0.0;
+    for (int t = 0; t < BN_CHUNKS; t++) { A += chunk[((long)t * 2 + 0) * N + n]; Bq += chunk[((long)t * 2 + 1) * N + n]; }
+    if (dbeta) dbeta[n] = (float)A;
+    if (dgamma) dgamma[n] = (float)Bq;
+    cst[4 * ld_c + n] = (float)(A / (double)rows);
+    cst[5 * ld_c + n] = (float)(Bq / (double)rows);
 }
 
 // dy for 4 consecutive channels: scale * (dyhat - c1 - xhat * c2)
@@ -453,106 +475,148 @@ __global__ __launch_bounds__(MLP_THREADS, (WNB == 1 ? 3 : 2)) void train_dgrad_k
     }
 }
 
-// dW[n, k] = sum_r dy[r, n] * a[r, k].  Workgroup tile: 128 input channels (k) x 128 output channels (n); wave (kh, nh) owns the
-// 64 x 64 quadrant as 2 x 2 MFMA blocks.  Per step a wave consumes TWO rows: lane (h, j) loads channels 2j, 2j+1 of its k-half from
-// row r + h (8 bytes; the 32 lanes of a half read 256 contiguous bytes) and the same for dy -- element x of the pair feeds block x,
-// whose C row / column i therefore stands for channel 2i + x.  Rows are dealt to the grid's x dimension in contiguous ranges; each
-// workgroup writes its partial tile, train_wgrad_reduce_kernel sums the partials in a fixed order.
+// dW[n, k] = sum_r dy[r, n] * a[r, k].  Both operands go from global memory straight into MFMA operand registers: per step a wave
+// consumes TWO rows; lane (h, j) loads KQ consecutive input channels (KQ * j ...) of row r + h and NQ consecutive output channels of
+// dy -- the 32 lanes of a half read one contiguous piece of the row -- and element x of its vector feeds the blocks (x, .), whose C
+// row i therefore stands for channel KQ * i + x.  A wave owns a (32 KQ) x (32 NQ) tile; the four waves of a workgroup are laid out
+// WK x WN over the channels and WR = 4 / (WK WN) over the ROWS: narrow layers (SA1: 3..64 channels, millions of rows) put all four
+// waves on different rows of ONE tile instead of computing padding -- they are HBM-bound then (one pass over a, G and y).
+// Rows are dealt to grid.x in contiguous ranges; every (range, row group) writes its partial tile, train_wgrad_reduce_kernel sums
+// the partials in a fixed order (deterministic).
 struct TrainWgrad {
     TrainBwd B;
-    const float* a; int lda; int K;          // a rows (rows x lda), K valid channels; lda even
-    const float* pro_scale;                  // optional relu(a * scale + shift) (the forward's prologue), padded to a multiple of 128
+    const float* a; int lda; int K;          // a rows (rows x lda), K valid channels; lda a multiple of 2
+    const float* pro_scale;                  // optional relu(a * scale + shift) (the forward's prologue), zero-padded to 128 floats
     const float* pro_shift;
-    long rows_per_split;                     // even
-    float* part;                             // (splits, N, K) partial dW
+    long rows_per_split;                     // multiple of 2 * WR
+    float* part;                             // (splits * WR, N, K) partial dW
 };
 #define WG_UNROLL 4
-__global__ __launch_bounds__(256, 2) void train_wgrad_kernel(const TrainWgrad W) {
+template <int KQ, int NQ, int WK, int WN>
+__global__ __launch_bounds__(256) void train_wgrad_kernel(const TrainWgrad W) {
+    constexpr int WR = 4 / (WK * WN);
     const TrainBwd& T = W.B;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kh = wave >> 1, nh = wave & 1;
+    const int wr = wave / (WK * WN), wk = (wave / WN) % WK, wn = wave % WN;
     const int h = lane >> 5, j = lane & 31;
-    const int k = blockIdx.y * 128 + kh * 64 + 2 * j;              // this lane's first input channel
-    const int n = blockIdx.z * 128 + nh * 64 + 2 * j;              // ... and first output channel
-    const bool k_ok = k < W.lda, n_ok = n < T.N;                   // (lda and N are even: a pair is in or out as a whole)
-    const float kmx = k < W.K ? 1.f : 0.f, kmy = k + 1 < W.K ? 1.f : 0.f;
-    float2 ps = make_float2(1.f, 1.f), pb = make_float2(0.f, 0.f);
+    const int kbase = (blockIdx.y * WK + wk) * 32 * KQ, nbase = (blockIdx.z * WN + wn) * 32 * NQ;
+    const int k = kbase + KQ * j, n = nbase + NQ * j;            // this lane's first input / output channel
+    const bool k_ok = k + KQ <= W.lda, n_ok = n + NQ <= T.N;     // (vector wholly inside the row; lda, N multiples of KQ, NQ)
     const bool pro = W.pro_scale != nullptr;
-    if (pro) { ps = *reinterpret_cast<const float2*>(W.pro_scale + k); pb = *reinterpret_cast<const float2*>(W.pro_shift + k); }
-    float2 sc = make_float2(0.f, 0.f), sh = sc, mu = sc, is = sc, c1 = sc, c2 = sc;
-    if (n_ok) {
-        sc = *reinterpret_cast<const float2*>(T.cst + n); sh = *reinterpret_cast<const float2*>(T.cst + T.ld_c + n);
-        mu = *reinterpret_cast<const float2*>(T.cst + 2 * T.ld_c + n); is = *reinterpret_cast<const float2*>(T.cst + 3 * T.ld_c + n);
-        c1 = *reinterpret_cast<const float2*>(T.cst + 4 * T.ld_c + n); c2 = *reinterpret_cast<const float2*>(T.cst + 5 * T.ld_c + n);
+    float ps[KQ], pb[KQ], km[KQ];
+#pragma unroll
+    for (int x = 0; x < KQ; x++) {
+        km[x] = k + x < W.K ? 1.f : 0.f;
+        ps[x] = (pro && k_ok) ? W.pro_scale[k + x] : 1.f;
+        pb[x] = (pro && k_ok) ? W.pro_shift[k + x] : 0.f;
     }
-    const long r_begin = (long)blockIdx.x * W.rows_per_split;
-    long r_end = r_begin + W.rows_per_split;
+    float sc[NQ], sh[NQ], mu[NQ], is[NQ], c1[NQ], c2[NQ];
+#pragma unroll
+    for (int z = 0; z < NQ; z++) {
+        sc[z] = n_ok ? T.cst[n + z] : 0.f; sh[z] = n_ok ? T.cst[T.ld_c + n + z] : 0.f;
+        mu[z] = n_ok ? T.cst[2 * T.ld_c + n + z] : 0.f; is[z] = n_ok ? T.cst[3 * T.ld_c + n + z] : 0.f;
+        c1[z] = n_ok ? T.cst[4 * T.ld_c + n + z] : 0.f; c2[z] = n_ok ? T.cst[5 * T.ld_c + n + z] : 0.f;
+    }
+    const long per_group = W.rows_per_split / WR;
+    const long r_begin = (long)blockIdx.x * W.rows_per_split + wr * per_group;
+    long r_end = r_begin + per_group;
     if (r_end > T.rows) r_end = T.rows;
-    f32x16 acc[2][2];
+    f32x16 acc[KQ][NQ];
 #pragma unroll
-    for (int x = 0; x < 2; x++)
+    for (int x = 0; x < KQ; x++)
 #pragma unroll
-        for (int z = 0; z < 2; z++) acc[x][z] = (f32x16){0};
+        for (int z = 0; z < NQ; z++) acc[x][z] = (f32x16){0};
     const int kk = k_ok ? k : 0, nn = n_ok ? n : 0;
+    typedef float vk_t __attribute__((ext_vector_type(KQ)));
+    typedef float vn_t __attribute__((ext_vector_type(NQ)));
     for (long r = r_begin; r < r_end; r += 2 * WG_UNROLL) {
-        float2 av[WG_UNROLL], gv[WG_UNROLL], yv[WG_UNROLL];
+        vk_t av[WG_UNROLL];
+        vn_t gv[WG_UNROLL], yv[WG_UNROLL];
         float valid[WG_UNROLL];
 #pragma unroll
         for (int u = 0; u < WG_UNROLL; u++) {
             long rr = r + 2 * u + h;
             valid[u] = rr < r_end ? 1.f : 0.f;
             if (rr >= r_end) rr = r_end - 1;
-            av[u] = *reinterpret_cast<const float2*>(W.a + rr * (long)W.lda + kk);
-            yv[u] = *reinterpret_cast<const float2*>(T.y + rr * (long)T.ld_y + nn);
+            av[u] = *reinterpret_cast<const vk_t*>(W.a + rr * (long)W.lda + kk);
+            yv[u] = *reinterpret_cast<const vn_t*>(T.y + rr * (long)T.ld_y + nn);
             if (T.pool_ns == 0) {
-                gv[u] = *reinterpret_cast<const float2*>(T.G + rr * (long)T.ldG + nn);
+                gv[u] = *reinterpret_cast<const vn_t*>(T.G + rr * (long)T.ldG + nn);
             } else {
                 const long g = rr / T.pool_ns;
                 const int s = (int)(rr - g * T.pool_ns);
-                const float2 v = *reinterpret_cast<const float2*>(T.G + g * (long)T.ldG + nn);
-                const uchar2 ag = *reinterpret_cast<const uchar2*>(T.arg + g * (long)T.N + nn);
-                gv[u] = make_float2(ag.x == s ? v.x : 0.f, ag.y == s ? v.y : 0.f);
+                const vn_t v = *reinterpret_cast<const vn_t*>(T.G + g * (long)T.ldG + nn);
+                const uint8_t* ap = T.arg + g * (long)T.N + nn;
+#pragma unroll
+                for (int z = 0; z < NQ; z++) gv[u][z] = ap[z] == s ? v[z] : 0.f;
             }
         }
 #pragma unroll
         for (int u = 0; u < WG_UNROLL; u++) {
-            float2 a = av[u];
-            if (pro) { a.x = fmaxf(a.x * ps.x + pb.x, 0.f); a.y = fmaxf(a.y * ps.y + pb.y, 0.f); }
-            a.x *= kmx * valid[u]; a.y *= kmy * valid[u];           // channels past K and rows past the range contribute zero
-            float2 d;
-            d.x = sc.x * (((yv[u].x * sc.x + sh.x > 0.f) ? gv[u].x : 0.f) - c1.x - ((yv[u].x - mu.x) * is.x) * c2.x);
-            d.y = sc.y * (((yv[u].y * sc.y + sh.y > 0.f) ? gv[u].y : 0.f) - c1.y - ((yv[u].y - mu.y) * is.y) * c2.y);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, d.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, d.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, d.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, d.y, acc[1][1], 0, 0, 0);
+            float a[KQ], d[NQ];
+#pragma unroll
+            for (int x = 0; x < KQ; x++) {
+                float t = av[u][x];
+                if (pro) t = fmaxf(t * ps[x] + pb[x], 0.f);
+                a[x] = t * (km[x] * valid[u]);                   // channels past K and rows past the range contribute zero
+            }
+#pragma unroll
+            for (int z = 0; z < NQ; z++) {
+                const float yy = yv[u][z];
+                d[z] = sc[z] * (((yy * sc[z] + sh[z] > 0.f) ? gv[u][z] : 0.f) - c1[z] - ((yy - mu[z]) * is[z]) * c2[z]);
+            }
+#pragma unroll
+            for (int x = 0; x < KQ; x++)
+#pragma unroll
+                for (int z = 0; z < NQ; z++) acc[x][z] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], d[z], acc[x][z], 0, 0, 0);
         }
     }
-    // C[i][jj] of block (x, z): input channel kbase + 2 i + x, output channel nbase + 2 jj + z
-    float* P = W.part + (long)blockIdx.x * T.N * W.K;
-    const int kbase = blockIdx.y * 128 + kh * 64, nbase = blockIdx.z * 128 + nh * 64;
+    // C[i][jj] of block (x, z): input channel kbase + KQ i + x, output channel nbase + NQ jj + z
+    float* P = W.part + ((long)blockIdx.x * WR + wr) * T.N * W.K;
 #pragma unroll
-    for (int x = 0; x < 2; x++)
+    for (int x = 0; x < KQ; x++)
 #pragma unroll
-        for (int z = 0; z < 2; z++) {
-            const int no = nbase + 2 * j + z;
+        for (int z = 0; z < NQ; z++) {
+            const int no = nbase + NQ * j + z;
             if (no >= T.N) continue;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int ko = kbase + 2 * i + x;
+                const int ko = kbase + KQ * i + x;
                 if (ko < W.K) P[(long)no * W.K + ko] = acc[x][z][e];
             }
         }
 }
 
-__global__ void train_wgrad_reduce_kernel(const float* __restrict__ part, int splits, long count, float* __restrict__ out) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= count) return;
+// out[n, (k + k_unrot) % K] = sum over the partials, in order.  Block = 64 elements x 4 lanes over the partial index; k_unrot = 3
+// turns the kernel's [feat | dxyz] column order of a grouped first layer back into torch's [dxyz | feat].
+__global__ __launch_bounds__(256) void train_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, long count, int K, int k_unrot,
+                                                                 float* __restrict__ out) {
+    __shared__ float sm[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int t = 0; t < splits; t++) s += part[(long)t * count + e];
-    out[e] = s;
+    if (e < count) {
+        const int per = (nparts + 3) >> 2;
+        const int t0 = q * per, t1 = min(nparts, t0 + per);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int t = t0;
+        for (; t + 4 <= t1; t += 4) {
+            s0 += part[(long)t * count + e]; s1 += part[(long)(t + 1) * count + e];
+            s2 += part[(long)(t + 2) * count + e]; s3 += part[(long)(t + 3) * count + e];
+        }
+        for (; t < t1; t++) s0 += part[(long)t * count + e];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    sm[q][c] = s;
+    __syncthreads();
+    if (q == 0 && e < count) {
+        const float tot = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+        const long n = e / K;
+        const int kk = (int)(e - n * K);
+        out[n * K + (kk + k_unrot) % K] = tot;
+    }
 }
 
 // Backward of the grouped first layer's gather, channels-last: dfeat[b, idx[b, m, s], 0:C] += G[(b, m, s), 0:C].  ball_query pads a
@@ -611,10 +675,41 @@ __global__ __launch_bounds__(256) void interp_rows_grad_kernel(const float* __re
 }
 
 
-// ---- C ABI (include/prcnn_pointops.h, "training-mode SharedMLP") -------------------------------------------------------------
+// Both weight images of a layer in one launch: wpack = pack(W (Nout x K), k_rot) for the forward GEMM and, when wpack_t is given,
+// pack(T (kin_t x Nout)) with T[k][n] = W[n][t_col0 + k] for dgrad (a grouped first layer only needs its feature columns: t_col0 = 3).
+__global__ void train_pack_kernel(const float* __restrict__ w, int Nout, int K, int k_rot, float* __restrict__ wpack,
+                                  float* __restrict__ wpack_t, int kin_t, int t_col0) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KB = (K + 7) / 8, NB = (Nout + 31) / 32;
+    const long total = (long)NB * KB * 256;
+    if (e < total) {
+        const int s = e & 3, jj = (e >> 2) & 31, hh = (e >> 7) & 1;
+        const long blk = e >> 8;
+        const int kb = (int)(blk % KB), nb = (int)(blk / KB);
+        const int n = nb * 32 + jj, kp = kb * 8 + 4 * hh + s;
+        float val = 0.f;
+        if (n < Nout && kp < K) {
+            const int ko = kp < K - k_rot ? kp + k_rot : kp - (K - k_rot);
+            val = w[(long)n * K + ko];
+        }
+        wpack[e] = val;
+        return;
+    }
+    if (!wpack_t) return;
+    const long e2 = e - total;
+    const int KBt = (Nout + 7) / 8, NBt = (kin_t + 31) / 32;
+    if (e2 >= (long)NBt * KBt * 256) return;
+    const int s = e2 & 3, jj = (e2 >> 2) & 31, hh = (e2 >> 7) & 1;
+    const long blk = e2 >> 8;
+    const int kb = (int)(blk % KBt), nb = (int)(blk / KBt);
+    const int kin = nb * 32 + jj, np = kb * 8 + 4 * hh + s;        // "output" index = input channel, "k" index = output channel
+    wpack_t[e2] = (kin < kin_t && np < Nout) ? w[(long)np * K + t_col0 + kin] : 0.f;
+}
+
+// ---- host side: one SharedMLP stack per call (include/prcnn_pointops.h, "training-mode SharedMLP") ---------------------------
 static int train_fill_src(const prcnn_train_src_t* S, MlpParams& P) {
     PRCNN_REQUIRE(S, "prcnn_train: null source descriptor");
-    PRCNN_REQUIRE(S->rows >= 0 && S->K > 0, "prcnn_train: bad shape rows=%ld K=%d", (long)S->rows, S->K);
+    PRCNN_REQUIRE(S->rows > 0 && S->K > 0, "prcnn_train: bad shape rows=%ld K=%d", (long)S->rows, S->K);
     P.rows = S->rows; P.K = S->K;
     if (S->mode == MODE_PLAIN) {
         PRCNN_REQUIRE(S->in && S->ld_in >= S->K, "prcnn_train: plain source needs `in` with ld_in >= K");
@@ -641,135 +736,214 @@ static int train_fill_src(const prcnn_train_src_t* S, MlpParams& P) {
     return PRCNN_OK;
 }
 
-PRCNN_API size_t prcnn_train_part_floats(int64_t rows, int ld_part) { return (size_t)((rows + 63) / 64) * 2 * (size_t)ld_part; }
+static inline size_t up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
-PRCNN_API int prcnn_train_fwd(const prcnn_train_src_t* src, const float* wpack, int Nout, float* y, int ld_y, float* a_dump,
-                              int ld_dump, float* part, int ld_part, prcnn_stream_t stream) {
-    TrainFwd T = {};
-    int rc = train_fill_src(src, T.P);
+// wgrad tile choice: per-wave vector widths (KQ, NQ) and the wave layout (WK x WN over channels, the rest over rows)
+struct WgradPlan { int KQ, NQ, WK, WN, WR, tiles_k, tiles_n, splits; long rows_per_split; };
+static WgradPlan wgrad_plan(long rows, int N, int K) {
+    WgradPlan p;
+    p.KQ = K <= 32 ? 1 : 2; p.WK = K <= 64 ? 1 : 2;
+    p.NQ = N <= 32 ? 1 : 2; p.WN = N <= 64 ? 1 : 2;
+    p.WR = 4 / (p.WK * p.WN);
+    p.tiles_k = prcnn_divup(K, 32 * p.KQ * p.WK); p.tiles_n = prcnn_divup(N, 32 * p.NQ * p.WN);
+    const long tiles = (long)p.tiles_k * p.tiles_n;
+    long s = (1024 + tiles - 1) / tiles;                       // enough workgroups to fill the chip four deep
+    const long by_rows = (rows + 511) / 512;                   // at least 512 rows per workgroup
+    if (s > by_rows) s = by_rows;
+    const long by_mem = (48L << 20) / ((long)N * K * 4 * p.WR);  // partial buffer <= 48 MB
+    if (s > by_mem) s = by_mem;
+    if (s < 1) s = 1;
+    long per = (rows + s - 1) / s;
+    per = (long)up_sz((size_t)per, (size_t)(2 * p.WR));
+    p.splits = (int)((rows + per - 1) / per);
+    p.rows_per_split = per;
+    return p;
+}
+
+struct TrainWork { float* part; double* chunk; float* wpart; float* G[2]; };
+static size_t train_work_layout(int64_t rows, int nl, const prcnn_train_layer_t* L, int K0, bool backward, char* base, TrainWork* w) {
+    int nmax = 0;
+    size_t wg = 0;
+    for (int l = 0; l < nl; l++) {
+        nmax = L[l].Nout > nmax ? L[l].Nout : nmax;
+        const int K = l == 0 ? K0 : L[l - 1].Nout;
+        const WgradPlan p = wgrad_plan(rows, L[l].Nout, K);
+        const size_t f = (size_t)p.splits * p.WR * L[l].Nout * K;
+        wg = f > wg ? f : wg;
+    }
+    const int ldp = (int)up_sz((size_t)nmax, 4);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += up_sz(bytes, 256); return base ? base + o : (char*)nullptr; };
+    char* part = take((size_t)((rows + 63) / 64) * 2 * ldp * sizeof(float));
+    char* chunk = take((size_t)BN_CHUNKS * 2 * nmax * sizeof(double));
+    char *wpart = nullptr, *g0 = nullptr, *g1 = nullptr;
+    if (backward) {
+        wpart = take(wg * sizeof(float));
+        g0 = take((size_t)rows * ldp * sizeof(float));
+        g1 = take((size_t)rows * ldp * sizeof(float));
+    }
+    if (w) { w->part = (float*)part; w->chunk = (double*)chunk; w->wpart = (float*)wpart; w->G[0] = (float*)g0; w->G[1] = (float*)g1; }
+    return off;
+}
+
+static int train_check_layers(const prcnn_train_layer_t* L, int nl) {
+    PRCNN_REQUIRE(L && nl > 0 && nl <= 8, "prcnn_train_stack: 1..8 layers");
+    for (int l = 0; l < nl; l++) {
+        PRCNN_REQUIRE(L[l].Nout > 0 && L[l].Nout % 4 == 0, "prcnn_train_stack: layer %d: Nout=%d must be a positive multiple of 4", l, L[l].Nout);
+        PRCNN_REQUIRE(L[l].W && L[l].y && L[l].cst && L[l].wpack, "prcnn_train_stack: layer %d: null W / y / cst / wpack", l);
+        PRCNN_REQUIRE(L[l].ld_c % 128 == 0 && L[l].ld_c >= L[l].Nout && aligned16(L[l].cst) && aligned16(L[l].y) && aligned16(L[l].wpack),
+                      "prcnn_train_stack: layer %d: ld_c must be a multiple of 128 >= Nout; cst, y, wpack 16-byte aligned", l);
+    }
+    return PRCNN_OK;
+}
+
+PRCNN_API size_t prcnn_train_stack_work_bytes(int64_t rows, const prcnn_train_layer_t* layers, int nl, int K0, int backward) {
+    if (!layers || nl <= 0 || rows <= 0) return 0;
+    return train_work_layout(rows, nl, layers, K0, backward != 0, nullptr, nullptr);
+}
+
+PRCNN_API int prcnn_train_stack_fwd(const prcnn_train_src_t* src, const prcnn_train_layer_t* L, int nl, int pool_ns, float* a_dump,
+                                    int ld_dump, float* out, int ld_out, int col_off, uint8_t* arg, void* work, size_t work_bytes,
+                                    prcnn_stream_t stream) {
+    TrainFwd T0 = {};
+    int rc = train_fill_src(src, T0.P);
     if (rc) return rc;
-    MlpParams& P = T.P;
-    PRCNN_REQUIRE(wpack && y && Nout > 0 && ld_y >= Nout && aligned16(wpack), "prcnn_train_fwd: bad output / weight arguments");
-    PRCNN_REQUIRE(!part || ld_part >= Nout, "prcnn_train_fwd: ld_part %d < Nout %d", ld_part, Nout);
+    rc = train_check_layers(L, nl);
+    if (rc) return rc;
+    const long rows = src->rows;
+    const int ns = pool_ns > 0 ? pool_ns : 1;
+    PRCNN_REQUIRE(out && ns <= 255 && rows % ns == 0 && (ns == 1 || arg), "prcnn_train_stack_fwd: bad pooling arguments (ns=%d)", ns);
+    PRCNN_REQUIRE(ld_out % 4 == 0 && col_off % 4 == 0 && aligned16(out) && ld_out >= col_off + L[nl - 1].Nout,
+                  "prcnn_train_stack_fwd: out rows must be 16-byte aligned (ld_out, col_off multiples of 4)");
     PRCNN_REQUIRE(!a_dump || (src->mode != MODE_PLAIN && ld_dump % 4 == 0 && ld_dump >= src->K && aligned16(a_dump)),
-                  "prcnn_train_fwd: a_dump needs a gathered source, 16-byte alignment and ld_dump %% 4 == 0, >= K");
-    PRCNN_REQUIRE((src->pro_scale == nullptr) == (src->pro_shift == nullptr), "prcnn_train_fwd: pro_scale and pro_shift go together");
-    if (P.rows == 0) return PRCNN_OK;
-    P.wpack = wpack; P.Nout = Nout; P.out = y; P.ld_out = ld_y; P.col_off = 0;
-    P.KB = (P.K + 7) / 8; P.NB = (Nout + 31) / 32;
-    T.pro_scale = src->mode == MODE_PLAIN ? src->pro_scale : nullptr; T.pro_shift = src->mode == MODE_PLAIN ? src->pro_shift : nullptr;
-    T.a_dump = a_dump; T.ld_dump = ld_dump; T.part = part; T.ld_part = ld_part;
-    const long tiles = prcnn_divup(P.rows, MLP_BM);
-    const bool wide = P.NB >= 4 && tiles * prcnn_divup(P.NB, 4) >= 192;
-    const dim3 grid((unsigned)tiles, prcnn_divup(P.NB, wide ? 4 : 2));
+                  "prcnn_train_stack_fwd: a_dump needs a gathered source, 16-byte alignment and ld_dump %% 4 == 0, >= K");
+    PRCNN_REQUIRE((src->pro_scale == nullptr) == (src->pro_shift == nullptr), "prcnn_train_stack_fwd: pro_scale and pro_shift go together");
+    TrainWork W;
+    const size_t need = train_work_layout(rows, nl, L, src->K, false, (char*)work, &W);
+    PRCNN_REQUIRE(work && work_bytes >= need && ((uintptr_t)work & 255) == 0, "prcnn_train_stack_fwd: workspace too small or misaligned (%zu < %zu)", work_bytes, need);
     hipStream_t s = (hipStream_t)stream;
+    for (int l = 0; l < nl; l++) {
+        const int K = l == 0 ? src->K : L[l - 1].Nout, N = L[l].Nout;
+        const bool group0 = l == 0 && src->mode == MODE_GROUP;
+        const int kin_t = group0 ? K - 3 : K;
+        float* wt = (L[l].wpack_t && kin_t > 0) ? L[l].wpack_t : nullptr;
+        const long tot = (long)prcnn_divup(N, 32) * prcnn_divup(K, 8) * 256 + (wt ? (long)prcnn_divup(kin_t, 32) * prcnn_divup(N, 8) * 256 : 0);
+        hipLaunchKernelGGL(train_pack_kernel, dim3(prcnn_divup(tot, 256)), dim3(256), 0, s, L[l].W, N, K, group0 ? 3 : 0, L[l].wpack, wt, kin_t,
+                           group0 ? 3 : 0);
+        TrainFwd T = {};
+        if (l == 0) {
+            T = T0;
+            T.pro_scale = src->mode == MODE_PLAIN ? src->pro_scale : nullptr;
+            T.pro_shift = src->mode == MODE_PLAIN ? src->pro_shift : nullptr;
+            T.a_dump = a_dump; T.ld_dump = ld_dump;
+        } else {
+            T.P.rows = rows; T.P.K = K; T.P.in = L[l - 1].y; T.P.ld_in = L[l - 1].Nout; T.P.vec_a = 1;
+            T.pro_scale = L[l - 1].cst; T.pro_shift = L[l - 1].cst + L[l - 1].ld_c;
+        }
+        MlpParams& P = T.P;
+        P.wpack = L[l].wpack; P.Nout = N; P.out = L[l].y; P.ld_out = N; P.col_off = 0;
+        P.KB = (K + 7) / 8; P.NB = (N + 31) / 32;
+        T.part = W.part; T.ld_part = N;
+        const long tiles = prcnn_divup(rows, MLP_BM);
+        const bool wide = P.NB >= 4 && tiles * prcnn_divup(P.NB, 4) >= 192;
+        const dim3 grid((unsigned)tiles, prcnn_divup(P.NB, wide ? 4 : 2));
+        const int mode = l == 0 ? src->mode : MODE_PLAIN;
 #define TRAIN_FWD(M)                                                                                            \
     do {                                                                                                        \
         if (wide) hipLaunchKernelGGL((train_fwd_kernel<M, 2>), grid, dim3(MLP_THREADS), 0, s, T);               \
         else hipLaunchKernelGGL((train_fwd_kernel<M, 1>), grid, dim3(MLP_THREADS), 0, s, T);                    \
     } while (0)
-    if (src->mode == MODE_PLAIN) TRAIN_FWD(MODE_PLAIN);
-    else if (src->mode == MODE_GROUP) TRAIN_FWD(MODE_GROUP);
-    else TRAIN_FWD(MODE_INTERP);
+        if (mode == MODE_PLAIN) TRAIN_FWD(MODE_PLAIN);
+        else if (mode == MODE_GROUP) TRAIN_FWD(MODE_GROUP);
+        else TRAIN_FWD(MODE_INTERP);
 #undef TRAIN_FWD
-    PRCNN_LAUNCH_CHECK("prcnn_train_fwd");
+        hipLaunchKernelGGL(bn_chunk_kernel, dim3(prcnn_divup(N, 64), BN_CHUNKS), dim3(256), 0, s, W.part, N, rows, N, W.chunk);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(prcnn_divup(N, 64)), dim3(64), 0, s, W.chunk, rows, N, L[l].gamma, L[l].beta, L[l].eps,
+                           L[l].momentum, L[l].running_mean, L[l].running_var, L[l].cst, L[l].ld_c);
+    }
+    const int N = L[nl - 1].Nout;
+    const long groups = rows / ns;
+    hipLaunchKernelGGL(train_pool_kernel, dim3(prcnn_divup(groups * (N / 4), 256)), dim3(256), 0, s, L[nl - 1].y, N, groups, ns, N,
+                       L[nl - 1].cst, L[nl - 1].ld_c, out, ld_out, col_off, ns > 1 ? arg : nullptr);
+    PRCNN_LAUNCH_CHECK("prcnn_train_stack_fwd");
     return PRCNN_OK;
 }
 
-PRCNN_API int prcnn_train_bn_finalize(const float* part, int ld_part, int64_t rows, int N, const float* gamma, const float* beta,
-                                      float eps, float momentum, float* running_mean, float* running_var, float* cst, int ld_c,
-                                      prcnn_stream_t stream) {
-    PRCNN_REQUIRE(part && cst && rows > 0 && N > 0 && ld_part >= N && ld_c >= N, "prcnn_train_bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(prcnn_divup(N, 64)), dim3(1024), 0, (hipStream_t)stream, part, ld_part, (long)rows, N,
-                       gamma, beta, eps, momentum, running_mean, running_var, cst, ld_c);
-    PRCNN_LAUNCH_CHECK("prcnn_train_bn_finalize");
-    return PRCNN_OK;
+template <int KQ, int NQ, int WK, int WN>
+static void launch_wgrad(const TrainWgrad& W, const WgradPlan& p, hipStream_t s) {
+    hipLaunchKernelGGL((train_wgrad_kernel<KQ, NQ, WK, WN>), dim3(p.splits, p.tiles_k, p.tiles_n), dim3(256), 0, s, W);
 }
 
-PRCNN_API int prcnn_train_pool(const float* y, int ld_y, int64_t groups, int ns, int N, const float* cst, int ld_c, float* out,
-                               int ld_out, int col_off, uint8_t* arg, prcnn_stream_t stream) {
-    PRCNN_REQUIRE(y && cst && out && groups >= 0 && ns > 0 && ns <= 255 && N > 0, "prcnn_train_pool: bad arguments");
-    PRCNN_REQUIRE(N % 4 == 0 && ld_y % 4 == 0 && ld_out % 4 == 0 && col_off % 4 == 0 && ld_c % 4 == 0 && aligned16(y) && aligned16(out) &&
-                      aligned16(cst) && ld_out >= col_off + N,
-                  "prcnn_train_pool: channels, strides and offsets must be multiples of 4 floats (16-byte rows)");
-    if (groups == 0) return PRCNN_OK;
-    hipLaunchKernelGGL(train_pool_kernel, dim3(prcnn_divup(groups * (N / 4), 256)), dim3(256), 0, (hipStream_t)stream, y, ld_y,
-                       (long)groups, ns, N, cst, ld_c, out, ld_out, col_off, arg);
-    PRCNN_LAUNCH_CHECK("prcnn_train_pool");
-    return PRCNN_OK;
-}
-
-static int train_fill_grad(const prcnn_train_grad_t* g, TrainBwd& T) {
-    PRCNN_REQUIRE(g && g->G && g->y && g->cst, "prcnn_train backward: null pointer");
-    PRCNN_REQUIRE(g->rows > 0 && g->N > 0 && g->N % 4 == 0 && g->ldG % 4 == 0 && g->ld_y % 4 == 0 && g->ld_c % 4 == 0 && g->ld_c >= g->N,
-                  "prcnn_train backward: N, ldG, ld_y, ld_c must be multiples of 4 (N=%d)", g->N);
-    PRCNN_REQUIRE(aligned16(g->G) && aligned16(g->y) && aligned16(g->cst), "prcnn_train backward: 16-byte aligned G / y / cst");
-    PRCNN_REQUIRE(g->pool_ns == 0 || (g->arg && g->rows % g->pool_ns == 0), "prcnn_train backward: pooled layer needs arg and rows %% ns == 0");
-    T.rows = g->rows; T.N = g->N; T.G = g->G; T.ldG = g->ldG; T.arg = g->arg; T.pool_ns = g->pool_ns; T.y = g->y; T.ld_y = g->ld_y;
-    T.cst = g->cst; T.ld_c = g->ld_c;
-    return PRCNN_OK;
-}
-
-PRCNN_API size_t prcnn_train_bwd_part_floats(int64_t rows, int ld_part) { return (size_t)((rows + 127) / 128) * 2 * (size_t)ld_part; }
-
-PRCNN_API int prcnn_train_bn_backward(const prcnn_train_grad_t* g, float* part, int ld_part, float* dgamma, float* dbeta,
-                                      prcnn_stream_t stream) {
-    TrainBwd T;
-    int rc = train_fill_grad(g, T);
+PRCNN_API int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_train_layer_t* L, int nl, int pool_ns, const float* a_dump,
+                                    int ld_dump, const float* gout, int ld_gout, const uint8_t* arg, float* gin, int ld_gin, void* work,
+                                    size_t work_bytes, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(src && gout, "prcnn_train_stack_bwd: null pointer");
+    int rc = train_check_layers(L, nl);
     if (rc) return rc;
-    PRCNN_REQUIRE(part && ld_part >= T.N && ld_part % 4 == 0 && aligned16(part), "prcnn_train_bn_backward: bad partial buffer");
-    const long tiles = prcnn_divup(T.rows, 128);
+    const long rows = src->rows;
+    const int ns = pool_ns > 1 ? pool_ns : 0;
+    PRCNN_REQUIRE(rows > 0 && ld_gout % 4 == 0 && aligned16(gout) && (!ns || (arg && rows % ns == 0)), "prcnn_train_stack_bwd: bad gradient / pooling arguments");
+    const float* a0 = src->mode == MODE_PLAIN ? src->in : a_dump;
+    const int lda0 = src->mode == MODE_PLAIN ? src->ld_in : ld_dump;
+    PRCNN_REQUIRE(a0 && lda0 % 2 == 0 && ((uintptr_t)a0 & 7) == 0 && lda0 >= src->K,
+                  "prcnn_train_stack_bwd: the first layer's input rows (plain `in` or a_dump) need an even row stride and 8-byte alignment");
+    const int kin0 = src->mode == MODE_GROUP ? src->K - 3 : src->K;
+    PRCNN_REQUIRE(!gin || (kin0 > 0 && ld_gin >= kin0 && L[0].wpack_t), "prcnn_train_stack_bwd: gin needs ld_gin >= %d and layer 0's wpack_t", kin0);
+    TrainWork W;
+    const size_t need = train_work_layout(rows, nl, L, src->K, true, (char*)work, &W);
+    PRCNN_REQUIRE(work && work_bytes >= need && ((uintptr_t)work & 255) == 0, "prcnn_train_stack_bwd: workspace too small or misaligned (%zu < %zu)", work_bytes, need);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)tiles, prcnn_divup(T.N, 64)), dim3(256), 0, s, T, part, ld_part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(prcnn_divup(T.N, 64)), dim3(1024), 0, s, part, ld_part, tiles, T.rows, T.N,
-                       g->cst, T.ld_c, dgamma, dbeta);
-    PRCNN_LAUNCH_CHECK("prcnn_train_bn_backward");
-    return PRCNN_OK;
-}
-
-PRCNN_API int prcnn_train_dgrad(const prcnn_train_grad_t* g, const float* wpack_t, int Kin, float* out, int ld_out, prcnn_stream_t stream) {
-    TrainDgrad D = {};
-    int rc = train_fill_grad(g, D.B);
-    if (rc) return rc;
-    PRCNN_REQUIRE(wpack_t && out && Kin > 0 && ld_out >= Kin && aligned16(wpack_t), "prcnn_train_dgrad: bad arguments");
-    D.wpack = wpack_t; D.Kin = Kin; D.KB = (D.B.N + 7) / 8; D.NB = (Kin + 31) / 32; D.out = out; D.ld_out = ld_out;
-    const long tiles = prcnn_divup(D.B.rows, MLP_BM);
-    const bool wide = D.NB >= 4 && tiles * prcnn_divup(D.NB, 4) >= 192;
-    const dim3 grid((unsigned)tiles, prcnn_divup(D.NB, wide ? 4 : 2));
-    if (wide) hipLaunchKernelGGL(train_dgrad_kernel<2>, grid, dim3(MLP_THREADS), 0, (hipStream_t)stream, D);
-    else hipLaunchKernelGGL(train_dgrad_kernel<1>, grid, dim3(MLP_THREADS), 0, (hipStream_t)stream, D);
-    PRCNN_LAUNCH_CHECK("prcnn_train_dgrad");
-    return PRCNN_OK;
-}
-
-PRCNN_API int prcnn_train_wgrad_splits(int64_t rows, int N, int K) {
-    // enough workgroups to fill the chip (>= ~768 over all tiles), at least 256 rows each, partial buffer <= 64 MB
-    const long tiles = (long)prcnn_divup(K, 128) * prcnn_divup(N, 128);
-    long s = (768 + tiles - 1) / tiles;
-    const long by_rows = (rows + 255) / 256;
-    if (s > by_rows) s = by_rows;
-    const long by_mem = (64L << 20) / ((long)N * K * 4);
-    if (s > by_mem) s = by_mem;
-    return (int)(s < 1 ? 1 : s);
-}
-
-PRCNN_API int prcnn_train_wgrad(const prcnn_train_grad_t* g, const float* a, int lda, int K, const float* pro_scale,
-                                const float* pro_shift, float* part, int splits, float* dW, prcnn_stream_t stream) {
-    TrainWgrad W = {};
-    int rc = train_fill_grad(g, W.B);
-    if (rc) return rc;
-    PRCNN_REQUIRE(a && part && dW && K > 0 && lda >= K && lda % 2 == 0 && splits > 0 && ((uintptr_t)a & 7) == 0,
-                  "prcnn_train_wgrad: bad arguments (lda must be even, a 8-byte aligned)");
-    PRCNN_REQUIRE((pro_scale == nullptr) == (pro_shift == nullptr), "prcnn_train_wgrad: pro_scale and pro_shift go together");
-    W.a = a; W.lda = lda; W.K = K; W.pro_scale = pro_scale; W.pro_shift = pro_shift; W.part = part;
-    long per = (W.B.rows + splits - 1) / splits;
-    per = (per + 1) & ~1L;
-    W.rows_per_split = per;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(train_wgrad_kernel, dim3(splits, prcnn_divup(K, 128), prcnn_divup(W.B.N, 128)), dim3(256), 0, s, W);
-    const long count = (long)W.B.N * K;
-    hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3(prcnn_divup(count, 256)), dim3(256), 0, s, part, splits, count, dW);
-    PRCNN_LAUNCH_CHECK("prcnn_train_wgrad");
+    const float* G = gout;
+    int ldG = ld_gout;
+    for (int l = nl - 1; l >= 0; l--) {
+        const int N = L[l].Nout, K = l == 0 ? src->K : L[l - 1].Nout;
+        PRCNN_REQUIRE(L[l].dW && L[l].dgamma && L[l].dbeta, "prcnn_train_stack_bwd: layer %d: null gradient outputs", l);
+        TrainBwd T;
+        T.rows = rows; T.N = N; T.G = G; T.ldG = ldG;
+        T.arg = (l == nl - 1 && ns) ? arg : nullptr; T.pool_ns = (l == nl - 1) ? ns : 0;
+        T.y = L[l].y; T.ld_y = N; T.cst = L[l].cst; T.ld_c = L[l].ld_c;
+        // BatchNorm backward reductions -> dgamma, dbeta, cst rows 4, 5
+        const int ldp = (int)up_sz((size_t)N, 4);
+        const long tiles = prcnn_divup(rows, 128);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)tiles, prcnn_divup(N, 64)), dim3(256), 0, s, T, W.part, ldp);
+        hipLaunchKernelGGL(bn_bwd_chunk_kernel, dim3(prcnn_divup(N, 64), BN_CHUNKS), dim3(256), 0, s, W.part, ldp, tiles, N, W.chunk);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(prcnn_divup(N, 64)), dim3(64), 0, s, W.chunk, rows, N, L[l].cst, L[l].ld_c, L[l].dgamma,
+                           L[l].dbeta);
+        // wgrad
+        TrainWgrad Wg = {};
+        Wg.B = T; Wg.K = K; Wg.part = W.wpart;
+        if (l > 0) { Wg.a = L[l - 1].y; Wg.lda = L[l - 1].Nout; Wg.pro_scale = L[l - 1].cst; Wg.pro_shift = L[l - 1].cst + L[l - 1].ld_c; }
+        else { Wg.a = a0; Wg.lda = lda0; }
+        const WgradPlan p = wgrad_plan(rows, N, K);
+        Wg.rows_per_split = p.rows_per_split;
+        if (p.KQ == 1 && p.NQ == 1) launch_wgrad<1, 1, 1, 1>(Wg, p, s);
+        else if (p.KQ == 1 && p.NQ == 2 && p.WN == 1) launch_wgrad<1, 2, 1, 1>(Wg, p, s);
+        else if (p.KQ == 1 && p.NQ == 2) launch_wgrad<1, 2, 1, 2>(Wg, p, s);
+        else if (p.KQ == 2 && p.WK == 1 && p.NQ == 1) launch_wgrad<2, 1, 1, 1>(Wg, p, s);
+        else if (p.KQ == 2 && p.WK == 1 && p.WN == 1) launch_wgrad<2, 2, 1, 1>(Wg, p, s);
+        else if (p.KQ == 2 && p.WK == 1) launch_wgrad<2, 2, 1, 2>(Wg, p, s);
+        else if (p.NQ == 1) launch_wgrad<2, 1, 2, 1>(Wg, p, s);
+        else if (p.WN == 1) launch_wgrad<2, 2, 2, 1>(Wg, p, s);
+        else launch_wgrad<2, 2, 2, 2>(Wg, p, s);
+        const long count = (long)N * K;
+        hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3(prcnn_divup(count, 64)), dim3(256), 0, s, W.wpart, p.splits * p.WR, count, K,
+                           (l == 0 && src->mode == MODE_GROUP && K > 3) ? 3 : 0, L[l].dW);
+        // dgrad
+        if (l == 0 && !gin) break;
+        PRCNN_REQUIRE(L[l].wpack_t, "prcnn_train_stack_bwd: layer %d needs wpack_t (its input takes a gradient)", l);
+        TrainDgrad D = {};
+        D.B = T; D.wpack = L[l].wpack_t;
+        D.Kin = l == 0 ? kin0 : K;
+        D.KB = (N + 7) / 8; D.NB = (D.Kin + 31) / 32;
+        D.out = l == 0 ? gin : W.G[l & 1]; D.ld_out = l == 0 ? ld_gin : K;
+        const long dt = prcnn_divup(rows, MLP_BM);
+        const bool wide = D.NB >= 4 && dt * prcnn_divup(D.NB, 4) >= 192;
+        const dim3 grid((unsigned)dt, prcnn_divup(D.NB, wide ? 4 : 2));
+        if (wide) hipLaunchKernelGGL(train_dgrad_kernel<2>, grid, dim3(MLP_THREADS), 0, s, D);
+        else hipLaunchKernelGGL(train_dgrad_kernel<1>, grid, dim3(MLP_THREADS), 0, s, D);
+        G = D.out; ldG = D.ld_out;
+    }
+    PRCNN_LAUNCH_CHECK("prcnn_train_stack_bwd");
     return PRCNN_OK;
 }
 

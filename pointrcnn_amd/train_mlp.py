@@ -114,9 +114,67 @@ def _rows2(t):
     return pad[:, :K]
 
 
+def _wpack_floats(nout, k):
+    return ((nout + 31) // 32) * ((k + 7) // 8) * 256
+
+
+class _Stack:
+    """device buffers + the prcnn_train_layer_t array of one stack invocation (kept alive by the autograd context)"""
+
+    def __init__(self, params, bns, rows, K0, kin0, need_x, dev):
+        nl = len(bns)
+        nout = [int(params[3 * l].shape[0]) for l in range(nl)]
+        ks = [K0] + nout[:-1]
+        kins = [kin0] + nout[:-1]
+        self.nl, self.nout, self.ks, self.rows = nl, nout, ks, rows
+        ld_c = [_up(n, 128) for n in nout]
+        # one allocation each for: saved outputs, constant tables (zeroed), weight images, parameter gradients
+        self.ybuf = torch.empty((rows * sum(nout),), dtype=_F32, device=dev)
+        self.cbuf = torch.zeros((6 * sum(ld_c),), dtype=_F32, device=dev)
+        wt_need = [need_x or l > 0 for l in range(nl)]
+        wsz = [_wpack_floats(nout[l], ks[l]) for l in range(nl)]
+        wtsz = [_wpack_floats(kins[l], nout[l]) if (wt_need[l] and kins[l] > 0) else 0 for l in range(nl)]
+        self.wbuf = torch.empty((sum(wsz) + sum(wtsz),), dtype=_F32, device=dev)
+        gsz = [nout[l] * ks[l] + 2 * nout[l] for l in range(nl)]
+        self.gbuf = torch.empty((sum(gsz),), dtype=_F32, device=dev)
+        self.layers = (_cabi.TrainLayer * nl)()
+        yo = co = wo = go = 0
+        self.grad_views = []
+        for l in range(nl):
+            W, gamma, beta = params[3 * l: 3 * l + 3]
+            bn, Ly = bns[l], self.layers[l]
+            if not (W.is_contiguous() and gamma.is_contiguous() and beta.is_contiguous()):
+                raise RuntimeError("SharedMLP parameters must be contiguous")
+            Ly.Nout, Ly.W, Ly.gamma, Ly.beta = nout[l], _p(W), _p(gamma), _p(beta)
+            Ly.eps, Ly.momentum = float(bn.eps), float(bn.momentum)
+            Ly.running_mean, Ly.running_var = _p(bn.running_mean), _p(bn.running_var)
+            Ly.y = self.ybuf.data_ptr() + 4 * yo
+            yo += rows * nout[l]
+            Ly.cst, Ly.ld_c = self.cbuf.data_ptr() + 4 * co, ld_c[l]
+            co += 6 * ld_c[l]
+            Ly.wpack = self.wbuf.data_ptr() + 4 * wo
+            wo += wsz[l]
+            Ly.wpack_t = (self.wbuf.data_ptr() + 4 * wo) if wtsz[l] else None
+            wo += wtsz[l]
+            n, k = nout[l], ks[l]
+            dW, dg, db = self.gbuf[go: go + n * k], self.gbuf[go + n * k: go + n * k + n], self.gbuf[go + n * k + n: go + n * k + 2 * n]
+            go += gsz[l]
+            Ly.dW, Ly.dgamma, Ly.dbeta = _p(dW), _p(dg), _p(db)
+            self.grad_views.append((dW, dg, db))
+
+    def work(self, K0, backward, dev):
+        nbytes = _cabi.lib().prcnn_train_stack_work_bytes(self.rows, self.layers, self.nl, K0, 1 if backward else 0)
+        return torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev), nbytes
+
+
+def _aligned_ptr(buf):
+    return (buf.data_ptr() + 255) // 256 * 256
+
+
 class SharedMLPTrain(torch.autograd.Function):
     """apply(src, bns, pool_ns, x0, x1, W_0, gamma_0, beta_0, W_1, ...) -> (groups, N_last) activated (and pooled) rows.
-    x0: features (B,N,C) / known features (B,m,C2) / plain rows (R,K); x1: skip features (B,n,C1) or None."""
+    x0: features (B,N,C) / known features (B,m,C2) / plain rows (R,K); x1: skip features (B,n,C1) or None.
+    Forward and backward are ONE library call each (prcnn_train_stack_fwd / _bwd): the per-layer launch sequence is host C++."""
 
     @staticmethod
     def forward(ctx, src, bns, pool_ns, x0, x1, *params):
@@ -131,124 +189,67 @@ class SharedMLPTrain(torch.autograd.Function):
         S = _cabi.TrainSrc()
         _fill_src(S, src, x0, x1)
         rows, K0 = int(S.rows), int(S.K)
-        ys, csts = [], []
-        a_dump, ld_dump = None, 0
+        kin0 = K0 - 3 if src.mode == "group" else K0
+        need_x = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        ns = pool_ns if pool_ns and pool_ns > 1 else 1
         with torch.no_grad():
-            for l in range(nl):
-                W, gamma, beta = params[3 * l: 3 * l + 3]
-                bn = bns[l]
-                N = W.shape[0]
-                K = K0 if l == 0 else ys[-1].shape[1]
-                w2 = W.reshape(N, K)
-                wp = _pack(w2, 3 if (l == 0 and src.mode == "group") else 0)
-                y = torch.empty((rows, N), dtype=_F32, device=dev)
-                ld_c = _up(N, 128)
-                cst = torch.zeros((6, ld_c), dtype=_F32, device=dev)
-                part = torch.empty((L.prcnn_train_part_floats(rows, N),), dtype=_F32, device=dev)
-                if l == 0:
-                    Sl = S
-                    if src.mode != "plain":
-                        ld_dump = _up(K0, 4)
-                        a_dump = torch.empty((rows, ld_dump), dtype=_F32, device=dev)
-                else:
-                    Sl = _cabi.TrainSrc()
-                    Sl.mode, Sl.rows, Sl.K = 0, rows, K
-                    Sl.in_, Sl.ld_in = _p(ys[-1]), ys[-1].stride(0)
-                    Sl.pro_scale, Sl.pro_shift = _p(csts[-1][0]), _p(csts[-1][1])
-                _cabi.check(L.prcnn_train_fwd(ctypes.byref(Sl), _p(wp), N, _p(y), N, _p(a_dump) if l == 0 else None, ld_dump if l == 0 else 0,
-                                              _p(part), N, _stream()), "prcnn_train_fwd")
-                _cabi.check(L.prcnn_train_bn_finalize(_p(part), N, rows, N, _p(gamma), _p(beta), float(bn.eps), float(bn.momentum),
-                                                      _p(bn.running_mean), _p(bn.running_var), _p(cst), ld_c, _stream()),
-                            "prcnn_train_bn_finalize")
-                bn.num_batches_tracked += 1
-                ys.append(y)
-                csts.append(cst)
-            ns = pool_ns if pool_ns else 1
-            groups, N = rows // ns, ys[-1].shape[1]
+            st = _Stack(params, bns, rows, K0, kin0, need_x, dev)
+            a_dump, ld_dump = None, 0
+            if src.mode != "plain":
+                ld_dump = _up(K0, 4)
+                a_dump = torch.empty((rows, ld_dump), dtype=_F32, device=dev)
+            groups, N = rows // ns, st.nout[-1]
             out = torch.empty((groups, N), dtype=_F32, device=dev)
             arg = torch.empty((groups, N), dtype=torch.uint8, device=dev) if ns > 1 else None
-            _cabi.check(L.prcnn_train_pool(_p(ys[-1]), N, groups, ns, N, _p(csts[-1]), csts[-1].stride(0), _p(out), N, 0, _p(arg),
-                                           _stream()), "prcnn_train_pool")
-        ctx.src, ctx.nl, ctx.pool_ns, ctx.K0, ctx.rows = src, nl, (ns if ns > 1 else 0), K0, rows
+            work, nbytes = st.work(K0, False, dev)
+            _cabi.check(L.prcnn_train_stack_fwd(ctypes.byref(S), st.layers, nl, ns, _p(a_dump), ld_dump, _p(out), N, 0, _p(arg),
+                                                _aligned_ptr(work), nbytes, _stream()), "prcnn_train_stack_fwd")
+            for bn in bns:
+                bn.num_batches_tracked += 1
+        ctx.src, ctx.S, ctx.st, ctx.ns, ctx.K0, ctx.kin0, ctx.rows = src, S, st, ns, K0, kin0, rows
+        ctx.a_dump, ctx.ld_dump, ctx.arg = a_dump, ld_dump, arg
         ctx.x_shapes = (None if x0 is None else tuple(x0.shape), None if x1 is None else tuple(x1.shape))
-        ctx.ld_dump = ld_dump
-        ctx.save_for_backward(*[t for t in (x0, x1, a_dump, arg) if t is not None], *ys, *csts, *params)
-        ctx.have = (x0 is not None, x1 is not None, a_dump is not None, arg is not None)
+        ctx.keep = (x0, x1, params)                 # the descriptor holds raw pointers into these
         return out
 
     @staticmethod
     def backward(ctx, gout):
         L = _cabi.lib()
-        saved = list(ctx.saved_tensors)
-        x0 = saved.pop(0) if ctx.have[0] else None
-        x1 = saved.pop(0) if ctx.have[1] else None
-        a_dump = saved.pop(0) if ctx.have[2] else None
-        arg = saved.pop(0) if ctx.have[3] else None
-        nl, rows, src = ctx.nl, ctx.rows, ctx.src
-        ys, csts, params = saved[:nl], saved[nl:2 * nl], saved[2 * nl:]
+        st, src, rows = ctx.st, ctx.src, ctx.rows
         dev = gout.device
-        need_x = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
-        grads = [None] * (3 * nl)
+        need_x = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
         G = gout.contiguous()
-        ldG, pool = G.stride(0), ctx.pool_ns
-        for l in range(nl - 1, -1, -1):
-            W = params[3 * l]
-            N = W.shape[0]
-            K = ctx.K0 if l == 0 else ys[l - 1].shape[1]
-            y, cst = ys[l], csts[l]
-            g = _cabi.TrainGrad()
-            g.rows, g.N, g.G, g.ldG = rows, N, _p(G), ldG
-            g.arg, g.pool_ns = (_p(arg), pool) if (l == nl - 1 and pool) else (None, 0)
-            g.y, g.ld_y, g.cst, g.ld_c = _p(y), y.stride(0), _p(cst), cst.stride(0)
-            part = torch.empty((L.prcnn_train_bwd_part_floats(rows, N),), dtype=_F32, device=dev)
-            dgamma, dbeta = torch.empty((N,), dtype=_F32, device=dev), torch.empty((N,), dtype=_F32, device=dev)
-            _cabi.check(L.prcnn_train_bn_backward(ctypes.byref(g), _p(part), N, _p(dgamma), _p(dbeta), _stream()), "prcnn_train_bn_backward")
-            # wgrad: dW = dy^T . a, a = the rows that entered this layer's convolution
-            if l > 0:
-                a, lda, ps, pb = ys[l - 1], ys[l - 1].stride(0), _p(csts[l - 1][0]), _p(csts[l - 1][1])
-            elif a_dump is not None:
-                a, lda, ps, pb = a_dump, ctx.ld_dump, None, None
-            else:
-                a, lda, ps, pb = x0, x0.stride(0), None, None
-            splits = L.prcnn_train_wgrad_splits(rows, N, K)
-            wpart = torch.empty((splits, N, K), dtype=_F32, device=dev)
-            dW = torch.empty((N, K), dtype=_F32, device=dev)
-            _cabi.check(L.prcnn_train_wgrad(ctypes.byref(g), _p(a), lda, K, ps, pb, _p(wpart), splits, _p(dW), _stream()), "prcnn_train_wgrad")
-            if l == 0 and src.mode == "group" and K > 3:      # kernel order [feat | dxyz] -> torch order [dxyz | feat]
-                dW = torch.cat([dW[:, K - 3:], dW[:, :K - 3]], 1)
-            grads[3 * l], grads[3 * l + 1], grads[3 * l + 2] = dW.view_as(W), dgamma, dbeta
-            if l == 0 and not need_x:
-                break
-            # dgrad: gradient w.r.t. the rows that entered the convolution
-            w2 = W.reshape(N, K)
-            if l == 0 and src.mode == "group":
-                kin = K - 3                                   # only the feature columns have a consumer (xyz carries no gradient)
-                wt = w2[:, 3:].t().contiguous()
-            else:
-                kin = K
-                wt = w2.t().contiguous()
-            wpt = _pack(wt)
-            Gp = torch.empty((rows, _up(kin, 4)), dtype=_F32, device=dev)
-            _cabi.check(L.prcnn_train_dgrad(ctypes.byref(g), _p(wpt), kin, _p(Gp), Gp.stride(0), _stream()), "prcnn_train_dgrad")
-            G, ldG = Gp, Gp.stride(0)
+        gin, ld_gin = None, 0
+        if need_x:
+            ld_gin = _up(ctx.kin0, 4)
+            gin = torch.empty((rows, ld_gin), dtype=_F32, device=dev)
+        work, nbytes = st.work(ctx.K0, True, dev)
+        _cabi.check(L.prcnn_train_stack_bwd(ctypes.byref(ctx.S), st.layers, st.nl, ctx.ns, _p(ctx.a_dump), ctx.ld_dump, _p(G), G.stride(0),
+                                            _p(ctx.arg), _p(gin), ld_gin, _aligned_ptr(work), nbytes, _stream()), "prcnn_train_stack_bwd")
+        grads = []
+        params = ctx.keep[2]
+        for l in range(st.nl):
+            dW, dg, db = st.grad_views[l]
+            grads += [dW.view_as(params[3 * l]), dg, db]
         gx0 = gx1 = None
         if need_x:
             if src.mode == "plain":
-                gx0 = G[:, :ctx.K0]
+                gx0 = gin[:, :ctx.K0]
             elif src.mode == "group":
                 B, M, ns = src.idx.shape
-                N0, C = src.xyz.shape[1], ctx.K0 - 3
+                N0, C = src.xyz.shape[1], ctx.kin0
                 gx0 = torch.zeros((B, N0, C), dtype=_F32, device=dev)
-                _cabi.check(L.prcnn_group_rows_grad(_p(G), ldG, _p(src.idx), B, M, ns, C, N0, _p(gx0), C, _stream()), "prcnn_group_rows_grad")
+                _cabi.check(L.prcnn_group_rows_grad(_p(gin), ld_gin, _p(src.idx), B, M, ns, C, N0, _p(gx0), C, _stream()), "prcnn_group_rows_grad")
             else:
                 B, n, _ = src.idx3.shape
                 m, C2 = ctx.x_shapes[0][1], ctx.x_shapes[0][2]
                 if ctx.needs_input_grad[3]:
                     gx0 = torch.zeros((B, m, C2), dtype=_F32, device=dev)
-                    _cabi.check(L.prcnn_interp_rows_grad(_p(G), ldG, _p(src.idx3), _p(src.w3), B, n, m, C2, _p(gx0), C2, _stream()),
+                    _cabi.check(L.prcnn_interp_rows_grad(_p(gin), ld_gin, _p(src.idx3), _p(src.w3), B, n, m, C2, _p(gx0), C2, _stream()),
                                 "prcnn_interp_rows_grad")
-                if x1 is not None and ctx.needs_input_grad[4]:
-                    gx1 = G[:, C2:ctx.K0].reshape(B, n, ctx.K0 - C2)
+                if ctx.x_shapes[1] is not None and ctx.needs_input_grad[4]:
+                    gx1 = gin[:, C2:ctx.K0].reshape(B, n, ctx.K0 - C2)
+        ctx.st = ctx.a_dump = ctx.arg = ctx.keep = None          # release the saved activations now
         return (None, None, None, gx0, gx1, *grads)
 
 
