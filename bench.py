@@ -94,7 +94,7 @@ def parse(argv=None):
     if args.steps is None:
         args.steps = 20 if train else 320
     if args.warmup is None:
-        args.warmup = 3 if train else 16
+        args.warmup = 6 if train else 16
     if args.batch is None:
         args.batch = 16 if train else 32
     return args
@@ -481,18 +481,24 @@ def run_train(args, dev, rank, world, local_rank, dist):
         gt = torch.cat([ctr[..., 0:1], ctr[..., 1:2] + hwl[0] / 2, ctr[..., 2:3], hwl.expand(args.batch, 12, 3), ry], 2).contiguous()
         cls, reg = ops.rpn_labels(pts, gt)
         batches.append({"pts_input": pts, "rpn_cls_label": cls.long(), "rpn_reg_label": reg})
-    for k in range(max(1, args.warmup)):
-        loss = trainer.step(batches[k % nslots])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        loss = trainer.step(batches[k % nslots])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = reduce_elapsed(time.perf_counter() - t0, dist, dev)
+    prefetch = os.environ.get("PRCNN_TRAIN_PREFETCH", "1") != "0"
+
+    def timed_loop(steps, ahead):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            loss_ = trainer.step(batches[k % nslots], next_batch=batches[(k + 1) % nslots] if ahead else None)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return reduce_elapsed(time.perf_counter() - t0, dist, dev), loss_
+    # warm-up: MIOpen's kernel selection for the two torch convolutions of the heads and the caching allocator's block pool
+    # settle over the first handful of steps (three were not enough: 43 ms per step measured against 28.5 ms in steady state)
+    timed_loop(max(1, args.warmup), prefetch)
+    elapsed, loss = timed_loop(args.steps, prefetch)
+    elapsed_other, _ = timed_loop(min(args.steps, 10), not prefetch)
     nparam = sum(p.numel() for p in model.parameters() if p.requires_grad)
     allreduce_ms = None
     if dist is not None:                                     # the gradient all-reduce on its own: one flat fp32 buffer of the same size
@@ -534,8 +540,17 @@ def run_train(args, dev, rank, world, local_rank, dist):
                   "allreduce_ms_flat_buffer": allreduce_ms,
                   "forward_loss_ms": round(ev[0].elapsed_time(ev[1]), 3), "backward_ms": round(ev[1].elapsed_time(ev[2]), 3),
                   "clip_optimizer_ms": round(ev[2].elapsed_time(ev[3]), 3),
-                  "note": "point operators (FPS, ball query, grouping, 3-NN, interpolation) forward AND backward are this package's HIP "
-                          "kernels; 1x1 conv + training-mode BatchNorm run through torch (MIOpen/rocBLAS)"}}
+                  "train_fused": os.environ.get("PRCNN_TRAIN_FUSED", "1") != "0",
+                  "fps_prefetch": prefetch,
+                  ("ms_per_step_without_fps_prefetch" if prefetch else "ms_per_step_with_fps_prefetch"):
+                      round(1e3 * elapsed_other / min(args.steps, 10), 3),
+                  "fps_prefetch_note": "the furthest-point sample sets of batch k+1 (a function of its coordinates only) are drawn on a "
+                                       "side stream during step k, as a prefetching data loader allows; every step still does the same work",
+                  "note": "every SharedMLP stack (gather / interpolation, 1x1 convs, training-mode BatchNorm, ReLU, max-pool) forward AND "
+                          "backward is this package's hand-written kernels (csrc/mlp_train.h: MFMA forward / dgrad / wgrad, BatchNorm "
+                          "reductions), one library call per stack and direction; torch runs the two bias-only output convolutions of "
+                          "the heads, dropout, the loss and the optimizer.  PRCNN_TRAIN_FUSED=0 = the composed torch path (MIOpen / "
+                          "rocBLAS convolutions + BatchNorm) for A/B"}}
 
 
 def main():

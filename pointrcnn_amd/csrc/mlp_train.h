@@ -589,6 +589,113 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const TrainWgrad W) {
         }
 }
 
+// Wide layers (K > 64 and N > 64): the 128 x 128 tile through LDS.  The direct kernel above has every wave fetch its own operands,
+// so the two waves that share a k-half (or an n-half) read the same rows twice and rebuild dy twice -- at 6 bytes per cycle and
+// wave it ran into the L2 bandwidth (203 us for 262 144 x 128 x 128, 42 TFLOP/s).  Here a workgroup stages 32 rows at a time:
+// thread (row lane t / 32, channel quad t % 32) loads a, G, y as 16-byte pieces, applies the forward's prologue to a and rebuilds
+// dy ONCE, and writes both tiles to LDS; a wave then reads its operands as one ds_read_b64 each per two rows (lane j: channels
+// 2j, 2j+1 of its half -- 256 contiguous bytes per half-wave, conflict-free).  Register-staged double buffer, one barrier per chunk.
+#define WL_ROWS 32
+#define WL_LD 128
+__global__ __launch_bounds__(256, 2) void train_wgrad_lds_kernel(const TrainWgrad W) {
+    const TrainBwd& T = W.B;
+    __shared__ __attribute__((aligned(16))) float As[2][WL_ROWS * WL_LD], Ds[2][WL_ROWS * WL_LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, j = lane & 31;
+    const int kt0 = blockIdx.y * 128, nt0 = blockIdx.z * 128;
+    // staging role: rows rl + 8 u (u = 0..3), channels 4 cq .. 4 cq + 3 of the tile
+    const int cq = tid & 31, rl = tid >> 5;
+    const int ka = kt0 + 4 * cq, na = nt0 + 4 * cq;
+    const bool ka_ok = ka + 4 <= W.lda, na_ok = na + 4 <= T.N;            // (lda and N are multiples of 4 here)
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = zero4, km;
+    km.x = ka < W.K ? 1.f : 0.f; km.y = ka + 1 < W.K ? 1.f : 0.f; km.z = ka + 2 < W.K ? 1.f : 0.f; km.w = ka + 3 < W.K ? 1.f : 0.f;
+    const bool pro = W.pro_scale != nullptr;
+    if (pro && ka_ok) { ps = ld4(W.pro_scale + ka); pb = ld4(W.pro_shift + ka); }
+    float4 sc = zero4, sh = zero4, mu = zero4, is = zero4, c1 = zero4, c2 = zero4;
+    if (na_ok) {
+        sc = ld4(T.cst + na); sh = ld4(T.cst + T.ld_c + na); mu = ld4(T.cst + 2 * T.ld_c + na); is = ld4(T.cst + 3 * T.ld_c + na);
+        c1 = ld4(T.cst + 4 * T.ld_c + na); c2 = ld4(T.cst + 5 * T.ld_c + na);
+    }
+    const long r_begin = (long)blockIdx.x * W.rows_per_split;
+    long r_end = r_begin + W.rows_per_split;
+    if (r_end > T.rows) r_end = T.rows;
+    const int nchunks = r_end > r_begin ? (int)((r_end - r_begin + WL_ROWS - 1) / WL_ROWS) : 0;
+    float4 ra[4], rg[4], ry[4];
+    float rv[4];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            long rr = r_begin + (long)c * WL_ROWS + rl + 8 * u;
+            rv[u] = rr < r_end ? 1.f : 0.f;
+            if (rr >= r_end) rr = r_end - 1;
+            ra[u] = ka_ok ? ld4(W.a + rr * (long)W.lda + ka) : zero4;
+            if (na_ok) {
+                ry[u] = ld4(T.y + rr * (long)T.ld_y + na);
+                rg[u] = bwd_G4(T, rr, na);
+            } else {
+                ry[u] = zero4; rg[u] = zero4;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float4 a = ra[u];
+            if (pro) { a.x = fmaxf(a.x * ps.x + pb.x, 0.f); a.y = fmaxf(a.y * ps.y + pb.y, 0.f); a.z = fmaxf(a.z * ps.z + pb.z, 0.f); a.w = fmaxf(a.w * ps.w + pb.w, 0.f); }
+            const float v = rv[u];
+            a.x *= km.x * v; a.y *= km.y * v; a.z *= km.z * v; a.w *= km.w * v;
+            const float4 d = bwd_dy4(rg[u], ry[u], sc, sh, mu, is, c1, c2);
+            *reinterpret_cast<float4*>(&As[buf][(rl + 8 * u) * WL_LD + 4 * cq]) = a;
+            *reinterpret_cast<float4*>(&Ds[buf][(rl + 8 * u) * WL_LD + 4 * cq]) = d;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int z = 0; z < 2; z++) acc[x][z] = (f32x16){0};
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; c++) {
+            const int buf = c & 1;
+            load_chunk(min(c + 1, nchunks - 1));
+            const float* ap = &As[buf][h * WL_LD + wk * 64 + 2 * j];
+            const float* dp = &Ds[buf][h * WL_LD + wn * 64 + 2 * j];
+#pragma unroll
+            for (int t = 0; t < WL_ROWS / 2; t++) {
+                const float2 a = *reinterpret_cast<const float2*>(ap + 2 * t * WL_LD);
+                const float2 d = *reinterpret_cast<const float2*>(dp + 2 * t * WL_LD);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, d.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, d.y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, d.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, d.y, acc[1][1], 0, 0, 0);
+            }
+            if (c + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* P = W.part + (long)blockIdx.x * T.N * W.K;
+    const int kbase = kt0 + wk * 64, nbase = nt0 + wn * 64;
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int z = 0; z < 2; z++) {
+            const int no = nbase + 2 * j + z;
+            if (no >= T.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int ko = kbase + 2 * i + x;
+                if (ko < W.K) P[(long)no * W.K + ko] = acc[x][z][e];
+            }
+        }
+}
+
 // out[n, (k + k_unrot) % K] = sum over the partials, in order.  Block = 64 elements x 4 lanes over the partial index; k_unrot = 3
 // turns the kernel's [feat | dxyz] column order of a grouped first layer back into torch's [dxyz | feat].
 __global__ __launch_bounds__(256) void train_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, long count, int K, int k_unrot,
@@ -754,7 +861,7 @@ static WgradPlan wgrad_plan(long rows, int N, int K) {
     if (s > by_mem) s = by_mem;
     if (s < 1) s = 1;
     long per = (rows + s - 1) / s;
-    per = (long)up_sz((size_t)per, (size_t)(2 * p.WR));
+    per = (long)up_sz((size_t)per, (size_t)((p.WK == 2 && p.WN == 2) ? 32 : 2 * p.WR));
     p.splits = (int)((rows + per - 1) / per);
     p.rows_per_split = per;
     return p;
@@ -924,6 +1031,8 @@ PRCNN_API int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_tr
         else if (p.KQ == 2 && p.WK == 1) launch_wgrad<2, 2, 1, 2>(Wg, p, s);
         else if (p.NQ == 1) launch_wgrad<2, 1, 2, 1>(Wg, p, s);
         else if (p.WN == 1) launch_wgrad<2, 2, 2, 1>(Wg, p, s);
+        else if (Wg.lda % 4 == 0 && aligned16(Wg.a) && !getenv("PRCNN_WGRAD_DIRECT"))
+            hipLaunchKernelGGL(train_wgrad_lds_kernel, dim3(p.splits, p.tiles_k, p.tiles_n), dim3(256), 0, s, Wg);
         else launch_wgrad<2, 2, 2, 2>(Wg, p, s);
         const long count = (long)N * K;
         hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3(prcnn_divup(count, 64)), dim3(256), 0, s, W.wpart, p.splits * p.WR, count, K,
