@@ -151,6 +151,16 @@ def resolve_world(args, env, ndev):
     return 1, 0, 0, False
 
 
+def distributed_facts(dist, world):
+    """what the line's N > 1 claims rest on: the world size the process group actually has, backend and RCCL version"""
+    facts = {"world_size_seen": dist.get_world_size(), "backend": dist.get_backend(), "n_gpus_requested": world}
+    try:
+        facts["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:  # noqa: BLE001
+        facts["rccl_version"] = "unavailable (%s)" % type(e).__name__
+    return facts
+
+
 class EventProfiler:
     """Wraps the ctypes library: every prcnn_* launch is bracketed by HIP events recorded on the stream the
     kernel is launched on (torch's current stream).  Used only in the instrumented pass, never in the timed one."""
@@ -209,6 +219,7 @@ class EventProfiler:
             # scale, minus what the dense list (its own launches) carries
             undedup[sp.counts.data_ptr()] = sp.G * sp.ns - c[1] * sp.ns
         fam = {}
+        self.mlp_launches = []        # (entry point, live rows, flops per row, us) of every MLP-family launch, in launch order
         for name, s, e, (per_row, rows, ptr, unit) in self.records:
             key = "mlp" if name.startswith("prcnn_mlp_") else name[len("prcnn_"):]
             d = fam.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0, "rows": 0, "rows_launched": 0})
@@ -218,6 +229,8 @@ class EventProfiler:
                 us = s.elapsed_time(e) * 1e3
                 print("%-28s rows %8d / %8d  flop/row %8.0f  %7.2f GFLOP %8.1f us %6.1f TF/s" %
                       (name, live, rows, per_row, per_row * live / 1e9, us, per_row * live / us / 1e6 if us > 0 else 0), file=dump)
+            if key == "mlp":
+                self.mlp_launches.append((name[len("prcnn_"):], live, per_row, s.elapsed_time(e) * 1e3))
             d["ms"] += s.elapsed_time(e)
             d["launches"] += 1
             d["flops"] += per_row * live
@@ -455,7 +468,19 @@ def instrumented_pass(args, bench, nprof, dump=None):
     try:
         for _ in range(nprof):
             bench.step(0)
-        return prof.summary(dump)
+        fam = prof.summary(dump)
+        # per-launch table, averaged over the nprof repeats (the launch sequence of a step is static)
+        per_step = len(prof.mlp_launches) // max(1, nprof)
+        if per_step and per_step * nprof == len(prof.mlp_launches):
+            table = []
+            for i in range(per_step):
+                reps = prof.mlp_launches[i::per_step]
+                us = sum(r[3] for r in reps) / len(reps)
+                gflop = reps[0][1] * reps[0][2] / 1e9
+                table.append({"launch": reps[0][0], "rows": reps[0][1], "flop_per_row": reps[0][2], "us": round(us, 1), "GFLOP": round(gflop, 3),
+                              "frac_of_peak": round(gflop * 1e3 / us / FP32_MFMA_PEAK_TFLOPS, 3) if us > 0 else None})
+            fam["mlp_by_launch"] = table
+        return fam
     finally:
         _cabi._lib, _ops._split_log = real, None
 
@@ -574,6 +599,8 @@ def main():
     _cabi.lib()
     if args.workload == "train":
         line = run_train(args, dev, rank, world, local_rank, dist)
+        if dist is not None:
+            line["distributed"] = distributed_facts(dist, world)
         if rank == 0:
             print(json.dumps(line), flush=True)
         if dist is not None:
@@ -674,6 +701,9 @@ def main():
                             "reference_graph_TFLOPs": round(ref_flops / secs / 1e12, 3) if ref_flops and secs > 0 else None,
                             "note": "achieved/frac = executed flops (after exact first-layer hoisting and padding-free grouping) / "
                                     "MLP-family GPU time; reference_graph_TFLOPs = the reference's dense flop count over the same time"}
+        by_launch = fam.pop("mlp_by_launch", None)
+        if by_launch:
+            line["roofline"]["by_kernel"] = by_launch
         line["kernels"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "launches_per_step": v["launches"] // nprof}
                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         # HBM bytes per launch of the same kernel family from the PMC passes committed under profiles/ (rocprofv3
@@ -692,6 +722,21 @@ def main():
             line["fps_kernel"] = {"ms_per_step": round(fam["fps"]["ms"] / nprof, 3), "distance_evals_per_step": evals,
                                   "Gevals_per_s": round(evals / (fam["fps"]["ms"] / nprof * 1e-3) / 1e9, 1),
                                   "note": "serial chain, 1 workgroup/frame (32 of 256 CUs); hidden by --streams"}
+            if args.npoints == 16384 and list(rpn.RPNConfig.SA_NPOINTS) == [4096, 1024, 256, 64]:
+                # Issue-bound model of the serial chain: every sample is one trip of the kernel's sample loop on the critical
+                # wave; a lone wave issues at most one instruction per 4 cycles (wave64 on SIMD-32: two passes + dependency),
+                # so the floor of a frame's chain is (loop instructions) x 4 cycles x samples.  Static instruction counts of the
+                # sample loops from the gfx950 ISA (tools/fps_isa_count.py): level 0 fps_pruned_kernel<16> 513, level 1
+                # fps_pruned_kernel<4> 260, level 2 fps_reg_kernel<64,16> 211 (single wave), level 3 fps_reg_kernel<64,4> 95.
+                instr = (513 * 4095 + 260 * 1023 + 211 * 255 + 95 * 63)
+                floor_ms = instr * 4 / 2.4e9 * 1e3
+                line["fps_kernel"]["issue_model"] = {
+                    "bound": "instruction issue of one wave (serial chain)", "instructions_per_frame_chain": instr,
+                    "floor_ms_per_frame_chain": round(floor_ms, 3), "achieved_ms_per_frame_chain": round(fam["fps"]["ms"] / nprof, 3),
+                    "frac": round(floor_ms / (fam["fps"]["ms"] / nprof), 3),
+                    "note": "1 instruction / 4 cycles at 2.4 GHz; all frames of a batch run their chains concurrently (one workgroup "
+                            "each), so the per-step FPS time IS one frame's chain; frac = floor / measured.  The lever left is the "
+                            "instruction count per sample, not the issue rate"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "rpn" and args.input == "clouds":
         line["cpu_baseline"] = cpu_baseline(model, clouds_cpu, out)
@@ -723,7 +768,7 @@ def main():
         from pointnet2_lib.pointnet2 import pointnet2_modules as pm
         bench.release()
         vsteps, variants = min(args.steps, 96), {}
-        todo = (("dedup_off", "uniform", False), ("saturated", "saturated", True))
+        todo = (("dedup_off", "uniform", False), ("saturated", "saturated", True), ("lidar", "lidar", True))
         if os.environ.get("PRCNN_BENCH_VARIANT_SELFCHECK"):     # dev: the headline configuration again, as a variant
             todo = (("repeat", "uniform", True),) + todo + (("repeat2", "uniform", True),)
         for name, kind, dedup in todo:
@@ -743,13 +788,17 @@ def main():
             vb.release()
         pm.GROUP_DEDUP = os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"
         line["value_dedup_off"], line["value_saturated"] = variants["dedup_off"]["value"], variants["saturated"]["value"]
+        line["value_lidar"] = variants["lidar"]["value"]
         if "repeat" in variants:
             line["value_repeat"] = [variants["repeat"]["value"], variants["repeat2"]["value"]]
         line["data_dependence"] = {"typical (uniform clouds, this line's value)": {"value": line["value"],
                                                                                    "mlp_rows_per_step": line.get("roofline", {}).get("rows_per_step")},
                                    "dedup_off (uniform clouds, every padded row computed)": variants["dedup_off"],
-                                   "saturated (16384 pts in a 1.6 m cube: every ball full)": variants["saturated"]}
+                                   "saturated (16384 pts in a 1.6 m cube: every ball full)": variants["saturated"],
+                                   "lidar (range-dependent density, ground band + car clusters, same bounds)": variants["lidar"]}
 
+    if dist is not None:
+        line["distributed"] = distributed_facts(dist, world)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
