@@ -80,6 +80,9 @@ struct MlpParams {
     int xcd_tpf;
     // v2 layer kernel, plain rows: > 0 selects the XCD-aware 1-D tile order with this many column tiles per row tile
     int wgm_cols;
+    // hoisted-FP addend (addY): 0 = every workgroup builds the interpolated tile in its epilogue; 1 = workgroups alternate by
+    // dispatch slot between building it BEFORE the main loop (into the accumulators) and after it; 2 = all before (default)
+    int addy_phase;
 };
 
 // With live-row segments the 128-row tile a workgroup works on is NOT blockIdx.x: the live tiles are the first one or two
@@ -280,28 +283,9 @@ __device__ __forceinline__ float interp_gather(const MlpParams& P, long row, int
     return (w[0] * y[(long)id[0] * P.ldY] + w[1] * y[(long)id[1] * P.ldY]) + w[2] * y[(long)id[2] * P.ldY];
 }
 
-// Epilogue shared by the layer kernels: bias + ReLU (+ hoisted-FP interpolated addend, + max-pool over nsample rows) and the
-// stores.  As0 / Bs0: the (now idle) operand LDS, reused to stage the interpolated addend tile (128 x 72 and 128 x 64 floats).
-template <int MODE, int WNB, bool ADDY>
-__device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)[2][WNB], float* As0, float* Bs0, int tid, long row0,
-                                               int nb0, bool n_active) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int h = lane >> 5, j = lane & 31;
-    // ---- epilogue -------------------------------------------------------------------------------
-    // Hoisted FP first layer (addY): every output element needs sum_j w_j * Y[idx_j, n].  Fetching that per accumulator
-    // element costs three 4-byte gathers per element; instead the workgroup builds the interpolated 128 x (64*WNB) tile
-    // once -- 16-byte loads, a row's 64 columns = 256 contiguous bytes per neighbour -- into the now idle operand
-    // buffers (As: 128 x 72 floats, Bs: 128 x 64) and the accumulators pick their elements up from LDS.
-    // Bs0 == nullptr (v2 kernel: only the A half of the operand LDS exists): the two 64-column halves of a wide tile are staged
-    // one after the other into As0, each followed by the stores of the column blocks that lie in it.
-    bool staged = false;
-    int npass = 1;
-    // A thread stages the 16-byte column piece (tid % 16) of rows tid / 16 + 16 u, u = 0..7.  Four rows at a time: their index /
-    // weight triples first, then their twelve gathers, then the arithmetic -- two dependent round trips per four rows.  (Row by
-    // row, with a 64-bit division for the frame of each, the loop was eight times two exposed round trips: ~10 of the ~30 us a
-    // workgroup of FP1's layer stays resident, whatever the locality of the gathers -- tools/interp_volume_probe.py.)
-    auto stage_half = [&](int hf, float* T, int ldt) {
+// Interpolated addend tile of the hoisted FP first layer: T[row, c] = sum_j w3[row, j] * addY[idx3[row, j], ncol0 + c] for the
+// 128 rows of the tile and one 64-column half.  A thread stages the 16-byte column piece (tid % 16) of rows tid / 16 + 16 u.
+__device__ __forceinline__ void addy_stage_half(const MlpParams& P, int tid, long row0, int nb0, int hf, float* T, int ldt) {
         const int ncol0 = (nb0 + hf * 2) * 32;
         const int c = (tid & 15) * 4, n = ncol0 + c, rbase = tid >> 4;
         const bool col_ok = n < P.Nout;
@@ -344,8 +328,31 @@ __device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)
                 *reinterpret_cast<float4*>(T + (rbase + 16 * (q * 4 + u)) * ldt + c) = o;
             }
         }
-    };
-    if (MODE == MODE_PLAIN && ADDY && P.addY) {
+    }
+
+// Epilogue shared by the layer kernels: bias + ReLU (+ hoisted-FP interpolated addend, + max-pool over nsample rows) and the
+// stores.  As0 / Bs0: the (now idle) operand LDS, reused to stage the interpolated addend tile (128 x 72 and 128 x 64 floats).
+template <int MODE, int WNB, bool ADDY>
+__device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)[2][WNB], float* As0, float* Bs0, int tid, long row0,
+                                               int nb0, bool n_active, bool addy_done = false) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, j = lane & 31;
+    // ---- epilogue -------------------------------------------------------------------------------
+    // Hoisted FP first layer (addY): every output element needs sum_j w_j * Y[idx_j, n].  Fetching that per accumulator
+    // element costs three 4-byte gathers per element; instead the workgroup builds the interpolated 128 x (64*WNB) tile
+    // once -- 16-byte loads, a row's 64 columns = 256 contiguous bytes per neighbour -- into the now idle operand
+    // buffers (As: 128 x 72 floats, Bs: 128 x 64) and the accumulators pick their elements up from LDS.
+    // Bs0 == nullptr (v2 kernel: only the A half of the operand LDS exists): the two 64-column halves of a wide tile are staged
+    // one after the other into As0, each followed by the stores of the column blocks that lie in it.
+    bool staged = false;
+    int npass = 1;
+    // A thread stages the 16-byte column piece (tid % 16) of rows tid / 16 + 16 u, u = 0..7.  Four rows at a time: their index /
+    // weight triples first, then their twelve gathers, then the arithmetic -- two dependent round trips per four rows.  (Row by
+    // row, with a 64-bit division for the frame of each, the loop was eight times two exposed round trips: ~10 of the ~30 us a
+    // workgroup of FP1's layer stays resident, whatever the locality of the gathers -- tools/interp_volume_probe.py.)
+    auto stage_half = [&](int hf, float* T, int ldt) { addy_stage_half(P, tid, row0, nb0, hf, T, ldt); };
+    if (MODE == MODE_PLAIN && ADDY && P.addY && !addy_done) {
         staged = (P.Nout % 4 == 0) && (P.ldY % 4 == 0) && aligned16(P.addY);
         if (staged && Bs0) {
 #pragma unroll
@@ -382,7 +389,7 @@ __device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)
                 int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
                 long g0 = wrow0 + rin, g1 = wrow0 + 32 + rin;
                 float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
-                if (ADDY && P.addY && n_ok) {     // hoisted FP first layer: + sum_j w_j * Y[idx_j, n]
+                if (ADDY && P.addY && n_ok && !addy_done) {     // hoisted FP first layer: + sum_j w_j * Y[idx_j, n]
                     if (staged) {
                         const int blk = wn * WNB + nn;
                         const float* T = ((blk >> 1) == 0 || !Bs0) ? As0 : Bs0;
@@ -706,6 +713,41 @@ __global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST, ADDY>::W))
     for (int g = 0; g < RING; g++) load_b(g, g);
 
     load_chunk(0);
+    // Hoisted-FP addend, built FIRST.  In the epilogue the interpolated tile (per 16-byte piece three gathers, their addressing,
+    // 20 multiply-adds, an LDS store: ~400 instructions per thread) ran when the main loop was over, its gathers exposed.  Built
+    // before the main loop, straight into the accumulators (through the still idle operand LDS), its gathers are in flight
+    // together with the B ring and the first A chunk requested above, and the tail of the tile is the plain store epilogue.
+    // Measured (A/B by PRCNN_ADDY_PHASE, same box): FP1's 131072 x 96 -> 256 launch 119 -> 108 us; alternating first / last by
+    // dispatch slot (phase 1) gives the same 108 us, so it is the overlap with the prologue loads, not de-phasing, that pays;
+    // the two 512-wide launches are unchanged (their staging is 4 % of their time).
+    bool addy_done = false;
+    if constexpr (ADDY && WNB == 1) {            // (the wide tile has no registers to spare for the second code path: it spills)
+        const bool first = P.addY && (P.addy_phase == 2 || (P.addy_phase == 1 && ((blockIdx.x >> 8) & 1)));
+        const bool stageable = (P.Nout % 4 == 0) && (P.ldY % 4 == 0) && aligned16(P.addY);
+        if (first && stageable) {                           // workgroup-uniform
+            float* T = &As[0][0];
+#pragma unroll
+            for (int pass = 0; pass < WNB; pass++) {
+                if (pass > 0) __syncthreads();
+                addy_stage_half(P, tid, row0, nb0, pass, T, 72);
+                __syncthreads();
+#pragma unroll
+                for (int nn = 0; nn < WNB; nn++) {
+                    const int blk = wn * WNB + nn;
+                    if ((blk >> 1) != pass) continue;
+                    const int tc = (blk & 1) * 32 + j;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        acc[0][nn][r] = T[(wm * 64 + rin) * 72 + tc];
+                        acc[1][nn][r] = T[(wm * 64 + 32 + rin) * 72 + tc];
+                    }
+                }
+            }
+            __syncthreads();
+            addy_done = true;
+        }
+    }
     store_chunk(0, 0);
     __syncthreads();
     for (int c = 0; c < nchunks; c++) {
@@ -758,7 +800,7 @@ __global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST, ADDY>::W))
         if (sum == 123.456f) P.out[tid] = sum;
         return;
     }
-    layer_epilogue<MODE, WNB, ADDY>(P, acc, &As[0][0], nullptr, tid, row0, nb0, n_active);
+    layer_epilogue<MODE, WNB, ADDY>(P, acc, &As[0][0], nullptr, tid, row0, nb0, n_active, addy_done);
 }
 
 // =====================================================================================================
@@ -1615,6 +1657,8 @@ PRCNN_API int prcnn_mlp_rows_addinterp(const float* in, int ld_in, int K, const 
     P.in = in; P.ld_in = ld_in;
     P.vec_a = aligned16(in) && (ld_in % 4 == 0);
     P.addY = y_cl; P.ldY = ld_y; P.idx3 = idx3; P.w3 = w3; P.n = n; P.m = m;
+    static const int addy_phase = getenv("PRCNN_ADDY_PHASE") ? atoi(getenv("PRCNN_ADDY_PHASE")) : 2;      // A/B switch: 0 = all in the epilogue
+    P.addy_phase = addy_phase;
     return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
 }
 
