@@ -132,6 +132,25 @@ def test_gather_group_interp_forward_exact(dev, cpu):
     assert np.array_equal(got, cpu.three_interp(feat, i3, w3))        # same op order, no FMA -> bit equal
 
 
+@pytest.mark.parametrize("B,C,m,n", [(4, 64, 1024, 4096), (2, 37, 513, 3000), (8, 256, 4096, 16384)])
+def test_three_interpolate_lds_staged_kernel_is_bit_identical(dev, cpu, monkeypatch, B, C, m, n):
+    """n >= 2 m with enough (frame, channel group) workgroups: the source rows are staged in LDS (three_interp_lds_kernel);
+    bit-equal to the oracle and to the direct kernel (PRCNN_INTERP_DIRECT=1), odd m / ragged channel groups included"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(m + n)
+    feat = r.normal(size=(B, C, m)).astype(np.float32)
+    i3 = r.integers(0, m, (B, n, 3)).astype(np.int32)
+    w3 = r.random((B, n, 3)).astype(np.float32)
+    monkeypatch.delenv("PRCNN_INTERP_DIRECT", raising=False)
+    got = ops.three_interpolate(T(feat, dev), T(i3, dev), T(w3, dev))
+    monkeypatch.setenv("PRCNN_INTERP_DIRECT", "1")
+    direct = ops.three_interpolate(T(feat, dev), T(i3, dev), T(w3, dev))
+    monkeypatch.delenv("PRCNN_INTERP_DIRECT", raising=False)
+    assert torch.equal(got, direct)
+    if B * C * n <= 4_000_000:
+        assert np.array_equal(got.cpu().numpy(), cpu.three_interp(feat, i3, w3))
+
+
 def test_gather_group_interp_backward(dev, cpu):
     from pointrcnn_amd import ops
     r = np.random.default_rng(1)
