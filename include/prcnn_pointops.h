@@ -46,7 +46,7 @@ typedef void* prcnn_stream_t; /* hipStream_t */
 #define PRCNN_EHIP (-2)         /* HIP runtime / launch failure */
 #define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-int prcnn_abi_version(void);   /* 6: + prcnn_fps_status, training-mode SharedMLP (prcnn_train_*); 5: + prcnn_gt_aug_edit;
+int prcnn_abi_version(void);   /* 6: + prcnn_fps_status, training-mode SharedMLP (prcnn_train_*), prcnn_boxes_iou3d, prcnn_proposal_target_sample; 5: + prcnn_gt_aug_edit;
                                  * 4: + prcnn_host_* (host twins of the reference's *_cpu entry points), prcnn_build_id,
                                  * prcnn_fps_order (upstream tie order), prcnn_rpn_labels,
                                  * prcnn_ball_query2_grid takes xyz (dense-frame scan fallback);
@@ -525,6 +525,27 @@ int prcnn_group_rows_grad(const float* G, int ldG, const int32_t* idx, int B, in
                           prcnn_stream_t stream);
 int prcnn_interp_rows_grad(const float* G, int ldG, const int32_t* idx3, const float* w3, int B, int n, int m, int C, float* dknown,
                            int ld_d, prcnn_stream_t stream);
+
+/* ======================================================================================================
+ * RCNN-stage training targets (csrc/proposal_target.hip) -- `train_rcnn.py --train_mode rcnn`.
+ * prcnn_boxes_iou3d: iou3d_utils.boxes_iou3d_gpu (lib/utils/iou3d/iou3d_utils.py:20-53) as one kernel: a (Na,7), b (Nb,7)
+ * [x, y(bottom), z, h, w, l, ry] -> out (Na, Nb).
+ * prcnn_proposal_target_sample: ProposalTargetLayer.sample_rois_for_rcnn with sample_bg_inds, aug_roi_by_noise_torch and
+ * random_aug_box3d (lib/rpn/proposal_target_layer.py:75-300) for the whole batch in one launch, no host round trip:
+ *   roi_boxes3d (B, M, 7), gt_boxes3d (B, G, gt_cols >= 7) with all-zero rows padding the end (G <= 128);
+ *   cfg6 (HOST pointer): RCNN.REG_FG_THRESH, CLS_FG_THRESH, CLS_BG_THRESH, CLS_BG_THRESH_LO, FG_RATIO, HARD_BG_RATIO;
+ *   aug_times = RCNN.ROI_FG_AUG_TIMES; aug_method 0 = 'multiple', 1 = 'single' (RCNN.REG_AUG_METHOD);
+ *   -> rois, gt_of_rois (B, R, 7), roi_iou (B, R), src (B, R) the input RoI behind every slot, max_overlaps / gt_assignment
+ *   (B, M), counts (B, 4) = fg / hard-bg / easy-bg candidates and fg slots, status (B): 0 ok, 1 = neither foreground nor
+ *   background candidates (the reference raises NotImplementedError), 2 = no ground-truth box.
+ * The random draw is a counter-based table keyed by (seed, purpose, frame, position) -- see the kernel file; the reference's own
+ * methods, answered from the same table, return the same boxes (tests/golden/ref_proposal_target.py).
+ * ====================================================================================================== */
+int prcnn_boxes_iou3d(const float* a, int Na, const float* b, int Nb, float* out, prcnn_stream_t stream);
+int prcnn_proposal_target_sample(const float* roi_boxes3d, const float* gt_boxes3d, int B, int M, int G, int gt_cols, int roi_per_image,
+                                 const float* cfg6, int aug_times, int aug_method, uint32_t seed, float* rois, float* gt_of_rois,
+                                 float* roi_iou, int32_t* src, float* max_overlaps, int32_t* gt_assignment, int32_t* counts,
+                                 int32_t* status, prcnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -283,6 +283,32 @@ class _Cpu:
         return keep, num
 
 
+    def boxes_iou3d(self, a, b, trig_mode=1):
+        """iou3d_utils.boxes_iou3d_gpu: a (N,7), b (M,7) -> (N,M)"""
+        a, b = _f32(a), _f32(b)
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        self.lib.prcnn_cpu_boxes_iou3d(_p(a, _F), a.shape[0], _p(b, _F), b.shape[0], trig_mode, _p(out, _F))
+        return out
+
+    def proposal_target_sample(self, roi_boxes3d, gt_boxes3d, roi_per_image=64, cfgv=(0.55, 0.6, 0.45, 0.05, 0.5, 0.8), aug_times=10,
+                               aug_method="multiple", seed=0, trig_mode=1):
+        """ProposalTargetLayer.sample_rois_for_rcnn with the counter-based draw -> dict of arrays"""
+        roi, gt = _f32(roi_boxes3d), _f32(gt_boxes3d)
+        B, M, _ = roi.shape
+        G, gc = gt.shape[1], gt.shape[2]
+        R = roi_per_image
+        o = {"rois": np.zeros((B, R, 7), np.float32), "gt_of_rois": np.zeros((B, R, 7), np.float32), "roi_iou": np.zeros((B, R), np.float32),
+             "src": np.zeros((B, R), np.int32), "max_overlaps": np.zeros((B, M), np.float32), "gt_assignment": np.zeros((B, M), np.int32),
+             "counts": np.zeros((B, 4), np.int32), "status": np.zeros((B,), np.int32)}
+        c = np.asarray(cfgv, np.float32)
+        self.lib.prcnn_cpu_proposal_target_sample(_p(roi, _F), _p(gt, _F), B, M, G, gc, R, _p(c, _F), int(aug_times),
+                                                  {"multiple": 0, "single": 1}[aug_method], ctypes.c_uint32(seed), trig_mode,
+                                                  _p(o["rois"], _F), _p(o["gt_of_rois"], _F), _p(o["roi_iou"], _F), _p(o["src"], _I),
+                                                  _p(o["max_overlaps"], _F), _p(o["gt_assignment"], _I), _p(o["counts"], _I),
+                                                  _p(o["status"], _I))
+        return o
+
+
 class _Ref:
     """numpy wrappers around the reference's own functions compiled for the host (oracle/_ref)."""
 

@@ -1192,3 +1192,172 @@ PRCNN_EXPORT void prcnn_cpu_scene_prepare(const float* raw, const int64_t* off, 
         free(cand); free(sel); free(rect); free(flag);
     }
 }
+
+/* ======================================================================================================
+ * RCNN-stage training targets: ProposalTargetLayer.sample_rois_for_rcnn + aug_roi_by_noise_torch +
+ * random_aug_box3d (lib/rpn/proposal_target_layer.py:75-300), iou3d_utils.boxes_iou3d_gpu (lib/utils/iou3d/iou3d_utils.py:20-53).
+ * The reference draws from numpy's and torch's global generators in a data-dependent order; the draw is re-specified with the
+ * counter-based generator of the input builder, one number per (purpose, frame, position) -- see csrc/proposal_target.hip for the
+ * table.  Everything else (3-D IoU, assignment, the fg / hard-bg / easy-bg candidate sets, the four sampling cases, the
+ * accept / retry loop of the noise augmentation) follows the reference line by line; tests/golden/ref_proposal_target.py runs the
+ * reference's own methods with its random calls answered from the same table and must get the same boxes.
+ * ====================================================================================================== */
+static uint32_t pt_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+static uint32_t pt_rand(uint32_t seed, uint32_t stream, uint32_t frame, uint32_t i) {
+    return pt_mix(i ^ pt_mix(frame * 0x9E3779B9U + pt_mix(seed + stream * 0x85EBCA6BU)));
+}
+static float pt_u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }          /* torch.rand: 24 random bits */
+static int pt_below(uint32_t r, int n) { return (int)(((uint64_t)r * (uint64_t)n) >> 32); } /* uniform integer in [0, n) */
+
+/* iou3d_utils.py:20-53 for one pair, every operation an individually rounded fp32 operation */
+static float pt_iou3d(const float* a, const float* b, int trig_mode) {
+    float abev[5] = { a[0] - a[5] / 2, a[2] - a[4] / 2, a[0] + a[5] / 2, a[2] + a[4] / 2, a[6] };    /* kitti_utils.py:134-147 */
+    float bbev[5] = { b[0] - b[5] / 2, b[2] - b[4] / 2, b[0] + b[5] / 2, b[2] + b[4] / 2, b[6] };
+    float ov = box_overlap(abev, bbev, trig_mode);
+    float amin = a[1] - a[3], bmin = b[1] - b[3];
+    float max_of_min = amin > bmin ? amin : bmin, min_of_max = a[1] < b[1] ? a[1] : b[1];
+    float h = min_of_max - max_of_min;
+    if (!(h > 0.0f)) h = 0.0f;
+    float ov3 = ov * h;
+    float va = a[3] * a[4];
+    va = va * a[5];
+    float vb = b[3] * b[4];
+    vb = vb * b[5];
+    float den = va + vb;
+    den = den - ov3;
+    if (den < 1e-7f) den = 1e-7f;
+    return ov3 / den;
+}
+
+PRCNN_EXPORT void prcnn_cpu_boxes_iou3d(const float* a, int Na, const float* b, int Nb, int trig_mode, float* out) {
+    for (int i = 0; i < Na; i++)
+        for (int j = 0; j < Nb; j++) out[(size_t)i * Nb + j] = pt_iou3d(a + (size_t)i * 7, b + (size_t)j * 7, trig_mode);
+}
+
+/* proposal_target_layer.py:240-300 random_aug_box3d, methods 'multiple' (0) and 'single' (1); draws r[0..7] */
+static void pt_random_aug(const float* box, int method, const uint32_t* r, float* out) {
+    float ps[3], hs[3], ar;
+    if (method == 0) {
+        static const double rc[5][3] = { {0.2, 0.1, 3.14159265358979323846 / 12}, {0.3, 0.15, 3.14159265358979323846 / 12},
+                                         {0.5, 0.15, 3.14159265358979323846 / 9}, {0.8, 0.15, 3.14159265358979323846 / 6},
+                                         {1.0, 0.15, 3.14159265358979323846 / 3} };
+        const int idx = pt_below(r[0], 5);
+        for (int c = 0; c < 3; c++) ps[c] = ((pt_u01(r[1 + c]) - 0.5f) / 0.5f) * (float)rc[idx][0];
+        for (int c = 0; c < 3; c++) hs[c] = ((pt_u01(r[4 + c]) - 0.5f) / 0.5f) * (float)rc[idx][1] + 1.0f;
+        ar = ((pt_u01(r[7]) - 0.5f) / 0.5f) * (float)rc[idx][2];
+    } else {
+        for (int c = 0; c < 3; c++) ps[c] = pt_u01(r[1 + c]) - 0.5f;
+        for (int c = 0; c < 3; c++) hs[c] = (pt_u01(r[4 + c]) - 0.5f) / (float)(0.5 / 0.15) + 1.0f;
+        ar = (pt_u01(r[7]) - 0.5f) / (float)(0.5 / (3.14159265358979323846 / 12));
+    }
+    for (int c = 0; c < 3; c++) { out[c] = box[c] + ps[c]; out[3 + c] = box[3 + c] * hs[c]; }
+    out[6] = box[6] + ar;
+}
+
+typedef struct { uint32_t key; int idx; } pt_cand;
+static int pt_cand_cmp(const void* x, const void* y) {
+    const pt_cand *a = (const pt_cand*)x, *b = (const pt_cand*)y;
+    if (a->key != b->key) return a->key < b->key ? -1 : 1;
+    return a->idx - b->idx;
+}
+
+/* cfgv: reg_fg_thresh, cls_fg_thresh, cls_bg_thresh, cls_bg_thresh_lo, fg_ratio, hard_bg_ratio
+ * outputs: rois / gt_of_rois (B,R,7), roi_iou (B,R), src (B,R) input RoI of every slot, max_overlaps / gt_assignment (B,M),
+ * counts (B,4): fg candidates, hard-bg candidates, easy-bg candidates, fg slots; status (B): 0 ok, 1 = neither foreground nor
+ * background candidates (the reference raises), 2 = no ground-truth box */
+PRCNN_EXPORT void prcnn_cpu_proposal_target_sample(const float* roi_boxes3d, const float* gt_boxes3d, int B, int M, int G, int gt_cols,
+                                                   int R, const float* cfgv, int aug_times, int aug_method, uint32_t seed, int trig_mode,
+                                                   float* rois, float* gt_of_rois, float* roi_iou, int32_t* src, float* max_overlaps,
+                                                   int32_t* gt_assignment, int32_t* counts, int32_t* status) {
+    const float reg_fg = cfgv[0], cls_fg = cfgv[1], cls_bg = cfgv[2], cls_bg_lo = cfgv[3], fg_ratio = cfgv[4], hard_ratio = cfgv[5];
+    const float fg_thresh = reg_fg < cls_fg ? reg_fg : cls_fg;
+    const int fg_per_image = (int)nearbyint((double)fg_ratio * (double)R);                  /* np.round: half to even */
+    pt_cand* cand = (pt_cand*)malloc(sizeof(pt_cand) * (size_t)(M > 0 ? M : 1));
+    int* fg = (int*)malloc(sizeof(int) * (size_t)(M > 0 ? M : 1) * 3);
+    int *hard = fg + M, *easy = fg + 2 * M;
+    for (int b = 0; b < B; b++) {
+        const float* roi = roi_boxes3d + (size_t)b * M * 7;
+        const float* gt = gt_boxes3d + (size_t)b * G * gt_cols;
+        float* o_roi = rois + (size_t)b * R * 7;
+        float* o_gt = gt_of_rois + (size_t)b * R * 7;
+        float* o_iou = roi_iou + (size_t)b * R;
+        int32_t* o_src = src + (size_t)b * R;
+        memset(o_roi, 0, sizeof(float) * (size_t)R * 7);
+        memset(o_gt, 0, sizeof(float) * (size_t)R * 7);
+        memset(o_iou, 0, sizeof(float) * (size_t)R);
+        for (int t = 0; t < R; t++) o_src[t] = -1;
+        int ng = G;                                              /* :96-99: drop the zero rows at the end */
+        while (ng > 0) {
+            float s = 0.f;
+            for (int c = 0; c < gt_cols; c++) s += gt[(size_t)(ng - 1) * gt_cols + c];
+            if (s != 0.f) break;
+            ng--;
+        }
+        status[b] = 0;
+        counts[b * 4] = counts[b * 4 + 1] = counts[b * 4 + 2] = counts[b * 4 + 3] = 0;
+        if (ng == 0) { status[b] = 2; continue; }
+        int nfg = 0, nhard = 0, neasy = 0;
+        for (int i = 0; i < M; i++) {
+            float best = 0.f; int arg = 0;
+            for (int j = 0; j < ng; j++) {
+                const float v = pt_iou3d(roi + (size_t)i * 7, gt + (size_t)j * gt_cols, trig_mode);
+                if (j == 0 || v > best) { best = v; arg = j; }     /* torch.max: first maximum */
+            }
+            max_overlaps[(size_t)b * M + i] = best; gt_assignment[(size_t)b * M + i] = arg;
+            if (best >= fg_thresh) fg[nfg++] = i;
+            if (best < cls_bg_lo) easy[neasy++] = i;
+            if (best < cls_bg && best >= cls_bg_lo) hard[nhard++] = i;
+        }
+        counts[b * 4] = nfg; counts[b * 4 + 1] = nhard; counts[b * 4 + 2] = neasy;
+        const int nbg = nhard + neasy;
+        int n_fg_slots = 0, n_bg_slots = 0;
+        if (nfg > 0 && nbg > 0) {
+            n_fg_slots = fg_per_image < nfg ? fg_per_image : nfg;
+            for (int t = 0; t < nfg; t++) { cand[t].key = pt_rand(seed, 10, (uint32_t)b, (uint32_t)fg[t]); cand[t].idx = fg[t]; }
+            qsort(cand, (size_t)nfg, sizeof(pt_cand), pt_cand_cmp);            /* a random permutation's prefix (:123-125) */
+            for (int t = 0; t < n_fg_slots; t++) o_src[t] = cand[t].idx;
+            n_bg_slots = R - n_fg_slots;
+        } else if (nfg > 0) {
+            n_fg_slots = R;                                                     /* :131-137: with replacement */
+            for (int t = 0; t < R; t++) o_src[t] = fg[pt_below(pt_rand(seed, 11, (uint32_t)b, (uint32_t)t), nfg)];
+        } else if (nbg > 0) {
+            n_bg_slots = R;
+        } else {
+            status[b] = 1;
+            continue;
+        }
+        counts[b * 4 + 3] = n_fg_slots;
+        if (n_bg_slots > 0) {                                                   /* sample_bg_inds (:190-220) */
+            int n_hard = 0;
+            if (nhard > 0 && neasy > 0) n_hard = (int)((double)n_bg_slots * (double)hard_ratio);     /* int(bg * HARD_BG_RATIO) */
+            else if (nhard > 0) n_hard = n_bg_slots;
+            for (int t = 0; t < n_bg_slots; t++) {
+                if (t < n_hard) o_src[n_fg_slots + t] = hard[pt_below(pt_rand(seed, 12, (uint32_t)b, (uint32_t)t), nhard)];
+                else o_src[n_fg_slots + t] = easy[pt_below(pt_rand(seed, 13, (uint32_t)b, (uint32_t)(t - n_hard)), neasy)];
+            }
+        }
+        for (int t = 0; t < R; t++) {                                           /* aug_roi_by_noise_torch (:222-250) */
+            const int i = o_src[t];
+            const float* box = roi + (size_t)i * 7;
+            const float* g = gt + (size_t)gt_assignment[(size_t)b * M + i] * gt_cols;
+            const float iou_src = max_overlaps[(size_t)b * M + i];
+            const int times = t < n_fg_slots ? aug_times : (aug_times > 0 ? 1 : 0);
+            float aug[7], temp_iou = 0.f;
+            int cnt = 0, keep = 1;
+            memcpy(aug, box, sizeof(aug));
+            while (temp_iou < fg_thresh && cnt < times) {
+                uint32_t r[9];
+                for (int q = 0; q < 9; q++) r[q] = pt_rand(seed, 20, (uint32_t)b, (uint32_t)((t * 16 + cnt) * 16 + q));
+                if (pt_u01(r[8]) < 0.2f) { memcpy(aug, box, sizeof(aug)); keep = 1; }
+                else { pt_random_aug(box, aug_method, r, aug); keep = 0; }
+                temp_iou = pt_iou3d(aug, g, trig_mode);
+                cnt++;
+            }
+            memcpy(o_roi + (size_t)t * 7, aug, sizeof(aug));
+            memcpy(o_gt + (size_t)t * 7, g, sizeof(float) * 7);
+            o_iou[t] = (cnt == 0 || keep) ? iou_src : temp_iou;
+        }
+    }
+    free(cand);
+    free(fg);
+}

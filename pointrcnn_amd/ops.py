@@ -557,6 +557,37 @@ def boxes_iou_bev(boxes_a, boxes_b, out=None):
     return out
 
 
+def boxes_iou3d(boxes_a, boxes_b):
+    """boxes_a (N,7), boxes_b (M,7) [x, y, z, h, w, l, ry] -> 3-D IoU (N,M)   [iou3d_utils.boxes_iou3d_gpu, iou3d_utils.py:20-53]"""
+    _chk(boxes_a, "boxes_a", ndim=2); _chk(boxes_b, "boxes_b", ndim=2)
+    out = torch.empty((boxes_a.shape[0], boxes_b.shape[0]), dtype=_F32, device=boxes_a.device)
+    _cabi.check(_cabi.lib().prcnn_boxes_iou3d(_p(boxes_a), boxes_a.shape[0], _p(boxes_b), boxes_b.shape[0], _p(out), _stream()),
+                "prcnn_boxes_iou3d")
+    return out
+
+
+def proposal_target_sample(roi_boxes3d, gt_boxes3d, roi_per_image=64, thresholds=(0.55, 0.6, 0.45, 0.05), fg_ratio=0.5, hard_bg_ratio=0.8,
+                           aug_times=10, aug_method="multiple", seed=0):
+    """ProposalTargetLayer.sample_rois_for_rcnn for the whole batch in one launch (lib/rpn/proposal_target_layer.py:75-250).
+    roi_boxes3d (B,M,7), gt_boxes3d (B,G,>=7, zero rows at the end); thresholds = (REG_FG, CLS_FG, CLS_BG, CLS_BG_LO).
+    -> dict: rois, gt_of_rois (B,R,7), roi_iou (B,R), src (B,R) i32, max_overlaps (B,M), gt_assignment (B,M) i32, counts (B,4), status (B)"""
+    _chk(roi_boxes3d, "roi_boxes3d", ndim=3); _chk(gt_boxes3d, "gt_boxes3d", ndim=3)
+    B, M, _ = roi_boxes3d.shape
+    G, gc = gt_boxes3d.shape[1], gt_boxes3d.shape[2]
+    R, dev = int(roi_per_image), roi_boxes3d.device
+    o = {"rois": torch.empty((B, R, 7), dtype=_F32, device=dev), "gt_of_rois": torch.empty((B, R, 7), dtype=_F32, device=dev),
+         "roi_iou": torch.empty((B, R), dtype=_F32, device=dev), "src": torch.empty((B, R), dtype=_INT, device=dev),
+         "max_overlaps": torch.empty((B, M), dtype=_F32, device=dev), "gt_assignment": torch.empty((B, M), dtype=_INT, device=dev),
+         "counts": torch.empty((B, 4), dtype=_INT, device=dev), "status": torch.empty((B,), dtype=_INT, device=dev)}
+    cfg6 = (ctypes.c_float * 6)(*[float(v) for v in tuple(thresholds) + (fg_ratio, hard_bg_ratio)])
+    _cabi.check(_cabi.lib().prcnn_proposal_target_sample(_p(roi_boxes3d), _p(gt_boxes3d), B, M, G, gc, R, ctypes.cast(cfg6, ctypes.c_void_p),
+                                                         int(aug_times), {"multiple": 0, "single": 1}[aug_method], seed & 0xFFFFFFFF,
+                                                         _p(o["rois"]), _p(o["gt_of_rois"]), _p(o["roi_iou"]), _p(o["src"]),
+                                                         _p(o["max_overlaps"]), _p(o["gt_assignment"]), _p(o["counts"]), _p(o["status"]),
+                                                         _stream()), "prcnn_proposal_target_sample")
+    return o
+
+
 def nms_sorted(boxes_sorted, thresh, rotated=True, max_keep=0):
     """Greedy NMS over boxes already sorted by descending score, fully on device.
     -> keep (N) int64 (first num entries valid), num (1) int32.  No host sync.
