@@ -46,7 +46,7 @@ typedef void* prcnn_stream_t; /* hipStream_t */
 #define PRCNN_EHIP (-2)         /* HIP runtime / launch failure */
 #define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-int prcnn_abi_version(void);   /* 6: + prcnn_fps_status, training-mode SharedMLP (prcnn_train_*), prcnn_boxes_iou3d, prcnn_proposal_target_sample; 5: + prcnn_gt_aug_edit;
+int prcnn_abi_version(void);   /* 6: + prcnn_fps_status, training-mode SharedMLP (prcnn_train_*), prcnn_boxes_iou3d, prcnn_proposal_target_sample, prcnn_ref_trig (box trigonometry = the reference's host libm, bit for bit); 5: + prcnn_gt_aug_edit;
                                  * 4: + prcnn_host_* (host twins of the reference's *_cpu entry points), prcnn_build_id,
                                  * prcnn_fps_order (upstream tie order), prcnn_rpn_labels,
                                  * prcnn_ball_query2_grid takes xyz (dense-frame scan fallback);
@@ -542,6 +542,10 @@ int prcnn_interp_rows_grad(const float* G, int ldG, const int32_t* idx3, const f
  * methods, answered from the same table, return the same boxes (tests/golden/ref_proposal_target.py).
  * ====================================================================================================== */
 int prcnn_boxes_iou3d(const float* a, int Na, const float* b, int Nb, float* out, prcnn_stream_t stream);
+/* The box trigonometry of roipool3d / iou3d / NMS / labels / RoI sampling is the reference's HOST libm arithmetic, restated bit for
+ * bit (csrc/ref_trig.h: glibc 2.35 sinf / cosf / atan2f).  Element-wise evaluation for inspection / tests: fn 0 sinf(a), 1 cosf(a),
+ * 2 atan2f(a, b). */
+int prcnn_ref_trig(const float* a, const float* b, int n, int fn, float* out, prcnn_stream_t stream);
 int prcnn_proposal_target_sample(const float* roi_boxes3d, const float* gt_boxes3d, int B, int M, int G, int gt_cols, int roi_per_image,
                                  const float* cfg6, int aug_times, int aug_method, uint32_t seed, float* rois, float* gt_of_rois,
                                  float* roi_iou, int32_t* src, float* max_overlaps, int32_t* gt_assignment, int32_t* counts,

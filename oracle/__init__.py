@@ -46,6 +46,12 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
+# the arithmetic the HIP kernels of roipool3d / iou3d / NMS / labels / RoI sampling implement: 2 = glibc's float sinf / cosf /
+# atan2f restated bit for bit (csrc/ref_trig.h) == the reference's host arithmetic (mode 0); 1 = the round-1/2 contract (double
+# rounded once, division-only vertex order), still what decode_bbox_target / the canonical transform use
+KERNEL_TRIG = 2
+
+
 class _Cpu:
     """numpy wrappers around prcnn_cpu_* (shapes follow the reference op surface)."""
 
@@ -72,7 +78,7 @@ class _Cpu:
         return idx
 
     def gt_aug_edit(self, pts, intensity, boxes3d, new_pts, new_intensity, num_pts=None, num_boxes=None, num_new=None,
-                    extra_h=2.0, trig_mode=1):
+                    extra_h=2.0, trig_mode=KERNEL_TRIG):
         """-> out_pts (B,N+P,3), out_intensity (B,N+P), count (B) i32, removed (B,N) i32"""
         pts, boxes3d, new_pts = _f32(pts), _f32(boxes3d), _f32(new_pts)
         intensity, new_intensity = _f32(intensity), _f32(new_intensity)
@@ -89,7 +95,7 @@ class _Cpu:
                                        _p(out_pts, _F), _p(out_int, _F), _p(count, _I), _p(removed, _I))
         return out_pts, out_int, count, removed
 
-    def rpn_labels(self, pts, gt_boxes3d, num_gt=None, extra_width=0.2, trig_mode=1):
+    def rpn_labels(self, pts, gt_boxes3d, num_gt=None, extra_width=0.2, trig_mode=KERNEL_TRIG):
         pts, gt = _f32(pts), _f32(gt_boxes3d)
         B, N, _ = pts.shape
         G = gt.shape[1]
@@ -181,14 +187,14 @@ class _Cpu:
         return out
 
     # ---- roipool3d ----
-    def pts_in_boxes3d(self, pts, boxes3d, trig_mode=1):
+    def pts_in_boxes3d(self, pts, boxes3d, trig_mode=KERNEL_TRIG):
         pts, boxes3d = _f32(pts), _f32(boxes3d)
         N, M = pts.shape[0], boxes3d.shape[0]
         flags = np.zeros((M, N), np.int64)
         self.lib.prcnn_cpu_pts_in_boxes3d(_p(pts, _F), _p(boxes3d, _F), N, M, trig_mode, _p(flags, _L))
         return flags
 
-    def roipool3d(self, xyz, boxes3d, feat, S, trig_mode=1):
+    def roipool3d(self, xyz, boxes3d, feat, S, trig_mode=KERNEL_TRIG):
         """boxes already enlarged.  -> pooled (B,M,S,3+C) f32, empty (B,M) i32"""
         xyz, boxes3d, feat = _f32(xyz), _f32(boxes3d), _f32(feat)
         B, N, _ = xyz.shape
@@ -208,19 +214,19 @@ class _Cpu:
         return out
 
     # ---- iou3d ----
-    def boxes_overlap_bev(self, a, b, trig_mode=1):
+    def boxes_overlap_bev(self, a, b, trig_mode=KERNEL_TRIG):
         a, b = _f32(a), _f32(b)
         out = np.zeros((a.shape[0], b.shape[0]), np.float32)
         self.lib.prcnn_cpu_boxes_overlap_bev(_p(a, _F), a.shape[0], _p(b, _F), b.shape[0], trig_mode, _p(out, _F))
         return out
 
-    def boxes_iou_bev(self, a, b, trig_mode=1):
+    def boxes_iou_bev(self, a, b, trig_mode=KERNEL_TRIG):
         a, b = _f32(a), _f32(b)
         out = np.zeros((a.shape[0], b.shape[0]), np.float32)
         self.lib.prcnn_cpu_boxes_iou_bev(_p(a, _F), a.shape[0], _p(b, _F), b.shape[0], trig_mode, _p(out, _F))
         return out
 
-    def nms(self, boxes_sorted, thresh, kind="rotated", trig_mode=1):
+    def nms(self, boxes_sorted, thresh, kind="rotated", trig_mode=KERNEL_TRIG):
         """boxes already sorted by descending score -> kept positions (int64)"""
         boxes = _f32(boxes_sorted)
         keep = np.zeros((boxes.shape[0],), np.int64)
@@ -228,7 +234,7 @@ class _Cpu:
                                    0 if kind == "rotated" else 1, trig_mode, _p(keep, _L))
         return keep[:n].copy()
 
-    def nms_mask(self, boxes_sorted, thresh, kind="rotated", trig_mode=1):
+    def nms_mask(self, boxes_sorted, thresh, kind="rotated", trig_mode=KERNEL_TRIG):
         boxes = _f32(boxes_sorted)
         N = boxes.shape[0]
         mask = np.zeros((N, (N + 63) // 64), np.uint64)
@@ -257,7 +263,7 @@ class _Cpu:
         self.lib.prcnn_cpu_argsort_desc(_p(scores, _F), scores.shape[0], _p(order, _I))
         return order
 
-    def proposal_layer(self, scores, boxes3d, pre, post, thresh, kind="normal", ranges=(0.0, 40.0, 80.0), trig_mode=1):
+    def proposal_layer(self, scores, boxes3d, pre, post, thresh, kind="normal", ranges=(0.0, 40.0, 80.0), trig_mode=KERNEL_TRIG):
         """pre / post = (n_area1, n_area2); ranges=None -> score_based_proposal"""
         scores, boxes3d = _f32(scores), _f32(boxes3d)
         B, N = scores.shape
@@ -270,7 +276,7 @@ class _Cpu:
                                           _p(ob, _F), _p(osc, _F), _p(cnt, _I))
         return ob, osc, cnt
 
-    def nms_batched(self, boxes3d, scores, valid, thresh, kind="rotated", max_keep=0, trig_mode=1):
+    def nms_batched(self, boxes3d, scores, valid, thresh, kind="rotated", max_keep=0, trig_mode=KERNEL_TRIG):
         boxes3d, scores = _f32(boxes3d), _f32(scores)
         B, M = scores.shape
         mk = M if max_keep <= 0 or max_keep > M else max_keep
@@ -283,7 +289,16 @@ class _Cpu:
         return keep, num
 
 
-    def boxes_iou3d(self, a, b, trig_mode=1):
+    def ref_trig(self, fn, a, b=None):
+        """fn in {"sinf", "cosf", "atan2f"} (csrc/ref_trig.h) or {"libm_sinf", "libm_cosf", "libm_atan2f"} (the host's libm)"""
+        a = _f32(a).reshape(-1)
+        b = a if b is None else _f32(b).reshape(-1)
+        out = np.zeros(a.shape, np.float32)
+        self.lib.prcnn_cpu_ref_trig(_p(a, _F), _p(b, _F), a.shape[0], ["sinf", "cosf", "atan2f", "libm_sinf", "libm_cosf", "libm_atan2f"].index(fn),
+                                    _p(out, _F))
+        return out
+
+    def boxes_iou3d(self, a, b, trig_mode=KERNEL_TRIG):
         """iou3d_utils.boxes_iou3d_gpu: a (N,7), b (M,7) -> (N,M)"""
         a, b = _f32(a), _f32(b)
         out = np.zeros((a.shape[0], b.shape[0]), np.float32)
@@ -291,7 +306,7 @@ class _Cpu:
         return out
 
     def proposal_target_sample(self, roi_boxes3d, gt_boxes3d, roi_per_image=64, cfgv=(0.55, 0.6, 0.45, 0.05, 0.5, 0.8), aug_times=10,
-                               aug_method="multiple", seed=0, trig_mode=1):
+                               aug_method="multiple", seed=0, trig_mode=KERNEL_TRIG):
         """ProposalTargetLayer.sample_rois_for_rcnn with the counter-based draw -> dict of arrays"""
         roi, gt = _f32(roi_boxes3d), _f32(gt_boxes3d)
         B, M, _ = roi.shape

@@ -36,9 +36,15 @@
  *       atan2 -- the contract the HIP kernels implement bit-for-bit (device
  *       libm differs from glibc by ULPs, so mode 0 cannot be bit-exact on a
  *       GPU; mode 1 can).  Mode 0 vs mode 1 agree to ~1e-6 relative.
+ *   2 = "reference arithmetic, restated" (round 3; what the HIP kernels of roipool3d / iou3d / NMS / labels / RoI sampling
+ *       implement now): pointrcnn_amd/csrc/ref_trig.h -- glibc's float sinf / cosf (double polynomial, FMA build) and atan2f
+ *       (fdlibm float) restated operation by operation, bit-identical to the host libm for every float |x| < 120 (exhaustive,
+ *       tools/ref_trig_check.c).  Mode 2 == mode 0 on any FMA-capable glibc 2.35 host; unlike mode 0 it does not depend on
+ *       which libm the test machine has.
  */
 #include <math.h>
 #include <stdint.h>
+#include "../pointrcnn_amd/csrc/ref_trig.h"   /* trig_mode 2: the kernels' restatement of glibc's sinf / cosf / atan2f */
 #include <stdlib.h>
 #include <string.h>
 
@@ -273,6 +279,7 @@ PRCNN_EXPORT void prcnn_cpu_linear_rows(const float* a, const float* w, const fl
  * ------------------------------------------------------------------ */
 static void box_trig(float angle, int trig_mode, float* cosa, float* sina) {
     if (trig_mode == 0) { *cosa = cosf(angle); *sina = sinf(angle); }      /* roipool3d.cpp:89 */
+    else if (trig_mode == 2) { *cosa = prcnn_ref_cosf(angle); *sina = prcnn_ref_sinf(angle); }
     else { *cosa = (float)cos((double)angle); *sina = (float)sin((double)angle); }
 }
 
@@ -508,6 +515,7 @@ static float angle_key(float dx, float dy) {
 
 static void iou_trig(float angle, int trig_mode, float* c, float* s) {
     if (trig_mode == 0) { *c = cosf(angle); *s = sinf(angle); }             /* iou3d_kernel.cu:135-136 */
+    else if (trig_mode == 2) { *c = prcnn_ref_cosf(angle); *s = prcnn_ref_sinf(angle); }
     else { *c = (float)cos((double)angle); *s = (float)sin((double)angle); }
 }
 
@@ -524,6 +532,8 @@ static float box_overlap(const float* box_a, const float* box_b, int trig_mode) 
     iou_trig(b_angle, trig_mode, &bc, &bs);
     if (trig_mode == 0) {   /* check_in_box2d evaluates cos(-angle), sin(-angle) itself (iou3d_kernel.cu:56) */
         acn = cosf(-a_angle); asn = sinf(-a_angle); bcn = cosf(-b_angle); bsn = sinf(-b_angle);
+    } else if (trig_mode == 2) {
+        acn = prcnn_ref_cosf(-a_angle); asn = prcnn_ref_sinf(-a_angle); bcn = prcnn_ref_cosf(-b_angle); bsn = prcnn_ref_sinf(-b_angle);
     } else {
         acn = ac; asn = -as; bcn = bc; bsn = -bs;
     }
@@ -561,7 +571,7 @@ static float box_overlap(const float* box_a, const float* box_b, int trig_mode) 
     float key[24];
     for (int i = 0; i < cnt; i++) {
         float dy = cp[i].y - poly_center.y, dx = cp[i].x - poly_center.x;
-        key[i] = trig_mode == 0 ? atan2f(dy, dx) : angle_key(dx, dy);      /* iou3d_kernel.cu:104-106 */
+        key[i] = trig_mode == 0 ? atan2f(dy, dx) : (trig_mode == 2 ? prcnn_ref_atan2f(dy, dx) : angle_key(dx, dy));   /* iou3d_kernel.cu:104-106 */
     }
     for (int j = 0; j < cnt - 1; j++)                                        /* iou3d_kernel.cu:188-196 */
         for (int i = 0; i < cnt - j - 1; i++)
@@ -1360,4 +1370,19 @@ PRCNN_EXPORT void prcnn_cpu_proposal_target_sample(const float* roi_boxes3d, con
     }
     free(cand);
     free(fg);
+}
+
+
+/* the restated libm functions (fn 0 sinf, 1 cosf, 2 atan2f(a, b)) and the host libm's own (fn 3, 4, 5), element-wise: tests */
+PRCNN_EXPORT void prcnn_cpu_ref_trig(const float* a, const float* b, int n, int fn, float* out) {
+    for (int i = 0; i < n; i++) {
+        switch (fn) {
+            case 0: out[i] = prcnn_ref_sinf(a[i]); break;
+            case 1: out[i] = prcnn_ref_cosf(a[i]); break;
+            case 2: out[i] = prcnn_ref_atan2f(a[i], b[i]); break;
+            case 3: out[i] = sinf(a[i]); break;
+            case 4: out[i] = cosf(a[i]); break;
+            default: out[i] = atan2f(a[i], b[i]); break;
+        }
+    }
 }

@@ -95,6 +95,7 @@ SIGNATURES = {
     "prcnn_train_stack_work_bytes": (_Z, [_L, ctypes.POINTER(TrainLayer), _I, _I, _I]),
     "prcnn_train_stack_fwd": (_I, [ctypes.POINTER(TrainSrc), ctypes.POINTER(TrainLayer), _I, _I, _P, _I, _P, _I, _I, _P, _P, _Z, _P]),
     "prcnn_train_stack_bwd": (_I, [ctypes.POINTER(TrainSrc), ctypes.POINTER(TrainLayer), _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _Z, _P]),
+    "prcnn_ref_trig": (_I, [_P, _P, _I, _I, _P, _P]),
     "prcnn_boxes_iou3d": (_I, [_P, _I, _P, _I, _P, _P]),
     "prcnn_proposal_target_sample": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prcnn_group_rows_grad": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),

@@ -183,3 +183,19 @@ PRCNN_API int prcnn_nms(const float* boxes, int N, float thresh, int kind, int m
     PRCNN_LAUNCH_CHECK("prcnn_nms(sweep)");
     return PRCNN_OK;
 }
+
+
+// ref_trig.h on the device, element-wise (tests: device bits == the oracle's == the host libm's): fn 0 sinf(a), 1 cosf(a), 2 atan2f(a, b)
+__global__ void ref_trig_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, int fn, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = fn == 0 ? prcnn_ref_sinf(a[i]) : (fn == 1 ? prcnn_ref_cosf(a[i]) : prcnn_ref_atan2f(a[i], b[i]));
+}
+PRCNN_API int prcnn_ref_trig(const float* a, const float* b, int n, int fn, float* out, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(n >= 0 && fn >= 0 && fn <= 2, "prcnn_ref_trig: bad arguments");
+    if (n == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(a && out && (fn != 2 || b), "prcnn_ref_trig: null pointer");
+    hipLaunchKernelGGL(ref_trig_kernel, dim3(prcnn_divup(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b ? b : a, n, fn, out);
+    PRCNN_LAUNCH_CHECK("prcnn_ref_trig");
+    return PRCNN_OK;
+}

@@ -1,17 +1,21 @@
 // iou3d_geom.h -- BEV box geometry shared by iou3d.hip (pair matrices, mask NMS) and proposal.hip (batched greedy NMS).
 //
 // The clipping algorithm follows the reference step for step (lib/utils/iou3d/src/iou3d_kernel.cu:34-221: edge-edge
-// intersections, contained corners, centroid, angular sort, shoelace) under the canonical arithmetic contract shared
-// with oracle/prcnn_oracle.c (trig_mode 1): every product/sum individually rounded, box cos/sin evaluated in double
-// and rounded once, polygon vertices ordered by a division-only monotone surrogate of atan2.
+// intersections, contained corners, centroid, angular sort, shoelace) in the REFERENCE'S arithmetic (oracle trig_mode 2 ==
+// trig_mode 0 == the reference's own sources compiled for the host): every product / sum individually rounded, the
+// box's cos / sin, the cos(-angle) / sin(-angle) of the containment test and the atan2 of the angular sort evaluated by
+// ref_trig.h -- glibc's float routines restated bit for bit (rounds 1-2 used double-rounded trigonometry and a division-only
+// surrogate of atan2, which agreed to 5e-7 in IoU but could flip a decision sitting within 3e-6 of its threshold).
 #pragma once
 #include "common.h"
+#include "ref_trig.h"
 
 struct Pt { float x, y; };
 struct RBox {
     float x1, y1, x2, y2;   // raw extents
     float cx, cy;           // centre
     float c, s;             // cos(angle), sin(angle)
+    float cn, sn;           // cos(-angle), sin(-angle) as the reference evaluates them (iou3d_kernel.cu:56)
     Pt p[5];                // rotated corners, p[4] == p[0]
     float rad;              // half diagonal: every corner lies on this circle around the centre
 };
@@ -31,8 +35,10 @@ __device__ __forceinline__ Pt rotate_around_center(float cx, float cy, float c, 
 __device__ void make_rbox(const float* __restrict__ b, RBox& r) {
     r.x1 = b[0]; r.y1 = b[1]; r.x2 = b[2]; r.y2 = b[3];
     r.cx = add(r.x1, r.x2) / 2; r.cy = add(r.y1, r.y2) / 2;
-    r.c = (float)cos((double)b[4]);
-    r.s = (float)sin((double)b[4]);
+    r.c = prcnn_ref_cosf(b[4]);
+    r.s = prcnn_ref_sinf(b[4]);
+    r.cn = prcnn_ref_cosf(-b[4]);
+    r.sn = prcnn_ref_sinf(-b[4]);
     r.p[0] = rotate_around_center(r.cx, r.cy, r.c, r.s, r.x1, r.y1);
     r.p[1] = rotate_around_center(r.cx, r.cy, r.c, r.s, r.x2, r.y1);
     r.p[2] = rotate_around_center(r.cx, r.cy, r.c, r.s, r.x2, r.y2);
@@ -61,13 +67,13 @@ __device__ __forceinline__ bool check_rect_cross(Pt p1, Pt p2, Pt q1, Pt q2) {  
            fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
 }
 
-// iou3d_kernel.cu:50-65 with (cos(-a), sin(-a)) = (c, -s)
+// iou3d_kernel.cu:50-65
 __device__ __forceinline__ bool check_in_box2d(const RBox& box, Pt p) {
     const float MARGIN = 1e-5f;
     float dx = sub(p.x, box.cx), dy = sub(p.y, box.cy);
-    float sn = -box.s;
-    float rot_x = add(add(mul(dx, box.c), mul(dy, sn)), box.cx);
-    float rot_y = add(add(mul(-dx, sn), mul(dy, box.c)), box.cy);
+    float sn = box.sn;
+    float rot_x = add(add(mul(dx, box.cn), mul(dy, sn)), box.cx);
+    float rot_y = add(add(mul(-dx, sn), mul(dy, box.cn)), box.cy);
     return rot_x > sub(box.x1, MARGIN) && rot_x < add(box.x2, MARGIN) && rot_y > sub(box.y1, MARGIN) &&
            rot_y < add(box.y2, MARGIN);
 }
@@ -93,14 +99,8 @@ __device__ __forceinline__ bool seg_intersection(Pt p1, Pt p0, Pt q1, Pt q0, Pt&
     return true;
 }
 
-// canonical ordering key: strictly increasing in atan2(dy,dx) over (-pi, pi]; IEEE +,-,/ only
-__device__ __forceinline__ float angle_key(float dx, float dy) {
-    float s = add(fabsf(dx), fabsf(dy));
-    if (!(s > 0.0f)) return 0.0f;
-    float t = dy / s;
-    if (dx >= 0.0f) return t;
-    return dy >= 0.0f ? sub(2.0f, t) : sub(-2.0f, t);
-}
+// ordering key of the angular sort: atan2(dy, dx) exactly as the reference's host libm evaluates it (iou3d_kernel.cu:104-106)
+__device__ __forceinline__ float angle_key(float dx, float dy) { return prcnn_ref_atan2f(dy, dx); }
 
 // iou3d_kernel.cu:108-212
 __device__ float box_overlap(const RBox& A, const RBox& B) {

@@ -12,6 +12,7 @@
 // S.  The gather then writes the box's contiguous S x (3+C) output block as one flat, fully coalesced stream
 // (reads are contiguous within a point's feature row).  Nothing but the inputs and the output touches HBM.
 #include "common.h"
+#include "ref_trig.h"
 
 #define RP_THREADS 256
 #define RP_WAVES 4
@@ -20,13 +21,14 @@ struct BoxConst { float cx, cy, cz, hh, hw, hl, cosa, sina; };
 
 __device__ __forceinline__ BoxConst make_box(const float* bx) {
     // roipool3d.cpp:82-95.  cy = bottom_y - h/2 in double then rounded (exactly what the reference's
-    // `h / 2.0` expression does); cos/sin in double rounded once to fp32 (canonical trig contract).
+    // `h / 2.0` expression does); cos/sin as the reference's host libm evaluates cos(float) / sin(float) (ref_trig.h:
+    // glibc's routines restated bit for bit -- points on a box face land on the reference's side of it).
     BoxConst b;
     b.cx = bx[0]; b.cz = bx[2];
     b.cy = (float)((double)bx[1] - (double)bx[3] / 2.0);
     b.hh = bx[3] * 0.5f; b.hw = bx[4] * 0.5f; b.hl = bx[5] * 0.5f;      // exact halvings
-    b.cosa = (float)cos((double)bx[6]);
-    b.sina = (float)sin((double)bx[6]);
+    b.cosa = prcnn_ref_cosf(bx[6]);
+    b.sina = prcnn_ref_sinf(bx[6]);
     return b;
 }
 

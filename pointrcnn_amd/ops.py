@@ -557,6 +557,14 @@ def boxes_iou_bev(boxes_a, boxes_b, out=None):
     return out
 
 
+def ref_trig(fn, a, b=None):
+    """csrc/ref_trig.h on the device, element-wise: fn in {"sinf", "cosf", "atan2f"} (atan2f(a, b)); float32 tensors"""
+    _chk(a, "a")
+    out = torch.empty_like(a)
+    _cabi.check(_cabi.lib().prcnn_ref_trig(_p(a), _p(b), a.numel(), ["sinf", "cosf", "atan2f"].index(fn), _p(out), _stream()), "prcnn_ref_trig")
+    return out
+
+
 def boxes_iou3d(boxes_a, boxes_b):
     """boxes_a (N,7), boxes_b (M,7) [x, y, z, h, w, l, ry] -> 3-D IoU (N,M)   [iou3d_utils.boxes_iou3d_gpu, iou3d_utils.py:20-53]"""
     _chk(boxes_a, "boxes_a", ndim=2); _chk(boxes_b, "boxes_b", ndim=2)

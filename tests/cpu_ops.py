@@ -62,7 +62,7 @@ def _make(cpu):
 
 
 @contextlib.contextmanager
-def oracle_ops(trig_mode=1):
+def oracle_ops(trig_mode=2):
     """patch pointrcnn_amd.ops / iou3d_cuda / roipool3d_cuda.forward with oracle-backed CPU versions"""
     import oracle
     import pointrcnn_amd

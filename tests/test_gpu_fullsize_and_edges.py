@@ -101,6 +101,6 @@ def test_empty_and_degenerate_inputs(dev, cpu):
     # zero-area and zero-size boxes in NMS / IoU: no NaN, identical to the oracle
     boxes = np.array([[0, 0, 0, 0, 0.3], [0, 0, 2, 2, 0.0], [1, 1, 1, 3, 1.0], [0, 0, 2, 2, 0.0]], np.float32)
     iou = ops.boxes_iou_bev(T(boxes, dev), T(boxes, dev)).cpu().numpy()
-    assert np.array_equal(iou, cpu.boxes_iou_bev(boxes, boxes, 1)) and np.isfinite(iou).all()
+    assert np.array_equal(iou, cpu.boxes_iou_bev(boxes, boxes)) and np.isfinite(iou).all()
     keep, num = ops.nms_sorted(T(boxes, dev), 0.5)
-    assert np.array_equal(keep[: int(num.item())].cpu().numpy(), cpu.nms(boxes, 0.5, "rotated", 1))
+    assert np.array_equal(keep[: int(num.item())].cpu().numpy(), cpu.nms(boxes, 0.5, "rotated"))

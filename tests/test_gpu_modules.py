@@ -200,7 +200,7 @@ def test_rcnn_stage_fused_equals_composed_and_roipool_oracle(dev, cpu):
         scores = out_f["rcnn_cls"].view(B, M)[b]
         keep = rcnn.nms_gpu(bev, scores, 0.1).cpu().numpy()
         order = torch.sort(scores, descending=True)[1].cpu().numpy()
-        want_keep = order[cpu.nms(bev[torch.from_numpy(order).to(dev)].cpu().numpy(), 0.1, "rotated", 1)]
+        want_keep = order[cpu.nms(bev[torch.from_numpy(order).to(dev)].cpu().numpy(), 0.1, "rotated")]
         assert np.array_equal(keep, want_keep)
 
 

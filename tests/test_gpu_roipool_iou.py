@@ -26,7 +26,7 @@ def test_roipool3d_matches_oracle(dev, cpu, B, N, M, C, S):
     boxes = np.stack([enlarge(rand_boxes3d(xyz[b], M, seed=b + 1), 1.0) for b in range(B)])
     boxes[:, -1, 0] += 500.0                                  # one box far away from every point: empty
     feat = r.normal(size=(B, N, C)).astype(np.float32)
-    want, wempty = cpu.roipool3d(xyz, boxes, feat, S, trig_mode=1)
+    want, wempty = cpu.roipool3d(xyz, boxes, feat, S)
     got, gempty = ops.roipool3d(T(xyz, dev), T(boxes, dev), T(feat, dev), S)
     assert np.array_equal(gempty.cpu().numpy(), wempty) and wempty[:, -1].all()
     assert np.array_equal(got.cpu().numpy(), want)            # gathered copies: bit equal
@@ -87,8 +87,8 @@ def test_roipool3d_dropin_module(dev, cpu):
 def test_overlap_and_iou_match_oracle_bitexact(dev, cpu, na, nb, spread):
     from pointrcnn_amd import ops
     a, b = rand_bev(na, spread, seed=na), rand_bev(nb, spread, seed=nb + 100)
-    assert np.array_equal(ops.boxes_overlap_bev(T(a, dev), T(b, dev)).cpu().numpy(), cpu.boxes_overlap_bev(a, b, 1))
-    assert np.array_equal(ops.boxes_iou_bev(T(a, dev), T(b, dev)).cpu().numpy(), cpu.boxes_iou_bev(a, b, 1))
+    assert np.array_equal(ops.boxes_overlap_bev(T(a, dev), T(b, dev)).cpu().numpy(), cpu.boxes_overlap_bev(a, b))
+    assert np.array_equal(ops.boxes_iou_bev(T(a, dev), T(b, dev)).cpu().numpy(), cpu.boxes_iou_bev(a, b))
 
 
 def test_overlap_degenerate_pairs(dev, cpu):
@@ -98,7 +98,7 @@ def test_overlap_degenerate_pairs(dev, cpu):
                      [0, 0, 2, 4, np.pi / 2], [0, 0, 2, 4, 0.7], [0, 0, 2, 4, 0.7], [10, 10, 12, 14, 0.1],
                      [0, 0, 2, 4, np.pi], [0, 0, 2, 4, -0.7]], np.float32)
     got = ops.boxes_iou_bev(T(base, dev), T(base, dev)).cpu().numpy()
-    assert np.array_equal(got, cpu.boxes_iou_bev(base, base, 1))
+    assert np.array_equal(got, cpu.boxes_iou_bev(base, base))
     np.testing.assert_allclose(np.diag(got), 1.0, atol=1e-5)
 
 
@@ -109,7 +109,7 @@ def test_nms_keep_matches_oracle(dev, cpu, kind, N, thr):
     boxes = rand_bev(N, 8.0, seed=N)
     keep, num = ops.nms_sorted(T(boxes, dev), thr, rotated=(kind == "rotated"))
     got = keep[: int(num.item())].cpu().numpy()
-    assert np.array_equal(got, cpu.nms(boxes, thr, kind, 1))
+    assert np.array_equal(got, cpu.nms(boxes, thr, kind))
 
 
 def test_nms_empty_and_duplicates(dev, cpu):
@@ -120,7 +120,7 @@ def test_nms_empty_and_duplicates(dev, cpu):
     for kind in ("rotated", "normal"):
         keep, num = ops.nms_sorted(T(dup, dev), 0.7, rotated=(kind == "rotated"))
         got = keep[: int(num.item())].cpu().numpy()
-        assert np.array_equal(got, cpu.nms(dup, 0.7, kind, 1))
+        assert np.array_equal(got, cpu.nms(dup, 0.7, kind))
         assert (got % 3 == 0).all()
 
 
@@ -130,18 +130,18 @@ def test_nms_rpn_scale_normal(dev, cpu):
     boxes = rand_bev(6300, 30.0, seed=63)
     keep, num = ops.nms_sorted(T(boxes, dev), 0.8, rotated=False)
     got = keep[: int(num.item())].cpu().numpy()
-    assert np.array_equal(got, cpu.nms(boxes, 0.8, "normal", 1))
+    assert np.array_equal(got, cpu.nms(boxes, 0.8, "normal"))
 
 
 def test_iou3d_golden_from_reference(dev):
-    """fixtures produced by the reference's own iou3d sources run on the host (oracle/_ref): NMS keep sets
-    must be identical; overlap areas agree to 1e-5 (device trig differs from glibc's by ULPs)"""
+    """fixtures produced by the reference's own iou3d sources run on the host (oracle/_ref): overlaps, IoUs and NMS keep sets
+    are bit-identical (the kernels evaluate the reference's libm arithmetic, csrc/ref_trig.h)"""
     from pointrcnn_amd import ops
     g = np.load(os.path.join(GOLDEN, "iou3d_ref.npz"))
     ov = ops.boxes_overlap_bev(T(g["a"], dev), T(g["b"], dev)).cpu().numpy()
-    np.testing.assert_allclose(ov, g["overlap"], atol=1e-5, rtol=0)
+    assert np.array_equal(ov, g["overlap"])
     iou = ops.boxes_iou_bev(T(g["a"], dev), T(g["b"], dev)).cpu().numpy()
-    np.testing.assert_allclose(iou, g["iou"], atol=1e-5, rtol=0)
+    assert np.array_equal(iou, g["iou"])
     for kind in ("rotated", "normal"):
         for thr in (0.1, 0.5, 0.8):
             keep, num = ops.nms_sorted(T(g["nms_boxes"], dev), thr, rotated=(kind == "rotated"))
@@ -156,10 +156,10 @@ def test_iou3d_dropin_module(dev, cpu):
     tb, ts = T(boxes, dev), T(scores, dev)
     ans = torch.cuda.FloatTensor(torch.Size((500, 500))).zero_()
     assert iou3d_cuda.boxes_iou_bev_gpu(tb.contiguous(), tb.contiguous(), ans) == 1
-    assert np.array_equal(ans.cpu().numpy(), cpu.boxes_iou_bev(boxes, boxes, 1))
+    assert np.array_equal(ans.cpu().numpy(), cpu.boxes_iou_bev(boxes, boxes))
     ans.zero_()
     iou3d_cuda.boxes_overlap_bev_gpu(tb, tb, ans)
-    assert np.array_equal(ans.cpu().numpy(), cpu.boxes_overlap_bev(boxes, boxes, 1))
+    assert np.array_equal(ans.cpu().numpy(), cpu.boxes_overlap_bev(boxes, boxes))
     # iou3d_utils.nms_gpu, verbatim calling sequence
     order = ts.sort(0, descending=True)[1]
     sb = tb[order].contiguous()
@@ -167,7 +167,7 @@ def test_iou3d_dropin_module(dev, cpu):
         keep = torch.LongTensor(sb.size(0))
         num_out = fn(sb, keep, 0.4)
         picked = order[keep[:num_out].cuda()].contiguous().cpu().numpy()
-        want = order.cpu().numpy()[cpu.nms(sb.cpu().numpy(), 0.4, kind, 1)]
+        want = order.cpu().numpy()[cpu.nms(sb.cpu().numpy(), 0.4, kind)]
         assert np.array_equal(picked, want)
     with pytest.raises(RuntimeError):
         iou3d_cuda.nms_gpu(torch.from_numpy(boxes), torch.LongTensor(500), 0.4)      # CPU boxes rejected
@@ -179,7 +179,7 @@ def test_nms_max_keep_prefix(dev, cpu):
     from pointrcnn_amd import ops
     boxes = rand_bev(3000, 12.0, seed=77)
     for kind in ("rotated", "normal"):
-        full = cpu.nms(boxes, 0.5, kind, 1)
+        full = cpu.nms(boxes, 0.5, kind)
         for mk in (1, 30, 70, 200, 512):
             keep, num = ops.nms_sorted(T(boxes, dev), 0.5, rotated=(kind == "rotated"), max_keep=mk)
             n = int(num.item())

@@ -19,11 +19,13 @@ def test_golden_iou3d_reference_mode_is_bit_exact(cpu):
         for thr in (0.1, 0.5, 0.8):
             want = g["keep_%s_%s" % (kind, thr)]
             assert np.array_equal(cpu.nms(g["nms_boxes"], thr, kind, 0), want)
-            assert np.array_equal(cpu.nms(g["nms_boxes"], thr, kind, 1), want)      # the GPU contract agrees
+            assert np.array_equal(cpu.nms(g["nms_boxes"], thr, kind, 1), want)      # the legacy (round 1-2) kernel arithmetic agrees
+            assert np.array_equal(cpu.nms(g["nms_boxes"], thr, kind, 2), want)      # the kernels' arithmetic: the restated libm
+    assert np.array_equal(cpu.boxes_overlap_bev(g["a"], g["b"], 2), g["overlap"]) and np.array_equal(cpu.boxes_iou_bev(g["a"], g["b"], 2), g["iou"])
 
 
 def test_golden_iou3d_canonical_mode_within_tolerance(cpu):
-    """trig_mode 1 (what the HIP kernels implement bit-for-bit) vs the reference's libm arithmetic"""
+    """trig_mode 1 (the kernels' arithmetic of rounds 1-2; decode / canonical transform still use it) vs the reference's libm"""
     g = np.load(os.path.join(GOLDEN, "iou3d_ref.npz"))
     np.testing.assert_allclose(cpu.boxes_overlap_bev(g["a"], g["b"], 1), g["overlap"], atol=1e-5, rtol=0)
     np.testing.assert_allclose(cpu.boxes_iou_bev(g["a"], g["b"], 1), g["iou"], atol=1e-5, rtol=0)

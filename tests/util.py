@@ -40,6 +40,11 @@ def enlarge(boxes, e):
     return b
 
 
+# oracle trig_mode the HIP kernels of roipool3d / iou3d / NMS / labels / RoI sampling implement (2 = the reference's host libm,
+# restated bit for bit; see oracle/prcnn_oracle.c header)
+KERNEL_TRIG = 2
+
+
 def mlp_tol(ref):
     """absolute tolerance for the fp32-MFMA MLP against the double-accumulated oracle (1e-5 relative to scale)"""
     return 1e-5 * max(1.0, float(np.abs(ref).max()))
