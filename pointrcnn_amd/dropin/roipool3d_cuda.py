@@ -31,9 +31,34 @@ def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
     return 1
 
 
-# The reference keeps a one-thread-per-box variant of the same computation under this name (roipool3d.cpp:15-46 ->
-# roipool3d_kernel.cu roipool3dLauncher_slow); inputs, outputs and results are those of `forward`, so one kernel serves both.
-forward_slow = forward
+def forward_slow(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
+    """The reference keeps a second, one-thread-per-box implementation of the same computation under this name (roipool3d.cpp:15-46
+    -> roipool3d_kernel.cu:30-95 roipool3dLauncher_slow).  Here it is a second implementation too, sharing nothing with the fused
+    kernel but the point-in-box test: per frame the (M, N) flag matrix of prcnn_pts_in_boxes3d, then the reference's selection
+    rule spelled with tensor operations -- the first S in-box points in index order (a stable descending sort of the flags), slot
+    k >= count takes slot k mod count, empty boxes are flagged and zero-filled.  Same results as `forward`, bit for bit
+    (tests/test_gpu_roipool_iou.py); an independent path to check the fused kernel against, not a fast one."""
+    from pointrcnn_amd import ops
+    for t, n in ((xyz, "xyz"), (boxes3d, "boxes3d"), (pts_feature, "pts_feature"),
+                 (pooled_features, "pooled_features"), (pooled_empty_flag, "pooled_empty_flag")):
+        _check_input(t, n)
+    B, N = xyz.shape[0], xyz.shape[1]
+    M, S = boxes3d.shape[1], pooled_features.shape[2]
+    slots = torch.arange(S, device=xyz.device)
+    for b in range(B):
+        flags = ops.pts_in_boxes3d(xyz[b], boxes3d[b])                                   # (M, N) int32
+        cnt = flags.sum(1)
+        first = torch.sort(flags, dim=1, descending=True, stable=True).indices[:, :S]   # in-box points first, ascending index
+        if first.shape[1] < S:                                                          # N < S
+            first = torch.cat([first, first.new_zeros((M, S - first.shape[1]))], 1)
+        take = torch.minimum(cnt.clamp(min=1), cnt.new_tensor(S)).long()
+        src = torch.gather(first, 1, (slots[None, :] % take[:, None]))                  # wrap-duplicate (roipool3d.cpp:171-191)
+        rows = torch.cat([xyz[b][src], pts_feature[b][src]], 2)                         # (M, S, 3 + C)
+        empty = cnt == 0
+        rows[empty] = 0
+        pooled_features[b] = rows
+        pooled_empty_flag[b] = empty.to(pooled_empty_flag.dtype)
+    return 1
 
 
 def _host(t, name, dtype):

@@ -71,6 +71,21 @@ def test_roipool3d_dropin_module(dev, cpu):
     assert roipool3d_cuda.forward(T(xyz, dev), T(boxes, dev), T(feat, dev), pooled, empty) == 1
     want, wempty = cpu.roipool3d(xyz, boxes, feat, S)
     assert np.array_equal(pooled.cpu().numpy(), want) and np.array_equal(empty.cpu().numpy(), wempty)
+    # forward_slow: the independent second implementation (flag matrix + tensor selection) gives the same bits -- boxes with more
+    # than S points, fewer (wrap-duplication), and none (a box moved out of the cloud), two frames
+    xyz2 = np.concatenate([xyz, kitti_cloud(1, N, seed=78)])
+    boxes2 = np.concatenate([boxes, enlarge(rand_boxes3d(xyz2[1], M, seed=6), 1.0)[None]])
+    boxes2[1, 3, 0] += 500.0
+    boxes2[0, 5, 3:6] *= 3.0
+    feat2 = r.normal(size=(2, N, C)).astype(np.float32)
+    outs = []
+    for fn in (roipool3d_cuda.forward, roipool3d_cuda.forward_slow):
+        p2 = torch.cuda.FloatTensor(torch.Size((2, M, S, 3 + C))).zero_()
+        e2 = torch.cuda.IntTensor(torch.Size((2, M))).zero_()
+        assert fn(T(xyz2, dev), T(boxes2, dev), T(feat2, dev), p2, e2) == 1
+        outs.append((p2, e2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert int(outs[0][1].sum()) >= 1 and np.array_equal(outs[1][0].cpu().numpy(), cpu.roipool3d(xyz2, boxes2, feat2, S)[0])
     flags = torch.LongTensor(torch.Size((M, N)))
     roipool3d_cuda.pts_in_boxes3d_cpu(flags, torch.from_numpy(xyz[0]), torch.from_numpy(boxes[0]))
     assert np.array_equal(flags.numpy(), cpu.pts_in_boxes3d(xyz[0], boxes[0]))
