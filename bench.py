@@ -177,21 +177,23 @@ class EventProfiler:
         def chain(k0, nout):
             widths = [k0] + list(nout)
             return 2.0 * sum(x * y for x, y in zip(widths[:-1], widths[1:]))
+        def widths(k0, nout, n):
+            return "->".join(str(int(v)) for v in [k0] + [nout[i] for i in range(n)])
         if name == "prcnn_mlp_rows":
-            return 2.0 * a[3] * a[6], a[2], a[12], a[13]
+            return 2.0 * a[3] * a[6], a[2], a[12], a[13], "%d->%d" % (a[3], a[6])
         if name == "prcnn_mlp_rows_addinterp":
-            return 2.0 * (a[2] + 3) * a[5], a[11] * a[12], None, 1
+            return 2.0 * (a[2] + 3) * a[5], a[11] * a[12], None, 1, "%d->%d + interpolated addend" % (a[2], a[5])
         if name == "prcnn_mlp_group":
-            return 2.0 * (a[9] + (0 if a[10] else 3)) * a[14], a[5] * a[7] * a[8], a[20], a[8]
+            return 2.0 * (a[9] + (0 if a[10] else 3)) * a[14], a[5] * a[7] * a[8], a[20], a[8], "%d->%d" % (a[9] + (0 if a[10] else 3), a[14])
         if name == "prcnn_mlp_interp":
-            return 2.0 * (a[9] + a[10]) * a[14], a[6] * a[7], None, 1
+            return 2.0 * (a[9] + a[10]) * a[14], a[6] * a[7], None, 1, "%d->%d" % (a[9] + a[10], a[14])
         if name == "prcnn_mlp_chain_rows":
-            return chain(a[3], a[7]), a[2], None, 1
+            return chain(a[3], a[7]), a[2], None, 1, widths(a[3], a[7], a[4])
         if name == "prcnn_mlp_chain_group":
-            return chain(a[9] + (0 if a[10] else 3), a[15]), a[5] * a[7] * a[8], a[21], a[8]
+            return chain(a[9] + (0 if a[10] else 3), a[15]), a[5] * a[7] * a[8], a[21], a[8], widths(a[9] + (0 if a[10] else 3), a[15], a[12])
         if name == "prcnn_mlp_chain_interp":
-            return chain(a[9] + a[10], a[15]), a[6] * a[7], None, 1
-        return 0.0, 0, None, 1
+            return chain(a[9] + a[10], a[15]), a[6] * a[7], None, 1, widths(a[9] + a[10], a[15], a[12])
+        return 0.0, 0, None, 1, ""
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
@@ -220,7 +222,7 @@ class EventProfiler:
             undedup[sp.counts.data_ptr()] = sp.G * sp.ns - c[1] * sp.ns
         fam = {}
         self.mlp_launches = []        # (entry point, live rows, flops per row, us) of every MLP-family launch, in launch order
-        for name, s, e, (per_row, rows, ptr, unit) in self.records:
+        for name, s, e, (per_row, rows, ptr, unit, label) in self.records:
             key = "mlp" if name.startswith("prcnn_mlp_") else name[len("prcnn_"):]
             d = fam.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0, "rows": 0, "rows_launched": 0})
             ptr = getattr(ptr, "value", ptr)
@@ -230,7 +232,7 @@ class EventProfiler:
                 print("%-28s rows %8d / %8d  flop/row %8.0f  %7.2f GFLOP %8.1f us %6.1f TF/s" %
                       (name, live, rows, per_row, per_row * live / 1e9, us, per_row * live / us / 1e6 if us > 0 else 0), file=dump)
             if key == "mlp":
-                self.mlp_launches.append((name[len("prcnn_"):], live, per_row, s.elapsed_time(e) * 1e3))
+                self.mlp_launches.append((name[len("prcnn_"):], live, per_row, s.elapsed_time(e) * 1e3, label))
             d["ms"] += s.elapsed_time(e)
             d["launches"] += 1
             d["flops"] += per_row * live
@@ -477,7 +479,7 @@ def instrumented_pass(args, bench, nprof, dump=None):
                 reps = prof.mlp_launches[i::per_step]
                 us = sum(r[3] for r in reps) / len(reps)
                 gflop = reps[0][1] * reps[0][2] / 1e9
-                table.append({"launch": reps[0][0], "rows": reps[0][1], "flop_per_row": reps[0][2], "us": round(us, 1), "GFLOP": round(gflop, 3),
+                table.append({"launch": reps[0][0], "widths": reps[0][4], "rows": reps[0][1], "flop_per_row": reps[0][2], "us": round(us, 1), "GFLOP": round(gflop, 3),
                               "frac_of_peak": round(gflop * 1e3 / us / FP32_MFMA_PEAK_TFLOPS, 3) if us > 0 else None})
             fam["mlp_by_launch"] = table
         return fam
@@ -708,7 +710,7 @@ def main():
                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         # HBM bytes per launch of the same kernel family from the PMC passes committed under profiles/ (rocprofv3
         # --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied there); null when absent.
-        for tname in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        for tname in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and args.batch == 32 and args.npoints == 16384:
                 try:

@@ -2,11 +2,10 @@
 # copy the summaries produced by tools/refresh_profiles.sh (gpurun_out/refresh) into profiles/ (round tag = $1, default r02)
 set -e
 R=gpurun_out/refresh
-T=${1:-r02}
+T=${1:-r03}
 cp $R/bench_default.json profiles/${T}_final_bench.json
 cp $R/bench_driver_flags.json profiles/${T}_final_bench_steps20.json
 cp $R/bench_streams1.json profiles/${T}_final_bench_streams1.json
-cp $R/bench_lidar.json profiles/${T}_final_bench_lidar.json
 cp $R/bench_raw_input.json profiles/${T}_final_bench_raw_input.json
 cp $R/bench_rcnn.json profiles/${T}_final_bench_rcnn.json
 cp $R/bench_train.json profiles/${T}_final_bench_train.json

@@ -12,23 +12,22 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_FETCH_SI
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_WRITE_SIZE -- $B > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/pmc_mfma -- $B > /dev/null 2>&1
 python profiles/derive_hbm_traffic.py $O/pmc_ $O/hbm_traffic.json > $O/hbm_traffic.txt 2>&1
-cp $O/hbm_traffic.json profiles/r02_hbm_traffic.json
+cp $O/hbm_traffic.json profiles/r03_hbm_traffic.json
 python profiles/derive_mfma_util.py $O/pmc_mfma > $O/mfma_util.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2>> $O/bench_default.err
 python bench.py --streams 1 --no-cpu-baseline --no-variants > $O/bench_streams1.json 2>> $O/bench_default.err
-python bench.py --clouds lidar --no-cpu-baseline --no-variants > $O/bench_lidar.json 2>> $O/bench_default.err
 python bench.py --input raw --no-variants > $O/bench_raw_input.json 2>> $O/bench_default.err
 python bench.py --workload rcnn > $O/bench_rcnn.json 2>> $O/bench_default.err
 python bench.py --workload train > $O/bench_train.json 2>> $O/bench_default.err
 python bench.py --npoints 65536 --batch 8 --steps 64 --no-cpu-baseline --no-variants > $O/bench_config5_rpn.json 2>> $O/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python bench.py --no-cpu-baseline --no-roofline --no-variants > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-cpu-baseline --no-roofline --no-variants --streams 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python bench.py --workload train --steps 10 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python bench.py --workload train --steps 16 > /dev/null 2>&1
 python -m pointrcnn_amd.opbench > $O/opbench.jsonl 2> $O/opbench.err
 python profiles/summarize_rocprof.py $O/kt3 "default: python bench.py (20 batches in flight, hipGraph replay)" > $O/kernel_stats.txt
 python profiles/summarize_rocprof.py $O/kt1 "python bench.py --streams 1 (one batch in flight)" > $O/kernel_stats_streams1.txt
-python profiles/summarize_rocprof.py $O/ktt "python bench.py --workload train --steps 10 (RPN training step, bs16, eager)" > $O/kernel_stats_train.txt
+python profiles/summarize_rocprof.py $O/ktt "python bench.py --workload train --steps 16 (RPN training step, bs16, eager, fused training path)" > $O/kernel_stats_train.txt
 # keep the merge small: only summaries travel back
 find $O -name "*.csv" -size +2M -delete
 find $O -name "*.db" -size +2M -delete
