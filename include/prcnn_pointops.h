@@ -482,6 +482,13 @@ typedef struct prcnn_train_src {
     const float* in; int ld_in; const float* pro_scale; const float* pro_shift;
     const float* xyz; const float* new_xyz; const int32_t* idx; const float* feat; int ld_feat; int B, N, M, ns, C;
     const float* known; const int32_t* idx3; const float* w3; const float* skip; int ld_known, ld_skip, n, m, C2, C1;
+    /* padding-free rows (grouped source only; all NULL / 0 otherwise): the rows are the DISTINCT rows of the groups as built by
+     * prcnn_train_group_rows -- B = 1, N = frames * points, M = rows = the worst case frames * npoint * nsample, ns = 1, idx = ridx,
+     * new_xyz = rnx; mult (rows) row multiplicities, rows_dev the live row count on the device, norm_rows = frames * npoint *
+     * nsample (what the batch statistics are normalised by), seg_off / seg_cnt (groups) first row / row count of every group,
+     * row_grp (rows) the group of every row.  The pooled output has `groups` rows; arg holds the arg-max position inside the group. */
+    const float* mult; const int32_t* rows_dev; int64_t norm_rows; const int32_t* seg_off; const int32_t* seg_cnt; const int32_t* row_grp;
+    int groups;
 } prcnn_train_src_t;
 
 /* One layer of a stack.  The caller owns every buffer (nothing is allocated inside):
@@ -519,6 +526,13 @@ int prcnn_train_stack_fwd(const prcnn_train_src_t* src, const prcnn_train_layer_
 int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_train_layer_t* layers, int nl, int pool_ns, const float* a_dump,
                           int ld_dump, const float* gout, int ld_gout, const uint8_t* arg, float* gin, int ld_gin, void* work,
                           size_t work_bytes, prcnn_stream_t stream);
+/* Padding-free rows for a grouped stack (exact: ball_query pads a group with copies of its first hit; copies are identical rows).
+ * prcnn_train_group_rows builds the distinct-row list deterministically (count -> exclusive scan -> fill, group order);
+ * prcnn_flat_rows_grad scatters the first layer's row gradients back: dfeat[ridx[r], 0:C] += G[r, 0:C] for the live rows. */
+int prcnn_train_group_rows(const int32_t* idx, const float* new_xyz, int B, int N, int M, int ns, int32_t* cnt, int32_t* off,
+                           int32_t* rows_dev, int32_t* ridx, float* rnx, float* mult, int32_t* row_grp, prcnn_stream_t stream);
+int prcnn_flat_rows_grad(const float* G, int ldG, const int32_t* ridx, const int32_t* rows_dev, int64_t max_rows, int C, float* dfeat,
+                         int ld_d, prcnn_stream_t stream);
 /* backward of the gathers on channels-last rows: dfeat (B, N, ld_d) += scatter of G ((B, M, ns) rows, C channels) through idx;
  * dknown (B, m, ld_d) += w3-weighted scatter of G ((B, n) rows) through idx3.  Outputs pre-zeroed by the caller. */
 int prcnn_group_rows_grad(const float* G, int ldG, const int32_t* idx, int B, int M, int ns, int C, int N, float* dfeat, int ld_d,

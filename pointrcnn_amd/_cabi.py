@@ -25,7 +25,8 @@ class TrainSrc(ctypes.Structure):
                 ("xyz", _P), ("new_xyz", _P), ("idx", _P), ("feat", _P), ("ld_feat", _I),
                 ("B", _I), ("N", _I), ("M", _I), ("ns", _I), ("C", _I),
                 ("known", _P), ("idx3", _P), ("w3", _P), ("skip", _P), ("ld_known", _I), ("ld_skip", _I),
-                ("n", _I), ("m", _I), ("C2", _I), ("C1", _I)]
+                ("n", _I), ("m", _I), ("C2", _I), ("C1", _I),
+                ("mult", _P), ("rows_dev", _P), ("norm_rows", _L), ("seg_off", _P), ("seg_cnt", _P), ("row_grp", _P), ("groups", _I)]
 
 
 class TrainLayer(ctypes.Structure):
@@ -98,6 +99,8 @@ SIGNATURES = {
     "prcnn_ref_trig": (_I, [_P, _P, _I, _I, _P, _P]),
     "prcnn_boxes_iou3d": (_I, [_P, _I, _P, _I, _P, _P]),
     "prcnn_proposal_target_sample": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prcnn_train_group_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prcnn_flat_rows_grad": (_I, [_P, _I, _P, _P, _L, _I, _P, _I, _P]),
     "prcnn_group_rows_grad": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "prcnn_interp_rows_grad": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
 }

@@ -32,14 +32,21 @@ struct TrainFwd {
     int ld_dump;                  // multiple of 4, >= K
     float* part;                  // (nslab, 2, ld_part): column mean and M2 of every 64-row slab
     int ld_part;
+    // padding-free rows (training twin of dedup.hip): the rows are the DISTINCT rows of the groups, row r standing for mult[r]
+    // identical rows of the padded tensor (ball_query pads a group with copies of its first hit).  Statistics weigh a row by its
+    // multiplicity; slab_w (nslab) receives every slab's weight sum.  The live row count is P.rows_dev (device side).
+    const float* mult;
+    float* slab_w;
 };
 
 template <int MODE, int WNB>
 __global__ __launch_bounds__(MLP_THREADS, ((WNB == 1 && MODE != MODE_INTERP) ? 3 : 2)) void train_fwd_kernel(const TrainFwd T) {
-    const MlpParams& P = T.P;
+    MlpParams P = T.P;
+    P.rows = effective_rows(T.P);
     constexpr int QN = 2 * WNB;
     const long tile_id = blockIdx.x;
     const int nb0 = blockIdx.y * QN;
+    if (tile_id * MLP_BM >= P.rows) return;              // (device-side row count: tiles past the live rows exit at once)
     __shared__ __attribute__((aligned(16))) float As[2][MLP_BM * MLP_ALD];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,12 +141,24 @@ __global__ __launch_bounds__(MLP_THREADS, ((WNB == 1 && MODE != MODE_INTERP) ? 3
         store_chunk(min(c + 1, nchunks - 1), buf ^ 1);
         __syncthreads();
     }
-    if (!n_active) return;
+    if (!n_active && !(T.slab_w && nb0 == 0 && wn == 0)) return;
     // ---- epilogue: raw store + column statistics of this wave's 64-row slab ---------------------------------------------
     const long wrow0 = row0 + wm * 64;
     const long left = P.rows - wrow0;
     const int cnt = left >= 64 ? 64 : (left > 0 ? (int)left : 0);          // live rows of the slab (wave-uniform)
-    const float inv_cnt = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    // row weights (multiplicities; 1 without padding-free rows) of this lane's 32 rows, and the slab's weight sum
+    float w0[16], w1[16], wsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long g0 = wrow0 + rin, g1 = g0 + 32;
+        w0[r] = g0 < P.rows ? (T.mult ? T.mult[g0] : 1.f) : 0.f;
+        w1[r] = g1 < P.rows ? (T.mult ? T.mult[g1] : 1.f) : 0.f;
+        wsum += w0[r] + w1[r];
+    }
+    wsum += __shfl_xor(wsum, 32);                                           // (every lane of a half holds the same 32 rows)
+    const float inv_w = wsum > 0.f ? 1.0f / wsum : 0.f;
+    if (T.slab_w && lane == 0 && nb0 == 0 && wn == 0 && cnt > 0) T.slab_w[wrow0 >> 6] = wsum;
 #pragma unroll
     for (int nn = 0; nn < WNB; nn++) {
         const int nb = nb0 + wn * WNB + nn;
@@ -153,19 +172,18 @@ __global__ __launch_bounds__(MLP_THREADS, ((WNB == 1 && MODE != MODE_INTERP) ? 3
         for (int r = 0; r < 16; r++) {
             const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
             const long g0 = wrow0 + rin, g1 = g0 + 32;
-            if (g0 < P.rows) { s += a0[r]; if (n_ok) P.out[g0 * P.ld_out + P.col_off + n] = a0[r]; }
-            if (g1 < P.rows) { s += a1[r]; if (n_ok) P.out[g1 * P.ld_out + P.col_off + n] = a1[r]; }
+            s += w0[r] * a0[r] + w1[r] * a1[r];
+            if (n_ok && g0 < P.rows) P.out[g0 * P.ld_out + P.col_off + n] = a0[r];
+            if (n_ok && g1 < P.rows) P.out[g1 * P.ld_out + P.col_off + n] = a1[r];
         }
         if (T.part) {
             s += __shfl_xor(s, 32);
-            const float mean = s * inv_cnt;
+            const float mean = s * inv_w;
             float m2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const long g0 = wrow0 + rin, g1 = g0 + 32;
-                if (g0 < P.rows) { const float d = a0[r] - mean; m2 += d * d; }
-                if (g1 < P.rows) { const float d = a1[r] - mean; m2 += d * d; }
+                const float d0 = a0[r] - mean, d1 = a1[r] - mean;
+                m2 += w0[r] * (d0 * d0) + w1[r] * (d1 * d1);
             }
             m2 += __shfl_xor(m2, 32);
             if (h == 0 && n_ok && cnt > 0) {
@@ -183,10 +201,13 @@ __global__ __launch_bounds__(MLP_THREADS, ((WNB == 1 && MODE != MODE_INTERP) ? 3
 //                       1 shift = beta - mean * scale, 2 mean, 3 invstd; running statistics as nn.BatchNorm updates them.
 // A single block walking all 32 k slabs of a 2 M-row layer took 150 us -- per layer, forty layers a step.
 #define BN_CHUNKS 64
-__global__ __launch_bounds__(256) void bn_chunk_kernel(const float* __restrict__ part, int ld_part, long rows, int N, double* __restrict__ chunk) {
+__global__ __launch_bounds__(256) void bn_chunk_kernel(const float* __restrict__ part, int ld_part, long rows_static, const int32_t* rows_dev,
+                                                       const float* __restrict__ slab_w, int N, double* __restrict__ chunk) {
     __shared__ double s1[4][64], s2[4][64];
     const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
+    long rows = rows_static;
+    if (rows_dev && (long)*rows_dev < rows) rows = *rows_dev;
     const long nslab = (rows + 63) >> 6;
     const long per = (nslab + BN_CHUNKS - 1) / BN_CHUNKS;
     const long sl0 = (long)blockIdx.y * per;
@@ -194,7 +215,7 @@ __global__ __launch_bounds__(256) void bn_chunk_kernel(const float* __restrict__
     double a = 0.0, b = 0.0;
     if (n < N) {
         for (long sl = sl0 + q; sl < sl1; sl += 4) {
-            const double cn = (double)(sl == nslab - 1 ? rows - sl * 64 : 64);
+            const double cn = slab_w ? (double)slab_w[sl] : (double)(sl == nslab - 1 ? rows - sl * 64 : 64);
             const double m = (double)part[(sl * 2 + 0) * ld_part + n], m2 = (double)part[(sl * 2 + 1) * ld_part + n];
             a += cn * m;
             b += m2 + cn * m * m;
@@ -236,14 +257,18 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
 // max_pool2d backward route the gradient there).  ns == 1: plain normalise + ReLU, no arg.  Thread = (group, 4 channels).
 __global__ __launch_bounds__(256) void train_pool_kernel(const float* __restrict__ y, int ld_y, long groups, int ns, int N,
                                                          const float* __restrict__ cst, int ld_c, float* __restrict__ out, int ld_out,
-                                                         int col_off, uint8_t* __restrict__ arg) {
+                                                         int col_off, uint8_t* __restrict__ arg, const int32_t* __restrict__ seg_off,
+                                                         const int32_t* __restrict__ seg_cnt) {
     const int nq = N >> 2;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= groups * nq) return;
     const long g = e / nq;
     const int n = (int)(e - g * nq) * 4;
     const float4 sc = ld4(cst + n), sh = ld4(cst + ld_c + n);
-    const float* p = y + g * ns * (long)ld_y + n;
+    // padding-free rows: group g owns rows seg_off[g] .. + seg_cnt[g] (its distinct rows; the max over copies of a row is the row)
+    const long first = seg_off ? (long)seg_off[g] : g * ns;
+    if (seg_cnt) ns = seg_cnt[g];
+    const float* p = y + first * (long)ld_y + n;
     float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);           // relu output is >= 0: the first row always wins the first test
     uchar4 ba = make_uchar4(0, 0, 0, 0);
     for (int s = 0; s < ns; s++) {
@@ -269,12 +294,25 @@ struct TrainBwd {
     const uint8_t* arg; int pool_ns;
     const float* y; int ld_y;     // pre-normalisation output saved by the forward pass
     const float* cst; int ld_c;   // rows 0..3 from bn_finalize_kernel; rows 4, 5 = mean(dyhat), mean(dyhat * xhat) (bn_bwd_finalize)
+    // padding-free rows: live row count on the device, row multiplicities (the mean terms of dy count a row mult[r] times), and for
+    // the pooled last layer the group of every row + the first row of every group (pool_ns = -1: variable-length groups)
+    const int32_t* rows_dev;
+    const float* mult;
+    const int32_t* row_grp;
+    const int32_t* seg_off;
 };
+__device__ __forceinline__ long bwd_live_rows(const TrainBwd& T) {
+    if (!T.rows_dev) return T.rows;
+    const long r = *T.rows_dev;
+    return r < T.rows ? r : T.rows;
+}
 
 __device__ __forceinline__ float4 bwd_G4(const TrainBwd& T, long r, int n) {
     if (T.pool_ns == 0) return ld4(T.G + r * (long)T.ldG + n);
-    const long g = r / T.pool_ns;
-    const int s = (int)(r - g * T.pool_ns);
+    long g;
+    int s;
+    if (T.pool_ns < 0) { g = T.row_grp[r]; s = (int)(r - T.seg_off[g]); }
+    else { g = r / T.pool_ns; s = (int)(r - g * T.pool_ns); }
     const float4 v = ld4(T.G + g * (long)T.ldG + n);
     const uchar4 a = *reinterpret_cast<const uchar4*>(T.arg + g * (long)T.N + n);
     return make_float4(a.x == s ? v.x : 0.f, a.y == s ? v.y : 0.f, a.z == s ? v.z : 0.f, a.w == s ? v.w : 0.f);
@@ -286,13 +324,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const TrainBwd T, fl
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int n = blockIdx.y * 64 + cq * 4;
     const long row0 = (long)blockIdx.x * 128;
+    const long live = bwd_live_rows(T);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (n < T.N) {
+    if (n < T.N && row0 < live) {
         const float4 sc = ld4(T.cst + n), sh = ld4(T.cst + T.ld_c + n), mu = ld4(T.cst + 2 * T.ld_c + n), is = ld4(T.cst + 3 * T.ld_c + n);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const long r = row0 + rl + 16 * u;
-            if (r >= T.rows) break;
+            if (r >= live) break;
             const float4 g = bwd_G4(T, r, n);
             const float4 yv = ld4(T.y + r * (long)T.ld_y + n);
             const float d0 = (yv.x * sc.x + sh.x > 0.f) ? g.x : 0.f, d1 = (yv.y * sc.y + sh.y > 0.f) ? g.y : 0.f;
@@ -318,10 +357,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const TrainBwd T, fl
 
 // tile partials -> dbeta = sum dyhat, dgamma = sum dyhat * xhat (double, fixed order, the same two stages as the forward
 // statistics); cst rows 4, 5 = their means over the rows
-__global__ __launch_bounds__(256) void bn_bwd_chunk_kernel(const float* __restrict__ part, int ld_part, long tiles, int N, double* __restrict__ chunk) {
+__global__ __launch_bounds__(256) void bn_bwd_chunk_kernel(const float* __restrict__ part, int ld_part, long tiles, const int32_t* rows_dev, int N,
+                                                           double* __restrict__ chunk) {
     __shared__ double s1[4][64], s2[4][64];
     const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
+    if (rows_dev) { const long lt = ((long)*rows_dev + 127) >> 7; if (lt < tiles) tiles = lt; }
     const long per = (tiles + BN_CHUNKS - 1) / BN_CHUNKS;
     const long t0 = (long)blockIdx.y * per;
     const long t1 = t0 + per < tiles ? t0 + per : tiles;
@@ -348,13 +389,15 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __res
 }
 
 // dy for 4 consecutive channels: scale * (dyhat - c1 - xhat * c2)
+// m: the row's multiplicity (1 without padding-free rows): the row stands for m identical rows of the padded tensor, G is already
+// the SUM of their gradients (only the arg-max copy had one), the two mean terms apply to each of the m copies
 __device__ __forceinline__ float4 bwd_dy4(const float4 g, const float4 yv, const float4 sc, const float4 sh, const float4 mu,
-                                          const float4 is, const float4 c1, const float4 c2) {
+                                          const float4 is, const float4 c1, const float4 c2, const float m = 1.f) {
     float4 o;
-    o.x = sc.x * (((yv.x * sc.x + sh.x > 0.f) ? g.x : 0.f) - c1.x - ((yv.x - mu.x) * is.x) * c2.x);
-    o.y = sc.y * (((yv.y * sc.y + sh.y > 0.f) ? g.y : 0.f) - c1.y - ((yv.y - mu.y) * is.y) * c2.y);
-    o.z = sc.z * (((yv.z * sc.z + sh.z > 0.f) ? g.z : 0.f) - c1.z - ((yv.z - mu.z) * is.z) * c2.z);
-    o.w = sc.w * (((yv.w * sc.w + sh.w > 0.f) ? g.w : 0.f) - c1.w - ((yv.w - mu.w) * is.w) * c2.w);
+    o.x = sc.x * (((yv.x * sc.x + sh.x > 0.f) ? g.x : 0.f) - m * (c1.x + ((yv.x - mu.x) * is.x) * c2.x));
+    o.y = sc.y * (((yv.y * sc.y + sh.y > 0.f) ? g.y : 0.f) - m * (c1.y + ((yv.y - mu.y) * is.y) * c2.y));
+    o.z = sc.z * (((yv.z * sc.z + sh.z > 0.f) ? g.z : 0.f) - m * (c1.z + ((yv.z - mu.z) * is.z) * c2.z));
+    o.w = sc.w * (((yv.w * sc.w + sh.w > 0.f) ? g.w : 0.f) - m * (c1.w + ((yv.w - mu.w) * is.w) * c2.w));
     return o;
 }
 
@@ -380,9 +423,16 @@ __global__ __launch_bounds__(MLP_THREADS, (WNB == 1 ? 3 : 2)) void train_dgrad_k
     const long row0 = tile_id * MLP_BM;
     const int nchunks = (D.KB + 3) >> 2;
     const int c4 = tid & 7, r0 = tid >> 3;
+    const long live = bwd_live_rows(T);
+    if (row0 >= live) return;                          // (device-side row count)
     long grow[4];
+    float rm[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { grow[u] = row0 + r0 + 32 * u; if (grow[u] >= T.rows) grow[u] = T.rows - 1; }
+    for (int u = 0; u < 4; u++) {
+        grow[u] = row0 + r0 + 32 * u;
+        if (grow[u] >= live) grow[u] = live - 1;
+        rm[u] = T.mult ? T.mult[grow[u]] : 1.f;
+    }
     float4 rg[4], ry[4], sc, sh, mu, is, c1, c2;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_chunk = [&](int c) {
@@ -401,7 +451,7 @@ __global__ __launch_bounds__(MLP_THREADS, (WNB == 1 ? 3 : 2)) void train_dgrad_k
     auto store_chunk = [&](int c, int buf) {
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * u) * MLP_ALD + c4 * 4]) = bwd_dy4(rg[u], ry[u], sc, sh, mu, is, c1, c2);
+            *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * u) * MLP_ALD + c4 * 4]) = bwd_dy4(rg[u], ry[u], sc, sh, mu, is, c1, c2, rm[u]);
     };
     f32x16 acc[2][WNB];
 #pragma unroll
@@ -469,8 +519,8 @@ __global__ __launch_bounds__(MLP_THREADS, (WNB == 1 ? 3 : 2)) void train_dgrad_k
         for (int r = 0; r < 16; r++) {
             const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
             const long g0 = wrow0 + rin, g1 = g0 + 32;
-            if (g0 < T.rows) D.out[g0 * D.ld_out + n] = acc[0][nn][r];
-            if (g1 < T.rows) D.out[g1 * D.ld_out + n] = acc[1][nn][r];
+            if (g0 < live) D.out[g0 * D.ld_out + n] = acc[0][nn][r];
+            if (g1 < live) D.out[g1 * D.ld_out + n] = acc[1][nn][r];
         }
     }
 }
@@ -521,7 +571,8 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const TrainWgrad W) {
     const long per_group = W.rows_per_split / WR;
     const long r_begin = (long)blockIdx.x * W.rows_per_split + wr * per_group;
     long r_end = r_begin + per_group;
-    if (r_end > T.rows) r_end = T.rows;
+    const long live = bwd_live_rows(T);
+    if (r_end > live) r_end = live;
     f32x16 acc[KQ][NQ];
 #pragma unroll
     for (int x = 0; x < KQ; x++)
@@ -533,19 +584,22 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const TrainWgrad W) {
     for (long r = r_begin; r < r_end; r += 2 * WG_UNROLL) {
         vk_t av[WG_UNROLL];
         vn_t gv[WG_UNROLL], yv[WG_UNROLL];
-        float valid[WG_UNROLL];
+        float valid[WG_UNROLL], rmu[WG_UNROLL];
 #pragma unroll
         for (int u = 0; u < WG_UNROLL; u++) {
             long rr = r + 2 * u + h;
             valid[u] = rr < r_end ? 1.f : 0.f;
             if (rr >= r_end) rr = r_end - 1;
+            rmu[u] = T.mult ? T.mult[rr] : 1.f;
             av[u] = *reinterpret_cast<const vk_t*>(W.a + rr * (long)W.lda + kk);
             yv[u] = *reinterpret_cast<const vn_t*>(T.y + rr * (long)T.ld_y + nn);
             if (T.pool_ns == 0) {
                 gv[u] = *reinterpret_cast<const vn_t*>(T.G + rr * (long)T.ldG + nn);
             } else {
-                const long g = rr / T.pool_ns;
-                const int s = (int)(rr - g * T.pool_ns);
+                long g;
+                int s;
+                if (T.pool_ns < 0) { g = T.row_grp[rr]; s = (int)(rr - T.seg_off[g]); }
+                else { g = rr / T.pool_ns; s = (int)(rr - g * T.pool_ns); }
                 const vn_t v = *reinterpret_cast<const vn_t*>(T.G + g * (long)T.ldG + nn);
                 const uint8_t* ap = T.arg + g * (long)T.N + nn;
 #pragma unroll
@@ -564,7 +618,7 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const TrainWgrad W) {
 #pragma unroll
             for (int z = 0; z < NQ; z++) {
                 const float yy = yv[u][z];
-                d[z] = sc[z] * (((yy * sc[z] + sh[z] > 0.f) ? gv[u][z] : 0.f) - c1[z] - ((yy - mu[z]) * is[z]) * c2[z]);
+                d[z] = sc[z] * (((yy * sc[z] + sh[z] > 0.f) ? gv[u][z] : 0.f) - rmu[u] * (c1[z] + ((yy - mu[z]) * is[z]) * c2[z]));
             }
 #pragma unroll
             for (int x = 0; x < KQ; x++)
@@ -621,17 +675,23 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_lds_kernel(const TrainWgra
     }
     const long r_begin = (long)blockIdx.x * W.rows_per_split;
     long r_end = r_begin + W.rows_per_split;
-    if (r_end > T.rows) r_end = T.rows;
+    const long live = bwd_live_rows(T);
+    if (r_end > live) r_end = live;
     const int nchunks = r_end > r_begin ? (int)((r_end - r_begin + WL_ROWS - 1) / WL_ROWS) : 0;
     float4 ra[4], rg[4], ry[4];
-    float rv[4];
+    float rmw[4];
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             long rr = r_begin + (long)c * WL_ROWS + rl + 8 * u;
-            rv[u] = rr < r_end ? 1.f : 0.f;
-            if (rr >= r_end) rr = r_end - 1;
-            ra[u] = ka_ok ? ld4(W.a + rr * (long)W.lda + ka) : zero4;
+            const bool row_ok = rr < r_end;
+            if (!row_ok) rr = r_end - 1;
+            rmw[u] = T.mult ? T.mult[rr] : 1.f;
+            float4 a = ka_ok ? ld4(W.a + rr * (long)W.lda + ka) : zero4;
+            if (pro) { a.x = fmaxf(a.x * ps.x + pb.x, 0.f); a.y = fmaxf(a.y * ps.y + pb.y, 0.f); a.z = fmaxf(a.z * ps.z + pb.z, 0.f); a.w = fmaxf(a.w * ps.w + pb.w, 0.f); }
+            const float v = row_ok ? 1.f : 0.f;                   // rows past the range and channels past K contribute zero
+            a.x *= km.x * v; a.y *= km.y * v; a.z *= km.z * v; a.w *= km.w * v;
+            ra[u] = a;
             if (na_ok) {
                 ry[u] = ld4(T.y + rr * (long)T.ld_y + na);
                 rg[u] = bwd_G4(T, rr, na);
@@ -643,11 +703,8 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_lds_kernel(const TrainWgra
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            float4 a = ra[u];
-            if (pro) { a.x = fmaxf(a.x * ps.x + pb.x, 0.f); a.y = fmaxf(a.y * ps.y + pb.y, 0.f); a.z = fmaxf(a.z * ps.z + pb.z, 0.f); a.w = fmaxf(a.w * ps.w + pb.w, 0.f); }
-            const float v = rv[u];
-            a.x *= km.x * v; a.y *= km.y * v; a.z *= km.z * v; a.w *= km.w * v;
-            const float4 d = bwd_dy4(rg[u], ry[u], sc, sh, mu, is, c1, c2);
+            const float4 a = ra[u];
+            const float4 d = bwd_dy4(rg[u], ry[u], sc, sh, mu, is, c1, c2, rmw[u]);
             *reinterpret_cast<float4*>(&As[buf][(rl + 8 * u) * WL_LD + 4 * cq]) = a;
             *reinterpret_cast<float4*>(&Ds[buf][(rl + 8 * u) * WL_LD + 4 * cq]) = d;
         }
@@ -782,6 +839,84 @@ __global__ __launch_bounds__(256) void interp_rows_grad_kernel(const float* __re
 }
 
 
+// ---- padding-free rows for training (the training twin of dedup.hip) -------------------------------------------------------
+// ball_query pads a group that has fewer than nsample neighbours by repeating its first hit; the reference pushes every copy
+// through all layers.  Copies are identical rows, so a group is represented by its DISTINCT rows, the first one carrying the
+// multiplicity 1 + (number of copies): batch statistics weigh rows by multiplicity, the max over copies is the row, and in
+// backward the copies' gradients add up on the one row (see bwd_dy4).  Exact algebra, deterministic layout: counts -> exclusive
+// scan -> fill (no atomics, the row order is the group order).  Correct for any index tensor: an entry is a copy iff it equals
+// the group's first entry and is not the first.
+__global__ void train_group_count_kernel(const int32_t* __restrict__ idx, long groups, int ns, int32_t* __restrict__ cnt) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const int32_t* ip = idx + g * ns;
+    const int first = ip[0];
+    int c = 1;
+    for (int s = 1; s < ns; s++) c += ip[s] != first ? 1 : 0;
+    cnt[g] = c;
+}
+// exclusive scan of cnt[0 .. groups) by ONE workgroup (groups <= a few hundred thousand); total -> *rows_dev
+__global__ __launch_bounds__(1024) void train_group_scan_kernel(const int32_t* __restrict__ cnt, long groups, int32_t* __restrict__ off,
+                                                                int32_t* __restrict__ total) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const long per = (groups + 1023) / 1024;
+    const long g0 = (long)tid * per;
+    const long g1 = g0 + per < groups ? g0 + per : groups;
+    int s = 0;
+    for (long g = g0; g < g1; g++) s += cnt[g];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                     // Hillis-Steele inclusive scan of the 1024 partial sums
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (long g = g0; g < g1; g++) { off[g] = run; run += cnt[g]; }
+    if (tid == 1023) *total = part[1023];
+}
+__global__ void train_group_fill_kernel(const int32_t* __restrict__ idx, const float* __restrict__ new_xyz, long groups, int per_frame_groups,
+                                        int ns, int N, const int32_t* __restrict__ off, int32_t* __restrict__ ridx, float* __restrict__ rnx,
+                                        float* __restrict__ mult, int32_t* __restrict__ row_grp) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const int32_t* ip = idx + g * ns;
+    const int first = ip[0];
+    const long base = (g / per_frame_groups) * (long)N;
+    const float cx = new_xyz[g * 3], cy = new_xyz[g * 3 + 1], cz = new_xyz[g * 3 + 2];
+    int r = off[g], copies = 0;
+    const int r0 = r;
+    for (int s = 0; s < ns; s++) {
+        const int id = ip[s];
+        if (s > 0 && id == first) { copies++; continue; }
+        ridx[r] = (int32_t)(base + id);
+        rnx[(long)r * 3] = cx; rnx[(long)r * 3 + 1] = cy; rnx[(long)r * 3 + 2] = cz;
+        mult[r] = 1.f;
+        row_grp[r] = (int32_t)g;
+        r++;
+    }
+    mult[r0] = (float)(1 + copies);
+}
+// dfeat[ridx[r], 0:C] += G[r, 0:C] for the live rows (distinct rows: one atomic per element)
+__global__ __launch_bounds__(256) void flat_rows_grad_kernel(const float* __restrict__ G, int ldG, const int32_t* __restrict__ ridx,
+                                                             const int32_t* __restrict__ rows_dev, long max_rows, int C,
+                                                             float* __restrict__ dfeat, int ld_d) {
+    const int cq = (C + 3) >> 2;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long live = rows_dev ? ((long)*rows_dev < max_rows ? (long)*rows_dev : max_rows) : max_rows;
+    if (e >= live * cq) return;
+    const long r = e / cq;
+    const int c = (int)(e - r * cq) * 4;
+    const float* gp = G + r * (long)ldG + c;
+    float* d = dfeat + (long)ridx[r] * ld_d + c;
+    atomicAdd(d, gp[0]);
+    if (c + 1 < C) atomicAdd(d + 1, gp[1]);
+    if (c + 2 < C) atomicAdd(d + 2, gp[2]);
+    if (c + 3 < C) atomicAdd(d + 3, gp[3]);
+}
+
 // Both weight images of a layer in one launch: wpack = pack(W (Nout x K), k_rot) for the forward GEMM and, when wpack_t is given,
 // pack(T (kin_t x Nout)) with T[k][n] = W[n][t_col0 + k] for dgrad (a grouped first layer only needs its feature columns: t_col0 = 3).
 __global__ void train_pack_kernel(const float* __restrict__ w, int Nout, int K, int k_rot, float* __restrict__ wpack,
@@ -867,7 +1002,7 @@ static WgradPlan wgrad_plan(long rows, int N, int K) {
     return p;
 }
 
-struct TrainWork { float* part; double* chunk; float* wpart; float* G[2]; };
+struct TrainWork { float* part; double* chunk; float* slab_w; float* wpart; float* G[2]; };
 static size_t train_work_layout(int64_t rows, int nl, const prcnn_train_layer_t* L, int K0, bool backward, char* base, TrainWork* w) {
     int nmax = 0;
     size_t wg = 0;
@@ -883,13 +1018,14 @@ static size_t train_work_layout(int64_t rows, int nl, const prcnn_train_layer_t*
     auto take = [&](size_t bytes) { size_t o = off; off += up_sz(bytes, 256); return base ? base + o : (char*)nullptr; };
     char* part = take((size_t)((rows + 63) / 64) * 2 * ldp * sizeof(float));
     char* chunk = take((size_t)BN_CHUNKS * 2 * nmax * sizeof(double));
+    char* slabw = take((size_t)((rows + 63) / 64) * sizeof(float));
     char *wpart = nullptr, *g0 = nullptr, *g1 = nullptr;
     if (backward) {
         wpart = take(wg * sizeof(float));
         g0 = take((size_t)rows * ldp * sizeof(float));
         g1 = take((size_t)rows * ldp * sizeof(float));
     }
-    if (w) { w->part = (float*)part; w->chunk = (double*)chunk; w->wpart = (float*)wpart; w->G[0] = (float*)g0; w->G[1] = (float*)g1; }
+    if (w) { w->part = (float*)part; w->chunk = (double*)chunk; w->slab_w = (float*)slabw; w->wpart = (float*)wpart; w->G[0] = (float*)g0; w->G[1] = (float*)g1; }
     return off;
 }
 
@@ -918,7 +1054,12 @@ PRCNN_API int prcnn_train_stack_fwd(const prcnn_train_src_t* src, const prcnn_tr
     rc = train_check_layers(L, nl);
     if (rc) return rc;
     const long rows = src->rows;
-    const int ns = pool_ns > 0 ? pool_ns : 1;
+    const bool flat = src->mult != nullptr;            // padding-free rows: variable-length groups (seg_off / seg_cnt), weighted statistics
+    PRCNN_REQUIRE(!flat || (src->mode == MODE_GROUP && src->rows_dev && src->seg_off && src->seg_cnt && src->row_grp && src->groups > 0 &&
+                            src->norm_rows > 0 && arg),
+                  "prcnn_train_stack_fwd: padding-free rows need a grouped source with rows_dev, seg_off, seg_cnt, row_grp, groups, norm_rows, arg");
+    const int ns = flat ? 1 : (pool_ns > 0 ? pool_ns : 1);
+    const long norm_rows = flat ? src->norm_rows : rows;
     PRCNN_REQUIRE(out && ns <= 255 && rows % ns == 0 && (ns == 1 || arg), "prcnn_train_stack_fwd: bad pooling arguments (ns=%d)", ns);
     PRCNN_REQUIRE(ld_out % 4 == 0 && col_off % 4 == 0 && aligned16(out) && ld_out >= col_off + L[nl - 1].Nout,
                   "prcnn_train_stack_fwd: out rows must be 16-byte aligned (ld_out, col_off multiples of 4)");
@@ -943,10 +1084,13 @@ PRCNN_API int prcnn_train_stack_fwd(const prcnn_train_src_t* src, const prcnn_tr
             T.pro_scale = src->mode == MODE_PLAIN ? src->pro_scale : nullptr;
             T.pro_shift = src->mode == MODE_PLAIN ? src->pro_shift : nullptr;
             T.a_dump = a_dump; T.ld_dump = ld_dump;
+            if (flat) { T.P.rows_dev = src->rows_dev; T.P.rows_unit = 1; }
         } else {
             T.P.rows = rows; T.P.K = K; T.P.in = L[l - 1].y; T.P.ld_in = L[l - 1].Nout; T.P.vec_a = 1;
             T.pro_scale = L[l - 1].cst; T.pro_shift = L[l - 1].cst + L[l - 1].ld_c;
+            if (flat) { T.P.rows_dev = src->rows_dev; T.P.rows_unit = 1; }
         }
+        if (flat) { T.mult = src->mult; T.slab_w = W.slab_w; }
         MlpParams& P = T.P;
         P.wpack = L[l].wpack; P.Nout = N; P.out = L[l].y; P.ld_out = N; P.col_off = 0;
         P.KB = (K + 7) / 8; P.NB = (N + 31) / 32;
@@ -964,14 +1108,16 @@ PRCNN_API int prcnn_train_stack_fwd(const prcnn_train_src_t* src, const prcnn_tr
         else if (mode == MODE_GROUP) TRAIN_FWD(MODE_GROUP);
         else TRAIN_FWD(MODE_INTERP);
 #undef TRAIN_FWD
-        hipLaunchKernelGGL(bn_chunk_kernel, dim3(prcnn_divup(N, 64), BN_CHUNKS), dim3(256), 0, s, W.part, N, rows, N, W.chunk);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(prcnn_divup(N, 64)), dim3(64), 0, s, W.chunk, rows, N, L[l].gamma, L[l].beta, L[l].eps,
+        hipLaunchKernelGGL(bn_chunk_kernel, dim3(prcnn_divup(N, 64), BN_CHUNKS), dim3(256), 0, s, W.part, N, rows, flat ? src->rows_dev : nullptr,
+                           flat ? W.slab_w : nullptr, N, W.chunk);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(prcnn_divup(N, 64)), dim3(64), 0, s, W.chunk, norm_rows, N, L[l].gamma, L[l].beta, L[l].eps,
                            L[l].momentum, L[l].running_mean, L[l].running_var, L[l].cst, L[l].ld_c);
     }
     const int N = L[nl - 1].Nout;
-    const long groups = rows / ns;
+    const long groups = flat ? src->groups : rows / ns;
     hipLaunchKernelGGL(train_pool_kernel, dim3(prcnn_divup(groups * (N / 4), 256)), dim3(256), 0, s, L[nl - 1].y, N, groups, ns, N,
-                       L[nl - 1].cst, L[nl - 1].ld_c, out, ld_out, col_off, ns > 1 ? arg : nullptr);
+                       L[nl - 1].cst, L[nl - 1].ld_c, out, ld_out, col_off, (flat || ns > 1) ? arg : nullptr, flat ? src->seg_off : nullptr,
+                       flat ? src->seg_cnt : nullptr);
     PRCNN_LAUNCH_CHECK("prcnn_train_stack_fwd");
     return PRCNN_OK;
 }
@@ -988,8 +1134,12 @@ PRCNN_API int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_tr
     int rc = train_check_layers(L, nl);
     if (rc) return rc;
     const long rows = src->rows;
-    const int ns = pool_ns > 1 ? pool_ns : 0;
-    PRCNN_REQUIRE(rows > 0 && ld_gout % 4 == 0 && aligned16(gout) && (!ns || (arg && rows % ns == 0)), "prcnn_train_stack_bwd: bad gradient / pooling arguments");
+    const bool flat = src->mult != nullptr;
+    PRCNN_REQUIRE(!flat || (src->rows_dev && src->seg_off && src->row_grp && src->norm_rows > 0 && arg),
+                  "prcnn_train_stack_bwd: padding-free rows need rows_dev, seg_off, row_grp, norm_rows, arg");
+    const int ns = flat ? -1 : (pool_ns > 1 ? pool_ns : 0);
+    const long norm_rows = flat ? src->norm_rows : rows;
+    PRCNN_REQUIRE(rows > 0 && ld_gout % 4 == 0 && aligned16(gout) && (ns <= 0 || (arg && rows % ns == 0)), "prcnn_train_stack_bwd: bad gradient / pooling arguments");
     const float* a0 = src->mode == MODE_PLAIN ? src->in : a_dump;
     const int lda0 = src->mode == MODE_PLAIN ? src->ld_in : ld_dump;
     PRCNN_REQUIRE(a0 && lda0 % 2 == 0 && ((uintptr_t)a0 & 7) == 0 && lda0 >= src->K,
@@ -1009,12 +1159,14 @@ PRCNN_API int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_tr
         T.rows = rows; T.N = N; T.G = G; T.ldG = ldG;
         T.arg = (l == nl - 1 && ns) ? arg : nullptr; T.pool_ns = (l == nl - 1) ? ns : 0;
         T.y = L[l].y; T.ld_y = N; T.cst = L[l].cst; T.ld_c = L[l].ld_c;
+        T.rows_dev = flat ? src->rows_dev : nullptr; T.mult = flat ? src->mult : nullptr;
+        T.row_grp = flat ? src->row_grp : nullptr; T.seg_off = flat ? src->seg_off : nullptr;
         // BatchNorm backward reductions -> dgamma, dbeta, cst rows 4, 5
         const int ldp = (int)up_sz((size_t)N, 4);
         const long tiles = prcnn_divup(rows, 128);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)tiles, prcnn_divup(N, 64)), dim3(256), 0, s, T, W.part, ldp);
-        hipLaunchKernelGGL(bn_bwd_chunk_kernel, dim3(prcnn_divup(N, 64), BN_CHUNKS), dim3(256), 0, s, W.part, ldp, tiles, N, W.chunk);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(prcnn_divup(N, 64)), dim3(64), 0, s, W.chunk, rows, N, L[l].cst, L[l].ld_c, L[l].dgamma,
+        hipLaunchKernelGGL(bn_bwd_chunk_kernel, dim3(prcnn_divup(N, 64), BN_CHUNKS), dim3(256), 0, s, W.part, ldp, tiles, T.rows_dev, N, W.chunk);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(prcnn_divup(N, 64)), dim3(64), 0, s, W.chunk, norm_rows, N, L[l].cst, L[l].ld_c, L[l].dgamma,
                            L[l].dbeta);
         // wgrad
         TrainWgrad Wg = {};
@@ -1076,5 +1228,33 @@ PRCNN_API int prcnn_interp_rows_grad(const float* G, int ldG, const int32_t* idx
     hipLaunchKernelGGL(interp_rows_grad_kernel, dim3(prcnn_divup(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, G, ldG, idx3, w3, rows,
                        n, m, C, dknown, ld_d);
     PRCNN_LAUNCH_CHECK("prcnn_interp_rows_grad");
+    return PRCNN_OK;
+}
+
+
+// distinct rows of every group (see train_group_count_kernel): cnt / off (B*M) i32 scratch + outputs, total -> *rows_dev;
+// ridx (B*M*ns) global point index b*N + p, rnx (B*M*ns, 3) the group's centroid, mult (B*M*ns), row_grp (B*M*ns)
+PRCNN_API int prcnn_train_group_rows(const int32_t* idx, const float* new_xyz, int B, int N, int M, int ns, int32_t* cnt, int32_t* off,
+                                     int32_t* rows_dev, int32_t* ridx, float* rnx, float* mult, int32_t* row_grp, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(B > 0 && N > 0 && M > 0 && ns > 0, "prcnn_train_group_rows: bad shape B=%d N=%d M=%d ns=%d", B, N, M, ns);
+    PRCNN_REQUIRE(idx && new_xyz && cnt && off && rows_dev && ridx && rnx && mult && row_grp, "prcnn_train_group_rows: null pointer");
+    PRCNN_REQUIRE((long)B * N < 2147483647L, "prcnn_train_group_rows: B * N must fit in 31 bits");
+    const long groups = (long)B * M;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(train_group_count_kernel, dim3(prcnn_divup(groups, 256)), dim3(256), 0, s, idx, groups, ns, cnt);
+    hipLaunchKernelGGL(train_group_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, groups, off, rows_dev);
+    hipLaunchKernelGGL(train_group_fill_kernel, dim3(prcnn_divup(groups, 256)), dim3(256), 0, s, idx, new_xyz, groups, M, ns, N, off, ridx, rnx,
+                       mult, row_grp);
+    PRCNN_LAUNCH_CHECK("prcnn_train_group_rows");
+    return PRCNN_OK;
+}
+
+PRCNN_API int prcnn_flat_rows_grad(const float* G, int ldG, const int32_t* ridx, const int32_t* rows_dev, int64_t max_rows, int C, float* dfeat,
+                                   int ld_d, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(G && ridx && dfeat && max_rows >= 0 && C > 0 && ldG >= C && ld_d >= C, "prcnn_flat_rows_grad: bad arguments");
+    if (max_rows == 0) return PRCNN_OK;
+    hipLaunchKernelGGL(flat_rows_grad_kernel, dim3(prcnn_divup(max_rows * ((C + 3) / 4), 256)), dim3(256), 0, (hipStream_t)stream, G, ldG, ridx,
+                       rows_dev, (long)max_rows, C, dfeat, ld_d);
+    PRCNN_LAUNCH_CHECK("prcnn_flat_rows_grad");
     return PRCNN_OK;
 }

@@ -33,6 +33,7 @@ DEDUP_SPARSE_DIV = int(os.environ.get("PRCNN_DEDUP_SPARSE_DIV", "4"))  # groups 
 STACK_ALL_FLAT = os.environ.get("PRCNN_STACK_ALL_FLAT", "1") != "0"      # A/B switch: stack-kernel scales keep a dense list when off
 STACK_ALL_FLAT_MAX_ROWS = 1 << 20
 TRAIN_FUSED = os.environ.get("PRCNN_TRAIN_FUSED", "1") != "0"          # hand-written training-mode SharedMLP (train_mlp.py)
+TRAIN_DEDUP = os.environ.get("PRCNN_TRAIN_DEDUP", "1") != "0"          # ... on padding-free rows (exact; A/B switch)
 
 
 def _channels_last(features):
@@ -156,7 +157,13 @@ class _PointnetSAModuleBase(nn.Module):
         M = new_xyz.shape[1]
         outs = []
         for g, mlp, idx in zip(self.groupers, self.mlps, idxs):
-            src = train_mlp.Source("group", xyz=xyz, new_xyz=new_xyz, idx=idx)
+            if TRAIN_DEDUP:
+                # padding-free rows: the distinct rows of every group + multiplicities instead of the nsample-padded rows
+                with torch.no_grad():
+                    rows = train_mlp.GroupRows(idx, new_xyz, xyz.shape[1])
+                src = train_mlp.Source("group", xyz=xyz.view(1, -1, 3), rows=rows)
+            else:
+                src = train_mlp.Source("group", xyz=xyz, new_xyz=new_xyz, idx=idx)
             outs.append(train_mlp.run_stack(mlp.layers(), src, feat_cl, None, pool_ns=g.nsample).view(B, M, -1))
         out_cl = outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
         return new_xyz, out_cl.transpose(1, 2)

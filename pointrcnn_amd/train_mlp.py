@@ -59,6 +59,26 @@ class Source:
         self.__dict__.update(kw)
 
 
+class GroupRows:
+    """Padding-free rows of one grouping scale for training (prcnn_train_group_rows): ball_query pads a group with copies of its
+    first hit; the distinct rows + a multiplicity per row carry the same batch statistics, maxima and gradients (exact algebra,
+    csrc/mlp_train.h).  Deterministic layout (group order).  The live row count stays on the device."""
+
+    def __init__(self, idx, new_xyz, N):
+        B, M, ns = idx.shape
+        dev = idx.device
+        G, R = B * M, B * M * ns
+        self.B, self.M, self.ns, self.N, self.G, self.max_rows = B, M, ns, N, G, R
+        ibuf = torch.empty((2 * G + 1 + 2 * R,), dtype=torch.int32, device=dev)
+        self.cnt, self.off, self.rows_dev = ibuf[:G], ibuf[G:2 * G], ibuf[2 * G:2 * G + 1]
+        self.ridx, self.row_grp = ibuf[2 * G + 1:2 * G + 1 + R], ibuf[2 * G + 1 + R:]
+        fbuf = torch.empty((4 * R,), dtype=_F32, device=dev)
+        self.rnx, self.mult = fbuf[:3 * R].view(R, 3), fbuf[3 * R:]
+        _cabi.check(_cabi.lib().prcnn_train_group_rows(_p(idx), _p(new_xyz), B, N, M, ns, _p(self.cnt), _p(self.off), _p(self.rows_dev),
+                                                       _p(self.ridx), _p(self.rnx), _p(self.mult), _p(self.row_grp), _stream()),
+                    "prcnn_train_group_rows")
+
+
 def _pack(w2d, k_rot=0):
     L = _cabi.lib()
     nout, k = w2d.shape
@@ -71,6 +91,15 @@ def _fill_src(S, src, x0, x1):
     if src.mode == "plain":
         S.mode, S.rows, S.K = 0, x0.shape[0], x0.shape[1]
         S.in_, S.ld_in = _p(x0), x0.stride(0)
+    elif src.mode == "group" and getattr(src, "rows", None) is not None:
+        gr = src.rows                                  # padding-free rows: one long "frame" of distinct rows, nsample 1
+        C = 0 if x0 is None else x0.shape[-1]
+        S.mode, S.rows, S.K = 1, gr.max_rows, C + 3
+        S.xyz, S.new_xyz, S.idx = _p(src.xyz), _p(gr.rnx), _p(gr.ridx)
+        S.feat, S.ld_feat = _p(x0), (0 if x0 is None else x0.stride(1))
+        S.B, S.N, S.M, S.ns, S.C = 1, gr.B * gr.N, gr.max_rows, 1, C
+        S.mult, S.rows_dev, S.norm_rows = _p(gr.mult), _p(gr.rows_dev), gr.max_rows
+        S.seg_off, S.seg_cnt, S.row_grp, S.groups = _p(gr.off), _p(gr.cnt), _p(gr.row_grp), gr.G
     elif src.mode == "group":
         B, M, ns = src.idx.shape
         C = 0 if x0 is None else x0.shape[-1]
@@ -192,15 +221,16 @@ class SharedMLPTrain(torch.autograd.Function):
         kin0 = K0 - 3 if src.mode == "group" else K0
         need_x = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
         ns = pool_ns if pool_ns and pool_ns > 1 else 1
+        flat = getattr(src, "rows", None)
         with torch.no_grad():
             st = _Stack(params, bns, rows, K0, kin0, need_x, dev)
             a_dump, ld_dump = None, 0
             if src.mode != "plain":
                 ld_dump = _up(K0, 4)
                 a_dump = torch.empty((rows, ld_dump), dtype=_F32, device=dev)
-            groups, N = rows // ns, st.nout[-1]
+            groups, N = (flat.G if flat is not None else rows // ns), st.nout[-1]
             out = torch.empty((groups, N), dtype=_F32, device=dev)
-            arg = torch.empty((groups, N), dtype=torch.uint8, device=dev) if ns > 1 else None
+            arg = torch.empty((groups, N), dtype=torch.uint8, device=dev) if (ns > 1 or flat is not None) else None
             work, nbytes = st.work(K0, False, dev)
             _cabi.check(L.prcnn_train_stack_fwd(ctypes.byref(S), st.layers, nl, ns, _p(a_dump), ld_dump, _p(out), N, 0, _p(arg),
                                                 _aligned_ptr(work), nbytes, _stream()), "prcnn_train_stack_fwd")
@@ -235,6 +265,11 @@ class SharedMLPTrain(torch.autograd.Function):
         if need_x:
             if src.mode == "plain":
                 gx0 = gin[:, :ctx.K0]
+            elif src.mode == "group" and getattr(src, "rows", None) is not None:
+                gr, C = src.rows, ctx.kin0
+                gx0 = torch.zeros((gr.B, gr.N, C), dtype=_F32, device=dev)
+                _cabi.check(L.prcnn_flat_rows_grad(_p(gin), ld_gin, _p(gr.ridx), _p(gr.rows_dev), gr.max_rows, C, _p(gx0), C, _stream()),
+                            "prcnn_flat_rows_grad")
             elif src.mode == "group":
                 B, M, ns = src.idx.shape
                 N0, C = src.xyz.shape[1], ctx.kin0

@@ -127,11 +127,13 @@ def _compare_modules(ma, mb, pooled):
             assert int(ba) == int(bb)
 
 
+@pytest.mark.parametrize("dedup", [True, False])
 @pytest.mark.parametrize("C", [0, 8, 96])
-def test_sa_module_fused_training_equals_composed_torch_path(dev, C):
+def test_sa_module_fused_training_equals_composed_torch_path(dev, C, dedup, monkeypatch):
     """PointnetSAModuleMSG in training mode: hand-written path == the composed path (HIP grouping ops + torch Conv2d /
     BatchNorm2d / ReLU / max, the reference's own structure): outputs, feature gradient, every parameter gradient and
-    BatchNorm buffer.  Clouds dense enough that groups are partly padded, partly full."""
+    BatchNorm buffer.  Clouds dense enough that groups are partly padded, partly full.  dedup: on the padding-free rows
+    (distinct rows + multiplicities) or on the nsample-padded rows."""
     B, N = 3, 1500
     pm, fused, comp = _modules("sa", dev, 5 + C, npoint=200, radii=[0.15, 0.3], nsamples=[16, 32],
                                mlps=[[C, 16, 16, 32], [C, 32, 48, 64]], use_xyz=True, bn=True)
@@ -141,6 +143,7 @@ def test_sa_module_fused_training_equals_composed_torch_path(dev, C):
     fa = None if feat is None else feat.clone().requires_grad_(True)
     fb = None if feat is None else feat.clone().requires_grad_(True)
     assert fused._train_ok(xyz, fa)
+    monkeypatch.setattr(pm, "TRAIN_DEDUP", dedup)
     nx_a, out_a = fused(xyz, fa)
     pm.TRAIN_FUSED = False
     try:
