@@ -242,6 +242,13 @@ int prcnn_maxpool_rows(const float* in, int ld_in, int64_t rows_out, int ns, int
  * ------------------------------------------------------------------------------------------- */
 int prcnn_roipool3d(const float* xyz, const float* boxes3d, const float* feat, int B, int N, int M, int C, int S,
                     float* pooled, int32_t* empty, prcnn_stream_t stream);
+/* The same operator with a caller-provided scratch buffer (>= prcnn_roipool3d_work_bytes(B, N) device bytes; 0 = this N has no
+ * binned form): the frame's points are first bucketed into x-z bins, and each RoI tests only the points of the bins its footprint
+ * touches instead of all N (identical selection: same membership test, ascending index order).  work == NULL or too small:
+ * the linear scan of prcnn_roipool3d.  Worth it from a handful of RoIs per frame upwards. */
+size_t prcnn_roipool3d_work_bytes(int B, int N);
+int prcnn_roipool3d_ws(const float* xyz, const float* boxes3d, const float* feat, int B, int N, int M, int C, int S, float* pooled,
+                       int32_t* empty, void* work, size_t work_bytes, prcnn_stream_t stream);
 
 /* point-in-box flags on the device: flags (M,N) i32 (device twin of roipool3d.cpp:97-125) */
 int prcnn_pts_in_boxes3d(const float* pts, const float* boxes3d, int N, int M, int32_t* flags, prcnn_stream_t stream);
@@ -361,6 +368,11 @@ int prcnn_roipool3d_canonical(const float* xyz, const float* pool_boxes3d, const
                               const float* extra1, const float* feat, int ld_feat, int B, int N, int M, int C, int S,
                               float* out_pts, int ld_pts, float* out_feat, int ld_out, int32_t* empty, int32_t* distinct,
                               prcnn_stream_t stream);
+/* ... with the scratch buffer of prcnn_roipool3d_ws (binned point selection) */
+int prcnn_roipool3d_canonical_ws(const float* xyz, const float* pool_boxes3d, const float* rois, const float* extra0,
+                                 const float* extra1, const float* feat, int ld_feat, int B, int N, int M, int C, int S,
+                                 float* out_pts, int ld_pts, float* out_feat, int ld_out, int32_t* empty, int32_t* distinct,
+                                 void* work, size_t work_bytes, prcnn_stream_t stream);
 
 /* ======================================================================================================
  * Grid-accelerated neighbour search: the same results as prcnn_ball_query / prcnn_ball_query2 / prcnn_three_nn

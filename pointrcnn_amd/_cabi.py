@@ -70,6 +70,8 @@ SIGNATURES = {
     "prcnn_mlp_chain_interp": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "prcnn_maxpool_rows": (_I, [_P, _I, _L, _I, _I, _P, _I, _I, _P]),
     "prcnn_roipool3d": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "prcnn_roipool3d_work_bytes": (_Z, [_I, _I]),
+    "prcnn_roipool3d_ws": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "prcnn_pts_in_boxes3d": (_I, [_P, _P, _I, _I, _P, _P]),
     "prcnn_boxes_overlap_bev": (_I, [_P, _I, _P, _I, _P, _P]),
     "prcnn_boxes_iou_bev": (_I, [_P, _I, _P, _I, _P, _P]),
@@ -80,6 +82,7 @@ SIGNATURES = {
     "prcnn_proposal_layer": (_I, [_P, _P, _I, _I, _I, _F, _F, _F, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "prcnn_nms_batched_workspace_bytes": (_Z, [_I, _I]),
     "prcnn_roipool3d_canonical": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
+    "prcnn_roipool3d_canonical_ws": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _P]),
     "prcnn_grid_bytes": (_Z, [_I, _I]),
     "prcnn_grid_build": (_I, [_P, _I, _I, _F, _I, _P, _Z, _P]),
     "prcnn_ball_query2_grid": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _P, _F, _I, _P, _P]),

@@ -94,6 +94,52 @@ __global__ __launch_bounds__(TI_THREADS) void three_interp_lds_kernel(const floa
     }
 }
 
+// The same with the staged rows stored POINT-major in LDS (CGT floats per source point, contiguous): a neighbour's CGT channel
+// values are one or two 16-byte LDS reads instead of CGT scalar reads at a 4 m-byte stride (24 -> 6 LDS instructions per output
+// point at CGT = 8, on random addresses either way), and the next point's index / weight triple is requested before the current
+// point's arithmetic.  Same individually rounded arithmetic, same bits.
+template <int CGT>
+__global__ __launch_bounds__(TI_THREADS) void three_interp_pm_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx,
+                                                                     const float* __restrict__ w, int C, int m, int n,
+                                                                     float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float spm[];     // m rows of CGT floats
+    const int b = blockIdx.y, c0 = blockIdx.x * CGT;
+    const float* f = feat + ((size_t)b * C + c0) * m;
+    for (int i = threadIdx.x; i < m; i += TI_THREADS) {
+        float v[CGT];
+#pragma unroll
+        for (int c = 0; c < CGT; c++) v[c] = f[(size_t)c * m + i];
+#pragma unroll
+        for (int q = 0; q < CGT / 4; q++)
+            *reinterpret_cast<float4*>(spm + (size_t)i * CGT + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+    __syncthreads();
+    float* o = out + ((size_t)b * C + c0) * n;
+    int i = threadIdx.x;
+    if (i >= n) return;
+    const int32_t* __restrict__ ib = idx + (size_t)b * n * 3;
+    const float* __restrict__ wb = w + (size_t)b * n * 3;
+    int i0 = ib[i * 3], i1 = ib[i * 3 + 1], i2 = ib[i * 3 + 2];
+    float w0 = wb[i * 3], w1 = wb[i * 3 + 1], w2 = wb[i * 3 + 2];
+    while (true) {
+        const int nx = i + TI_THREADS, nc = min(nx, n - 1);
+        const int j0 = ib[nc * 3], j1 = ib[nc * 3 + 1], j2 = ib[nc * 3 + 2];
+        const float u0 = wb[nc * 3], u1 = wb[nc * 3 + 1], u2 = wb[nc * 3 + 2];
+#pragma unroll
+        for (int q = 0; q < CGT / 4; q++) {
+            const float4 a = *reinterpret_cast<const float4*>(spm + (size_t)i0 * CGT + 4 * q);
+            const float4 bq = *reinterpret_cast<const float4*>(spm + (size_t)i1 * CGT + 4 * q);
+            const float4 cq = *reinterpret_cast<const float4*>(spm + (size_t)i2 * CGT + 4 * q);
+            o[(size_t)(4 * q + 0) * n + i] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.x), __fmul_rn(w1, bq.x)), __fmul_rn(w2, cq.x));
+            o[(size_t)(4 * q + 1) * n + i] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.y), __fmul_rn(w1, bq.y)), __fmul_rn(w2, cq.y));
+            o[(size_t)(4 * q + 2) * n + i] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.z), __fmul_rn(w1, bq.z)), __fmul_rn(w2, cq.z));
+            o[(size_t)(4 * q + 3) * n + i] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.w), __fmul_rn(w1, bq.w)), __fmul_rn(w2, cq.w));
+        }
+        if (nx >= n) break;
+        i = nx; i0 = j0; i1 = j1; i2 = j2; w0 = u0; w1 = u1; w2 = u2;
+    }
+}
+
 __global__ __launch_bounds__(G_THREADS) void three_interp_grad_kernel(const float* __restrict__ grad_out,
                                                                       const int32_t* __restrict__ idx,
                                                                       const float* __restrict__ w, int C, int n, int m,
@@ -301,6 +347,21 @@ PRCNN_API int prcnn_three_interp(const float* feat, const int32_t* idx, const fl
     int CG = (128 * 1024 / 4) / m;
     if (CG > C) CG = C;
     if (CG > 16) CG = 16;                                                                 // (more workgroups beat longer rows)
+    const char* lay = getenv("PRCNN_INTERP_LAYOUT");                                       // "rows": channel-major LDS rows (A/B switch)
+    const int CGT = CG >= 8 ? 8 : 4;
+    if (!no_lds && !(lay && lay[0] == 'r') && CG >= 4 && C % CGT == 0 && n >= 2 * m && (long)B * (C / CGT) >= 16) {
+        static PrcnnLdsLimit lim4, lim8;
+        const size_t bytes = (size_t)CGT * m * sizeof(float);
+        if (CGT == 8) {
+            if (!lim8.raise((const void*)three_interp_pm_kernel<8>, 128 * 1024)) return prcnn_fail(PRCNN_EHIP, "prcnn_three_interp: cannot raise the dynamic LDS limit");
+            hipLaunchKernelGGL(three_interp_pm_kernel<8>, dim3(C / 8, B), dim3(TI_THREADS), bytes, (hipStream_t)stream, feat, idx, weight, C, m, n, out);
+        } else {
+            if (!lim4.raise((const void*)three_interp_pm_kernel<4>, 128 * 1024)) return prcnn_fail(PRCNN_EHIP, "prcnn_three_interp: cannot raise the dynamic LDS limit");
+            hipLaunchKernelGGL(three_interp_pm_kernel<4>, dim3(C / 4, B), dim3(TI_THREADS), bytes, (hipStream_t)stream, feat, idx, weight, C, m, n, out);
+        }
+        PRCNN_LAUNCH_CHECK("prcnn_three_interp(point-major lds)");
+        return PRCNN_OK;
+    }
     if (!no_lds && CG >= 4 && n >= 2 * m && (long)B * prcnn_divup(C, CG) >= 16) {
         static PrcnnLdsLimit lim;
         if (!lim.raise((const void*)three_interp_lds_kernel, 128 * 1024))

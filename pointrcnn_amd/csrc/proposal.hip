@@ -46,32 +46,44 @@ __device__ __forceinline__ int argmax_first(const float* v, int n) {      // tor
     return best;
 }
 
-// One wave per 64 rows: the (64, C) slab is read with unit-stride dword loads into LDS (row stride C|1 words, so the
-// per-lane row walks below are bank-conflict free), then every lane decodes its own row.
-__global__ __launch_bounds__(64) void decode_kernel(DecodeParams P) {
+// One workgroup per 64 rows: its four waves read the (64, C) slab with unit-stride loads into LDS (row stride C|1 words, so
+// the per-lane row walks below are bank-conflict free) -- all of a thread's loads are issued before the first LDS store, and
+// LDS (not the wave count) bounds residency, so four loading waves per slab put four times the bytes in flight of one -- then
+// the first wave decodes a row per lane.
+#define DEC_THREADS 256
+__global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecodeParams P) {
     extern __shared__ float rows[];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid;
     const long row0 = (long)blockIdx.x * 64;
     const int nrows = (int)min(64L, P.N - row0);
     const int C = P.C, ld = C | 1;
     const float* __restrict__ src = P.reg + row0 * C;
     const int total = nrows * C;
     if ((C & 3) == 0 && ((uintptr_t)P.reg & 15) == 0) {      // 16-byte loads; a float4 never straddles two rows
-        int r = 0, c = lane * 4;
-        while (c >= C) { c -= C; r++; }
-        for (int e = lane * 4; e < total; e += 256) {
-            const float4 v = *reinterpret_cast<const float4*>(src + e);
-            float* d = rows + r * ld + c;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            c += 256;
-            while (c >= C) { c -= C; r++; }
+        constexpr int U = 5;                                  // 64 x 76 floats = 4.75 float4 per thread
+        for (int e0 = tid * 4; e0 < total; e0 += U * DEC_THREADS * 4) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = e0 + u * DEC_THREADS * 4;
+                if (e < total) v[u] = *reinterpret_cast<const float4*>(src + e);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = e0 + u * DEC_THREADS * 4;
+                if (e < total) {
+                    const int r = e / C, c = e - r * C;
+                    float* d = rows + r * ld + c;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+            }
         }
     } else {
-        int r = 0, c = lane;
+        int r = 0, c = tid;
         while (c >= C) { c -= C; r++; }
-        for (int e = lane; e < total; e += 64) {
+        for (int e = tid; e < total; e += DEC_THREADS) {
             rows[r * ld + c] = src[e];
-            c += 64;
+            c += DEC_THREADS;
             while (c >= C) { c -= C; r++; }
         }
     }
@@ -624,7 +636,7 @@ PRCNN_API int prcnn_decode_bbox_target(const float* roi, int roi_cols, const flo
     for (int c = 0; c < 3; c++) P.anchor[c] = anchor_size_host[c];
     const size_t lds = (size_t)64 * (C | 1) * sizeof(float);
     PRCNN_REQUIRE(lds <= 64 * 1024, "prcnn_decode_bbox_target: C=%d too wide", C);
-    hipLaunchKernelGGL(decode_kernel, dim3(prcnn_divup(N, 64)), dim3(64), lds, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(decode_kernel, dim3(prcnn_divup(N, 64)), dim3(DEC_THREADS), lds, (hipStream_t)stream, P);
     PRCNN_LAUNCH_CHECK("prcnn_decode_bbox_target");
     return PRCNN_OK;
 }

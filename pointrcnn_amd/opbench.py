@@ -51,6 +51,8 @@ def emit(name, shape, sec, **kw):
                  frac_of_8TBps=round(gbs / HBM_PEAK_GBS, 3), frac_of_6p3TBps_copy_ceiling=round(gbs / HBM_COPY_GBS, 3),
                  algorithmic_MB=round(kw["bytes"] / 1e6, 1), algorithmic_GBps=round(agbs, 1),
                  served_from_cache=bool(agbs > HBM_COPY_GBS))
+    if "kernels" in kw:            # [name substring, grid size in threads (0 = any)]: what profiles/join_op_traffic.py sums PMC bytes over
+        d["kernels"] = [[k, int(g)] for k, g in kw["kernels"]]
     if "pairs" in kw:
         d.update(bound="valu", pair_evals=kw["pairs"], achieved_Gpairs_per_s=round(kw["pairs"] / sec / 1e9, 1))
     if "flops" in kw:
@@ -82,14 +84,16 @@ def main():
     nx2 = ops.gather_rows(xyz1, ops.furthest_point_sample(xyz1, 1024))
     idx = ops.ball_query(1.0, 32, xyz1, nx2)
     emit("grouping_operation", "B%d C96 N4096 M1024 ns32" % B, timeit(lambda: ops.group(feat, idx)),
-         bytes=B * (1024 * 32 * 4 + 2 * 96 * 1024 * 32 * 4), compulsory=B * (1024 * 32 * 4 + 96 * 4096 * 4 + 96 * 1024 * 32 * 4))
+         bytes=B * (1024 * 32 * 4 + 2 * 96 * 1024 * 32 * 4), compulsory=B * (1024 * 32 * 4 + 96 * 4096 * 4 + 96 * 1024 * 32 * 4),
+         kernels=[("gather_kernel", B * 1024 * 32)])
     fidx = ops.furthest_point_sample(xyz1, 1024)
     emit("gather_operation", "B%d C96 N4096 M1024" % B, timeit(lambda: ops.gather(feat, fidx)),
-         bytes=B * (1024 * 4 + 2 * 96 * 1024 * 4), compulsory=B * (1024 * 4 + 2 * 96 * 1024 * 4))
+         bytes=B * (1024 * 4 + 2 * 96 * 1024 * 4), compulsory=B * (1024 * 4 + 2 * 96 * 1024 * 4), kernels=[("gather_kernel", B * 1024)])
     d2, i3, w3 = ops.three_nn(xyz, xyz1, want_weight=True)
     kf = torch.randn(B, 256, 4096, device=dev)
     emit("three_interpolate", "B%d C256 m4096 n%d" % (B, N), timeit(lambda: ops.three_interpolate(kf, i3, w3)),
-         bytes=B * (N * 24 + 3 * 256 * N * 4 + 256 * N * 4), compulsory=B * (N * 24 + 256 * 4096 * 4 + 256 * N * 4))
+         bytes=B * (N * 24 + 3 * 256 * N * 4 + 256 * N * 4), compulsory=B * (N * 24 + 256 * 4096 * 4 + 256 * N * 4),
+         kernels=[("three_interp", 0)])
 
     # ---- roipool3d: config 3 (M=100, C=130, S=512) and config 5 dense (65536 pts, 512 RoIs, batch 8)
     def rois_for(x, M, seed):
@@ -103,7 +107,8 @@ def main():
     pf = torch.randn(B, N, 130, device=dev)
     rois = rois_for(xyz, 100, 1)
     emit("roipool3d", "B%d N%d M100 C130 S512 (config 3)" % (B, N), timeit(lambda: ops.roipool3d(xyz, rois, pf, 512)),
-         bytes=B * 2 * 100 * 512 * 133 * 4, compulsory=B * (100 * 512 * 133 * 4 + N * 133 * 4))
+         bytes=B * 2 * 100 * 512 * 133 * 4, compulsory=B * (100 * 512 * 133 * 4 + N * 133 * 4),
+         kernels=[("roipool3d_kernel", B * 100 * 256)] + [("rp_bins_%s_kernel" % k, 0) for k in ("extent", "count", "scan", "fill")])
     if not args.quick:
         Bd, Nd, Md = 8, 65536, 512
         xd = rpn.synthetic_clouds(Bd, Nd, seed0=500, device=dev)
@@ -111,7 +116,8 @@ def main():
         rd = rois_for(xd, Md, 2)
         emit("roipool3d", "B%d N%d M%d C130 S512 (config 5 dense)" % (Bd, Nd, Md),
              timeit(lambda: ops.roipool3d(xd, rd, pfd, 512), 5, 1), bytes=Bd * 2 * Md * 512 * 133 * 4,
-             compulsory=Bd * (Md * 512 * 133 * 4 + Nd * 133 * 4))
+             compulsory=Bd * (Md * 512 * 133 * 4 + Nd * 133 * 4),
+             kernels=[("roipool3d_kernel", Bd * Md * 256)] + [("rp_bins_%s_kernel" % k, 0) for k in ("extent", "count", "scan", "fill")])
         del xd, pfd, rd
 
     # ---- GT-augmentation scene edit (kitti_rcnn_dataset.py:484-507): 15 accepted objects per scene, ~4000 pasted points
@@ -135,7 +141,7 @@ def main():
     anchor = (1.52563191462, 1.62856739989, 3.88311640418)
     emit("decode_bbox_target", "B%d N%d C76" % (B, N),
          timeit(lambda: ops.decode_bbox_target(xyz.view(-1, 3), reg, 3.0, 0.5, 12, anchor, y_to_bottom=True)),
-         bytes=B * N * (76 + 3 + 7) * 4)
+         bytes=B * N * (76 + 3 + 7) * 4, kernels=[("decode_kernel", 0)])
     gg = torch.Generator().manual_seed(3)
     nfg = int(N * 0.4)
     obj = torch.rand(B, 24, 7, generator=gg) * torch.tensor([70., .4, 62., .3, .3, 1., 6.28]) + torch.tensor([-35., .8, 4., 1.4, 1.5, 3.4, -3.14])

@@ -423,6 +423,20 @@ def maxpool_rows(x, ns, out=None):
 
 
 # ------------------------------------------------------------------ roipool3d
+ROIPOOL_BINS = os.environ.get("PRCNN_ROIPOOL_BINS", "1") != "0"        # binned point selection (A/B switch; same results)
+ROIPOOL_BINS_MIN_BOXES = 8
+
+
+def _roipool_work(B, N, M, dev):
+    """scratch for the binned point selection of roipool3d (None: linear scan -- few RoIs, or N beyond the LDS bitmap)"""
+    if not ROIPOOL_BINS or M < ROIPOOL_BINS_MIN_BOXES:
+        return None, 0
+    nbytes = _cabi.lib().prcnn_roipool3d_work_bytes(B, N)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty((nbytes,), dtype=torch.uint8, device=dev), nbytes
+
+
 def roipool3d(xyz, boxes3d_enlarged, pts_feature, sampled_pt_num):
     """xyz (B,N,3), boxes (B,M,7) already enlarged, pts_feature (B,N,C) -> pooled (B,M,S,3+C), empty (B,M) i32
     [roipool3d_cuda.forward, lib/utils/roipool3d/src/roipool3d.cpp:48-79]"""
@@ -431,8 +445,9 @@ def roipool3d(xyz, boxes3d_enlarged, pts_feature, sampled_pt_num):
     M, C = boxes3d_enlarged.shape[1], pts_feature.shape[2]
     pooled = torch.empty((B, M, sampled_pt_num, 3 + C), dtype=_F32, device=xyz.device)
     empty = torch.empty((B, M), dtype=_INT, device=xyz.device)
-    _cabi.check(_cabi.lib().prcnn_roipool3d(_p(xyz), _p(boxes3d_enlarged), _p(pts_feature), B, N, M, C, sampled_pt_num,
-                                            _p(pooled), _p(empty), _stream()), "prcnn_roipool3d")
+    work, nbytes = _roipool_work(B, N, M, xyz.device)
+    _cabi.check(_cabi.lib().prcnn_roipool3d_ws(_p(xyz), _p(boxes3d_enlarged), _p(pts_feature), B, N, M, C, sampled_pt_num,
+                                               _p(pooled), _p(empty), _p(work), nbytes, _stream()), "prcnn_roipool3d")
     return pooled, empty
 
 
@@ -469,10 +484,11 @@ def roipool3d_canonical(xyz, pool_boxes3d, rois, extras, feat_cl, sampled_pt_num
     distinct = torch.empty((B, M), dtype=_INT, device=dev) if want_distinct else None
     if rois is not None:
         _chk(rois, "rois", ndim=3)
-    _cabi.check(_cabi.lib().prcnn_roipool3d_canonical(
+    work, nbytes = _roipool_work(B, N, M, dev)
+    _cabi.check(_cabi.lib().prcnn_roipool3d_canonical_ws(
         _p(xyz), _p(pool_boxes3d), _p(rois), _p(ex[0]) if ex else None, _p(ex[1]) if len(ex) > 1 else None, _p(feat_cl),
         _row_stride(feat_cl), B, N, M, C, S, _p(pts), P, fbuf.data_ptr() + 4 * col, fbuf.stride(0), _p(empty), _p(distinct),
-        _stream()), "prcnn_roipool3d_canonical")
+        _p(work), nbytes, _stream()), "prcnn_roipool3d_canonical")
     return (pts, fbuf, empty, distinct) if want_distinct else (pts, fbuf, empty)
 
 

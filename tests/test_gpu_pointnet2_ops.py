@@ -132,10 +132,12 @@ def test_gather_group_interp_forward_exact(dev, cpu):
     assert np.array_equal(got, cpu.three_interp(feat, i3, w3))        # same op order, no FMA -> bit equal
 
 
-@pytest.mark.parametrize("B,C,m,n", [(4, 64, 1024, 4096), (2, 37, 513, 3000), (8, 256, 4096, 16384)])
+@pytest.mark.parametrize("B,C,m,n", [(4, 64, 1024, 4096), (2, 37, 513, 3000), (8, 256, 4096, 16384), (3, 36, 6000, 12001)])
 def test_three_interpolate_lds_staged_kernel_is_bit_identical(dev, cpu, monkeypatch, B, C, m, n):
-    """n >= 2 m with enough (frame, channel group) workgroups: the source rows are staged in LDS (three_interp_lds_kernel);
-    bit-equal to the oracle and to the direct kernel (PRCNN_INTERP_DIRECT=1), odd m / ragged channel groups included"""
+    """n >= 2 m with enough (frame, channel group) workgroups: the source rows are staged in LDS (point-major
+    three_interp_pm_kernel<8 | 4> when the channel count divides, channel-major three_interp_lds_kernel otherwise /
+    PRCNN_INTERP_LAYOUT=rows); bit-equal to the oracle and to the direct kernel (PRCNN_INTERP_DIRECT=1), odd m / ragged
+    channel groups included"""
     from pointrcnn_amd import ops
     r = np.random.default_rng(m + n)
     feat = r.normal(size=(B, C, m)).astype(np.float32)
@@ -146,7 +148,10 @@ def test_three_interpolate_lds_staged_kernel_is_bit_identical(dev, cpu, monkeypa
     monkeypatch.setenv("PRCNN_INTERP_DIRECT", "1")
     direct = ops.three_interpolate(T(feat, dev), T(i3, dev), T(w3, dev))
     monkeypatch.delenv("PRCNN_INTERP_DIRECT", raising=False)
-    assert torch.equal(got, direct)
+    monkeypatch.setenv("PRCNN_INTERP_LAYOUT", "rows")
+    rows = ops.three_interpolate(T(feat, dev), T(i3, dev), T(w3, dev))
+    monkeypatch.delenv("PRCNN_INTERP_LAYOUT", raising=False)
+    assert torch.equal(got, direct) and torch.equal(rows, direct)
     if B * C * n <= 4_000_000:
         assert np.array_equal(got.cpu().numpy(), cpu.three_interp(feat, i3, w3))
 

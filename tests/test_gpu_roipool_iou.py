@@ -47,6 +47,59 @@ def test_roipool3d_dense_box_truncates_at_S(dev, cpu):
     assert (np.diff(ids) > 0).all()                           # strictly ascending point indices, no wrap
 
 
+def test_roipool3d_binned_selection_is_the_linear_scan(dev, cpu, monkeypatch):
+    """prcnn_roipool3d_ws (points bucketed into x-z bins, a box tests the bins under its footprint) == the linear scan == the
+    oracle, bit for bit, on inputs built to break a culled search: boxes outside the cloud's extent, boxes covering all of it,
+    zero / negative / infinite / NaN boxes, NaN and infinite points, a frame whose points all coincide, N not a multiple of
+    32, boxes hugging bin borders, more than S points in a box"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(7)
+    B, N, M, C, S = 4, 3001, 48, 5, 64
+    xyz = kitti_cloud(B, N, seed=3)
+    xyz[1] = xyz[1, :1]                                        # every point of frame 1 at the same place
+    xyz[2, ::97] = np.nan
+    xyz[2, 5::89, 0] = np.inf
+    xyz[2, 7::83, 2] = -np.inf
+    boxes = np.stack([enlarge(rand_boxes3d(xyz[0], M, seed=b + 11), 1.0) for b in range(B)])
+    boxes[1, :, :3] = xyz[1, 0] + r.normal(size=(M, 3)).astype(np.float32) * 0.3
+    boxes[:, 0, 0] += 700.0                                    # far outside
+    boxes[:, 1, 3:6] = [3.0, 19.9, 19.9]                       # covers everything the 10 m gate lets through
+    boxes[:, 2, 3:6] = 0.0
+    boxes[:, 3, 4] = -1.0
+    boxes[:, 4, 5] = np.inf
+    boxes[:, 5, 6] = np.nan
+    boxes[:, 6, 0] = np.nan
+    boxes[:, 7, 6] = np.inf
+    boxes[:, 8, 4:6] = [40.0, 40.0]
+    lo, hi = np.nanmin(np.where(np.isfinite(xyz[0]), xyz[0], np.nan), 0), np.nanmax(np.where(np.isfinite(xyz[0]), xyz[0], np.nan), 0)
+    for i in range(9, 20):                                     # centres on bin borders of the 64 x 64 grid, axis-aligned and rotated
+        boxes[0, i, 0] = lo[0] + (hi[0] - lo[0]) * (i - 4) / 64.0
+        boxes[0, i, 2] = lo[2] + (hi[2] - lo[2]) * (2 * i) / 64.0
+        boxes[0, i, 6] = [0.0, np.pi / 2, np.pi, -np.pi / 2, 0.3][i % 5]
+    feat = r.normal(size=(B, N, C)).astype(np.float32)
+    want, wempty = cpu.roipool3d(xyz, boxes, feat, S)
+    a = [t.cpu().numpy() for t in ops.roipool3d(T(xyz, dev), T(boxes, dev), T(feat, dev), S)]
+    monkeypatch.setattr(ops, "ROIPOOL_BINS", False)
+    b = [t.cpu().numpy() for t in ops.roipool3d(T(xyz, dev), T(boxes, dev), T(feat, dev), S)]
+    monkeypatch.setattr(ops, "ROIPOOL_BINS", True)
+    assert ops._roipool_work(B, N, M, dev)[1] > 0 and ops._roipool_work(B, N, 2, dev)[1] == 0
+    for u, v, w in zip(a, b, (want, wempty)):
+        assert np.array_equal(u, v, equal_nan=True) and np.array_equal(u, w, equal_nan=True)
+    assert 0 < wempty.sum() < wempty.size and (np.diff(a[0][0, 1, :, 0]) != 0).any()
+    # canonical (fused RCNN input) form: same selection
+    ex = [T(r.random((B, N)).astype(np.float32), dev), T(r.random((B, N)).astype(np.float32), dev)]
+    rois = T(boxes, dev)
+    c1 = ops.roipool3d_canonical(T(xyz, dev), T(boxes, dev), rois, ex, T(feat, dev), S, want_distinct=True)
+    monkeypatch.setattr(ops, "ROIPOOL_BINS", False)
+    c0 = ops.roipool3d_canonical(T(xyz, dev), T(boxes, dev), rois, ex, T(feat, dev), S, want_distinct=True)
+    d = c0[3].cpu().numpy().reshape(-1)
+    assert np.array_equal(c1[3].cpu().numpy().reshape(-1), d) and np.array_equal(c1[2].cpu().numpy(), c0[2].cpu().numpy())
+    assert np.array_equal(c1[0].cpu().numpy(), c0[0].cpu().numpy(), equal_nan=True)
+    f1, f0 = c1[1].cpu().numpy().reshape(B * M, S, C), c0[1].cpu().numpy().reshape(B * M, S, C)
+    for i in range(B * M):                                     # feature rows of the wrap-copies are not written (distinct)
+        assert np.array_equal(f1[i, :d[i]], f0[i, :d[i]], equal_nan=True)
+
+
 def test_roipool3d_golden_from_reference(dev):
     """fixture produced by the reference's own roipool3d.cpp CPU code (oracle/_ref)"""
     from pointrcnn_amd import ops

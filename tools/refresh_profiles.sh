@@ -24,7 +24,10 @@ python bench.py --npoints 65536 --batch 8 --steps 64 --no-cpu-baseline --no-vari
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python bench.py --no-cpu-baseline --no-roofline --no-variants > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-cpu-baseline --no-roofline --no-variants --streams 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python bench.py --workload train --steps 16 > /dev/null 2>&1
-python -m pointrcnn_amd.opbench > $O/opbench.jsonl 2> $O/opbench.err
+python -m pointrcnn_amd.opbench > $O/opbench_raw.jsonl 2> $O/opbench.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/op_FETCH_SIZE -- python -m pointrcnn_amd.opbench > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/op_WRITE_SIZE -- python -m pointrcnn_amd.opbench > /dev/null 2>&1
+python profiles/join_op_traffic.py $O/opbench_raw.jsonl /tmp/op_ $O/opbench.jsonl > /dev/null 2>> $O/opbench.err
 python profiles/summarize_rocprof.py $O/kt3 "default: python bench.py (20 batches in flight, hipGraph replay)" > $O/kernel_stats.txt
 python profiles/summarize_rocprof.py $O/kt1 "python bench.py --streams 1 (one batch in flight)" > $O/kernel_stats_streams1.txt
 python profiles/summarize_rocprof.py $O/ktt "python bench.py --workload train --steps 16 (RPN training step, bs16, eager, fused training path)" > $O/kernel_stats_train.txt
