@@ -651,6 +651,14 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const TrainWgrad W) {
 // 2j, 2j+1 of its half -- 256 contiguous bytes per half-wave, conflict-free).  Register-staged double buffer, one barrier per chunk.
 #define WL_ROWS 32
 #define WL_LD 128
+// POOL: how the layer's upstream gradient reaches a row (0: G is (rows, N); 1: max-pooled over fixed groups of pool_ns rows; 2: over
+// the variable-length groups of padding-free rows), MULT: padding-free rows (row multiplicities), PRO: the A operand is the previous
+// layer's saved y (its BatchNorm + ReLU applied while staging).  Compile-time, and every load of a chunk is issued back to back from
+// clamped addresses (rows past the range and channels past K / N are zeroed by multiplication afterwards, never by a branch around
+// the load): with run-time branches the compiler put an s_waitcnt vmcnt(0) at every join, i.e. a dozen exposed global round trips
+// per 32-row chunk against 1.7 us of MFMA work in it.  The one dependent load of the flat form (row -> group) is requested a chunk
+// ahead of the data that needs it.
+template <int POOL, bool MULT, bool PRO>
 __global__ __launch_bounds__(256, 2) void train_wgrad_lds_kernel(const TrainWgrad W) {
     const TrainBwd& T = W.B;
     __shared__ __attribute__((aligned(16))) float As[2][WL_ROWS * WL_LD], Ds[2][WL_ROWS * WL_LD];
@@ -662,49 +670,76 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_lds_kernel(const TrainWgra
     // staging role: rows rl + 8 u (u = 0..3), channels 4 cq .. 4 cq + 3 of the tile
     const int cq = tid & 31, rl = tid >> 5;
     const int ka = kt0 + 4 * cq, na = nt0 + 4 * cq;
-    const bool ka_ok = ka + 4 <= W.lda, na_ok = na + 4 <= T.N;            // (lda and N are multiples of 4 here)
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = zero4, km;
-    km.x = ka < W.K ? 1.f : 0.f; km.y = ka + 1 < W.K ? 1.f : 0.f; km.z = ka + 2 < W.K ? 1.f : 0.f; km.w = ka + 3 < W.K ? 1.f : 0.f;
-    const bool pro = W.pro_scale != nullptr;
-    if (pro && ka_ok) { ps = ld4(W.pro_scale + ka); pb = ld4(W.pro_shift + ka); }
-    float4 sc = zero4, sh = zero4, mu = zero4, is = zero4, c1 = zero4, c2 = zero4;
-    if (na_ok) {
-        sc = ld4(T.cst + na); sh = ld4(T.cst + T.ld_c + na); mu = ld4(T.cst + 2 * T.ld_c + na); is = ld4(T.cst + 3 * T.ld_c + na);
-        c1 = ld4(T.cst + 4 * T.ld_c + na); c2 = ld4(T.cst + 5 * T.ld_c + na);
-    }
+    const int kc = (ka + 4 <= W.lda) ? ka : 0, nc = (na + 4 <= T.N) ? na : 0;      // (lda and N are multiples of 4 here)
+    const float dead_n = (na + 4 <= T.N) ? 1.f : 0.f;
+    float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f), km;
+    const bool ka_ok = ka + 4 <= W.lda;
+    km.x = (ka_ok && ka < W.K) ? 1.f : 0.f; km.y = (ka_ok && ka + 1 < W.K) ? 1.f : 0.f;
+    km.z = (ka_ok && ka + 2 < W.K) ? 1.f : 0.f; km.w = (ka_ok && ka + 3 < W.K) ? 1.f : 0.f;
+    if (PRO) { ps = ld4(W.pro_scale + kc); pb = ld4(W.pro_shift + kc); }
+    const float4 sc = ld4(T.cst + nc), sh = ld4(T.cst + T.ld_c + nc), mu = ld4(T.cst + 2 * T.ld_c + nc), is = ld4(T.cst + 3 * T.ld_c + nc);
+    const float4 c1 = ld4(T.cst + 4 * T.ld_c + nc), c2 = ld4(T.cst + 5 * T.ld_c + nc);
     const long r_begin = (long)blockIdx.x * W.rows_per_split;
     long r_end = r_begin + W.rows_per_split;
     const long live = bwd_live_rows(T);
     if (r_end > live) r_end = live;
     const int nchunks = r_end > r_begin ? (int)((r_end - r_begin + WL_ROWS - 1) / WL_ROWS) : 0;
     float4 ra[4], rg[4], ry[4];
-    float rmw[4];
-    auto load_chunk = [&](int c) {
+    uchar4 rarg[4];
+    int rso[4], gcur[4], gnext[4];
+    float mcur[4], mnext[4];
+    auto row_of = [&](int c, int u, bool& ok) {
+        long rr = r_begin + (long)c * WL_ROWS + rl + 8 * u;
+        ok = rr < r_end;
+        return ok ? rr : r_end - 1;
+    };
+    auto load_meta = [&](int c, int (&g)[4], float (&m)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            long rr = r_begin + (long)c * WL_ROWS + rl + 8 * u;
-            const bool row_ok = rr < r_end;
-            if (!row_ok) rr = r_end - 1;
-            rmw[u] = T.mult ? T.mult[rr] : 1.f;
-            float4 a = ka_ok ? ld4(W.a + rr * (long)W.lda + ka) : zero4;
-            if (pro) { a.x = fmaxf(a.x * ps.x + pb.x, 0.f); a.y = fmaxf(a.y * ps.y + pb.y, 0.f); a.z = fmaxf(a.z * ps.z + pb.z, 0.f); a.w = fmaxf(a.w * ps.w + pb.w, 0.f); }
-            const float v = row_ok ? 1.f : 0.f;                   // rows past the range and channels past K contribute zero
-            a.x *= km.x * v; a.y *= km.y * v; a.z *= km.z * v; a.w *= km.w * v;
-            ra[u] = a;
-            if (na_ok) {
-                ry[u] = ld4(T.y + rr * (long)T.ld_y + na);
-                rg[u] = bwd_G4(T, rr, na);
+            bool ok;
+            const long rr = row_of(c, u, ok);
+            g[u] = POOL == 2 ? T.row_grp[rr] : 0;
+            m[u] = MULT ? T.mult[rr] : 1.f;
+        }
+    };
+    auto load_data = [&](int c, const int (&g)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            bool ok;
+            const long rr = row_of(c, u, ok);
+            ra[u] = ld4(W.a + rr * (long)W.lda + kc);
+            ry[u] = ld4(T.y + rr * (long)T.ld_y + nc);
+            if (POOL == 0) {
+                rg[u] = ld4(T.G + rr * (long)T.ldG + nc);
             } else {
-                ry[u] = zero4; rg[u] = zero4;
+                const long grp = POOL == 2 ? (long)g[u] : rr / T.pool_ns;
+                rg[u] = ld4(T.G + grp * (long)T.ldG + nc);
+                rarg[u] = *reinterpret_cast<const uchar4*>(T.arg + grp * (long)T.N + nc);
+                rso[u] = POOL == 2 ? (int)rr - T.seg_off[grp] : (int)(rr - grp * T.pool_ns);
             }
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto pin4 = [](float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
+    auto store_chunk = [&](int c, int buf, const float (&m)[4]) {
+        // (the optimiser otherwise hoists this arithmetic -- and with it the wait for the chunk's loads -- above the MFMA loop)
+#pragma unroll
+        for (int u = 0; u < 4; u++) { pin4(ra[u]); pin4(rg[u]); pin4(ry[u]); }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const float4 a = ra[u];
-            const float4 d = bwd_dy4(rg[u], ry[u], sc, sh, mu, is, c1, c2, rmw[u]);
+            bool ok;
+            (void)row_of(c, u, ok);
+            float4 a = ra[u];
+            if (PRO) { a.x = fmaxf(a.x * ps.x + pb.x, 0.f); a.y = fmaxf(a.y * ps.y + pb.y, 0.f); a.z = fmaxf(a.z * ps.z + pb.z, 0.f); a.w = fmaxf(a.w * ps.w + pb.w, 0.f); }
+            const float v = ok ? 1.f : 0.f;                       // rows past the range and channels past K contribute zero
+            a.x *= km.x * v; a.y *= km.y * v; a.z *= km.z * v; a.w *= km.w * v;
+            float4 g = rg[u];
+            if (POOL != 0) {
+                const int sl = rso[u];
+                g.x = rarg[u].x == sl ? g.x : 0.f; g.y = rarg[u].y == sl ? g.y : 0.f;
+                g.z = rarg[u].z == sl ? g.z : 0.f; g.w = rarg[u].w == sl ? g.w : 0.f;
+            }
+            float4 d = bwd_dy4(g, ry[u], sc, sh, mu, is, c1, c2, m[u]);
+            d.x *= dead_n; d.y *= dead_n; d.z *= dead_n; d.w *= dead_n;
             *reinterpret_cast<float4*>(&As[buf][(rl + 8 * u) * WL_LD + 4 * cq]) = a;
             *reinterpret_cast<float4*>(&Ds[buf][(rl + 8 * u) * WL_LD + 4 * cq]) = d;
         }
@@ -715,12 +750,19 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_lds_kernel(const TrainWgra
 #pragma unroll
         for (int z = 0; z < 2; z++) acc[x][z] = (f32x16){0};
     if (nchunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
+        load_meta(0, gcur, mcur);
+        load_data(0, gcur);
+        load_meta(min(1, nchunks - 1), gnext, mnext);
+        store_chunk(0, 0, mcur);
         __syncthreads();
         for (int c = 0; c < nchunks; c++) {
             const int buf = c & 1;
-            load_chunk(min(c + 1, nchunks - 1));
+            const int c1n = min(c + 1, nchunks - 1);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { gcur[u] = gnext[u]; mcur[u] = mnext[u]; }
+            load_data(c1n, gcur);
+            load_meta(min(c + 2, nchunks - 1), gnext, mnext);
+            __builtin_amdgcn_sched_barrier(0);     // the requests go out BEFORE the chunk's 64 MFMAs (the scheduler sinks them to mid-loop otherwise)
             const float* ap = &As[buf][h * WL_LD + wk * 64 + 2 * j];
             const float* dp = &Ds[buf][h * WL_LD + wn * 64 + 2 * j];
 #pragma unroll
@@ -732,7 +774,8 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_lds_kernel(const TrainWgra
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, d.x, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, d.y, acc[1][1], 0, 0, 0);
             }
-            if (c + 1 < nchunks) store_chunk(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            store_chunk(c1n, buf ^ 1, mcur);      // (the last iteration re-stages the last chunk into the idle buffer: no branch around the loads' consumer)
             __syncthreads();
         }
     }
@@ -751,6 +794,12 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_lds_kernel(const TrainWgra
                 if (ko < W.K) P[(long)no * W.K + ko] = acc[x][z][e];
             }
         }
+}
+
+template <int POOL, bool MULT>
+static void launch_wgrad_lds(const TrainWgrad& Wg, dim3 grid, hipStream_t s) {
+    if (Wg.pro_scale) hipLaunchKernelGGL((train_wgrad_lds_kernel<POOL, MULT, true>), grid, dim3(256), 0, s, Wg);
+    else hipLaunchKernelGGL((train_wgrad_lds_kernel<POOL, MULT, false>), grid, dim3(256), 0, s, Wg);
 }
 
 // out[n, (k + k_unrot) % K] = sum over the partials, in order.  Block = 64 elements x 4 lanes over the partial index; k_unrot = 3
@@ -1183,9 +1232,12 @@ PRCNN_API int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_tr
         else if (p.KQ == 2 && p.WK == 1) launch_wgrad<2, 2, 1, 2>(Wg, p, s);
         else if (p.NQ == 1) launch_wgrad<2, 1, 2, 1>(Wg, p, s);
         else if (p.WN == 1) launch_wgrad<2, 2, 2, 1>(Wg, p, s);
-        else if (Wg.lda % 4 == 0 && aligned16(Wg.a) && !getenv("PRCNN_WGRAD_DIRECT"))
-            hipLaunchKernelGGL(train_wgrad_lds_kernel, dim3(p.splits, p.tiles_k, p.tiles_n), dim3(256), 0, s, Wg);
-        else launch_wgrad<2, 2, 2, 2>(Wg, p, s);
+        else if (Wg.lda % 4 == 0 && aligned16(Wg.a) && !getenv("PRCNN_WGRAD_DIRECT")) {
+            const dim3 wg(p.splits, p.tiles_k, p.tiles_n);
+            if (Wg.B.pool_ns == 0) { if (Wg.B.mult) launch_wgrad_lds<0, true>(Wg, wg, s); else launch_wgrad_lds<0, false>(Wg, wg, s); }
+            else if (Wg.B.pool_ns > 0) launch_wgrad_lds<1, false>(Wg, wg, s);
+            else launch_wgrad_lds<2, true>(Wg, wg, s);
+        } else launch_wgrad<2, 2, 2, 2>(Wg, p, s);
         const long count = (long)N * K;
         hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3(prcnn_divup(count, 64)), dim3(256), 0, s, W.wpart, p.splits * p.WR, count, K,
                            (l == 0 && src->mode == MODE_GROUP && K > 3) ? 3 : 0, L[l].dW);

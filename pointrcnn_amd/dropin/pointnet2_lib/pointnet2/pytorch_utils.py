@@ -10,6 +10,7 @@ CPU construction) the modules behave as plain torch Conv/BN/ReLU stacks.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from pointrcnn_amd import ops
 
@@ -71,6 +72,9 @@ def _inference_input(x):
 def fused_sequential(seq, x):
     """Run an nn.Sequential of pt_utils conv layers (+ eval-mode Dropout) -- e.g. the RPN heads, lib/net/rpn.py:20-46
     -- through run_conv_stack when every member allows it; otherwise exactly seq(x)."""
+    if torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3:
+        y = _train_rows_sequential(seq, x)
+        return seq(x) if y is None else y
     mods = []
     for m in seq:
         if isinstance(m, nn.Dropout):
@@ -83,6 +87,88 @@ def fused_sequential(seq, x):
     if not mods or not _inference_input(x):
         return seq(x)
     return run_conv_stack(mods, x)
+
+
+class _LinearRows(torch.autograd.Function):
+    """y = x W^T + b on (R, K) rows with R >> K, N (an output layer over every point of the batch).  The forward and the input
+    gradient are plain library GEMMs; the weight gradient g^T x reduces over R = 262144 rows into a 76 x 128 result, which the
+    library runs as ONE skinny GEMM without splitting the reduction (640 us, 8 TFLOP/s): here it is a batched product over row
+    chunks followed by a sum over the chunks (split-K by hand, deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            R = x.shape[0]
+            chunks = 1
+            while chunks < 512 and R % (chunks * 2) == 0 and R // (chunks * 2) >= 512:
+                chunks *= 2
+            if chunks > 1 and x.is_contiguous():
+                gw = torch.bmm(g.view(chunks, R // chunks, -1).transpose(1, 2), x.view(chunks, R // chunks, -1)).sum(0)
+            else:
+                gw = g.t() @ x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+def _train_rows_sequential(seq, x):
+    """Training: a Sequential of 1 x 1 Conv1d layers and Dropout on (B, C, L) (the RPN / RCNN heads, lib/net/rpn.py:20-46) computed
+    on channels-last ROWS from end to end: runs of Conv -> BatchNorm -> ReLU are one hand-written autograd node each
+    (train_mlp.SharedMLPTrain), Dropout is elementwise on the rows, a bare Conv (bias, no norm: the output layer) is F.linear on the
+    rows.  Module by module the Sequential would transpose (B, C, L) <-> rows around every fused layer and run the output layer as
+    an MIOpen convolution forward + backward: four full-size copies and 1.2 ms of a 15 ms step for a 128 -> 76 product.
+    The result is returned as a (B, C_out, L) VIEW of the (B, L, C_out) rows, so the caller's `.transpose(1, 2).contiguous()` is
+    free.  None: some member is not covered (the caller runs seq(x))."""
+    from pointrcnn_amd import train_mlp
+    from . import pointnet2_modules
+    if not pointnet2_modules.TRAIN_FUSED:
+        return None
+    plan, run = [], []
+    for m in seq:
+        if isinstance(m, nn.Dropout):
+            if run:
+                plan.append(("stack", run))
+                run = []
+            plan.append(("dropout", m))
+        elif isinstance(m, _ConvBase) and isinstance(m._parts()[0], nn.Conv1d) and train_mlp.stack_ok([m]):
+            run.append(m)
+        elif isinstance(m, _ConvBase) and isinstance(m._parts()[0], nn.Conv1d) and m._prcnn_fusable and m._parts()[1] is None:
+            conv = m._parts()[0]
+            if conv.kernel_size != (1,) or conv.stride != (1,) or conv.padding != (0,) or conv.groups != 1:
+                return None
+            if run:
+                plan.append(("stack", run))
+                run = []
+            plan.append(("linear", m))
+        else:
+            return None
+    if run:
+        plan.append(("stack", run))
+    if not any(k == "stack" for k, _ in plan):
+        return None
+    B, C, L = x.shape
+    rows = _rows_view(x.permute(0, 2, 1)).reshape(B * L, C)
+    for kind, m in plan:
+        if kind == "stack":
+            rows = train_mlp.run_stack(m, train_mlp.Source("plain"), rows)
+        elif kind == "dropout":
+            rows = F.dropout(rows, m.p, m.training, False)
+        else:
+            conv, _, act = m._parts()
+            rows = _LinearRows.apply(rows, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+            if act is not None:
+                rows = F.relu(rows) if isinstance(act, nn.ReLU) else act(rows)
+    return rows.view(B, L, -1).permute(0, 2, 1)
 
 
 class _BNBase(nn.Sequential):

@@ -248,7 +248,9 @@ class SharedMLPTrain(torch.autograd.Function):
         st, src, rows = ctx.st, ctx.src, ctx.rows
         dev = gout.device
         need_x = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
-        G = gout.contiguous()
+        G = gout                                      # rows of any 16-byte-aligned stride are taken as they are (slices of a concatenation)
+        if G.stride(1) != 1 or G.stride(0) % 4 or G.data_ptr() % 16 or G.dtype != _F32:
+            G = gout.contiguous().float()
         gin, ld_gin = None, 0
         if need_x:
             ld_gin = _up(ctx.kin0, 4)

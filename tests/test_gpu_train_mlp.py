@@ -210,6 +210,41 @@ def test_conv1d_head_layer_fused_training_equals_torch(dev):
     _compare_modules(a, b, pooled=False)
 
 
+def test_head_sequential_on_rows_equals_module_by_module(dev):
+    """pt_utils.fused_sequential in training mode (the RPN heads: Conv1d+BN+ReLU -> Dropout -> Conv1d with bias): the rows path
+    (one fused node, elementwise dropout, F.linear; output a view whose transpose is contiguous) == running the Sequential
+    module by module through torch, for outputs, input gradient and every parameter gradient; with p > 0 the masks differ (a
+    different element order draws them) but the zero fraction and the scaling are dropout's"""
+    import pointrcnn_amd
+    pointrcnn_amd.install()
+    from pointnet2_lib.pointnet2 import pointnet2_modules as pm, pytorch_utils as pt
+    torch.manual_seed(3)
+    seq = nn.Sequential(pt.Conv1d(128, 128, bn=True), nn.Dropout(0.0), pt.Conv1d(128, 76, activation=None)).to(dev).train()
+    ref = copy.deepcopy(seq)
+    base = torch.randn(2, 3000, 128, device=dev)
+    xa, xb = base.clone().requires_grad_(True), base.clone().requires_grad_(True)
+    ya = pt.fused_sequential(seq, xa.transpose(1, 2))
+    assert ya.shape == (2, 76, 3000) and ya.transpose(1, 2).is_contiguous()
+    pm.TRAIN_FUSED = False
+    try:
+        yb = ref(xb.transpose(1, 2))
+    finally:
+        pm.TRAIN_FUSED = True
+    _close(ya, yb, 1e-5, "head output")
+    gout = torch.randn_like(yb)
+    ya.backward(gout)
+    yb.backward(gout)
+    _close(xa.grad, xb.grad, 1e-4, "input gradient")
+    _compare_modules(seq, ref, pooled=False)
+    seq[1].p = 0.5
+    y = pt.fused_sequential(seq, base.transpose(1, 2))
+    seq[2]._parts()[0].weight.data.fill_(1.0)
+    seq[2]._parts()[0].bias.data.zero_()
+    h = pt.fused_sequential(nn.Sequential(seq[0], seq[1]), base.transpose(1, 2))
+    frac = (h == 0).float().mean().item()
+    assert 0.5 < frac < 0.9 and torch.isfinite(y).all()          # relu zeros + half of the rest dropped
+
+
 def test_eval_mode_and_unsupported_layers_keep_their_paths(dev):
     """BatchNorm in eval mode / a layer without BatchNorm is not this path's business: stack_ok says no, modules fall back"""
     import pointrcnn_amd
