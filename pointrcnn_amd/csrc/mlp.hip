@@ -335,7 +335,7 @@ __device__ __forceinline__ void addy_stage_half(const MlpParams& P, int tid, lon
 template <int MODE, int WNB, bool ADDY>
 __device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)[2][WNB], float* As0, float* Bs0, int tid, long row0,
                                                int nb0, bool n_active, bool addy_done = false) {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // SGPR: the full-tile test below is a scalar branch
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, j = lane & 31;
     // ---- epilogue -------------------------------------------------------------------------------
@@ -383,7 +383,31 @@ __device__ __forceinline__ void layer_epilogue(const MlpParams& P, f32x16 (&acc)
         const float bias = (P.bias && n_ok) ? P.bias[n] : 0.f;
         const f32x16& acc0 = acc[0][nn];
         const f32x16& acc1 = acc[1][nn];
-        if (P.pool_ns == 0) {
+        const bool use_addy = ADDY && P.addY && !addy_done;
+        if (P.pool_ns == 0 && wrow0 + 64 <= P.rows && nb * 32 + 32 <= P.Nout && (!use_addy || staged)) {
+            // The wave's whole 64 x 32 block lies inside the output (all but the last row tile / a ragged last column block):
+            // no bounds test per element.  With one, every store sits in its own exec-masked region and the compiler opens each
+            // with s_waitcnt vmcnt(0) -- on gfx9 that counter includes STORES, so the 32 stores of a block went out one
+            // memory round trip after the other.
+            const int blk = wn * WNB + nn;
+            const float* T = ((blk >> 1) == 0 || !Bs0) ? As0 : Bs0;
+            const int ldt = ((blk >> 1) == 0 || !Bs0) ? 72 : 64, tc = (blk & 1) * 32 + j;
+            float* o = P.out + (wrow0 + 4 * h) * P.ld_out + P.col_off + n;
+            const long ld = P.ld_out;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
+                if (ADDY && use_addy) {
+                    v0 += T[(wm * 64 + rr + 4 * h) * ldt + tc];
+                    v1 += T[(wm * 64 + 32 + rr + 4 * h) * ldt + tc];
+                }
+                v0 = P.relu ? fmaxf(v0, 0.f) : v0;
+                v1 = P.relu ? fmaxf(v1, 0.f) : v1;
+                o[rr * ld] = v0;
+                o[(32 + rr) * ld] = v1;
+            }
+        } else if (P.pool_ns == 0) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1921,13 +1945,26 @@ __global__ __launch_bounds__(256, 1) void mlp_stack2_kernel(const ChainParams Ci
         const int n = nb * 32 + j;
         const bool n_ok = n < Cin.N1;
         const float bias = (Cin.bias1 && n_ok) ? Cin.bias1[n] : 0.f;
+        if (row0 + 32 <= P.rows && nb * 32 + 32 <= Cin.N1) {
+            // whole block inside the output: unguarded stores, issued back to back (a bounds branch per element makes the compiler
+            // open every store with s_waitcnt vmcnt(0) -- the counter includes stores on gfx9: one round trip per store)
+            float* o = P.out + (row0 + 4 * h) * P.ld_out + P.col_off + n;
+            const long ld = P.ld_out;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const long g = row0 + rin;
-            float v = acc[0][r] + bias;
-            if (Cin.relu1) v = fmaxf(v, 0.f);
-            if (n_ok && g < P.rows) P.out[g * P.ld_out + P.col_off + n] = v;
+            for (int r = 0; r < 16; r++) {
+                float v = acc[0][r] + bias;
+                v = Cin.relu1 ? fmaxf(v, 0.f) : v;
+                o[((r & 3) + 8 * (r >> 2)) * ld] = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const long g = row0 + rin;
+                float v = acc[0][r] + bias;
+                if (Cin.relu1) v = fmaxf(v, 0.f);
+                if (n_ok && g < P.rows) P.out[g * P.ld_out + P.col_off + n] = v;
+            }
         }
     }
     __syncthreads();                                        // the LDS tiles are rebuilt by the next unit
@@ -2007,13 +2044,24 @@ __global__ __launch_bounds__(256, 1) void mlp_rows32_kernel(const MlpParams Pin,
             const int n = nb * 32 + j;
             const bool n_ok = n < P.Nout;
             const float bias = (P.bias && n_ok) ? P.bias[n] : 0.f;
+            if (row0 + 32 <= P.rows && nb * 32 + 32 <= P.Nout) {      // whole block inside the output: unguarded stores (see mlp_stack2_kernel)
+                float* o = P.out + (row0 + 4 * h) * P.ld_out + P.col_off + n;
+                const long ld = P.ld_out;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const long g = row0 + rin;
-                float v = acc[r] + bias;
-                if (P.relu) v = fmaxf(v, 0.f);
-                if (n_ok && g < P.rows) P.out[g * P.ld_out + P.col_off + n] = v;
+                for (int r = 0; r < 16; r++) {
+                    float v = acc[r] + bias;
+                    v = P.relu ? fmaxf(v, 0.f) : v;
+                    o[((r & 3) + 8 * (r >> 2)) * ld] = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const long g = row0 + rin;
+                    float v = acc[r] + bias;
+                    if (P.relu) v = fmaxf(v, 0.f);
+                    if (n_ok && g < P.rows) P.out[g * P.ld_out + P.col_off + n] = v;
+                }
             }
         }
         __syncthreads();

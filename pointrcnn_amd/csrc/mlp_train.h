@@ -628,6 +628,19 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const TrainWgrad W) {
     }
     // C[i][jj] of block (x, z): input channel kbase + KQ i + x, output channel nbase + NQ jj + z
     float* P = W.part + ((long)blockIdx.x * WR + wr) * T.N * W.K;
+    if (kbase + 32 * KQ <= W.K && nbase + 32 * NQ <= T.N) {
+        // the wave's block lies inside dW: unguarded stores, back to back (with a bounds branch per element the compiler opens every
+        // store with s_waitcnt vmcnt(0), and that counter includes the stores themselves on gfx9)
+#pragma unroll
+        for (int x = 0; x < KQ; x++)
+#pragma unroll
+            for (int z = 0; z < NQ; z++) {
+                float* q = P + (long)(nbase + NQ * j + z) * W.K + kbase + 4 * h * KQ + x;
+#pragma unroll
+                for (int e = 0; e < 16; e++) q[((e & 3) + 8 * (e >> 2)) * KQ] = acc[x][z][e];
+            }
+        return;
+    }
 #pragma unroll
     for (int x = 0; x < KQ; x++)
 #pragma unroll
@@ -781,6 +794,17 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_lds_kernel(const TrainWgra
     }
     float* P = W.part + (long)blockIdx.x * T.N * W.K;
     const int kbase = kt0 + wk * 64, nbase = nt0 + wn * 64;
+    if (kbase + 64 <= W.K && nbase + 64 <= T.N) {        // block inside dW: unguarded stores (see train_wgrad_kernel)
+#pragma unroll
+        for (int x = 0; x < 2; x++)
+#pragma unroll
+            for (int z = 0; z < 2; z++) {
+                float* q = P + (long)(nbase + 2 * j + z) * W.K + kbase + 8 * h + x;
+#pragma unroll
+                for (int e = 0; e < 16; e++) q[((e & 3) + 8 * (e >> 2)) * 2] = acc[x][z][e];
+            }
+        return;
+    }
 #pragma unroll
     for (int x = 0; x < 2; x++)
 #pragma unroll
