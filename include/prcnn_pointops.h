@@ -551,6 +551,12 @@ int prcnn_group_rows_grad(const float* G, int ldG, const int32_t* idx, int B, in
                           prcnn_stream_t stream);
 int prcnn_interp_rows_grad(const float* G, int ldG, const int32_t* idx3, const float* w3, int B, int n, int m, int C, float* dknown,
                            int ld_d, prcnn_stream_t stream);
+/* The same as a gather (no atomics, summed in ascending row order: the result does not depend on scheduling) with a scratch buffer of
+ * >= prcnn_interp_rows_grad_work_bytes(B, n, m) device bytes (0: this shape has no gather form).  dknown is WRITTEN, not accumulated
+ * into, and need not be zeroed.  work == NULL / too small / rows not 16-byte aligned: dknown is cleared and prcnn_interp_rows_grad runs. */
+size_t prcnn_interp_rows_grad_work_bytes(int B, int n, int m);
+int prcnn_interp_rows_grad_ws(const float* G, int ldG, const int32_t* idx3, const float* w3, int B, int n, int m, int C, float* dknown,
+                              int ld_d, void* work, size_t work_bytes, prcnn_stream_t stream);
 
 /* ======================================================================================================
  * RCNN-stage training targets (csrc/proposal_target.hip) -- `train_rcnn.py --train_mode rcnn`.

@@ -106,6 +106,8 @@ SIGNATURES = {
     "prcnn_flat_rows_grad": (_I, [_P, _I, _P, _P, _L, _I, _P, _I, _P]),
     "prcnn_group_rows_grad": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "prcnn_interp_rows_grad": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "prcnn_interp_rows_grad_work_bytes": (_Z, [_I, _I, _I]),
+    "prcnn_interp_rows_grad_ws": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _Z, _P]),
 }
 
 _lib = None

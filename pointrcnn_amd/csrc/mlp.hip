@@ -1004,6 +1004,33 @@ __device__ __forceinline__ void chain_store(const ChainParams& C, f32x16 (&acc)[
         }
 }
 
+// ONE output channel after a hidden layer (the classification head, 128 -> 128 -> 1): the last layer as a dot product on the VALU.
+// On the matrix pipe the single column occupies a whole 32-column block: 4 NB MFMAs per k-block = 4096 pipe cycles per 32 rows for
+// 1/32 of their result -- a fifth of that launch's MFMA time.  The lane already holds its row's 16 NB activations of each half
+// (channel 32 ob + 8 q + 4 h + s), so it is 16 NB multiply-adds and one exchange between the halves.  Shared by every chain variant
+// (bit-identical among them).  wpack: the pack image of the (1, 32 NB) weight, whose row 0 sits at lane 32 h of k-block 4 ob + q.
+template <int NB>
+__device__ __forceinline__ void chain_out1(const ChainParams& C, const f32x16 (&a)[NB], long row, bool valid, int lane, int h) {
+    const MlpParams& P = C.a;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < NB; ob++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 w = ld4(C.wpack1 + ((4 * ob + q) * 64 + h * 32) * 4);
+            s0 = fmaf(a[ob][4 * q + 0], w.x, s0); s1 = fmaf(a[ob][4 * q + 1], w.y, s1);
+            s2 = fmaf(a[ob][4 * q + 2], w.z, s2); s3 = fmaf(a[ob][4 * q + 3], w.w, s3);
+        }
+    float sum = (s0 + s1) + (s2 + s3);
+    sum += __shfl_xor(sum, 32);
+    sum += C.bias1 ? C.bias1[0] : 0.f;
+    if (C.relu1) sum = fmaxf(sum, 0.f);
+    if (valid && h == 0) P.out[row * P.ld_out + P.col_off] = sum;
+}
+template <int NB1, int NB2> __device__ __forceinline__ bool chain_out1_applies(const ChainParams& C) {
+    return NB1 == 1 && NB2 == 0 && C.N1 == 1 && C.a.pool_ns == 0;
+}
+
 template <int MODE, int NB0, int NB1, int NB2>
 __global__ __launch_bounds__(256) void mlp_chain_kernel(const ChainParams Cin) {
     ChainParams C = Cin;
@@ -1062,6 +1089,7 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(const ChainParams Cin) {
     }
     bias_act<NB0>(a0, P.bias, P.relu, h);
     if (NB1 == 0) { chain_store<NB0>(C, a0, P.Nout, row, meta.valid, lane, h); return; }
+    if (chain_out1_applies<NB1, NB2>(C)) { chain_out1<NB0>(C, a0, row, meta.valid, lane, h); return; }
 
     f32x16 a1[NB1 ? NB1 : 1];
     chain_layer<NB0, (NB1 ? NB1 : 1)>(a0, a1, C.wpack1, C.KB1, Ws, wave, lane);
@@ -1278,6 +1306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == MO
         }
     }
     bias_act<NB0>(a0, s_bias[0], P.relu, h);
+    if (chain_out1_applies<NB1, NB2>(C)) { chain_out1<NB0>(C, a0, row, valid, lane, h); return; }
     if constexpr (NB1 == 0) {
         chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
     } else {
@@ -1403,6 +1432,8 @@ __global__ __launch_bounds__(PERS_WAVES * 64) void mlp_chain_pers_kernel(const C
         bias_act<NB0>(a0, P.bias, P.relu, h);
         if constexpr (NB1 == 0) {
             chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
+        } else if (chain_out1_applies<NB1, NB2>(C)) {
+            chain_out1<NB0>(C, a0, row, valid, lane, h);
         } else {
             f32x16 a1[NB1];
             pers_layer<NB0, NB1>(a0, a1, W1, lane);

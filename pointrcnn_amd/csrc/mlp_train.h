@@ -912,6 +912,114 @@ __global__ __launch_bounds__(256) void interp_rows_grad_kernel(const float* __re
 }
 
 
+// The same backward as a GATHER, no atomics: the (row, weight) pairs are first bucketed by the known point they refer to (a
+// counting sort per frame, counters in LDS), then one wave per known point adds up its references -- in ascending row order, so the
+// result does not depend on scheduling -- and writes the row once (dknown need not be zeroed).  181 M float atomics per RPN training
+// step (1.05 ms) become 400 MB of coalesced row reads.
+#define ICSR_THREADS 1024
+#define ICSR_MAX_M 8192
+#define ICSR_SORT_CAP 512                    // references to one known point sorted in LDS (more: taken in bucket order, not repeatable)
+__global__ __launch_bounds__(ICSR_THREADS) void interp_csr_build_kernel(const int32_t* __restrict__ idx3, const float* __restrict__ w3, int n,
+                                                                        int m, int32_t* __restrict__ off_all, int2* __restrict__ ent_all) {
+    __shared__ int cnt[ICSR_MAX_M];
+    __shared__ int wsum[ICSR_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int E = 3 * n;
+    const int32_t* __restrict__ ib = idx3 + (size_t)b * E;
+    const float* __restrict__ wb = w3 + (size_t)b * E;
+    int32_t* __restrict__ off = off_all + (size_t)b * (m + 1);
+    int2* __restrict__ ent = ent_all + (size_t)b * E;
+    for (int i = tid; i < m; i += ICSR_THREADS) cnt[i] = 0;
+    __syncthreads();
+    for (int e0 = tid; e0 < E; e0 += 8 * ICSR_THREADS) {
+        int jv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) jv[u] = ib[min(e0 + u * ICSR_THREADS, E - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (e0 + u * ICSR_THREADS < E) atomicAdd(&cnt[min(max(jv[u], 0), m - 1)], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the m counters: ceil(m / 1024) consecutive counters per thread
+    const int per = (m + ICSR_THREADS - 1) / ICSR_THREADS;
+    const int j0 = tid * per, j1 = min(m, j0 + per);
+    int tsum = 0;
+    for (int jj = j0; jj < j1; jj++) tsum += cnt[jj];
+    int incl = tsum;
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - tsum;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+    for (int jj = j0; jj < j1; jj++) { const int c = cnt[jj]; off[jj] = run; cnt[jj] = run; run += c; }
+    if (tid == ICSR_THREADS - 1) off[m] = E;
+    __syncthreads();
+    for (int e0 = tid; e0 < E; e0 += 8 * ICSR_THREADS) {
+        int jv[8]; float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int e = min(e0 + u * ICSR_THREADS, E - 1); jv[u] = ib[e]; wv[u] = wb[e]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * ICSR_THREADS;
+            if (e < E) {
+                const int pos = atomicAdd(&cnt[min(max(jv[u], 0), m - 1)], 1);
+                ent[pos] = make_int2(e / 3, __float_as_int(wv[u]));      // (row of the frame, weight); rows ascend with e
+            }
+        }
+    }
+}
+
+// one wave per known point; lanes = channel quads (C <= 1024)
+__global__ __launch_bounds__(256) void interp_csr_gather_kernel(const float* __restrict__ G, int ldG, const int32_t* __restrict__ off_all,
+                                                                const int2* __restrict__ ent_all, long total, int n, int m, int C,
+                                                                float* __restrict__ dknown, int ld_d) {
+    __shared__ int2 sl[4][2][ICSR_SORT_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long gj = (long)blockIdx.x * 4 + wave;               // b * m + j
+    if (gj >= total) return;
+    const int b = (int)(gj / m), j = (int)(gj - (long)b * m);
+    const int32_t* off = off_all + (size_t)b * (m + 1);
+    const int2* ent = ent_all + (size_t)b * 3 * n;
+    const int s0 = off[j], len = off[j + 1] - s0;
+    int2* U = sl[wave][0];
+    int2* L = sl[wave][1];
+    const bool sorted = len <= ICSR_SORT_CAP;
+    if (sorted) {
+        // rank by row (a row refers to a known point at most three times; those tie-break on their position in the bucket), then
+        // place by rank.  One wave per list: its LDS operations execute in order, no barrier.
+        for (int k = lane; k < len; k += 64) U[k] = ent[s0 + k];
+        for (int k = lane; k < len; k += 64) {
+            const int2 mine = U[k];
+            int rank = 0;
+            for (int t = 0; t < len; t++) { const int rt = U[t].x; rank += (rt < mine.x || (rt == mine.x && t < k)) ? 1 : 0; }
+            L[rank] = mine;
+        }
+    }
+    const float* Gb = G + (size_t)b * n * ldG;
+    float* d = dknown + ((size_t)b * m + j) * ld_d;
+    for (int c = lane * 4; c < C; c += 256) {                  // (ld and C multiples of 4: host-checked)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = 0; k0 < len; k0 += 4) {                  // four rows requested before the first is added (same order of additions)
+            int2 e[4]; float4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = min(k0 + u, len - 1);
+                e[u] = sorted ? L[k] : ent[s0 + k];
+                g[u] = ld4(Gb + (size_t)e[u].x * ldG + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float w = k0 + u < len ? __int_as_float(e[u].y) : 0.f;
+                if (k0 + u < len) {
+                    acc.x = __fadd_rn(acc.x, __fmul_rn(g[u].x, w)); acc.y = __fadd_rn(acc.y, __fmul_rn(g[u].y, w));
+                    acc.z = __fadd_rn(acc.z, __fmul_rn(g[u].z, w)); acc.w = __fadd_rn(acc.w, __fmul_rn(g[u].w, w));
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(d + c) = acc;
+    }
+}
+
 // ---- padding-free rows for training (the training twin of dedup.hip) -------------------------------------------------------
 // ball_query pads a group that has fewer than nsample neighbours by repeating its first hit; the reference pushes every copy
 // through all layers.  Copies are identical rows, so a group is represented by its DISTINCT rows, the first one carrying the
@@ -1293,6 +1401,36 @@ PRCNN_API int prcnn_group_rows_grad(const float* G, int ldG, const int32_t* idx,
     hipLaunchKernelGGL(group_rows_grad_kernel, dim3(prcnn_divup(groups * ((C + 3) / 4), 256)), dim3(256), 0, (hipStream_t)stream, G, ldG,
                        idx, groups, M, ns, C, N, dfeat, ld_d);
     PRCNN_LAUNCH_CHECK("prcnn_group_rows_grad");
+    return PRCNN_OK;
+}
+
+PRCNN_API size_t prcnn_interp_rows_grad_work_bytes(int B, int n, int m) {
+    if (B <= 0 || n <= 0 || m <= 0 || m > ICSR_MAX_M || (long)n * 3 >= 2147483647L) return 0;
+    return (size_t)B * (((size_t)(m + 1) * 4 + 15) / 16 * 16 + (size_t)n * 3 * 8);
+}
+
+// dknown is WRITTEN (not accumulated into) when the scratch buffer is given; without it: prcnn_interp_rows_grad (atomics into a
+// zeroed dknown)
+PRCNN_API int prcnn_interp_rows_grad_ws(const float* G, int ldG, const int32_t* idx3, const float* w3, int B, int n, int m, int C,
+                                        float* dknown, int ld_d, void* work, size_t work_bytes, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(G && idx3 && w3 && dknown && B >= 0 && n > 0 && m > 0 && C > 0 && ldG >= C && ld_d >= C, "prcnn_interp_rows_grad: bad arguments");
+    if (B == 0) return PRCNN_OK;
+    const size_t need = prcnn_interp_rows_grad_work_bytes(B, n, m);
+    const bool vec = C % 4 == 0 && ldG % 4 == 0 && ld_d % 4 == 0 && aligned16(G) && aligned16(dknown);
+    if (!work || need == 0 || work_bytes < need || C > 1024 || !vec) {
+        hipStream_t s = (hipStream_t)stream;
+        if (hipMemsetAsync(dknown, 0, (size_t)B * m * ld_d * sizeof(float), s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_interp_rows_grad: memset failed");
+        return prcnn_interp_rows_grad(G, ldG, idx3, w3, B, n, m, C, dknown, ld_d, stream);
+    }
+    const size_t off_bytes = ((size_t)(m + 1) * 4 + 15) / 16 * 16;
+    int32_t* off = (int32_t*)work;                                        // B x (m + 1), frames back to back ...
+    int2* ent = (int2*)((char*)work + (size_t)B * off_bytes);             // ... then B x 3n entries
+    // (the offsets of frame b live at off + b * (m + 1): the kernels index them that way; off_bytes only pads the total)
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(interp_csr_build_kernel, dim3(B), dim3(ICSR_THREADS), 0, s, idx3, w3, n, m, off, ent);
+    hipLaunchKernelGGL(interp_csr_gather_kernel, dim3(prcnn_divup((long)B * m, 4)), dim3(256), 0, s, G, ldG, (const int32_t*)off, (const int2*)ent,
+                       (long)B * m, n, m, C, dknown, ld_d);
+    PRCNN_LAUNCH_CHECK("prcnn_interp_rows_grad_ws");
     return PRCNN_OK;
 }
 

@@ -16,6 +16,7 @@ does (momentum, unbiased variance, num_batches_tracked).  No CPU / torch fallbac
 whether a stack takes this path or the composed torch path.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -24,6 +25,7 @@ from . import _cabi, ops
 from .ops import _p, _stream
 
 _F32 = torch.float32
+INTERP_GRAD_GATHER = os.environ.get("PRCNN_INTERP_GRAD_GATHER", "1") != "0"      # A/B switch: 0 = atomics
 MODE = {"plain": 0, "group": 1, "interp": 2}
 
 
@@ -281,9 +283,12 @@ class SharedMLPTrain(torch.autograd.Function):
                 B, n, _ = src.idx3.shape
                 m, C2 = ctx.x_shapes[0][1], ctx.x_shapes[0][2]
                 if ctx.needs_input_grad[3]:
-                    gx0 = torch.zeros((B, m, C2), dtype=_F32, device=dev)
-                    _cabi.check(L.prcnn_interp_rows_grad(_p(gin), ld_gin, _p(src.idx3), _p(src.w3), B, n, m, C2, _p(gx0), C2, _stream()),
-                                "prcnn_interp_rows_grad")
+                    # gather form (references bucketed by known point, summed in row order): written, not accumulated
+                    gx0 = torch.empty((B, m, C2), dtype=_F32, device=dev)
+                    nbytes = L.prcnn_interp_rows_grad_work_bytes(B, n, m) if INTERP_GRAD_GATHER else 0
+                    work = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
+                    _cabi.check(L.prcnn_interp_rows_grad_ws(_p(gin), ld_gin, _p(src.idx3), _p(src.w3), B, n, m, C2, _p(gx0), C2, _p(work), nbytes,
+                                                            _stream()), "prcnn_interp_rows_grad")
                 if ctx.x_shapes[1] is not None and ctx.needs_input_grad[4]:
                     gx1 = gin[:, C2:ctx.K0].reshape(B, n, ctx.K0 - C2)
         ctx.st = ctx.a_dump = ctx.arg = ctx.keep = None          # release the saved activations now

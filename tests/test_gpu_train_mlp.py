@@ -210,6 +210,46 @@ def test_conv1d_head_layer_fused_training_equals_torch(dev):
     _compare_modules(a, b, pooled=False)
 
 
+def test_interp_rows_grad_gather_form_equals_the_atomic_form_and_is_repeatable(dev):
+    """prcnn_interp_rows_grad_ws: references bucketed per known point, summed in ascending row order (bit-repeatable), against the
+    atomic scatter and a float64 reference; a hub referenced by > 256 rows, unreferenced points, m not a multiple of anything"""
+    from pointrcnn_amd import _cabi
+    from pointrcnn_amd.ops import _p, _stream
+    L = _cabi.lib()
+    g = torch.Generator().manual_seed(5)
+    B, n, m, C = 3, 5000, 777, 96
+    idx3 = torch.randint(0, m - 40, (B, n, 3), generator=g, dtype=torch.int32)
+    idx3[0, :450, 1] = 5                                       # a hub (sorted in LDS up to 512 references: repeatable)
+    w3 = torch.rand(B, n, 3, generator=g)
+    G = torch.randn(B * n, C + 4, generator=g)
+    idx3, w3, G = idx3.to(dev), w3.to(dev), G.to(dev)
+    want = torch.zeros(B, m, C, dtype=torch.float64, device=dev)
+    Gv = G[:, :C].view(B, n, C).double()
+    for t in range(3):
+        want.scatter_add_(1, idx3[:, :, t].long().unsqueeze(-1).expand(-1, -1, C), Gv * w3[:, :, t].double().unsqueeze(-1))
+    outs = []
+    for rep in range(2):
+        out = torch.full((B, m, C), float("nan"), device=dev)
+        nbytes = L.prcnn_interp_rows_grad_work_bytes(B, n, m)
+        assert nbytes > 0
+        work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _cabi.check(L.prcnn_interp_rows_grad_ws(_p(G), C + 4, _p(idx3), _p(w3), B, n, m, C, _p(out), C, _p(work), nbytes, _stream()), "ws")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    atom = torch.full((B, m, C), float("nan"), device=dev)
+    _cabi.check(L.prcnn_interp_rows_grad_ws(_p(G), C + 4, _p(idx3), _p(w3), B, n, m, C, _p(atom), C, None, 0, _stream()), "fallback")
+    scale = want.abs().max().item()
+    assert (outs[0].double() - want).abs().max().item() <= 2e-6 * scale and (atom.double() - want).abs().max().item() <= 2e-6 * scale
+    assert (outs[0][:, m - 40:] == 0).all()                    # unreferenced known points: exact zeros, written
+    idx3[1, :1500, 2] = 9                                      # beyond the sort capacity: bucket order, same sum to rounding
+    want[1].zero_()
+    for t in range(3):
+        want[1].scatter_add_(0, idx3[1, :, t].long().unsqueeze(-1).expand(-1, C), Gv[1] * w3[1, :, t].double().unsqueeze(-1))
+    out = torch.empty((B, m, C), device=dev)
+    _cabi.check(L.prcnn_interp_rows_grad_ws(_p(G), C + 4, _p(idx3), _p(w3), B, n, m, C, _p(out), C, _p(work), nbytes, _stream()), "ws")
+    assert (out.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
 def test_head_sequential_on_rows_equals_module_by_module(dev):
     """pt_utils.fused_sequential in training mode (the RPN heads: Conv1d+BN+ReLU -> Dropout -> Conv1d with bias): the rows path
     (one fused node, elementwise dropout, F.linear; output a view whose transpose is contiguous) == running the Sequential
