@@ -39,8 +39,13 @@ struct TrainFwd {
     float* slab_w;
 };
 
-template <int MODE, int WNB>
+// FASTP (plain rows, 16-byte aligned, K a multiple of 4): the chunk loads are unconditional 16-byte loads from clamped addresses (rows
+// past the end are clamped -- never stored or counted --, k-pieces past K re-read the last piece and are zeroed by multiplication), so
+// the four loads of a chunk go out back to back; with the bounds-checked fetch every piece is its own branch and the compiler waits for
+// each load before the next (s_waitcnt vmcnt(0) at the joins).
+template <int MODE, int WNB, bool FASTP = false>
 __global__ __launch_bounds__(MLP_THREADS, ((WNB == 1 && MODE != MODE_INTERP) ? 3 : 2)) void train_fwd_kernel(const TrainFwd T) {
+    static_assert(!FASTP || MODE == MODE_PLAIN, "FASTP is the plain-rows form");
     MlpParams P = T.P;
     P.rows = effective_rows(T.P);
     constexpr int QN = 2 * WNB;
@@ -70,14 +75,22 @@ __global__ __launch_bounds__(MLP_THREADS, ((WNB == 1 && MODE != MODE_INTERP) ? 3
     auto load_chunk = [&](int c) {
         const int k = c * MLP_BK + c4 * 4;
         if (pro) { ps = ld4(T.pro_scale + k); pb = ld4(T.pro_shift + k); }
+        if constexpr (FASTP) {
+            const int kc = min(k, P.K - 4);
 #pragma unroll
-        for (int u = 0; u < 4; u++) fetch<MODE>(P, meta[u], k, ra[u]);
+            for (int u = 0; u < 4; u++) ra[u].a = ld4(P.in + meta[u].off + kc);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) fetch<MODE>(P, meta[u], k, ra[u]);
+        }
     };
     auto store_chunk = [&](int c, int buf) {
         const int k = c * MLP_BK + c4 * 4;
+        const float kz = (FASTP && k >= P.K) ? 0.f : 1.f;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             float4 v = finish<MODE>(P, meta[u], k, ra[u]);
+            if (FASTP) { v.x *= kz; v.y *= kz; v.z *= kz; v.w *= kz; }
             if (pro) {                                    // (scale / shift are zero beyond K: the padding stays zero)
                 v.x = fmaxf(v.x * ps.x + pb.x, 0.f); v.y = fmaxf(v.y * ps.y + pb.y, 0.f);
                 v.z = fmaxf(v.z * ps.z + pb.z, 0.f); v.w = fmaxf(v.w * ps.w + pb.w, 0.f);
@@ -168,13 +181,25 @@ __global__ __launch_bounds__(MLP_THREADS, ((WNB == 1 && MODE != MODE_INTERP) ? 3
         const f32x16& a0 = acc[0][nn];
         const f32x16& a1 = acc[1][nn];
         float s = 0.f;
+        if (cnt == 64 && nb * 32 + 32 <= P.Nout) {       // whole slab x block inside y: unguarded stores, back to back (see layer_epilogue)
+            float* o = P.out + (wrow0 + 4 * h) * P.ld_out + P.col_off + n;
+            const long ld = P.ld_out;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const long g0 = wrow0 + rin, g1 = g0 + 32;
-            s += w0[r] * a0[r] + w1[r] * a1[r];
-            if (n_ok && g0 < P.rows) P.out[g0 * P.ld_out + P.col_off + n] = a0[r];
-            if (n_ok && g1 < P.rows) P.out[g1 * P.ld_out + P.col_off + n] = a1[r];
+            for (int r = 0; r < 16; r++) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                s += w0[r] * a0[r] + w1[r] * a1[r];
+                o[rr * ld] = a0[r];
+                o[(32 + rr) * ld] = a1[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const long g0 = wrow0 + rin, g1 = g0 + 32;
+                s += w0[r] * a0[r] + w1[r] * a1[r];
+                if (n_ok && g0 < P.rows) P.out[g0 * P.ld_out + P.col_off + n] = a0[r];
+                if (n_ok && g1 < P.rows) P.out[g1 * P.ld_out + P.col_off + n] = a1[r];
+            }
         }
         if (T.part) {
             s += __shfl_xor(s, 32);
@@ -409,7 +434,10 @@ struct TrainDgrad {
     int KB, NB, Kin;              // k-blocks over N, n-blocks over Kin
     float* out; int ld_out;
 };
-template <int WNB>
+// POOL as in train_wgrad_lds_kernel (0: G per row; 1: pooled over fixed groups; 2: over the groups of padding-free rows).  The rows a
+// thread stages are the same for every chunk, so their group / slot are looked up once; the chunk loads themselves are unconditional
+// 16-byte loads from clamped addresses (pieces past N zeroed by multiplication).
+template <int WNB, int POOL>
 __global__ __launch_bounds__(MLP_THREADS, (WNB == 1 ? 3 : 2)) void train_dgrad_kernel(const TrainDgrad D) {
     const TrainBwd& T = D.B;
     constexpr int QN = 2 * WNB;
@@ -425,33 +453,45 @@ __global__ __launch_bounds__(MLP_THREADS, (WNB == 1 ? 3 : 2)) void train_dgrad_k
     const int c4 = tid & 7, r0 = tid >> 3;
     const long live = bwd_live_rows(T);
     if (row0 >= live) return;                          // (device-side row count)
-    long grow[4];
+    long grow[4], ggrp[4];
+    int gslot[4];
     float rm[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         grow[u] = row0 + r0 + 32 * u;
         if (grow[u] >= live) grow[u] = live - 1;
         rm[u] = T.mult ? T.mult[grow[u]] : 1.f;
+        if (POOL == 2) { ggrp[u] = T.row_grp[grow[u]]; gslot[u] = (int)(grow[u] - T.seg_off[ggrp[u]]); }
+        else if (POOL == 1) { ggrp[u] = grow[u] / T.pool_ns; gslot[u] = (int)(grow[u] - ggrp[u] * T.pool_ns); }
+        else { ggrp[u] = grow[u]; gslot[u] = 0; }
     }
     float4 rg[4], ry[4], sc, sh, mu, is, c1, c2;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uchar4 rarg[4];
     auto load_chunk = [&](int c) {
-        const int k = c * MLP_BK + c4 * 4;
-        if (k < T.N) {
-            sc = ld4(T.cst + k); sh = ld4(T.cst + T.ld_c + k); mu = ld4(T.cst + 2 * T.ld_c + k); is = ld4(T.cst + 3 * T.ld_c + k);
-            c1 = ld4(T.cst + 4 * T.ld_c + k); c2 = ld4(T.cst + 5 * T.ld_c + k);
+        const int k = min(c * MLP_BK + c4 * 4, T.N - 4);          // (N is a multiple of 4)
+        sc = ld4(T.cst + k); sh = ld4(T.cst + T.ld_c + k); mu = ld4(T.cst + 2 * T.ld_c + k); is = ld4(T.cst + 3 * T.ld_c + k);
+        c1 = ld4(T.cst + 4 * T.ld_c + k); c2 = ld4(T.cst + 5 * T.ld_c + k);
 #pragma unroll
-            for (int u = 0; u < 4; u++) { rg[u] = bwd_G4(T, grow[u], k); ry[u] = ld4(T.y + grow[u] * (long)T.ld_y + k); }
-        } else {
-            sc = sh = mu = is = c1 = c2 = zero4;
-#pragma unroll
-            for (int u = 0; u < 4; u++) { rg[u] = zero4; ry[u] = zero4; }
+        for (int u = 0; u < 4; u++) {
+            rg[u] = ld4(T.G + ggrp[u] * (long)T.ldG + k);
+            if (POOL != 0) rarg[u] = *reinterpret_cast<const uchar4*>(T.arg + ggrp[u] * (long)T.N + k);
+            ry[u] = ld4(T.y + grow[u] * (long)T.ld_y + k);
         }
     };
     auto store_chunk = [&](int c, int buf) {
+        const float kz = (c * MLP_BK + c4 * 4 < T.N) ? 1.f : 0.f;   // pieces past N: zero operand (the weight image re-reads its last k-block there)
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * u) * MLP_ALD + c4 * 4]) = bwd_dy4(rg[u], ry[u], sc, sh, mu, is, c1, c2, rm[u]);
+        for (int u = 0; u < 4; u++) {
+            float4 g = rg[u];
+            if (POOL != 0) {
+                const int sl = gslot[u];
+                g.x = rarg[u].x == sl ? g.x : 0.f; g.y = rarg[u].y == sl ? g.y : 0.f;
+                g.z = rarg[u].z == sl ? g.z : 0.f; g.w = rarg[u].w == sl ? g.w : 0.f;
+            }
+            float4 d = bwd_dy4(g, ry[u], sc, sh, mu, is, c1, c2, rm[u]);
+            d.x *= kz; d.y *= kz; d.z *= kz; d.w *= kz;
+            *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * u) * MLP_ALD + c4 * 4]) = d;
+        }
     };
     f32x16 acc[2][WNB];
 #pragma unroll
@@ -514,6 +554,17 @@ __global__ __launch_bounds__(MLP_THREADS, (WNB == 1 ? 3 : 2)) void train_dgrad_k
         const int nb = nb0 + wn * WNB + nn;
         if (nb >= D.NB) continue;
         const int n = nb * 32 + j;
+        if (wrow0 + 64 <= live && nb * 32 + 32 <= D.Kin) {     // whole block inside the output: unguarded stores (see layer_epilogue)
+            float* o = D.out + (wrow0 + 4 * h) * D.ld_out + n;
+            const long ld = D.ld_out;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                o[rr * ld] = acc[0][nn][r];
+                o[(32 + rr) * ld] = acc[1][nn][r];
+            }
+            continue;
+        }
         if (n >= D.Kin) continue;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -1285,7 +1336,12 @@ PRCNN_API int prcnn_train_stack_fwd(const prcnn_train_src_t* src, const prcnn_tr
         if (wide) hipLaunchKernelGGL((train_fwd_kernel<M, 2>), grid, dim3(MLP_THREADS), 0, s, T);               \
         else hipLaunchKernelGGL((train_fwd_kernel<M, 1>), grid, dim3(MLP_THREADS), 0, s, T);                    \
     } while (0)
-        if (mode == MODE_PLAIN) TRAIN_FWD(MODE_PLAIN);
+        const bool fastp = mode == MODE_PLAIN && P.vec_a && K % 4 == 0 && K >= 4 && P.ld_in % 4 == 0 && aligned16(P.in) &&
+                           (!T.pro_scale || l > 0) && !getenv("PRCNN_TRAIN_FWD_GENERIC");
+        if (fastp) {
+            if (wide) hipLaunchKernelGGL((train_fwd_kernel<MODE_PLAIN, 2, true>), grid, dim3(MLP_THREADS), 0, s, T);
+            else hipLaunchKernelGGL((train_fwd_kernel<MODE_PLAIN, 1, true>), grid, dim3(MLP_THREADS), 0, s, T);
+        } else if (mode == MODE_PLAIN) TRAIN_FWD(MODE_PLAIN);
         else if (mode == MODE_GROUP) TRAIN_FWD(MODE_GROUP);
         else TRAIN_FWD(MODE_INTERP);
 #undef TRAIN_FWD
@@ -1384,8 +1440,15 @@ PRCNN_API int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_tr
         const long dt = prcnn_divup(rows, MLP_BM);
         const bool wide = D.NB >= 4 && dt * prcnn_divup(D.NB, 4) >= 192;
         const dim3 grid((unsigned)dt, prcnn_divup(D.NB, wide ? 4 : 2));
-        if (wide) hipLaunchKernelGGL(train_dgrad_kernel<2>, grid, dim3(MLP_THREADS), 0, s, D);
-        else hipLaunchKernelGGL(train_dgrad_kernel<1>, grid, dim3(MLP_THREADS), 0, s, D);
+#define TRAIN_DGRAD(POOL)                                                                                        \
+    do {                                                                                                         \
+        if (wide) hipLaunchKernelGGL((train_dgrad_kernel<2, POOL>), grid, dim3(MLP_THREADS), 0, s, D);           \
+        else hipLaunchKernelGGL((train_dgrad_kernel<1, POOL>), grid, dim3(MLP_THREADS), 0, s, D);                \
+    } while (0)
+        if (T.pool_ns == 0) TRAIN_DGRAD(0);
+        else if (T.pool_ns > 0) TRAIN_DGRAD(1);
+        else TRAIN_DGRAD(2);
+#undef TRAIN_DGRAD
         G = D.out; ldG = D.ld_out;
     }
     PRCNN_LAUNCH_CHECK("prcnn_train_stack_bwd");
