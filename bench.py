@@ -568,6 +568,8 @@ def run_train(args, dev, rank, world, local_rank, dist):
                   "forward_loss_ms": round(ev[0].elapsed_time(ev[1]), 3), "backward_ms": round(ev[1].elapsed_time(ev[2]), 3),
                   "clip_optimizer_ms": round(ev[2].elapsed_time(ev[3]), 3),
                   "train_fused": os.environ.get("PRCNN_TRAIN_FUSED", "1") != "0",
+                  "padding_free_rows": os.environ.get("PRCNN_TRAIN_DEDUP", "1") != "0",
+                  "host_syncs_per_step": 0 if tf.SYNC_FREE_LOSS else 4,
                   "fps_prefetch": prefetch,
                   ("ms_per_step_without_fps_prefetch" if prefetch else "ms_per_step_with_fps_prefetch"):
                       round(1e3 * elapsed_other / min(args.steps, 10), 3),
@@ -575,9 +577,12 @@ def run_train(args, dev, rank, world, local_rank, dist):
                                        "side stream during step k, as a prefetching data loader allows; every step still does the same work",
                   "note": "every SharedMLP stack (gather / interpolation, 1x1 convs, training-mode BatchNorm, ReLU, max-pool) forward AND "
                           "backward is this package's hand-written kernels (csrc/mlp_train.h: MFMA forward / dgrad / wgrad, BatchNorm "
-                          "reductions), one library call per stack and direction; torch runs the two bias-only output convolutions of "
-                          "the heads, dropout, the loss and the optimizer.  PRCNN_TRAIN_FUSED=0 = the composed torch path (MIOpen / "
-                          "rocBLAS convolutions + BatchNorm) for A/B"}}
+                          "reductions), one library call per stack and direction, on the padding-free rows of every group (distinct "
+                          "rows + multiplicities: exact); the heads run on channels-last rows end to end; torch runs the two bias-only "
+                          "output layers (library GEMMs, weight gradient split over row chunks), dropout, the loss (masked means: no "
+                          "device-to-host read inside the step) and the optimizer.  A/B switches: PRCNN_TRAIN_FUSED=0 the composed "
+                          "torch path (MIOpen / rocBLAS convolutions + BatchNorm), PRCNN_TRAIN_DEDUP=0 nsample-padded rows, "
+                          "PRCNN_SYNC_FREE_LOSS=0 the reference's select-then-mean loss"}}
 
 
 def main():

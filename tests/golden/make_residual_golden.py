@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/residual_ref.npz: the two places where the kernels' arithmetic is NOT the reference's, pinned on
-adversarial inputs by the reference's OWN native code (oracle/_ref = lib/utils/iou3d/src/*, lib/utils/roipool3d/src/*
-compiled in place).  Needs /root/reference; the fixture travels to the GPU box.
+"""Generate tests/golden/residual_ref.npz: adversarial inputs for the decisions that sit within rounding distance of a threshold,
+pinned by the reference's OWN native code (oracle/_ref = lib/utils/iou3d/src/*, lib/utils/roipool3d/src/* compiled in place).
+Needs /root/reference; the fixture travels to the GPU box.
 
-The kernels evaluate a box's cos / sin in double and round once (and order polygon vertices without atan2); the reference
-calls float cosf / sinf (and atan2).  glibc's cosf differs from the correctly rounded value for 1.3 % of angles, by one ulp.
-That can only matter where a decision sits within rounding distance of its threshold -- exactly the inputs built here:
+The reference calls float cosf / sinf / atan2 on the box angle.  Rounds 1-2 of the kernels evaluated cos / sin in double, rounded
+once, and ordered polygon vertices without atan2 (oracle trig_mode 1): glibc's cosf differs from the correctly rounded value for
+1.3 % of angles, by one ulp, which flipped a handful of the decisions built here.  Since round 3 the kernels restate glibc's
+routines operation by operation (csrc/ref_trig.h, oracle trig_mode 2) and reproduce EVERY reference column of this fixture bit
+for bit; the trig_mode-1 columns are kept as the record of what the old arithmetic gave.
 
   nms_*    box pairs bisected to within 1e-5 of the IoU threshold (3 x 150 pairs), and 12 whole NMS problems seeded with ten
-           such pairs each: the reference's IoUs and keep sets, next to what the kernels' arithmetic (oracle trig_mode 1) gives;
+           such pairs each: the reference's IoUs and keep sets (and the legacy arithmetic's);
   pib_*    point-in-box: points exactly ON box faces / one and two ulps either side / on the 10 m gate, for boxes at
            ry in {0, +-pi/2, +-pi} (on-grid coordinates: the face points are exact) and at random angles (face points
-           rounded to fp32): the reference's flags and pooled tensors, next to the kernels' arithmetic.
+           rounded to fp32): the reference's flags and pooled tensors (and the legacy arithmetic's).
 
-The GPU tests (tests/test_gpu_parity_residuals.py) assert that the HIP kernels reproduce the trig_mode-1 columns bit for bit and
-the reference columns wherever the two agree, and that the SET of disagreeing entries is exactly the one recorded here -- a
-kernel change cannot silently widen the budget.  Seeds are fixed; re-running reproduces the file byte for byte.
+tests/test_gpu_parity_residuals.py asserts equality of the HIP kernels with the reference columns, and that the legacy columns
+still differ from them in exactly the recorded entries (the fixture has not lost its teeth).  Seeds are fixed; re-running
+reproduces the file byte for byte.
 """
 import os
 import sys
