@@ -511,7 +511,9 @@ typedef struct prcnn_train_src {
  *   wpack           prcnn_wpack_floats(Nout, K) floats: the forward weight image (written by forward);
  *   wpack_t         prcnn_wpack_floats(Kin, Nout) floats: the dgrad weight image, Kin = K (K - 3 for a grouped layer 0, whose
  *                   xyz columns carry no gradient); NULL when the layer's input takes no gradient (layer 0 only);
- *   dW (Nout, K) in torch's channel order, dgamma, dbeta (Nout): written by backward. */
+ *   dW (Nout, K) in torch's channel order, dgamma, dbeta (Nout): written by backward.
+ * gamma == NULL: a layer WITHOUT normalisation -- Conv (bias in `beta`, or NULL) -> ReLU, the form of the RCNN stage
+ * (cfg.RCNN.USE_BN = False, lib/net/rcnn_net.py:24-60): no statistics, dbeta receives the bias gradient, dgamma / running_* unused. */
 typedef struct prcnn_train_layer {
     int Nout;
     const float* W; const float* gamma; const float* beta;
@@ -545,6 +547,12 @@ int prcnn_train_group_rows(const int32_t* idx, const float* new_xyz, int B, int 
                            int32_t* rows_dev, int32_t* ridx, float* rnx, float* mult, int32_t* row_grp, prcnn_stream_t stream);
 int prcnn_flat_rows_grad(const float* G, int ldG, const int32_t* ridx, const int32_t* rows_dev, int64_t max_rows, int C, float* dfeat,
                          int ld_d, prcnn_stream_t stream);
+/* ... as a gather (no atomics, summed in ascending row order): frame b's rows are those of its M groups (seg_off from
+ * prcnn_train_group_rows); dfeat is WRITTEN.  Scratch: >= prcnn_flat_rows_grad_work_bytes(B, N, max_rows) device bytes (0: no gather
+ * form for this shape); work == NULL / too small: dfeat is cleared and prcnn_flat_rows_grad runs. */
+size_t prcnn_flat_rows_grad_work_bytes(int B, int N, int64_t max_rows);
+int prcnn_flat_rows_grad_ws(const float* G, int ldG, const int32_t* ridx, const int32_t* rows_dev, int64_t max_rows, int C, float* dfeat,
+                            int ld_d, const int32_t* seg_off, int B, int N, int M, void* work, size_t work_bytes, prcnn_stream_t stream);
 /* backward of the gathers on channels-last rows: dfeat (B, N, ld_d) += scatter of G ((B, M, ns) rows, C channels) through idx;
  * dknown (B, m, ld_d) += w3-weighted scatter of G ((B, n) rows) through idx3.  Outputs pre-zeroed by the caller. */
 int prcnn_group_rows_grad(const float* G, int ldG, const int32_t* idx, int B, int M, int ns, int C, int N, float* dfeat, int ld_d,

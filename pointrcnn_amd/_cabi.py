@@ -104,6 +104,8 @@ SIGNATURES = {
     "prcnn_proposal_target_sample": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prcnn_train_group_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prcnn_flat_rows_grad": (_I, [_P, _I, _P, _P, _L, _I, _P, _I, _P]),
+    "prcnn_flat_rows_grad_work_bytes": (_Z, [_I, _I, _L]),
+    "prcnn_flat_rows_grad_ws": (_I, [_P, _I, _P, _P, _L, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P]),
     "prcnn_group_rows_grad": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "prcnn_interp_rows_grad": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "prcnn_interp_rows_grad_work_bytes": (_Z, [_I, _I, _I]),

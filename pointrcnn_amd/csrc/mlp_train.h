@@ -401,16 +401,25 @@ __global__ __launch_bounds__(256) void bn_bwd_chunk_kernel(const float* __restri
         chunk[((long)blockIdx.y * 2 + 1) * N + n] = (s2[0][c] + s2[1][c]) + (s2[2][c] + s2[3][c]);
     }
 }
+// no_bn: a layer WITHOUT normalisation (Conv with bias -> ReLU, the RCNN stage: cfg.RCNN.USE_BN = False): the column sum of dyhat is
+// the bias gradient and dy = dyhat (constants 4, 5 stay zero)
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ chunk, long rows, int N, float* __restrict__ cst,
-                                                             int ld_c, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                             int ld_c, float* __restrict__ dgamma, float* __restrict__ dbeta, int no_bn) {
     const int n = blockIdx.x * 64 + threadIdx.x;
     if (n >= N) return;
     double A = 0.0, Bq = 0.0;
     for (int t = 0; t < BN_CHUNKS; t++) { A += chunk[((long)t * 2 + 0) * N + n]; Bq += chunk[((long)t * 2 + 1) * N + n]; }
     if (dbeta) dbeta[n] = (float)A;
     if (dgamma) dgamma[n] = (float)Bq;
-    cst[4 * ld_c + n] = (float)(A / (double)rows);
-    cst[5 * ld_c + n] = (float)(Bq / (double)rows);
+    cst[4 * ld_c + n] = no_bn ? 0.f : (float)(A / (double)rows);
+    cst[5 * ld_c + n] = no_bn ? 0.f : (float)(Bq / (double)rows);
+}
+// constants of a layer without normalisation: scale 1, shift = bias (or 0), mean 0, invstd 1
+__global__ __launch_bounds__(64) void nobn_cst_kernel(const float* __restrict__ bias, int N, float* __restrict__ cst, int ld_c) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    cst[n] = 1.f; cst[ld_c + n] = bias ? bias[n] : 0.f; cst[2 * ld_c + n] = 0.f; cst[3 * ld_c + n] = 1.f;
+    cst[4 * ld_c + n] = 0.f; cst[5 * ld_c + n] = 0.f;
 }
 
 // dy for 4 consecutive channels: scale * (dyhat - c1 - xhat * c2)
@@ -970,25 +979,36 @@ __global__ __launch_bounds__(256) void interp_rows_grad_kernel(const float* __re
 #define ICSR_THREADS 1024
 #define ICSR_MAX_M 8192
 #define ICSR_SORT_CAP 512                    // references to one known point sorted in LDS (more: taken in bucket order, not repeatable)
-__global__ __launch_bounds__(ICSR_THREADS) void interp_csr_build_kernel(const int32_t* __restrict__ idx3, const float* __restrict__ w3, int n,
-                                                                        int m, int32_t* __restrict__ off_all, int2* __restrict__ ent_all) {
+// Frames of the reference list: frame b owns rows [b n, (b + 1) n) (row_off == NULL: the interpolation's (B, n, refs) triples), or --
+// padding-free rows -- the rows of its groups, [row_off[b gpf], row_off[(b + 1) gpf]) with the list's live length *rows_dev as
+// the last bound.  A row holds `refs` references; a reference is (idx[e] - b idx_sub) in [0, m), weight w[e] (NULL: 1).
+struct CsrFrames { const int32_t* row_off; int gpf; const int32_t* rows_dev; int n; int B; };
+__global__ __launch_bounds__(ICSR_THREADS) void interp_csr_build_kernel(const int32_t* __restrict__ idx, const float* __restrict__ w, int refs,
+                                                                        int m, int idx_sub, int32_t* __restrict__ off_all,
+                                                                        int2* __restrict__ ent, CsrFrames F) {
     __shared__ int cnt[ICSR_MAX_M];
     __shared__ int wsum[ICSR_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int E = 3 * n;
-    const int32_t* __restrict__ ib = idx3 + (size_t)b * E;
-    const float* __restrict__ wb = w3 + (size_t)b * E;
+    long r0, r1;
+    if (F.row_off) {
+        r0 = F.row_off[(long)b * F.gpf];
+        r1 = b + 1 < F.B ? (long)F.row_off[(long)(b + 1) * F.gpf] : (long)*F.rows_dev;
+    } else {
+        r0 = (long)b * F.n; r1 = r0 + F.n;
+    }
+    const int e0 = (int)(r0 * refs), E = (int)((r1 - r0) * refs);
+    const int32_t* __restrict__ ib = idx + e0;
+    const int base = b * idx_sub;
     int32_t* __restrict__ off = off_all + (size_t)b * (m + 1);
-    int2* __restrict__ ent = ent_all + (size_t)b * E;
     for (int i = tid; i < m; i += ICSR_THREADS) cnt[i] = 0;
     __syncthreads();
-    for (int e0 = tid; e0 < E; e0 += 8 * ICSR_THREADS) {
+    for (int q0 = tid; q0 < E; q0 += 8 * ICSR_THREADS) {
         int jv[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) jv[u] = ib[min(e0 + u * ICSR_THREADS, E - 1)];
+        for (int u = 0; u < 8; u++) jv[u] = ib[min(q0 + u * ICSR_THREADS, E - 1)] - base;
 #pragma unroll
         for (int u = 0; u < 8; u++)
-            if (e0 + u * ICSR_THREADS < E) atomicAdd(&cnt[min(max(jv[u], 0), m - 1)], 1);
+            if (q0 + u * ICSR_THREADS < E) atomicAdd(&cnt[min(max(jv[u], 0), m - 1)], 1);
     }
     __syncthreads();
     // exclusive scan over the m counters: ceil(m / 1024) consecutive counters per thread
@@ -1000,21 +1020,21 @@ __global__ __launch_bounds__(ICSR_THREADS) void interp_csr_build_kernel(const in
     for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int run = incl - tsum;
-    for (int w = 0; w < wave; w++) run += wsum[w];
+    int run = e0 + incl - tsum;                           // absolute positions in the entry array
+    for (int wv = 0; wv < wave; wv++) run += wsum[wv];
     for (int jj = j0; jj < j1; jj++) { const int c = cnt[jj]; off[jj] = run; cnt[jj] = run; run += c; }
-    if (tid == ICSR_THREADS - 1) off[m] = E;
+    if (tid == ICSR_THREADS - 1) off[m] = e0 + E;
     __syncthreads();
-    for (int e0 = tid; e0 < E; e0 += 8 * ICSR_THREADS) {
+    for (int q0 = tid; q0 < E; q0 += 8 * ICSR_THREADS) {
         int jv[8]; float wv[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int e = min(e0 + u * ICSR_THREADS, E - 1); jv[u] = ib[e]; wv[u] = wb[e]; }
+        for (int u = 0; u < 8; u++) { const int q = min(q0 + u * ICSR_THREADS, E - 1); jv[u] = ib[q] - base; wv[u] = w ? w[e0 + q] : 1.f; }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int e = e0 + u * ICSR_THREADS;
-            if (e < E) {
+            const int q = q0 + u * ICSR_THREADS;
+            if (q < E) {
                 const int pos = atomicAdd(&cnt[min(max(jv[u], 0), m - 1)], 1);
-                ent[pos] = make_int2(e / 3, __float_as_int(wv[u]));      // (row of the frame, weight); rows ascend with e
+                ent[pos] = make_int2((e0 + q) / refs, __float_as_int(wv[u]));      // (row of the whole list, weight); rows ascend with q
             }
         }
     }
@@ -1022,7 +1042,7 @@ __global__ __launch_bounds__(ICSR_THREADS) void interp_csr_build_kernel(const in
 
 // one wave per known point; lanes = channel quads (C <= 1024)
 __global__ __launch_bounds__(256) void interp_csr_gather_kernel(const float* __restrict__ G, int ldG, const int32_t* __restrict__ off_all,
-                                                                const int2* __restrict__ ent_all, long total, int n, int m, int C,
+                                                                const int2* __restrict__ ent, long total, int m, int C,
                                                                 float* __restrict__ dknown, int ld_d) {
     __shared__ int2 sl[4][2][ICSR_SORT_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1030,7 +1050,6 @@ __global__ __launch_bounds__(256) void interp_csr_gather_kernel(const float* __r
     if (gj >= total) return;
     const int b = (int)(gj / m), j = (int)(gj - (long)b * m);
     const int32_t* off = off_all + (size_t)b * (m + 1);
-    const int2* ent = ent_all + (size_t)b * 3 * n;
     const int s0 = off[j], len = off[j + 1] - s0;
     int2* U = sl[wave][0];
     int2* L = sl[wave][1];
@@ -1046,7 +1065,7 @@ __global__ __launch_bounds__(256) void interp_csr_gather_kernel(const float* __r
             L[rank] = mine;
         }
     }
-    const float* Gb = G + (size_t)b * n * ldG;
+    const float* Gb = G;                                       // entries carry rows of the whole list
     float* d = dknown + ((size_t)b * m + j) * ld_d;
     for (int c = lane * 4; c < C; c += 256) {                  // (ld and C multiples of 4: host-checked)
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1326,7 +1345,8 @@ PRCNN_API int prcnn_train_stack_fwd(const prcnn_train_src_t* src, const prcnn_tr
         MlpParams& P = T.P;
         P.wpack = L[l].wpack; P.Nout = N; P.out = L[l].y; P.ld_out = N; P.col_off = 0;
         P.KB = (K + 7) / 8; P.NB = (N + 31) / 32;
-        T.part = W.part; T.ld_part = N;
+        const bool no_bn = L[l].gamma == nullptr;              // Conv (+ bias in `beta`) -> ReLU, no normalisation
+        T.part = no_bn ? nullptr : W.part; T.ld_part = N;
         const long tiles = prcnn_divup(rows, MLP_BM);
         const bool wide = P.NB >= 4 && tiles * prcnn_divup(P.NB, 4) >= 192;
         const dim3 grid((unsigned)tiles, prcnn_divup(P.NB, wide ? 4 : 2));
@@ -1345,10 +1365,14 @@ PRCNN_API int prcnn_train_stack_fwd(const prcnn_train_src_t* src, const prcnn_tr
         else if (mode == MODE_GROUP) TRAIN_FWD(MODE_GROUP);
         else TRAIN_FWD(MODE_INTERP);
 #undef TRAIN_FWD
-        hipLaunchKernelGGL(bn_chunk_kernel, dim3(prcnn_divup(N, 64), BN_CHUNKS), dim3(256), 0, s, W.part, N, rows, flat ? src->rows_dev : nullptr,
-                           flat ? W.slab_w : nullptr, N, W.chunk);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(prcnn_divup(N, 64)), dim3(64), 0, s, W.chunk, norm_rows, N, L[l].gamma, L[l].beta, L[l].eps,
-                           L[l].momentum, L[l].running_mean, L[l].running_var, L[l].cst, L[l].ld_c);
+        if (no_bn) {
+            hipLaunchKernelGGL(nobn_cst_kernel, dim3(prcnn_divup(N, 64)), dim3(64), 0, s, L[l].beta, N, L[l].cst, L[l].ld_c);
+        } else {
+            hipLaunchKernelGGL(bn_chunk_kernel, dim3(prcnn_divup(N, 64), BN_CHUNKS), dim3(256), 0, s, W.part, N, rows, flat ? src->rows_dev : nullptr,
+                               flat ? W.slab_w : nullptr, N, W.chunk);
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3(prcnn_divup(N, 64)), dim3(64), 0, s, W.chunk, norm_rows, N, L[l].gamma, L[l].beta, L[l].eps,
+                               L[l].momentum, L[l].running_mean, L[l].running_var, L[l].cst, L[l].ld_c);
+        }
     }
     const int N = L[nl - 1].Nout;
     const long groups = flat ? src->groups : rows / ns;
@@ -1391,7 +1415,8 @@ PRCNN_API int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_tr
     int ldG = ld_gout;
     for (int l = nl - 1; l >= 0; l--) {
         const int N = L[l].Nout, K = l == 0 ? src->K : L[l - 1].Nout;
-        PRCNN_REQUIRE(L[l].dW && L[l].dgamma && L[l].dbeta, "prcnn_train_stack_bwd: layer %d: null gradient outputs", l);
+        PRCNN_REQUIRE(L[l].dW && (L[l].gamma == nullptr || L[l].dgamma) && (L[l].beta == nullptr || L[l].dbeta),
+                      "prcnn_train_stack_bwd: layer %d: null gradient outputs", l);
         TrainBwd T;
         T.rows = rows; T.N = N; T.G = G; T.ldG = ldG;
         T.arg = (l == nl - 1 && ns) ? arg : nullptr; T.pool_ns = (l == nl - 1) ? ns : 0;
@@ -1404,7 +1429,7 @@ PRCNN_API int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_tr
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)tiles, prcnn_divup(N, 64)), dim3(256), 0, s, T, W.part, ldp);
         hipLaunchKernelGGL(bn_bwd_chunk_kernel, dim3(prcnn_divup(N, 64), BN_CHUNKS), dim3(256), 0, s, W.part, ldp, tiles, T.rows_dev, N, W.chunk);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(prcnn_divup(N, 64)), dim3(64), 0, s, W.chunk, norm_rows, N, L[l].cst, L[l].ld_c, L[l].dgamma,
-                           L[l].dbeta);
+                           L[l].dbeta, L[l].gamma == nullptr ? 1 : 0);
         // wgrad
         TrainWgrad Wg = {};
         Wg.B = T; Wg.K = K; Wg.part = W.wpart;
@@ -1490,9 +1515,10 @@ PRCNN_API int prcnn_interp_rows_grad_ws(const float* G, int ldG, const int32_t* 
     int2* ent = (int2*)((char*)work + (size_t)B * off_bytes);             // ... then B x 3n entries
     // (the offsets of frame b live at off + b * (m + 1): the kernels index them that way; off_bytes only pads the total)
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(interp_csr_build_kernel, dim3(B), dim3(ICSR_THREADS), 0, s, idx3, w3, n, m, off, ent);
+    CsrFrames F = {nullptr, 0, nullptr, n, B};
+    hipLaunchKernelGGL(interp_csr_build_kernel, dim3(B), dim3(ICSR_THREADS), 0, s, idx3, w3, 3, m, 0, off, ent, F);
     hipLaunchKernelGGL(interp_csr_gather_kernel, dim3(prcnn_divup((long)B * m, 4)), dim3(256), 0, s, G, ldG, (const int32_t*)off, (const int2*)ent,
-                       (long)B * m, n, m, C, dknown, ld_d);
+                       (long)B * m, m, C, dknown, ld_d);
     PRCNN_LAUNCH_CHECK("prcnn_interp_rows_grad_ws");
     return PRCNN_OK;
 }
@@ -1523,6 +1549,35 @@ PRCNN_API int prcnn_train_group_rows(const int32_t* idx, const float* new_xyz, i
     hipLaunchKernelGGL(train_group_fill_kernel, dim3(prcnn_divup(groups, 256)), dim3(256), 0, s, idx, new_xyz, groups, M, ns, N, off, ridx, rnx,
                        mult, row_grp);
     PRCNN_LAUNCH_CHECK("prcnn_train_group_rows");
+    return PRCNN_OK;
+}
+
+PRCNN_API size_t prcnn_flat_rows_grad_work_bytes(int B, int N, int64_t max_rows) {
+    if (B <= 0 || N <= 0 || N > ICSR_MAX_M || max_rows <= 0 || max_rows >= 2147483647L) return 0;
+    return ((size_t)B * (N + 1) * 4 + 15) / 16 * 16 + (size_t)max_rows * 8;
+}
+
+// The scatter of padding-free rows' gradients as a gather (no atomics, repeatable): the rows of frame b are those of its M groups
+// (seg_off from prcnn_train_group_rows); dfeat (B * N rows) is WRITTEN, not accumulated into.  work NULL / too small / N beyond the
+// LDS counters / rows not 16-byte aligned: dfeat is cleared and prcnn_flat_rows_grad runs.
+PRCNN_API int prcnn_flat_rows_grad_ws(const float* G, int ldG, const int32_t* ridx, const int32_t* rows_dev, int64_t max_rows, int C, float* dfeat,
+                                      int ld_d, const int32_t* seg_off, int B, int N, int M, void* work, size_t work_bytes, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(G && ridx && rows_dev && dfeat && seg_off && max_rows >= 0 && C > 0 && ldG >= C && ld_d >= C && B > 0 && N > 0 && M > 0,
+                  "prcnn_flat_rows_grad_ws: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = prcnn_flat_rows_grad_work_bytes(B, N, max_rows);
+    const bool vec = C % 4 == 0 && ldG % 4 == 0 && ld_d % 4 == 0 && aligned16(G) && aligned16(dfeat);
+    if (!work || need == 0 || work_bytes < need || C > 1024 || !vec) {
+        if (hipMemsetAsync(dfeat, 0, (size_t)B * N * ld_d * sizeof(float), s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_flat_rows_grad: memset failed");
+        return prcnn_flat_rows_grad(G, ldG, ridx, rows_dev, max_rows, C, dfeat, ld_d, stream);
+    }
+    int32_t* off = (int32_t*)work;
+    int2* ent = (int2*)((char*)work + ((size_t)B * (N + 1) * 4 + 15) / 16 * 16);
+    CsrFrames F = {seg_off, M, rows_dev, 0, B};
+    hipLaunchKernelGGL(interp_csr_build_kernel, dim3(B), dim3(ICSR_THREADS), 0, s, ridx, (const float*)nullptr, 1, N, N, off, ent, F);
+    hipLaunchKernelGGL(interp_csr_gather_kernel, dim3(prcnn_divup((long)B * N, 4)), dim3(256), 0, s, G, ldG, (const int32_t*)off, (const int2*)ent,
+                       (long)B * N, N, C, dfeat, ld_d);
+    PRCNN_LAUNCH_CHECK("prcnn_flat_rows_grad_ws");
     return PRCNN_OK;
 }
 

@@ -132,8 +132,12 @@ class _PointnetSAModuleBase(nn.Module):
 
     # ---- fused training path ------------------------------------------------------------------
     def _train_ok(self, xyz, features):
-        if not TRAIN_FUSED or not train_mlp.usable(xyz, features) or self.pool_method != "max_pool" or self.npoint is None:
+        if not TRAIN_FUSED or not train_mlp.usable(xyz, features) or self.pool_method != "max_pool":
             return False
+        if self.npoint is None:         # GroupAll (the RCNN stage's last level): one group of all N points, no centring
+            g = self.groupers[0]
+            return len(self.groupers) == 1 and isinstance(g, pointnet2_utils.GroupAll) and g.use_xyz and features is not None \
+                and xyz.shape[1] <= 255 and train_mlp.stack_ok(self.mlps[0].layers())
         for g, m in zip(self.groupers, self.mlps):
             if not isinstance(g, pointnet2_utils.QueryAndGroup) or not g.use_xyz or g.nsample > 255 or not train_mlp.stack_ok(m.layers()):
                 return False
@@ -144,6 +148,14 @@ class _PointnetSAModuleBase(nn.Module):
         node over the channels-last features (train_mlp.SharedMLPTrain)"""
         xyz = xyz.contiguous()
         B = xyz.shape[0]
+        if self.npoint is None:
+            # GroupAll: rows [feat | xyz - 0] of every point, one group per frame (pointnet2_utils.GroupAll: xyz channels first, no
+            # centring), max over the N points
+            N = xyz.shape[1]
+            idx = torch.arange(N, dtype=torch.int32, device=xyz.device).view(1, 1, N).expand(B, 1, N).contiguous()
+            src = train_mlp.Source("group", xyz=xyz, new_xyz=torch.zeros((B, 1, 3), dtype=xyz.dtype, device=xyz.device), idx=idx)
+            out = train_mlp.run_stack(self.mlps[0].layers(), src, _channels_last(features), None, pool_ns=N)
+            return None, out.view(B, 1, -1).transpose(1, 2)
         with torch.no_grad():
             if new_xyz is None:
                 new_xyz = ops.gather_rows(xyz, ops.furthest_point_sample(xyz, self.npoint))

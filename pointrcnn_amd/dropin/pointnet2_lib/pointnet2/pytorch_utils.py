@@ -364,6 +364,16 @@ class SharedMLP(nn.Sequential):
     def forward(self, x):
         if _inference_input(x) and self.fusable():
             return run_conv_stack(self.layers(), x)
+        if torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[3] == 1:
+            # training on a (B, C, N, 1) "image" of per-point rows (rcnn_net.py:160-166 xyz_up_layer / merge_down_layer): the whole
+            # stack as one hand-written autograd node on channels-last rows
+            from pointrcnn_amd import train_mlp
+            from . import pointnet2_modules
+            if pointnet2_modules.TRAIN_FUSED and train_mlp.stack_ok(self.layers()):
+                B, C, N, _ = x.shape
+                rows = _rows_view(x.squeeze(3).permute(0, 2, 1)).reshape(B * N, C)
+                y = train_mlp.run_stack(self.layers(), train_mlp.Source("plain"), rows)
+                return y.view(B, N, -1).permute(0, 2, 1).unsqueeze(3)
         return super().forward(x)
 
 

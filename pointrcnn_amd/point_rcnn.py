@@ -27,6 +27,8 @@ class PointRCNN(nn.Module):
     def forward(self, input_data):
         output = {}
         with torch.no_grad():                                                     # point_rcnn.py:30-52 (RPN.FIXED)
+            if self.training:
+                self.rpn.eval()                                                   # :31-32: a fixed RPN stays in eval mode
             rpn_output = self.rpn(input_data)
             output.update(rpn_output)
             rpn_cls, rpn_reg = rpn_output["rpn_cls"], rpn_output["rpn_reg"]
@@ -39,6 +41,8 @@ class PointRCNN(nn.Module):
             output["rois"], output["roi_scores_raw"], output["seg_result"] = rois, roi_scores_raw, seg_mask
         rcnn_input_info = {"rpn_xyz": backbone_xyz, "rpn_features": backbone_features.permute((0, 2, 1)),
                            "seg_mask": seg_mask, "roi_boxes3d": rois, "pts_depth": pts_depth}
+        if self.training:
+            rcnn_input_info["gt_boxes3d"] = input_data["gt_boxes3d"]              # point_rcnn.py:59-60
         output.update(self.rcnn_net(rcnn_input_info))
         return output
 

@@ -48,7 +48,26 @@ class RCNNConfig:
     LOC_BIN_SIZE = 0.5
     NUM_HEAD_BIN = 9
     LOC_Y_BY_BIN = False
+    LOC_Y_SCOPE = 0.5
+    LOC_Y_BIN_SIZE = 0.25
+    SIZE_RES_ON_ROI = False
     NMS_THRESH = 0.1
+    # training (tools/cfgs/default.yaml:111-126 + AUG_DATA / AUG_ROT_RANGE of the root)
+    LOSS_CLS = "BinaryCrossEntropy"
+    FOCAL_ALPHA = [0.25, 0.75]
+    FOCAL_GAMMA = 2.0
+    ROI_SAMPLE_JIT = True
+    ROI_PER_IMAGE = 64
+    FG_RATIO = 0.5
+    HARD_BG_RATIO = 0.8
+    REG_FG_THRESH = 0.55
+    CLS_FG_THRESH = 0.6
+    CLS_BG_THRESH = 0.45
+    CLS_BG_THRESH_LO = 0.05
+    ROI_FG_AUG_TIMES = 10
+    REG_AUG_METHOD = "multiple"
+    AUG_DATA = True
+    AUG_ROT_RANGE = 18
 
 
 def enlarge_box3d(boxes3d, extra_width):
@@ -120,6 +139,8 @@ class RCNNNet(nn.Module):
                 layers.insert(1, nn.Dropout(cfg.DP_RATIO))
             return nn.Sequential(*layers)
 
+        from .proposal_target_layer import ProposalTargetLayer
+        self.proposal_target_layer = ProposalTargetLayer(cfg)                    # rcnn_net.py:78 (ROI_SAMPLE_JIT, training only)
         self.cls_layer = head(cfg.CLS_FC, cls_channel)
         per_loc_bin_num = int(cfg.LOC_SCOPE / cfg.LOC_BIN_SIZE) * 2
         reg_channel = per_loc_bin_num * 4 + cfg.NUM_HEAD_BIN * 2 + 3 + 1
@@ -204,9 +225,19 @@ class RCNNNet(nn.Module):
         return {"rcnn_cls": rcnn_cls, "rcnn_reg": rcnn_reg, "pooled_empty_flag": empty}
 
     def forward(self, input_data):
-        if self._fused_ok(input_data):
+        target_dict = None
+        if self.training and self.cfg.ROI_SAMPLE_JIT:
+            # rcnn_net.py:120-126: RoI sampling, noise augmentation, pooling, canonical transform, labels (device sampler:
+            # proposal_target_layer.py) -- no gradient; the network below trains on its (B * 64, 512, 3 + C') rows
+            with torch.no_grad():
+                target_dict = self.proposal_target_layer(input_data)
+            pts_input = torch.cat((target_dict["sampled_pts"], target_dict["pts_feature"]), dim=2)
+            target_dict["pts_input"] = pts_input
+            empty = None
+        elif self._fused_ok(input_data):
             return self._forward_fused(input_data)
-        pts_input, empty = self.pool_rois(input_data)
+        else:
+            pts_input, empty = self.pool_rois(input_data)
         xyz = pts_input[..., 0:3].contiguous()
         c = self.rcnn_input_channel
         xyz_input = pts_input[..., 0:c].transpose(1, 2).unsqueeze(3)
@@ -220,4 +251,7 @@ class RCNNNet(nn.Module):
             l_features.append(li_features)
         rcnn_cls = pt_utils.fused_sequential(self.cls_layer, l_features[-1]).transpose(1, 2).contiguous().squeeze(1)
         rcnn_reg = pt_utils.fused_sequential(self.reg_layer, l_features[-1]).transpose(1, 2).contiguous().squeeze(1)
-        return {"rcnn_cls": rcnn_cls, "rcnn_reg": rcnn_reg, "pooled_empty_flag": empty, "pts_input": pts_input}
+        ret = {"rcnn_cls": rcnn_cls, "rcnn_reg": rcnn_reg, "pooled_empty_flag": empty, "pts_input": pts_input}
+        if target_dict is not None:
+            ret.update(target_dict)                                              # rcnn_net.py:186-188
+        return ret

@@ -34,17 +34,21 @@ def _up(x, m):
 
 
 def stack_ok(mods):
-    """True when every layer of a pt_utils conv stack is Conv(1x1, bias=False) -> BatchNorm(training, affine, running stats,
-    momentum) -> ReLU on CUDA fp32 -- what the kernels implement."""
+    """True when every layer of a pt_utils conv stack is one of the two forms the kernels implement, on CUDA fp32:
+    Conv(1x1, bias=False) -> BatchNorm(training, affine, running stats, momentum) -> ReLU, or -- the RCNN stage, USE_BN False --
+    Conv(1x1, with or without bias) -> ReLU."""
     from pointnet2_lib.pointnet2 import pytorch_utils as pt
     for m in mods:
         if not isinstance(m, pt._ConvBase) or not m._prcnn_fusable:
             return False
         conv, bn, act = m._parts()
-        if bn is None or act is None or conv.bias is not None or not bn.training:
+        if act is None or not isinstance(act, nn.ReLU):
             return False
-        if not bn.affine or not bn.track_running_stats or bn.momentum is None:
-            return False
+        if bn is not None:
+            if conv.bias is not None or not bn.training:
+                return False
+            if not bn.affine or not bn.track_running_stats or bn.momentum is None:
+                return False
         if any(k != 1 for k in conv.kernel_size) or any(s != 1 for s in conv.stride) or any(p != 0 for p in conv.padding):
             return False
         if not conv.weight.is_cuda or conv.weight.dtype != _F32 or conv.out_channels % 4:
@@ -172,13 +176,14 @@ class _Stack:
         yo = co = wo = go = 0
         self.grad_views = []
         for l in range(nl):
-            W, gamma, beta = params[3 * l: 3 * l + 3]
+            W, gamma, beta = params[3 * l: 3 * l + 3]           # gamma None: no normalisation, beta = the conv bias (or None)
             bn, Ly = bns[l], self.layers[l]
-            if not (W.is_contiguous() and gamma.is_contiguous() and beta.is_contiguous()):
+            if not all(t is None or t.is_contiguous() for t in (W, gamma, beta)):
                 raise RuntimeError("SharedMLP parameters must be contiguous")
             Ly.Nout, Ly.W, Ly.gamma, Ly.beta = nout[l], _p(W), _p(gamma), _p(beta)
-            Ly.eps, Ly.momentum = float(bn.eps), float(bn.momentum)
-            Ly.running_mean, Ly.running_var = _p(bn.running_mean), _p(bn.running_var)
+            if bn is not None:
+                Ly.eps, Ly.momentum = float(bn.eps), float(bn.momentum)
+                Ly.running_mean, Ly.running_var = _p(bn.running_mean), _p(bn.running_var)
             Ly.y = self.ybuf.data_ptr() + 4 * yo
             yo += rows * nout[l]
             Ly.cst, Ly.ld_c = self.cbuf.data_ptr() + 4 * co, ld_c[l]
@@ -190,8 +195,8 @@ class _Stack:
             n, k = nout[l], ks[l]
             dW, dg, db = self.gbuf[go: go + n * k], self.gbuf[go + n * k: go + n * k + n], self.gbuf[go + n * k + n: go + n * k + 2 * n]
             go += gsz[l]
-            Ly.dW, Ly.dgamma, Ly.dbeta = _p(dW), _p(dg), _p(db)
-            self.grad_views.append((dW, dg, db))
+            Ly.dW, Ly.dgamma, Ly.dbeta = _p(dW), (_p(dg) if gamma is not None else None), (_p(db) if beta is not None else None)
+            self.grad_views.append((dW, dg if gamma is not None else None, db if beta is not None else None))
 
     def work(self, K0, backward, dev):
         nbytes = _cabi.lib().prcnn_train_stack_work_bytes(self.rows, self.layers, self.nl, K0, 1 if backward else 0)
@@ -237,7 +242,8 @@ class SharedMLPTrain(torch.autograd.Function):
             _cabi.check(L.prcnn_train_stack_fwd(ctypes.byref(S), st.layers, nl, ns, _p(a_dump), ld_dump, _p(out), N, 0, _p(arg),
                                                 _aligned_ptr(work), nbytes, _stream()), "prcnn_train_stack_fwd")
             for bn in bns:
-                bn.num_batches_tracked += 1
+                if bn is not None:
+                    bn.num_batches_tracked += 1
         ctx.src, ctx.S, ctx.st, ctx.ns, ctx.K0, ctx.kin0, ctx.rows = src, S, st, ns, K0, kin0, rows
         ctx.a_dump, ctx.ld_dump, ctx.arg = a_dump, ld_dump, arg
         ctx.x_shapes = (None if x0 is None else tuple(x0.shape), None if x1 is None else tuple(x1.shape))
@@ -264,16 +270,19 @@ class SharedMLPTrain(torch.autograd.Function):
         params = ctx.keep[2]
         for l in range(st.nl):
             dW, dg, db = st.grad_views[l]
-            grads += [dW.view_as(params[3 * l]), dg, db]
+            grads += [dW.view_as(params[3 * l]), dg, db]      # (None for the parameters a layer does not have)
         gx0 = gx1 = None
         if need_x:
             if src.mode == "plain":
                 gx0 = gin[:, :ctx.K0]
             elif src.mode == "group" and getattr(src, "rows", None) is not None:
                 gr, C = src.rows, ctx.kin0
-                gx0 = torch.zeros((gr.B, gr.N, C), dtype=_F32, device=dev)
-                _cabi.check(L.prcnn_flat_rows_grad(_p(gin), ld_gin, _p(gr.ridx), _p(gr.rows_dev), gr.max_rows, C, _p(gx0), C, _stream()),
-                            "prcnn_flat_rows_grad")
+                # gather form (rows bucketed by source point, summed in row order): written, not accumulated
+                gx0 = torch.empty((gr.B, gr.N, C), dtype=_F32, device=dev)
+                nbytes = L.prcnn_flat_rows_grad_work_bytes(gr.B, gr.N, gr.max_rows) if INTERP_GRAD_GATHER else 0
+                work = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
+                _cabi.check(L.prcnn_flat_rows_grad_ws(_p(gin), ld_gin, _p(gr.ridx), _p(gr.rows_dev), gr.max_rows, C, _p(gx0), C, _p(gr.off),
+                                                      gr.B, gr.N, gr.M, _p(work), nbytes, _stream()), "prcnn_flat_rows_grad")
             elif src.mode == "group":
                 B, M, ns = src.idx.shape
                 N0, C = src.xyz.shape[1], ctx.kin0
@@ -300,7 +309,7 @@ def run_stack(mods, src, x0, x1=None, pool_ns=0):
     params, bns = [], []
     for m in mods:
         conv, bn, _ = m._parts()
-        params += [conv.weight, bn.weight, bn.bias]
+        params += [conv.weight, bn.weight, bn.bias] if bn is not None else [conv.weight, None, conv.bias]
         bns.append(bn)
     return SharedMLPTrain.apply(src, bns, pool_ns, x0, x1, *params)
 

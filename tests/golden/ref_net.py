@@ -137,3 +137,71 @@ def reference_rpn_loss(rpn_cls, rpn_reg, label, reg_label, loss_cls="SigmoidFoca
     cfg.RPN.LOSS_CLS = "SigmoidFocalLoss"
     gz = lambda t: np.zeros(tuple(t.shape), np.float32) if t.grad is None else t.grad.numpy()      # noqa: E731 (no fg: reg unused)
     return float(ret.loss.item()), dict(ret.tb_dict), gz(cls_t), gz(reg_t)
+
+
+def rcnn_loss_case(seed, R=128, nfg=40, nign=16):
+    """seeded RCNN-stage network outputs and ProposalTargetLayer-style targets: (rcnn_cls (R,1), rcnn_reg (R,46), cls_label (R) in
+    {-1,0,1}, reg_valid_mask (R), roi_boxes3d (R,7), gt_of_rois (R,7) in the RoI's canonical frame)"""
+    r = np.random.default_rng(seed)
+    rcnn_cls = r.normal(0, 2, (R, 1)).astype(np.float32)
+    rcnn_reg = r.normal(0, 1, (R, 46)).astype(np.float32)
+    cls_label = np.zeros((R,), np.int64)
+    reg_valid = np.zeros((R,), np.int64)
+    order = r.permutation(R)
+    fg, ign = order[:nfg], order[nfg:nfg + nign]
+    cls_label[fg] = 1
+    cls_label[ign] = -1
+    reg_valid[fg] = 1
+    reg_valid[ign[: nign // 2]] = 1                      # IoU in (0.55, 0.6): regressed but ignored by the classifier
+    rois = np.zeros((R, 7), np.float32)
+    rois[:, 3:6] = r.uniform(0.8, 1.2, (R, 3)) * [1.52563191462, 1.62856739989, 3.88311640418]
+    rois[:, 6] = r.uniform(-np.pi, np.pi, R)
+    gt = np.zeros((R, 7), np.float32)
+    gt[:, 0:3] = r.uniform(-1.4, 1.4, (R, 3)) * [1, 0.3, 1]
+    gt[:, 3:6] = r.uniform(0.8, 1.2, (R, 3)) * [1.52563191462, 1.62856739989, 3.88311640418]
+    gt[:, 6] = r.uniform(-np.pi / 3, np.pi / 3, R)
+    return rcnn_cls, rcnn_reg, cls_label, reg_valid, rois, gt
+
+
+def reference_rcnn_loss(rcnn_cls, rcnn_reg, cls_label, reg_valid, rois, gt, loss_cls="BinaryCrossEntropy"):
+    """the reference's own get_rcnn_loss (train_functions.py:122-214, through model_fn with cfg.RPN.ENABLED = False) on given
+    network outputs and targets: -> loss value, tb_dict, d loss / d rcnn_cls, d loss / d rcnn_reg"""
+    import cpu_ops
+    ns = load()
+    cfg = ns.cfg
+    keep = (cfg.RPN.ENABLED, cfg.RCNN.ENABLED, cfg.RCNN.LOSS_CLS)
+    cfg.RPN.ENABLED, cfg.RCNN.ENABLED, cfg.RCNN.LOSS_CLS = False, True, loss_cls
+    import lib.utils.loss_utils as loss_utils
+    cls_t = torch.from_numpy(rcnn_cls).requires_grad_(True)
+    reg_t = torch.from_numpy(rcnn_reg).requires_grad_(True)
+
+    class FakeRCNN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.cls_loss_func = (loss_utils.SigmoidFocalClassificationLoss(alpha=cfg.RCNN.FOCAL_ALPHA[0], gamma=cfg.RCNN.FOCAL_GAMMA)
+                                  if loss_cls == "SigmoidFocalLoss" else torch.nn.functional.binary_cross_entropy)
+
+    class FakeModel(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.rcnn_net = FakeRCNN()
+
+        def forward(self, input_data):
+            return {"rcnn_cls": cls_t, "rcnn_reg": reg_t, "cls_label": torch.from_numpy(cls_label), "reg_valid_mask": torch.from_numpy(reg_valid),
+                    "roi_boxes3d": torch.from_numpy(rois), "gt_of_rois": torch.from_numpy(gt),
+                    "pts_input": torch.zeros((rcnn_cls.shape[0], 4, 3))}
+
+    # torch >= 1.? rejects binary_cross_entropy targets outside [0, 1]; the reference (torch 1.0) passes its ignore label -1 and
+    # masks those entries afterwards (train_functions.py:159-161).  Clamping the target changes only the masked entries.
+    F = torch.nn.functional
+    orig_bce = F.binary_cross_entropy
+    F.binary_cross_entropy = lambda inp, target, *a, **kw: orig_bce(inp, target.clamp(0, 1), *a, **kw)
+    try:
+        with cpu_ops.cuda_is_cpu():
+            ret = ns.train_functions.model_joint_fn_decorator()(FakeModel(), {"pts_input": np.zeros((1, 4, 3), np.float32)})
+            ret.loss.backward()
+    finally:
+        F.binary_cross_entropy = orig_bce
+        cfg.RPN.ENABLED, cfg.RCNN.ENABLED, cfg.RCNN.LOSS_CLS = keep
+    gz = lambda t: np.zeros(tuple(t.shape), np.float32) if t.grad is None else t.grad.numpy()      # noqa: E731
+    return float(ret.loss.item()), dict(ret.tb_dict), gz(cls_t), gz(reg_t)

@@ -250,6 +250,41 @@ def test_interp_rows_grad_gather_form_equals_the_atomic_form_and_is_repeatable(d
     assert (out.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
 
 
+def test_flat_rows_grad_gather_form_equals_the_atomic_form_and_is_repeatable(dev):
+    """prcnn_flat_rows_grad_ws (gradient of the padding-free rows' gather: rows bucketed by source point, frames delimited by their
+    groups' first rows on the device) against the atomic scatter and a float64 reference"""
+    from pointrcnn_amd import _cabi, ops, train_mlp
+    from pointrcnn_amd.ops import _p, _stream
+    L = _cabi.lib()
+    g = torch.Generator().manual_seed(9)
+    B, N, M, ns, C = 3, 900, 70, 16, 40
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    new_xyz = xyz[:, :M].contiguous()
+    idx = ops.ball_query(0.12, ns, xyz, new_xyz)
+    rows = train_mlp.GroupRows(idx, new_xyz, N)
+    live = int(rows.rows_dev.item())
+    assert 0 < live < B * M * ns
+    G = torch.randn(rows.max_rows, C + 4, generator=g).to(dev)
+    want = torch.zeros(B * N, C, dtype=torch.float64, device=dev)
+    want.index_add_(0, rows.ridx[:live].long(), G[:live, :C].double())
+    nbytes = L.prcnn_flat_rows_grad_work_bytes(B, N, rows.max_rows)
+    assert nbytes > 0
+    outs = []
+    for rep in range(2):
+        out = torch.full((B, N, C), float("nan"), device=dev)
+        work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _cabi.check(L.prcnn_flat_rows_grad_ws(_p(G), C + 4, _p(rows.ridx), _p(rows.rows_dev), rows.max_rows, C, _p(out), C, _p(rows.off),
+                                              B, N, M, _p(work), nbytes, _stream()), "ws")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    atom = torch.full((B, N, C), float("nan"), device=dev)
+    _cabi.check(L.prcnn_flat_rows_grad_ws(_p(G), C + 4, _p(rows.ridx), _p(rows.rows_dev), rows.max_rows, C, _p(atom), C, _p(rows.off),
+                                          B, N, M, None, 0, _stream()), "fallback")
+    scale = want.abs().max().item()
+    assert (outs[0].view(-1, C).double() - want).abs().max().item() <= 2e-6 * scale
+    assert (atom.view(-1, C).double() - want).abs().max().item() <= 2e-6 * scale
+
+
 def test_head_sequential_on_rows_equals_module_by_module(dev):
     """pt_utils.fused_sequential in training mode (the RPN heads: Conv1d+BN+ReLU -> Dropout -> Conv1d with bias): the rows path
     (one fused node, elementwise dropout, F.linear; output a view whose transpose is contiguous) == running the Sequential
@@ -286,12 +321,14 @@ def test_head_sequential_on_rows_equals_module_by_module(dev):
 
 
 def test_eval_mode_and_unsupported_layers_keep_their_paths(dev):
-    """BatchNorm in eval mode / a layer without BatchNorm is not this path's business: stack_ok says no, modules fall back"""
+    """BatchNorm in eval mode / a layer without activation / odd channel counts are not this path's business: stack_ok says no,
+    modules fall back.  (Conv + bias -> ReLU WITHOUT BatchNorm is covered since the RCNN stage trains on it: test_gpu_train_rcnn.py)"""
     import pointrcnn_amd
     pointrcnn_amd.install()
     from pointrcnn_amd import train_mlp
     from pointnet2_lib.pointnet2 import pytorch_utils as pt
     a = pt.Conv1d(16, 16, bn=True).to(dev)
     assert train_mlp.stack_ok([a.train()]) and not train_mlp.stack_ok([a.eval()])
-    assert not train_mlp.stack_ok([pt.Conv1d(16, 16, bn=False).to(dev).train()])
+    assert train_mlp.stack_ok([pt.Conv1d(16, 16, bn=False).to(dev).train()])
+    assert not train_mlp.stack_ok([pt.Conv1d(16, 16, bn=False, activation=None).to(dev).train()])
     assert not train_mlp.stack_ok([pt.Conv1d(16, 1, bn=True).to(dev).train()])            # channel count not a multiple of 4

@@ -9,6 +9,8 @@ cp $R/bench_streams1.json profiles/${T}_final_bench_streams1.json
 cp $R/bench_raw_input.json profiles/${T}_final_bench_raw_input.json
 cp $R/bench_rcnn.json profiles/${T}_final_bench_rcnn.json
 cp $R/bench_train.json profiles/${T}_final_bench_train.json
+cp $R/bench_train_rcnn.json profiles/${T}_final_bench_train_rcnn.json
+cp $R/kernel_stats_train_rcnn.txt profiles/${T}_final_kernel_stats_train_rcnn.txt
 cp $R/bench_config5_rpn.json profiles/${T}_final_bench_config5_rpn.json
 cp $R/kernel_stats.txt profiles/${T}_final_kernel_stats.txt
 cp $R/kernel_stats_streams1.txt profiles/${T}_final_kernel_stats_streams1.txt

@@ -20,10 +20,13 @@ python bench.py --streams 1 --no-cpu-baseline --no-variants > $O/bench_streams1.
 python bench.py --input raw --no-variants > $O/bench_raw_input.json 2>> $O/bench_default.err
 python bench.py --workload rcnn > $O/bench_rcnn.json 2>> $O/bench_default.err
 python bench.py --workload train > $O/bench_train.json 2>> $O/bench_default.err
+python bench.py --workload train-rcnn > $O/bench_train_rcnn.json 2>> $O/bench_default.err
 python bench.py --npoints 65536 --batch 8 --steps 64 --no-cpu-baseline --no-variants > $O/bench_config5_rpn.json 2>> $O/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python bench.py --no-cpu-baseline --no-roofline --no-variants > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-cpu-baseline --no-roofline --no-variants --streams 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python bench.py --workload train --steps 16 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktr -- python bench.py --workload train-rcnn --steps 16 > /dev/null 2>&1
+python profiles/summarize_rocprof.py $O/ktr "python bench.py --workload train-rcnn --steps 16 (RCNN-stage training step, bs4, eager, fused training path)" > $O/kernel_stats_train_rcnn.txt
 python -m pointrcnn_amd.opbench > $O/opbench_raw.jsonl 2> $O/opbench.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/op_FETCH_SIZE -- python -m pointrcnn_amd.opbench > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/op_WRITE_SIZE -- python -m pointrcnn_amd.opbench > /dev/null 2>&1
