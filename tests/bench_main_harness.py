@@ -118,6 +118,7 @@ class _Model:
 
 bench.InferenceBench = StubBench
 bench.run_train = _stub_train
+bench.run_train_rcnn = _stub_train
 from pointrcnn_amd import rpn  # noqa: E402
 
 rpn.RPN = lambda *a, **k: _Model()

@@ -33,7 +33,7 @@ def _json_lines(out):
     return [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
 
 
-@pytest.mark.parametrize("workload", ["rpn", "train"])
+@pytest.mark.parametrize("workload", ["rpn", "train", "train-rcnn"])
 def test_main_under_torch_distributed_run(workload):
     """launched exactly as the driver launches it: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py"""
     steps = 4
@@ -48,7 +48,7 @@ def test_main_under_torch_distributed_run(workload):
     assert line["n_gpus"] == 2 and line["steps"] == steps and line["scaling"] == "weak"
     # the slow rank (rank 1: 10 ms per step) sets the time; value = frames of BOTH ranks over it
     assert line["ms_per_step"] >= 9.5
-    batch = 32 if workload == "rpn" else 16
+    batch = {"rpn": 32, "train": 16, "train-rcnn": 4}[workload]
     assert abs(line["value"] - batch * 2 * 1e3 / line["ms_per_step"]) <= 0.01 * line["value"]
     if workload == "rpn":
         assert line["config"]["parallelism"] == "frames sharded, dp2" and line["value_h2d_inclusive"] > 0 and line["value_latency_mode"] > 0

@@ -213,6 +213,67 @@ def test_every_cls_loss_is_the_global_batch_loss_under_data_parallel():
                 assert np.abs(got / 2 - want).max() <= 1e-6 * max(1.0, float(np.abs(want).max())), (loss_cls, r)
 
 
+def _rcnn_case(world, R=96, seed=8):
+    g = torch.Generator().manual_seed(seed)
+    cls_o = torch.randn(world * R, 1, generator=g)
+    reg_o = torch.randn(world * R, 46, generator=g) * 0.3
+    label = (torch.rand(world * R, generator=g) < 0.3).long() - (torch.rand(world * R, generator=g) < 0.1).long()
+    valid = ((label > 0) | (torch.rand(world * R, generator=g) < 0.05)).long()
+    valid[R: R + R // 2] = 0                                          # ragged counts; with empty_rank: no regression target at all there
+    rois = torch.zeros(world * R, 7)
+    rois[:, 3:6] = torch.rand(world * R, 3, generator=g) + 1.0
+    gt = torch.randn(world * R, 7, generator=g) * 0.4
+    gt[:, 3:6] = gt[:, 3:6].abs() + 1.0
+    return cls_o, reg_o, label, valid, rois, gt
+
+
+def _rcnn_ret(case, sl, leaf=True):
+    a, b = case[0][sl].clone().requires_grad_(leaf), case[1][sl].clone().requires_grad_(leaf)
+    return a, b, {"rcnn_cls": a, "rcnn_reg": b, "cls_label": case[2][sl], "reg_valid_mask": case[3][sl], "roi_boxes3d": case[4][sl],
+                  "gt_of_rois": case[5][sl]}
+
+
+def _rcnn_loss_worker(rank, world, port, q, bn_eval, empty_rank, loss_cls):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pointrcnn_amd import train_functions as tf
+    from pointrcnn_amd.rcnn import RCNNConfig
+    case = _rcnn_case(world)
+    if empty_rank is not None:
+        R = case[0].shape[0] // world
+        case[3][empty_rank * R:(empty_rank + 1) * R] = 0
+    R = case[0].shape[0] // world
+    a, b, ret = _rcnn_ret(case, slice(rank * R, (rank + 1) * R))
+    loss = tf.get_rcnn_loss(ret, type("C", (RCNNConfig,), {"LOSS_CLS": loss_cls}), dist=dist)
+    loss.backward()
+    q.put((rank, float(loss.item()), a.grad.numpy(), b.grad.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rcnn_loss_is_the_global_batch_loss_under_data_parallel():
+    """get_rcnn_loss with `dist`: world x the DDP-averaged gradient is the gradient of the one loss the reference's DataParallel
+    computes over the gathered RoIs -- BCE and focal classification, ragged foreground counts, a rank without any regression
+    target (which must still take part in the count exchange and keep its regression head in the graph)"""
+    from pointrcnn_amd import train_functions as tf
+    from pointrcnn_amd.rcnn import RCNNConfig
+    for loss_cls, empty_rank in (("BinaryCrossEntropy", None), ("SigmoidFocalLoss", None), ("BinaryCrossEntropy", 1)):
+        res = _run(True, empty_rank, target=_rcnn_loss_worker, extra=(loss_cls,))
+        case = _rcnn_case(2)
+        R = case[0].shape[0] // 2
+        if empty_rank is not None:
+            case[3][empty_rank * R:(empty_rank + 1) * R] = 0
+        a, b, ret = _rcnn_ret(case, slice(None))
+        loss = tf.get_rcnn_loss(ret, type("C", (RCNNConfig,), {"LOSS_CLS": loss_cls}))
+        loss.backward()
+        assert abs(0.5 * (res[0][1] + res[1][1]) - float(loss.item())) <= 1e-5 * max(1.0, abs(float(loss.item()))), loss_cls
+        for r in range(2):
+            for got, want in ((res[r][2], a.grad[r * R:(r + 1) * R].numpy()), (res[r][3], b.grad[r * R:(r + 1) * R].numpy())):
+                assert np.abs(got / 2 - want).max() <= 1e-6 * max(1.0, float(np.abs(want).max())), (loss_cls, r)
+
+
 def test_ddp_with_training_mode_batchnorm_keeps_ranks_in_sync():
     res = _run(bn_eval=False)
     assert np.array_equal(res[0][3], res[1][3])
