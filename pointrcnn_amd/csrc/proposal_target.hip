@@ -75,6 +75,57 @@ struct PtParams {
     int32_t* counts; int32_t* status;                                 // (B,4) (B)
 };
 
+// :96-99: the ground truth of a frame without its all-zero rows at the end
+__device__ __forceinline__ int pt_live_gt(const float* gt, int G, int gt_cols) {
+    int ng = G;
+    while (ng > 0) {
+        float s = 0.f;
+        for (int c = 0; c < gt_cols; c++) s = add(s, gt[(size_t)(ng - 1) * gt_cols + c]);
+        if (s != 0.f) break;
+        ng--;
+    }
+    return ng;
+}
+
+// Phase 1 on the whole chip: max IoU and its ground-truth box for every RoI (iou3d_utils.boxes_iou3d_gpu + torch.max over dim 1,
+// :100-101).  The sampler kernel below is one workgroup per frame -- its branching is per frame -- and 512 RoIs x 12 boxes of
+// rotated-polygon clipping on one workgroup was 400 of its 650 us.  Here a wave takes 4 RoIs, 16 lanes per RoI over the ground truth;
+// lanes combine to the FIRST maximum (torch.max's rule: ties -> lowest index; a NaN only counts in column 0, as in the sequential
+// `j == 0 || v > best` scan of the sampler's own reference).
+__global__ __launch_bounds__(64) void pt_overlaps_kernel(const PtParams P) {
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const int i = blockIdx.x * 4 + (lane >> 4), sub = lane & 15;
+    const float* gt = P.gt + (size_t)b * P.G * P.gt_cols;
+    const int ng = pt_live_gt(gt, P.G, P.gt_cols);
+    if (ng == 0) return;
+    const bool live = i < P.M;
+    float a[7];
+    for (int c = 0; c < 7; c++) a[c] = P.roi[((size_t)b * P.M + (live ? i : 0)) * 7 + c];
+    float best = -INFINITY, v0 = 0.f;
+    int arg = 0x7fffffff;
+    for (int j = sub; j < ng; j += 16) {
+        float g[7], bev[5];
+        RBox rb;
+        for (int c = 0; c < 7; c++) g[c] = gt[(size_t)j * P.gt_cols + c];
+        bev_of(g, bev);
+        make_rbox(bev, rb);
+        const float v = iou3d_pair(a, g, rb);
+        if (j == 0) v0 = v;
+        if (v > best || (v == best && j < arg)) { best = v; arg = j; }
+    }
+    for (int o = 8; o > 0; o >>= 1) {                   // within the RoI's 16 lanes
+        const float ob = __shfl_xor(best, o);
+        const int oa = __shfl_xor(arg, o);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    v0 = __shfl(v0, lane & ~15);
+    if (v0 != v0 || arg == 0x7fffffff) { best = v0; arg = 0; }      // NaN in column 0 / nothing but NaNs: what the sequential scan keeps
+    if (live && sub == 0) {
+        P.max_overlaps[(size_t)b * P.M + i] = best;
+        P.gt_assignment[(size_t)b * P.M + i] = arg;
+    }
+}
+
 __global__ __launch_bounds__(PT_THREADS) void proposal_target_kernel(const PtParams P) {
     extern __shared__ int lds_i[];                    // fg[M], hard[M], easy[M] candidate lists, then keys[M]
     __shared__ RBox s_gt[PT_MAX_GT];
@@ -94,13 +145,7 @@ __global__ __launch_bounds__(PT_THREADS) void proposal_target_kernel(const PtPar
     const float fg_thresh = fminf(P.reg_fg, P.cls_fg);
 
     if (tid == 0) {                                   // :96-99: drop the all-zero rows at the end of the ground truth
-        int ng = P.G;
-        while (ng > 0) {
-            float s = 0.f;
-            for (int c = 0; c < P.gt_cols; c++) s = add(s, gt[(size_t)(ng - 1) * P.gt_cols + c]);
-            if (s != 0.f) break;
-            ng--;
-        }
+        const int ng = pt_live_gt(gt, P.G, P.gt_cols);
         s_ng = ng;
         P.status[b] = ng == 0 ? 2 : 0;
         for (int q = 0; q < 4; q++) P.counts[b * 4 + q] = 0;
@@ -119,20 +164,8 @@ __global__ __launch_bounds__(PT_THREADS) void proposal_target_kernel(const PtPar
         make_rbox(bev, s_gt[j]);
     }
     __syncthreads();
-    // phase 1
-    for (int i = tid; i < P.M; i += PT_THREADS) {
-        float a[7];
-        for (int c = 0; c < 7; c++) a[c] = roi[(size_t)i * 7 + c];
-        float best = 0.f;
-        int arg = 0;
-        for (int j = 0; j < ng; j++) {
-            const float v = iou3d_pair(a, s_gtraw[j], s_gt[j]);
-            if (j == 0 || v > best) { best = v; arg = j; }            // torch.max: first maximum
-        }
-        P.max_overlaps[(size_t)b * P.M + i] = best;
-        P.gt_assignment[(size_t)b * P.M + i] = arg;
-        keys[i] = pt_rand(P.seed, 10, (unsigned)b, (unsigned)i);
-    }
+    // phase 1 (max_overlaps / gt_assignment): pt_overlaps_kernel, launched before this one
+    for (int i = tid; i < P.M; i += PT_THREADS) keys[i] = pt_rand(P.seed, 10, (unsigned)b, (unsigned)i);
     __syncthreads();
     // phase 2: candidate lists in RoI order (one thread: M <= a few thousand), then the reference's four cases
     if (tid == 0) {
@@ -242,6 +275,7 @@ PRCNN_API int prcnn_proposal_target_sample(const float* roi_boxes3d, const float
     P.aug_times = aug_times; P.aug_method = aug_method; P.seed = seed;
     P.rois = rois; P.gt_of_rois = gt_of_rois; P.roi_iou = roi_iou; P.src = src; P.max_overlaps = max_overlaps;
     P.gt_assignment = gt_assignment; P.counts = counts; P.status = status;
+    hipLaunchKernelGGL(pt_overlaps_kernel, dim3(prcnn_divup(M, 4), B), dim3(64), 0, (hipStream_t)stream, P);
     hipLaunchKernelGGL(proposal_target_kernel, dim3(B), dim3(PT_THREADS), (size_t)M * 4 * sizeof(int), (hipStream_t)stream, P);
     PRCNN_LAUNCH_CHECK("prcnn_proposal_target_sample");
     return PRCNN_OK;
