@@ -411,13 +411,17 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
         }
         __syncthreads();
         FPS_T(unsigned long long t2 = __builtin_readcyclecounter(); t_wait += t2 - t1;)
+        // the winner's coordinates without a second, dependent LDS round trip: every lane reads one word of the 16 x 4 slot table
+        // (lane = 4 * wave + component, 256 contiguous bytes) TOGETHER with the cell, and the winner's three words are picked out of
+        // the wave's registers by lane index
+        const float sv = (&slot[j & 1][0][0])[lane];
         const unsigned long long kwin = cell[cb];
         const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)kwin);
         const int gorig = (int)(0xFFFFFFFu - (klo >> 4));
-        const float* r = slot[j & 1][klo & 15u];
-        x0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r[0])));
-        y0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r[1])));
-        z0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r[2])));
+        const int wl = (int)(klo & 15u) * 4;
+        x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl));
+        y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl + 1));
+        z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl + 2));
         cb = cb == 2 ? 0 : cb + 1;
         if (tid == 0) out[j] = gorig;
         FPS_T(t0 = __builtin_readcyclecounter(); t_red += t0 - t2;)
