@@ -83,3 +83,36 @@ def write_detections(pred_boxes3d, raw_scores, keep, num, sample_ids, calibs, im
         k = keep[b, : int(num[b])].astype(np.int64)
         out.append(save_kitti_format(sample_ids[b], calibs[b], pred[b][k], kitti_output_dir, raw[b][k], img_shapes[b], class_name))
     return out
+
+
+# ---- RPN feature dumps (the on-disk hand-over between `eval_rcnn.py --save_rpn_feature` and `--train_mode rcnn` / `rcnn_offline`) ----
+_FEATURE_SUFFIX = {"features": "", "xyz": "_xyz", "seg": "_seg", "intensity": "_intensity", "rawscore": "_rawscore"}
+
+
+def rpn_feature_files(kitti_features_dir, sample_id):
+    """the five .npy paths of a frame, by content (eval_rcnn.py:101-109, kitti_rcnn_dataset.py:139-150)"""
+    return {k: os.path.join(kitti_features_dir, "%06d%s.npy" % (int(sample_id), sfx)) for k, sfx in _FEATURE_SUFFIX.items()}
+
+
+def save_rpn_features(seg_result, rpn_scores_raw, pts_features, backbone_xyz, backbone_features, kitti_features_dir, sample_id):
+    """one frame's RPN outputs as the reference dumps them (eval_rcnn.py:97-110): backbone features (N,C), xyz (N,3), segmentation
+    mask (N), point intensity = pts_features[:, 0], raw segmentation scores (N); arrays as given (numpy, or tensors moved to host)"""
+    to_np = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)      # noqa: E731
+    f = rpn_feature_files(kitti_features_dir, sample_id)
+    np.save(f["features"], to_np(backbone_features))
+    np.save(f["xyz"], to_np(backbone_xyz))
+    np.save(f["seg"], to_np(seg_result))
+    np.save(f["intensity"], to_np(pts_features)[:, 0])
+    np.save(f["rawscore"], to_np(rpn_scores_raw))
+
+
+def get_rpn_features(rpn_feature_dir, idx, use_seg_score=False):
+    """-> xyz (N,3), features (N,C), intensity (N), seg score (N): the mask, or sigmoid(raw score) with cfg.RCNN.USE_SEG_SCORE
+    (kitti_rcnn_dataset.py:139-150; the sigmoid in float32 as torch evaluates it there)"""
+    f = rpn_feature_files(rpn_feature_dir, idx)
+    if use_seg_score:
+        import torch
+        seg = torch.sigmoid(torch.from_numpy(np.load(f["rawscore"]).reshape(-1))).numpy()
+    else:
+        seg = np.load(f["seg"]).reshape(-1)
+    return np.load(f["xyz"]), np.load(f["features"]), np.load(f["intensity"]).reshape(-1), seg

@@ -44,6 +44,25 @@ def reference_lines(boxes, scores, P2, img_shape, sample_id=7):
         return open(os.path.join(d, "%06d.txt" % sample_id)).read().splitlines()
 
 
+def reference_feature_roundtrip(arrays, sample_id=42, use_seg_score=False):
+    """the reference's own save_rpn_features (eval_rcnn.py:97-110) writes, its own KittiRCNNDataset.get_rpn_features
+    (kitti_rcnn_dataset.py:139-150) reads: -> (sorted file names, the four arrays it returns)"""
+    ns = ref_net.load()
+    src = open(os.path.join(ref_net.REFERENCE, "tools", "eval_rcnn.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "save_rpn_features")
+    env = {"np": np, "os": os}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "eval_rcnn.py", "exec"), env)
+    import lib.datasets.kitti_rcnn_dataset as d
+    keep = ns.cfg.RCNN.USE_SEG_SCORE
+    ns.cfg.RCNN.USE_SEG_SCORE = use_seg_score
+    try:
+        with tempfile.TemporaryDirectory() as t:
+            env["save_rpn_features"](arrays["seg"], arrays["raw"], arrays["pts_features"], arrays["xyz"], arrays["features"], t, sample_id)
+            return sorted(os.listdir(t)), d.KittiRCNNDataset.get_rpn_features(t, sample_id)
+    finally:
+        ns.cfg.RCNN.USE_SEG_SCORE = keep
+
+
 def make_golden():
     here = os.path.dirname(os.path.abspath(__file__))
     g = {}

@@ -59,3 +59,27 @@ def test_written_files_parse_back_through_the_evaluators_reader(tmp_path):
     # a frame without detections: an empty file, as the reference writes
     assert kitti_output.save_kitti_format(13, _Calib(P2), np.zeros((0, 7), np.float32), str(tmp_path), np.zeros((0,), np.float32), shape) == []
     assert open(os.path.join(tmp_path, "000013.txt")).read() == ""
+
+
+def _feature_arrays(seed=0, n=300, c=16):
+    r = np.random.default_rng(seed)
+    return {"seg": (r.random(n) > 0.6).astype(np.float32), "raw": r.normal(0, 2, n).astype(np.float32),
+            "pts_features": r.random((n, 1)).astype(np.float32), "xyz": r.normal(0, 10, (n, 3)).astype(np.float32),
+            "features": r.normal(size=(n, c)).astype(np.float32)}
+
+
+@pytest.mark.parametrize("use_seg_score", [False, True])
+def test_rpn_feature_dumps_round_trip(tmp_path, use_seg_score):
+    """eval_rcnn.py:97-110 file set (names, contents) and kitti_rcnn_dataset.py:139-150 reader"""
+    a = _feature_arrays()
+    kitti_output.save_rpn_features(a["seg"], a["raw"], a["pts_features"], a["xyz"], a["features"], str(tmp_path), 42)
+    assert sorted(os.listdir(tmp_path)) == ["000042.npy", "000042_intensity.npy", "000042_rawscore.npy", "000042_seg.npy", "000042_xyz.npy"]
+    xyz, feat, inten, seg = kitti_output.get_rpn_features(str(tmp_path), 42, use_seg_score)
+    assert np.array_equal(xyz, a["xyz"]) and np.array_equal(feat, a["features"]) and np.array_equal(inten, a["pts_features"][:, 0])
+    want = 1.0 / (1.0 + np.exp(-a["raw"].astype(np.float64))) if use_seg_score else a["seg"]
+    np.testing.assert_allclose(seg, want, rtol=2e-7)
+    if rko.available():                                    # the reference's own writer + reader on the same arrays
+        names, ref = rko.reference_feature_roundtrip(a, 42, use_seg_score)
+        assert names == sorted(os.listdir(tmp_path))
+        for g, w in zip((xyz, feat, inten, seg), ref):
+            assert np.array_equal(g, w)
