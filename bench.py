@@ -489,6 +489,26 @@ def instrumented_pass(args, bench, nprof, dump=None):
         _cabi._lib, _ops._split_log = real, None
 
 
+def stack_gemm_account(step, seconds_per_step):
+    """executed GEMM FLOPs of the hand-written training stacks in one step (forward, weight gradient, input gradient; on the LIVE rows
+    of padding-free lists) and what they amount to over the measured step time: a whole-step figure -- the step also holds the
+    BatchNorm reductions, gathers, the loss and the optimizer -- next to the 157.3 TFLOP/s fp32-MFMA peak"""
+    from pointrcnn_amd import train_mlp
+    train_mlp.FLOP_LOG = []
+    try:
+        step()
+        torch.cuda.synchronize()
+        flops = train_mlp.logged_flops(train_mlp.FLOP_LOG)
+        calls = len(train_mlp.FLOP_LOG)
+    finally:
+        train_mlp.FLOP_LOG = None
+    if calls == 0:
+        return None
+    tf = flops / seconds_per_step / 1e12
+    return {"stack_calls_per_step": calls, "executed_GFLOP_per_step": round(flops / 1e9, 2), "TFLOPs_over_the_whole_step": round(tf, 2),
+            "frac_of_fp32_mfma_peak_over_the_whole_step": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+
+
 def run_train(args, dev, rank, world, local_rank, dist):
     """BASELINE config 4: RPN training iterations under DDP; -> the JSON line"""
     from pointrcnn_amd import ops, rpn, train_functions as tf
@@ -554,6 +574,7 @@ def run_train(args, dev, rank, world, local_rank, dist):
     ev[3].record()
     torch.cuda.synchronize()
     fg = int((batches[0]["rpn_cls_label"] > 0).sum().item())
+    gemm = stack_gemm_account(lambda: trainer.step(batches[0]), elapsed / args.steps)
     return {
         "metric": "KITTI frames/sec, RPN training step (16384 pts/frame, bs%d per GPU, DDP over RCCL)" % args.batch,
         "value": round(whole_job_value(args.batch, world, args.steps, elapsed), 2), "unit": "frames/s", "n_gpus": world,
@@ -569,6 +590,7 @@ def run_train(args, dev, rank, world, local_rank, dist):
                   "allreduce_ms_flat_buffer": allreduce_ms,
                   "forward_loss_ms": round(ev[0].elapsed_time(ev[1]), 3), "backward_ms": round(ev[1].elapsed_time(ev[2]), 3),
                   "clip_optimizer_ms": round(ev[2].elapsed_time(ev[3]), 3),
+                  "stack_gemms": gemm,
                   "train_fused": os.environ.get("PRCNN_TRAIN_FUSED", "1") != "0",
                   "padding_free_rows": os.environ.get("PRCNN_TRAIN_DEDUP", "1") != "0",
                   "host_syncs_per_step": 0 if tf.SYNC_FREE_LOSS else 4,
@@ -659,6 +681,7 @@ def run_train_rcnn(args, dev, rank, world, local_rank, dist):
     torch.cuda.synchronize()
     last = model.rcnn_net.proposal_target_layer.last
     nparam = sum(p.numel() for p in trainer.params)
+    gemm = stack_gemm_account(lambda: trainer.step(batches[0]), elapsed / args.steps)
     return {
         "metric": "KITTI frames/sec, RCNN-stage training step (16384 pts/frame, bs%d per GPU, 64 RoIs x 512 pts per frame)" % args.batch,
         "value": round(whole_job_value(args.batch, world, args.steps, elapsed), 2), "unit": "frames/s", "n_gpus": world,
@@ -677,6 +700,7 @@ def run_train_rcnn(args, dev, rank, world, local_rank, dist):
         "train": {"loss_last": round(float(loss.item()), 4), "parameters_trained": nparam,
                   "rpn_and_sampling_ms": None, "forward_loss_ms": round(ev[0].elapsed_time(ev[1]), 3),
                   "backward_ms": round(ev[1].elapsed_time(ev[2]), 3), "clip_optimizer_ms": round(ev[2].elapsed_time(ev[3]), 3),
+                  "stack_gemms": gemm,
                   "train_fused": os.environ.get("PRCNN_TRAIN_FUSED", "1") != "0", "fps_prefetch": prefetch,
                   "sampler_status_frames_ok": int((last["status"] == 0).sum().item()),
                   "foreground_rois_last_step": int((last["counts"][:, 3]).sum().item()),

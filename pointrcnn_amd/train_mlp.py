@@ -26,6 +26,20 @@ from .ops import _p, _stream
 
 _F32 = torch.float32
 INTERP_GRAD_GATHER = os.environ.get("PRCNN_INTERP_GRAD_GATHER", "1") != "0"      # A/B switch: 0 = atomics
+# bench.py's accounting: when a list, every stack forward appends (rows (int) or live-row counter (device tensor), [(K, N) per layer],
+# first layer takes an input gradient) -- nothing is read back here
+FLOP_LOG = None
+
+
+def logged_flops(log):
+    """executed GEMM FLOPs of the logged stack calls for one step: forward + weight gradient for every layer, input gradient for
+    every layer but a first layer whose input takes none (2 rows K N each)"""
+    total = 0.0
+    for rows, dims, need_x in log:
+        r = float(rows.item()) if torch.is_tensor(rows) else float(rows)
+        for li, (k, n) in enumerate(dims):
+            total += 2.0 * r * k * n * (3.0 if (li > 0 or need_x) else 2.0)
+    return total
 MODE = {"plain": 0, "group": 1, "interp": 2}
 
 
@@ -244,6 +258,8 @@ class SharedMLPTrain(torch.autograd.Function):
             for bn in bns:
                 if bn is not None:
                     bn.num_batches_tracked += 1
+            if FLOP_LOG is not None:
+                FLOP_LOG.append((flat.rows_dev if flat is not None else rows, list(zip(st.ks, st.nout)), need_x))
         ctx.src, ctx.S, ctx.st, ctx.ns, ctx.K0, ctx.kin0, ctx.rows = src, S, st, ns, K0, kin0, rows
         ctx.a_dump, ctx.ld_dump, ctx.arg = a_dump, ld_dump, arg
         ctx.x_shapes = (None if x0 is None else tuple(x0.shape), None if x1 is None else tuple(x1.shape))
