@@ -201,6 +201,22 @@ int prcnn_mlp_rows_addinterp(const float* in, int ld_in, int K, const float* wpa
                              int relu, const float* y_cl, int ld_y, const int32_t* idx3, const float* w3, int B, int n,
                              int m, float* out, int ld_out, int col_off, prcnn_stream_t stream);
 
+/* Split-bf16 VARIANT of the two plain-row layer calls above (never the default arithmetic; the caller opts in per call).
+ * Every fp32 operand is cut exactly into three bf16 pieces (x = x0 + x1 + x2) and each fp32 product is rebuilt from `terms`
+ * bf16 MFMA products with fp32 accumulation: terms = 6 keeps everything above 2^-24 |x||w| (fp32-grade results), terms = 3
+ * everything above 2^-16 |x||w|.  wsplit: prcnn_wsplit_bytes(Nout, K) bytes written by prcnn_pack_weight_split from the
+ * (Nout, K) row-major fp32 weight.  The split kernel needs K % 32 == 0 and 16-byte aligned input rows; any other shape runs
+ * the fp32 kernel on `wpack`, exactly as prcnn_mlp_rows / prcnn_mlp_rows_addinterp would.  An infinite input yields NaN.
+ * (The reference computes these layers as fp32 cuDNN convolutions, [U] pytorch_utils.py SharedMLP) */
+size_t prcnn_wsplit_bytes(int Nout, int K);
+int prcnn_pack_weight_split(const float* w, int Nout, int K, void* wsplit, prcnn_stream_t stream);
+int prcnn_mlp_rows_split(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const void* wsplit, int terms,
+                         const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, prcnn_stream_t stream);
+int prcnn_mlp_rows_addinterp_split(const float* in, int ld_in, int K, const float* wpack, const void* wsplit, int terms,
+                                   const float* bias, int Nout, int relu, const float* y_cl, int ld_y, const int32_t* idx3,
+                                   const float* w3, int B, int n, int m, float* out, int ld_out, int col_off,
+                                   prcnn_stream_t stream);
+
 /* Register-resident layer CHAIN: up to 3 consecutive layers (a whole SharedMLP) in ONE kernel; one wave owns 32
  * rows and carries them through every layer inside the register file (the MFMA accumulator layout of layer l is
  * the B-operand layout of layer l+1), so intermediate activations touch neither LDS nor HBM and a gathered /

@@ -83,6 +83,9 @@ struct MlpParams {
     // hoisted-FP addend (addY): 0 = every workgroup builds the interpolated tile in its epilogue; 1 = workgroups alternate by
     // dispatch slot between building it BEFORE the main loop (into the accumulators) and after it; 2 = all before (default)
     int addy_phase;
+    // split-bf16 variant (mlp_layer_s_kernel): the pre-split weight image (prcnn_pack_weight_split) and the number of terms (3 / 6)
+    const void* wsplit;
+    int split_terms;
 };
 
 // With live-row segments the 128-row tile a workgroup works on is NOT blockIdx.x: the live tiles are the first one or two
@@ -825,6 +828,192 @@ __global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST, ADDY>::W))
         return;
     }
     layer_epilogue<MODE, WNB, ADDY>(P, acc, &As[0][0], nullptr, tid, row0, nb0, n_active, addy_done);
+}
+
+// =====================================================================================================
+// Split-bf16 plain layer (an explicitly requested VARIANT, never the default arithmetic): every fp32 operand is cut into three
+// bf16 pieces x = x0 + x1 + x2 -- EXACTLY: x0 = the top 16 bits of x, x1 = the top 16 bits of x - x0, x2 = x - x0 - x1, which
+// has at most 8 significant bits left -- and the product is rebuilt from bf16 MFMAs (v_mfma_f32_32x32x16_bf16, fp32
+// accumulate, 16x the fp32-MFMA rate):
+//   TERMS = 6:  x0w0 + x0w1 + x1w0 + x1w1 + x0w2 + x2w0   (drops terms below 2^-24 of |x||w|: fp32-grade results)
+//   TERMS = 3:  x0w0 + x0w1 + x1w0                        (drops terms below 2^-16 of |x||w|)
+// Six bf16 MFMAs per 16-wide k-step cost 192 matrix-pipe cycles where the eight fp32 MFMAs of the same 16 k cost 512.
+// The A rows are split ONCE, on their way from HBM into LDS (three bf16 planes per buffer, 80-byte rows: the 16 rows of a
+// ds_read_b128 lane group land on 16 distinct 16-byte bank slots); the weights come pre-split (prcnn_pack_weight_split: per
+// (32-column block, 16-wide k-step, piece) the 64 lanes' 16-byte B operands, contiguous) and stream from L2 through a two-step
+// register ring, as in mlp_layer_b_kernel.  Accumulator layout = mlp_layer_b_kernel's: the epilogue is shared.
+// Non-finite inputs: an infinity becomes NaN (inf - inf in the split).  Shapes: K a multiple of 32, 16-byte aligned rows.
+// =====================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define SPL_LDB 80                               // bytes per LDS row of one piece plane: 32 bf16 + 16 bytes of padding
+#define SPL_PLANE (MLP_BM * SPL_LDB)
+
+__device__ __forceinline__ void split3(float x, uint32_t& b0, uint32_t& b1, uint32_t& b2) {
+    b0 = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(b0 & 0xFFFF0000u);        // exact: <= 16 significant bits
+    b1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(b1 & 0xFFFF0000u);       // exact: <= 8 significant bits, i.e. a bf16 value
+    b2 = __float_as_uint(r2);
+}
+// the top halves of two fp32 bit patterns as a bf16 pair (element 0 in the low half)
+__device__ __forceinline__ uint32_t bf16_pair(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+__global__ void pack_weight_split_kernel(const float* __restrict__ w, int Nout, int K, int KS, int NB, uint4* __restrict__ img) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;            // one thread per (column block, k-step, lane)
+    if (e >= (long)NB * KS * 64) return;
+    const int lane = (int)(e & 63);
+    const long blk = e >> 6;
+    const int ks = (int)(blk % KS), nb = (int)(blk / KS);
+    const int n = nb * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+    uint32_t b[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float v = (n < Nout && k0 + i < K) ? w[(long)n * K + k0 + i] : 0.f;
+        split3(v, b[0][i], b[1][i], b[2][i]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+        img[(blk * 3 + p) * 64 + lane] = make_uint4(bf16_pair(b[p][0], b[p][1]), bf16_pair(b[p][2], b[p][3]),
+                                                    bf16_pair(b[p][4], b[p][5]), bf16_pair(b[p][6], b[p][7]));
+}
+
+template <int WNB, int TERMS, bool ADDY>
+__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpParams Pin) {
+    MlpParams P = Pin;
+    P.rows = effective_rows(Pin);
+    constexpr int QN = 2 * WNB;
+    constexpr int NP = TERMS == 6 ? 3 : 2;               // pieces in use
+    long tile_id;
+    int nb0;
+    if (P.wgm_cols > 0) {
+        const long bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+        const long rl = slot / P.wgm_cols;
+        tile_id = rl * 8 + xcd;
+        nb0 = (int)(slot - rl * P.wgm_cols) * QN;
+    } else {
+        tile_id = tile_of_block(P, blockIdx.x);
+        nb0 = blockIdx.y * QN;
+    }
+    if (tile_id * MLP_BM >= P.rows) return;
+    if (tile_dead(P, tile_id * MLP_BM)) return;
+    __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * 3 * SPL_PLANE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, j = lane & 31;
+    const long row0 = tile_id * MLP_BM;
+    const int nchunks = P.K / MLP_BK, KS = P.K / 16;
+
+    const int c4 = tid & 7, r0 = tid >> 3;
+    const float* arow[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        long grow = row0 + r0 + 32 * u;
+        if (grow >= P.rows) grow = P.rows - 1;           // clamped, never stored
+        arow[u] = P.in + grow * P.ld_in + c4 * 4;
+    }
+    float4 ra[4];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) ra[u] = ld4(arow[u] + c * MLP_BK);
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t b[3][4];
+            split3(ra[u].x, b[0][0], b[1][0], b[2][0]);
+            split3(ra[u].y, b[0][1], b[1][1], b[2][1]);
+            split3(ra[u].z, b[0][2], b[1][2], b[2][2]);
+            split3(ra[u].w, b[0][3], b[1][3], b[2][3]);
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+                *reinterpret_cast<uint2*>(Ls + (buf * 3 + p) * SPL_PLANE + (r0 + 32 * u) * SPL_LDB + c4 * 8) =
+                    make_uint2(bf16_pair(b[p][0], b[p][1]), bf16_pair(b[p][2], b[p][3]));
+        }
+    };
+
+    f32x16 acc[2][WNB];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int n = 0; n < WNB; n++) acc[r][n] = (f32x16){0};
+    const bool n_active = (nb0 + wn * WNB) < P.NB;      // (a wave without a column block computes the last block again, unstored)
+
+    // B ring: slot (g & 1) holds this wave's operands of k-step g, requested two steps (one chunk) ahead; unconditional loads
+    // (column blocks past the width re-read the last block, k-steps past K the last step -- neither result is stored / reached)
+    uint4 bq[2][WNB][NP];
+    const uint4* bptr[WNB];
+#pragma unroll
+    for (int n = 0; n < WNB; n++) bptr[n] = reinterpret_cast<const uint4*>(P.wsplit) + ((long)min(nb0 + wn * WNB + n, P.NB - 1) * KS) * 192 + lane;
+    auto load_b = [&](int g, int slot) {
+        const long off = (long)min(g, KS - 1) * 192;
+#pragma unroll
+        for (int n = 0; n < WNB; n++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) bq[slot][n][p] = bptr[n][off + p * 64];
+    };
+    bf16x8 a0[2][NP], a1[2][NP];                          // the A operands of the chunk's two k-steps
+    auto read_a = [&](int buf, int st, bf16x8 (&a)[2][NP]) {
+        const unsigned char* a_base = Ls + buf * 3 * SPL_PLANE + (wm * 64 + j) * SPL_LDB + h * 16 + st * 32;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+                a[r][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + p * SPL_PLANE + r * 32 * SPL_LDB));
+    };
+#define SPL_TERM(A, SL, PA, PB)                                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < 2; r++) _Pragma("unroll") for (int n = 0; n < WNB; n++)                                  \
+        acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[r][PA], __builtin_bit_cast(bf16x8, bq[SL][n][PB]), acc[r][n], 0, 0, 0)
+#define SPL_STEP(A, SL)                      /* smallest terms first */                                                           \
+    do {                                                                                                                          \
+        if constexpr (TERMS == 6) { SPL_TERM(A, SL, 0, 2); SPL_TERM(A, SL, 2, 0); SPL_TERM(A, SL, 1, 1); }                         \
+        SPL_TERM(A, SL, 0, 1); SPL_TERM(A, SL, 1, 0); SPL_TERM(A, SL, 0, 0);                                                       \
+    } while (0)
+    constexpr int NM = 2 * WNB * TERMS;                   // MFMAs per k-step
+    load_b(0, 0);
+    load_b(1, 1);
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    read_a(0, 0, a0);
+    // One chunk = two k-steps.  The matrix pipe takes a bf16 MFMA every 32 cycles; a wave's other instructions issue in the gaps.
+    // Step 0 carries the LDS reads of step 1 and the global loads (next chunk's A rows, B two steps ahead); step 1 carries the
+    // split of the next chunk (its loads were issued a step earlier) and the LDS writes into the idle buffer.  Left to itself the
+    // compiler issues each step's MFMAs as one run and the ~100 split instructions after it, with the pipe idle.
+    for (int c = 0; c < nchunks; c++) {
+        const int buf = c & 1;
+        load_chunk(min(c + 1, nchunks - 1));
+        read_a(buf, 1, a1);
+        SPL_STEP(a0, 0);
+        load_b(c * 2 + 2, 0);
+#pragma unroll
+        for (int q = 0; q < 2 * NP; q++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4 + WNB * NP; q++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(buf ^ 1);
+        SPL_STEP(a1, 1);
+        load_b(c * 2 + 3, 1);
+#pragma unroll
+        for (int q = 0; q < NM; q++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            if (q % 2 == 1 && q / 2 < 4 * NP) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        read_a(buf ^ 1, 0, a0);
+    }
+#undef SPL_STEP
+#undef SPL_TERM
+    layer_epilogue<MODE_PLAIN, WNB, ADDY>(P, acc, reinterpret_cast<float*>(Ls), nullptr, tid, row0, nb0, n_active, false);
 }
 
 // =====================================================================================================
@@ -1606,6 +1795,26 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     if (P.rows == 0) return PRCNN_OK;
     P.KB = (P.K + 7) / 8;
     P.NB = (P.Nout + 31) / 32;
+    if (P.wsplit && mode == MODE_PLAIN && P.K % MLP_BK == 0 && P.vec_a && P.pool_ns == 0) {
+        // split-bf16 variant: 128 x 128 tiles (128 x 64 for layers under 128 columns), XCD-aware 1-D tile order as below
+        PRCNN_REQUIRE(aligned16(P.wsplit) && (P.split_terms == 3 || P.split_terms == 6), "prcnn_mlp: bad split image / terms=%d", P.split_terms);
+        const bool wide = P.NB >= 4;
+        dim3 grid(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, wide ? 4 : 2));
+        if (!P.seg_cnt) {
+            P.wgm_cols = (int)grid.y;
+            grid = dim3((unsigned)(prcnn_divup(grid.x, 8) * 8 * grid.y), 1);
+        }
+#define SPL_LAUNCH(W, T)                                                                                                  \
+    do {                                                                                                                  \
+        if (P.addY) hipLaunchKernelGGL((mlp_layer_s_kernel<W, T, true>), grid, dim3(MLP_THREADS), 0, s, P);               \
+        else hipLaunchKernelGGL((mlp_layer_s_kernel<W, T, false>), grid, dim3(MLP_THREADS), 0, s, P);                     \
+    } while (0)
+        if (wide) { if (P.split_terms == 6) SPL_LAUNCH(2, 6); else SPL_LAUNCH(2, 3); }
+        else { if (P.split_terms == 6) SPL_LAUNCH(1, 6); else SPL_LAUNCH(1, 3); }
+#undef SPL_LAUNCH
+        PRCNN_LAUNCH_CHECK("prcnn_mlp (split-bf16)");
+        return PRCNN_OK;
+    }
     if (rows32_ok(mode, P)) return launch_rows32(P, s);
     // >= 97 output channels: 128x128 workgroup tile -- unless that leaves most of the 256 CUs without a workgroup
     // (few rows, e.g. FP3's 2048 known points): then the 128x64 tile doubles the number of workgroups
@@ -1669,6 +1878,56 @@ PRCNN_API int prcnn_pack_weight(const float* w, int Nout, int K, int k_rot, floa
                        k_rot, KB, NB, wpack);
     PRCNN_LAUNCH_CHECK("prcnn_pack_weight");
     return PRCNN_OK;
+}
+
+PRCNN_API size_t prcnn_wsplit_bytes(int Nout, int K) {
+    if (Nout <= 0 || K <= 0) return 0;
+    return (size_t)((Nout + 31) / 32) * ((K + 15) / 16) * 3 * 1024;
+}
+
+PRCNN_API int prcnn_pack_weight_split(const float* w, int Nout, int K, void* wsplit, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(w && wsplit && aligned16(wsplit), "prcnn_pack_weight_split: null / misaligned pointer");
+    PRCNN_REQUIRE(Nout > 0 && K > 0, "prcnn_pack_weight_split: bad shape Nout=%d K=%d", Nout, K);
+    const int KS = (K + 15) / 16, NB = (Nout + 31) / 32;
+    hipLaunchKernelGGL(pack_weight_split_kernel, dim3(prcnn_divup((long)NB * KS * 64, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       Nout, K, KS, NB, reinterpret_cast<uint4*>(wsplit));
+    PRCNN_LAUNCH_CHECK("prcnn_pack_weight_split");
+    return PRCNN_OK;
+}
+
+PRCNN_API int prcnn_mlp_rows_split(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const void* wsplit, int terms,
+                                   const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(in && wsplit, "prcnn_mlp_rows_split: null pointer");
+    PRCNN_REQUIRE(ld_in >= K && ld_out >= col_off + Nout, "prcnn_mlp_rows_split: bad strides ld_in=%d K=%d ld_out=%d", ld_in, K, ld_out);
+    PRCNN_REQUIRE(terms == 3 || terms == 6, "prcnn_mlp_rows_split: terms=%d (3 or 6)", terms);
+    MlpParams P = {};
+    P.rows = rows; P.K = K; P.wpack = wpack; P.bias = bias; P.Nout = Nout; P.relu = relu;
+    P.out = out; P.ld_out = ld_out; P.col_off = col_off;
+    P.in = in; P.ld_in = ld_in;
+    P.vec_a = aligned16(in) && (ld_in % 4 == 0);
+    P.rows_unit = 1;
+    P.wsplit = wsplit; P.split_terms = terms;
+    return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
+}
+
+PRCNN_API int prcnn_mlp_rows_addinterp_split(const float* in, int ld_in, int K, const float* wpack, const void* wsplit, int terms,
+                                             const float* bias, int Nout, int relu, const float* y_cl, int ld_y, const int32_t* idx3,
+                                             const float* w3, int B, int n, int m, float* out, int ld_out, int col_off,
+                                             prcnn_stream_t stream) {
+    PRCNN_REQUIRE(in && y_cl && idx3 && w3 && wsplit, "prcnn_mlp_rows_addinterp_split: null pointer");
+    PRCNN_REQUIRE(B >= 0 && n > 0 && m > 0 && ld_in >= K && ld_y >= Nout && ld_out >= col_off + Nout,
+                  "prcnn_mlp_rows_addinterp_split: bad shape B=%d n=%d m=%d K=%d Nout=%d", B, n, m, K, Nout);
+    PRCNN_REQUIRE(terms == 3 || terms == 6, "prcnn_mlp_rows_addinterp_split: terms=%d (3 or 6)", terms);
+    MlpParams P = {};
+    P.rows = (long)B * n; P.K = K; P.wpack = wpack; P.bias = bias; P.Nout = Nout; P.relu = relu;
+    P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.pool_ns = 0;
+    P.in = in; P.ld_in = ld_in;
+    P.vec_a = aligned16(in) && (ld_in % 4 == 0);
+    P.addY = y_cl; P.ldY = ld_y; P.idx3 = idx3; P.w3 = w3; P.n = n; P.m = m;
+    P.addy_phase = 0;
+    P.rows_unit = 1;
+    P.wsplit = wsplit; P.split_terms = terms;
+    return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
 }
 
 PRCNN_API int prcnn_mlp_rows(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const float* bias,

@@ -235,6 +235,8 @@ class PackedLinear:
         self.wpack = torch.empty((L.prcnn_wpack_floats(self.nout, self.k),), dtype=_F32, device=weight.device)
         _cabi.check(L.prcnn_pack_weight(_p(weight), self.nout, self.k, k_rot, _p(self.wpack), _stream()),
                     "prcnn_pack_weight")
+        self._w = weight if k_rot == 0 else None         # kept for the split-bf16 variant's own weight image (built on first use)
+        self._wsplit = None
         # bias is kept zero-padded to a multiple of 32 entries (the chain kernel reads whole 32-channel blocks)
         self.bias = None
         if bias is not None:
@@ -242,6 +244,21 @@ class PackedLinear:
             self.bias = torch.zeros(((self.nout + 31) // 32 * 32,), dtype=_F32, device=weight.device)
             self.bias[: self.nout] = bias
 
+
+    def wsplit(self):
+        """the pre-split bf16 weight image of the split-bf16 variant (prcnn_pack_weight_split), or None when the layer does not
+        qualify (K a multiple of 32, no rotated input channels)"""
+        if self._wsplit is None and self._w is not None and self.k % 32 == 0:
+            L = _cabi.lib()
+            self._wsplit = torch.empty((L.prcnn_wsplit_bytes(self.nout, self.k),), dtype=torch.uint8, device=self._w.device)
+            _cabi.check(L.prcnn_pack_weight_split(_p(self._w.contiguous()), self.nout, self.k, _p(self._wsplit), _stream()),
+                        "prcnn_pack_weight_split")
+        return self._wsplit
+
+
+# Split-bf16 VARIANT of the plain-row layers (prcnn_mlp_rows_split): 0 = off (fp32 MFMA, the product's arithmetic), 3 / 6 = the
+# number of bf16 product terms per fp32 product.  Never on by default; bench.py reports it as a separate variant.
+MLP_SPLIT_TERMS = int(os.environ.get("PRCNN_MLP_SPLIT", "0"))
 
 _MODE_ROWS, _MODE_GROUP, _MODE_INTERP = 0, 1, 2
 _chain_ok = {}
@@ -355,6 +372,11 @@ def mlp_rows(x, lin, out=None, pool_ns=0, rows_dev=None, rows_unit=1, seg=None):
     ld_in = _row_stride(x)
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, lin, x.device)
+    if MLP_SPLIT_TERMS and not pool_ns and rows_dev is None and seg is None and ld_in % 4 == 0 and lin.wsplit() is not None:
+        _cabi.check(_cabi.lib().prcnn_mlp_rows_split(_p(x), ld_in, rows, K, _p(lin.wpack), _p(lin.wsplit()), MLP_SPLIT_TERMS,
+                                                     _p(lin.bias), lin.nout, int(lin.relu), _p(buf), ld_out, col_off, _stream()),
+                    "prcnn_mlp_rows_split")
+        return buf
     _cabi.check(_cabi.lib().prcnn_mlp_rows(_p(x), ld_in, rows, K, _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu),
                                            _p(buf), ld_out, col_off, pool_ns, _p(rows_dev), int(rows_unit),
                                            _p(None if seg is None else seg[0]), 0 if seg is None else int(seg[1]), _stream()), "prcnn_mlp_rows")
@@ -401,6 +423,12 @@ def mlp_rows_addinterp(skip_cl, lin_b, y_cl, idx3, w3, out=None):
     B, n, C1 = skip_cl.shape
     m = y_cl.shape[1]
     buf, ld_out, col_off = _out_buf(out, B * n, lin_b, skip_cl.device)
+    if MLP_SPLIT_TERMS and _row_stride(skip_cl) % 4 == 0 and lin_b.wsplit() is not None:
+        _cabi.check(_cabi.lib().prcnn_mlp_rows_addinterp_split(_p(skip_cl), _row_stride(skip_cl), C1, _p(lin_b.wpack), _p(lin_b.wsplit()),
+                                                               MLP_SPLIT_TERMS, _p(lin_b.bias), lin_b.nout, int(lin_b.relu), _p(y_cl),
+                                                               _row_stride(y_cl), _p(idx3), _p(w3), B, n, m, _p(buf), ld_out, col_off,
+                                                               _stream()), "prcnn_mlp_rows_addinterp_split")
+        return buf
     _cabi.check(_cabi.lib().prcnn_mlp_rows_addinterp(_p(skip_cl), _row_stride(skip_cl), C1, _p(lin_b.wpack), _p(lin_b.bias),
                                                      lin_b.nout, int(lin_b.relu), _p(y_cl), _row_stride(y_cl), _p(idx3),
                                                      _p(w3), B, n, m, _p(buf), ld_out, col_off, _stream()),
