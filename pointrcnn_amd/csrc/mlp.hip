@@ -610,6 +610,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_layer_kernel(const MlpParams 
 #ifndef PRCNN_ABL
 #define PRCNN_ABL 0            // ablation builds of mlp_layer_b_kernel (tools/build_ablation.py): bit 0 no epilogue, 1 no A loads in
 #endif                         // the loop, 2 no B loads in the loop, 3 no LDS refill + barrier in the loop -- never set in the product
+                               // (mlp_layer_s_kernel: 16 no epilogue, 32 no B loads in the loop, 64 no A loads / split / LDS writes, 128 no MFMAs, 256 no LDS reads / barrier in the loop)
 template <int MODE, int WNB, bool FAST, bool ADDY> struct LayerBOcc {
     // plain rows, straight-line form: FOUR workgroups per CU (<= 128 registers).  The plain GEMMs of the graph have power-of-two
     // tile counts (256 .. 4096): 1024 resident workgroups run them in whole rounds, whereas three per CU (768) leaves a
@@ -913,12 +914,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpPa
         if (grow >= P.rows) grow = P.rows - 1;           // clamped, never stored
         arow[u] = P.in + grow * P.ld_in + c4 * 4;
     }
-    float4 ra[4];
-    auto load_chunk = [&](int c) {
+    float4 raA[4], raB[4];                               // two chunks of A rows in flight (see the main loop)
+    auto load_chunk = [&](int c, float4 (&ra)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; u++) ra[u] = ld4(arow[u] + c * MLP_BK);
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const float4 (&ra)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             uint32_t b[3][4];
@@ -973,20 +974,23 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpPa
     constexpr int NM = 2 * WNB * TERMS;                   // MFMAs per k-step
     load_b(0, 0);
     load_b(1, 1);
-    load_chunk(0);
-    store_chunk(0);
+    load_chunk(0, raA);
+    load_chunk(min(1, nchunks - 1), raB);
+    store_chunk(0, raA);
     __syncthreads();
     read_a(0, 0, a0);
+    if (PRCNN_ABL & 256) read_a(0, 1, a1);
     // One chunk = two k-steps.  The matrix pipe takes a bf16 MFMA every 32 cycles; a wave's other instructions issue in the gaps.
-    // Step 0 carries the LDS reads of step 1 and the global loads (next chunk's A rows, B two steps ahead); step 1 carries the
-    // split of the next chunk (its loads were issued a step earlier) and the LDS writes into the idle buffer.  Left to itself the
-    // compiler issues each step's MFMAs as one run and the ~100 split instructions after it, with the pipe idle.
-    for (int c = 0; c < nchunks; c++) {
+    // Step 0 carries the LDS reads of step 1 and the global loads (A rows TWO chunks ahead -- a chunk is ~1500 matrix-pipe cycles,
+    // less than an HBM round trip under load -- and B two steps ahead); step 1 carries the split of the next chunk and the LDS
+    // writes into the idle buffer.  Left to itself the compiler issues each step's MFMAs as one run and the ~100 split
+    // instructions after it, with the pipe idle.
+    auto chunk_body = [&](int c, const float4 (&ra_split)[4], float4 (&ra_load)[4]) {
         const int buf = c & 1;
-        load_chunk(min(c + 1, nchunks - 1));
-        read_a(buf, 1, a1);
-        SPL_STEP(a0, 0);
-        load_b(c * 2 + 2, 0);
+        if (!(PRCNN_ABL & 64)) load_chunk(min(c + 2, nchunks - 1), ra_load);
+        if (!(PRCNN_ABL & 256)) read_a(buf, 1, a1);
+        if (!(PRCNN_ABL & 128)) SPL_STEP(a0, 0);
+        if (!(PRCNN_ABL & 32)) load_b(c * 2 + 2, 0);
 #pragma unroll
         for (int q = 0; q < 2 * NP; q++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -998,9 +1002,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpPa
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        store_chunk(buf ^ 1);
-        SPL_STEP(a1, 1);
-        load_b(c * 2 + 3, 1);
+        if (!(PRCNN_ABL & 64)) store_chunk(buf ^ 1, ra_split);
+        if (!(PRCNN_ABL & 128)) SPL_STEP(a1, 1);
+        if (!(PRCNN_ABL & 32)) load_b(c * 2 + 3, 1);
 #pragma unroll
         for (int q = 0; q < NM; q++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1008,11 +1012,34 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpPa
             if (q % 2 == 1 && q / 2 < 4 * NP) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        read_a(buf ^ 1, 0, a0);
+        if (!(PRCNN_ABL & 256)) {
+            __syncthreads();
+            read_a(buf ^ 1, 0, a0);
+        }
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk_body(c, raB, raA);                          // raA held chunk c (already in LDS): it takes chunk c + 2
+        if (c + 1 < nchunks) chunk_body(c + 1, raA, raB);
     }
 #undef SPL_STEP
 #undef SPL_TERM
+    if (PRCNN_ABL & (16 | 128)) {           // ablation builds only: keep the operands / accumulators alive with a store that never happens
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int n = 0; n < WNB; n++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) sum += acc[r][n][e];
+        if (PRCNN_ABL & 128) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int p = 0; p < NP; p++) sum += (float)a0[r][p][0] + (float)a1[r][p][3] + __uint_as_float(bq[0][0][p].x) + __uint_as_float(bq[1][WNB - 1][p].w);
+        }
+        if (sum == 123.456f) P.out[tid] = sum;
+        if (PRCNN_ABL & 16) return;
+    }
     layer_epilogue<MODE_PLAIN, WNB, ADDY>(P, acc, reinterpret_cast<float*>(Ls), nullptr, tid, row0, nb0, n_active, false);
 }
 
@@ -1795,10 +1822,13 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     if (P.rows == 0) return PRCNN_OK;
     P.KB = (P.K + 7) / 8;
     P.NB = (P.Nout + 31) / 32;
-    if (P.wsplit && mode == MODE_PLAIN && P.K % MLP_BK == 0 && P.vec_a && P.pool_ns == 0) {
-        // split-bf16 variant: 128 x 128 tiles (128 x 64 for layers under 128 columns), XCD-aware 1-D tile order as below
+    // split-bf16 variant: 128 x 128 tiles while they give most CUs a workgroup (two are resident per CU), else 128 x 64; a launch
+    // with fewer than 192 of those (FP3's 2048 rows) stays on the fp32 kernels below, which have forms for few rows
+    const long split_tiles_wide = (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4), split_tiles_narrow = (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 2);
+    static const long split_min = getenv("PRCNN_SPLIT_MIN_TILES") ? atol(getenv("PRCNN_SPLIT_MIN_TILES")) : 192;
+    if (P.wsplit && mode == MODE_PLAIN && P.K % MLP_BK == 0 && P.vec_a && P.pool_ns == 0 && split_tiles_narrow >= split_min) {
         PRCNN_REQUIRE(aligned16(P.wsplit) && (P.split_terms == 3 || P.split_terms == 6), "prcnn_mlp: bad split image / terms=%d", P.split_terms);
-        const bool wide = P.NB >= 4;
+        const bool wide = P.NB >= 4 && split_tiles_wide >= split_min;
         dim3 grid(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, wide ? 4 : 2));
         if (!P.seg_cnt) {
             P.wgm_cols = (int)grid.y;

@@ -370,3 +370,89 @@ def test_tile_order_remaps_are_bit_identical(dev, monkeypatch):
     up = [lin(dev, w, b, True) for w, b in zip(*_stack(r, (5, 128, 128), 0.2))]
     pts = T(r.normal(size=(nseg * S, 5)).astype(np.float32), dev)
     assert torch.equal(ops.mlp_chain_rows(pts, up)[live], ops.mlp_chain_rows(pts, up, seg=(cnt, S))[live])
+
+
+# ---------------------------------------------------------------- split-bf16 variant (opt-in, never the default arithmetic)
+def _scaled_rows(r, rows, K):
+    """rows whose magnitudes span several binades (the split must be exact whatever the exponent)"""
+    return (r.normal(size=(rows, K)) * np.exp2(r.integers(-12, 12, size=(rows, 1)))).astype(np.float32)
+
+
+@pytest.mark.parametrize("rows,K,Nout,relu,bias", [(24576, 32, 128, True, True), (25000, 96, 256, True, True), (12288, 512, 512, False, True),
+                                                   (24576, 64, 64, True, False), (3000, 256, 96, True, True), (200, 64, 64, True, True)])
+@pytest.mark.parametrize("terms", [6, 3])
+def test_split_bf16_rows_against_float64(dev, monkeypatch, rows, K, Nout, relu, bias, terms):
+    """the split-bf16 layer against a float64 product.  Six terms: every dropped partial product is below 2^-24 |x||w|, so the
+    result must sit within the fp32 kernel's own contract (1e-5 of the scale) -- checked here against the tighter, per-element
+    bound 2e-6 * (|x| . |w| + |b|).  Three terms: below 2^-16 |x||w| per product, bound 4e-5 * (|x| . |w| + |b|).  The last two
+    shapes are too small for the split kernel (fewer than 192 tiles): they must run, on the fp32 kernel."""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(rows + K + terms)
+    a = _scaled_rows(r, rows, K)
+    w = (r.normal(size=(Nout, K)) * 0.2).astype(np.float32)
+    b = r.normal(size=(Nout,)).astype(np.float32) if bias else None
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", terms)
+    got = ops.mlp_rows(T(a, dev), lin(dev, w, b, relu)).cpu().numpy().astype(np.float64)
+    want = a.astype(np.float64) @ w.astype(np.float64).T + (0.0 if b is None else b.astype(np.float64))
+    if relu:
+        want = np.maximum(want, 0.0)
+    scale = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T + (0.0 if b is None else np.abs(b).astype(np.float64))
+    bound = (2e-6 if terms == 6 else 4e-5) * scale + 1e-30
+    assert (np.abs(got - want) <= bound).all(), float((np.abs(got - want) / bound).max())
+    if terms == 6:
+        np.testing.assert_allclose(got, want, atol=mlp_tol(want), rtol=0)
+
+
+def test_split_bf16_identity_and_exact_pieces(dev, monkeypatch):
+    """A = identity with an asymmetric W whose entries need all 24 significand bits: with six terms the three pieces of W are
+    reassembled exactly (x = 1 has one piece), so the output IS W^T bit for bit -- catches a wrong lane / k mapping of the bf16
+    operands and a lossy split; a strided input and a column offset in the output go through the same path"""
+    from pointrcnn_amd import ops
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
+    K, Nout, rows = 128, 128, 24576
+    r = np.random.default_rng(3)
+    w = (r.integers(1 << 23, 1 << 24, size=(Nout, K)).astype(np.float32) * np.exp2(r.integers(-30, 10, size=(Nout, K)))).astype(np.float32)
+    a = np.zeros((rows, K + 4), np.float32)
+    a[np.arange(rows), np.arange(rows) % K] = 1.0
+    out = torch.full((rows, Nout + 8), -7.0, device=dev)
+    ops.mlp_rows(T(a, dev)[:, :K], lin(dev, w, None, False), out=(out, 4))
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, 4:4 + Nout], w.T[np.arange(rows) % K])
+    assert (got[:, :4] == -7.0).all() and (got[:, 4 + Nout:] == -7.0).all()
+
+
+def test_split_bf16_addinterp_equals_fp32_layer(dev, monkeypatch):
+    """hoisted FP first layer with the interpolated addend: the split variant against the fp32 kernel on the same inputs"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(11)
+    B, n, m, C1, Nout = 4, 8192, 2048, 96, 256
+    skip = T(r.normal(size=(B, n, C1)).astype(np.float32), dev)
+    y = T(r.normal(size=(B, m, Nout)).astype(np.float32), dev)
+    idx3 = T(r.integers(0, m, size=(B, n, 3)).astype(np.int32), dev)
+    w3 = r.random(size=(B, n, 3)).astype(np.float32)
+    w3 = T(w3 / w3.sum(-1, keepdims=True), dev)
+    l = lin(dev, (r.normal(size=(Nout, C1)) * 0.2).astype(np.float32), r.normal(size=(Nout,)).astype(np.float32), True)
+    want = ops.mlp_rows_addinterp(skip, l, y, idx3, w3).cpu().numpy()
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
+    got = ops.mlp_rows_addinterp(skip, l, y, idx3, w3).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=mlp_tol(want), rtol=0)
+
+
+def test_split_bf16_full_rpn_stays_within_the_fp32_contract(dev, monkeypatch):
+    """the whole RPN graph (default.yaml, 4 frames of 16384 points) with the plain-row layers on the six-term split kernel: sample
+    sets and neighbour lists are untouched (index operators see the same coordinates), features and head outputs stay within the
+    fused-vs-composed bound of test_full_rpn_fused_equals_composed -- and far inside it: 1e-5 of the output scale"""
+    from pointrcnn_amd import ops, rpn
+    torch.manual_seed(4)
+    model = rpn.randomize_bn_stats(rpn.RPN()).to(dev).eval()
+    pts = rpn.synthetic_clouds(4, 16384, device=dev)
+    with torch.no_grad():
+        ref = {k: v.clone() for k, v in model({"pts_input": pts}).items() if torch.is_tensor(v)}
+        monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
+        out = model({"pts_input": pts})
+    differs = False
+    for k in ("backbone_features", "rpn_cls", "rpn_reg"):
+        a, b = out[k].cpu().numpy(), ref[k].cpu().numpy()
+        np.testing.assert_allclose(a, b, atol=1e-5 * max(1.0, float(np.abs(b).max())), rtol=0)
+        differs = differs or not np.array_equal(a, b)
+    assert differs, "the split kernel did not run (outputs are bit-identical to the fp32 path)"
