@@ -185,6 +185,10 @@ class EventProfiler:
             return 2.0 * a[3] * a[6], a[2], a[12], a[13], "%d->%d" % (a[3], a[6])
         if name == "prcnn_mlp_rows_addinterp":
             return 2.0 * (a[2] + 3) * a[5], a[11] * a[12], None, 1, "%d->%d + interpolated addend" % (a[2], a[5])
+        if name == "prcnn_mlp_rows_split":              # (fp32-EQUIVALENT flops: 2 K N per row, whatever the number of bf16 terms)
+            return 2.0 * a[3] * a[8], a[2], None, 1, "%d->%d (bf16x%d)" % (a[3], a[8], a[6])
+        if name == "prcnn_mlp_rows_addinterp_split":
+            return 2.0 * (a[2] + 3) * a[7], a[13] * a[14], None, 1, "%d->%d + interpolated addend (bf16x%d)" % (a[2], a[7], a[5])
         if name == "prcnn_mlp_group":
             return 2.0 * (a[9] + (0 if a[10] else 3)) * a[14], a[5] * a[7] * a[8], a[20], a[8], "%d->%d" % (a[9] + (0 if a[10] else 3), a[14])
         if name == "prcnn_mlp_interp":
@@ -200,7 +204,7 @@ class EventProfiler:
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
         if not name.startswith("prcnn_") or name.endswith("_bytes") or name in ("prcnn_last_error", "prcnn_abi_version",
-                                                                              "prcnn_wpack_floats"):
+                                                                              "prcnn_wpack_floats", "prcnn_wsplit_bytes"):
             return fn
 
         def wrapped(*args):
@@ -797,6 +801,9 @@ def main():
                    "clouds": args.clouds, "group_dedup": os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0",
                    "roi_dedup": os.environ.get("PRCNN_ROI_DEDUP", "1") != "0"},
     }
+    from pointrcnn_amd import ops as _ops_split
+    if _ops_split.MLP_SPLIT_TERMS:                          # PRCNN_MLP_SPLIT set for the whole run (dev / profiling): say so, this is NOT the f32 line
+        line["dtype"] = "f32 + split-bf16x%d plain-row layers (PRCNN_MLP_SPLIT)" % _ops_split.MLP_SPLIT_TERMS
     plain = args.workload == "rpn" and args.input == "clouds" and not args.h2d
     if plain and not args.no_variants:
         # SURVEY 8(d)(i) counts the H2D copy: same graphs, every batch's clouds copied from pinned host memory on the batch's stream
@@ -919,6 +926,34 @@ def main():
                                            "mlp_TFLOPs_executed": round(f2["flops"] / (f2["ms"] * 1e-3) / 1e12, 2) if f2["ms"] > 0 else None})
             vb.release()
         pm.GROUP_DEDUP = os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"
+        # split-bf16 variant of the plain-row layers (FP / SA-hoisted GEMMs): each fp32 product rebuilt from 6 (or 3) bf16 MFMA
+        # products of exactly split operands, fp32 accumulate.  NOT this line's arithmetic (dtype stays "f32", value is the
+        # fp32-MFMA graph): reported beside it, with its distance from the fp32 outputs on the same batch.
+        if not os.environ.get("PRCNN_BENCH_NO_SPLIT") and not _ops_split.MLP_SPLIT_TERMS:
+            from pointrcnn_amd import ops as _ops
+            f32b = InferenceBench(args, model, dev, rank, world, "uniform", proposal_layer, None).warm()
+            f32_out = {k: f32b.out[k].clone() for k in ("backbone_features", "rpn_cls", "rpn_reg")}
+            f32b.release()
+            split = {"note": "plain-row layers (mlp_rows / mlp_rows_addinterp launches of at least 192 tiles) on mlp_layer_s_kernel; the "
+                             "register-resident chains (SA stacks, FP0, heads) stay fp32-MFMA.  max_diff_vs_f32 = max |out - out_f32| / "
+                             "max |out_f32| over backbone_features, rpn_cls, rpn_reg of slot 0's batch (contract: 1e-5)"}
+            for terms in (6, 3):
+                _ops.MLP_SPLIT_TERMS = terms
+                try:
+                    vb = InferenceBench(args, model, dev, rank, world, "uniform", proposal_layer, None).warm()
+                    diff = max(float((vb.out[k] - f32_out[k]).abs().max() / f32_out[k].abs().max()) for k in f32_out)
+                    f2 = instrumented_pass(args, vb, 1).get("mlp") if (rank == 0 and not args.no_roofline) else None
+                    vb.prepare()
+                    ev = vb.timed(vsteps, nstreams, dist)
+                    split["bf16x%d" % terms] = {"value": round(whole_job_value(args.batch, world, vsteps, ev), 2), "steps": vsteps,
+                                                 "ms_per_step": round(1e3 * ev / vsteps, 3), "max_diff_vs_f32": float("%.3g" % diff)}
+                    if f2:
+                        split["bf16x%d" % terms].update({"mlp_ms_per_step": round(f2["ms"], 3),
+                                                          "mlp_fp32_equivalent_TFLOPs": round(f2["flops"] / (f2["ms"] * 1e-3) / 1e12, 2)})
+                    vb.release()
+                finally:
+                    _ops.MLP_SPLIT_TERMS = 0
+            line["variant_split_bf16"] = split
         line["value_dedup_off"], line["value_saturated"] = variants["dedup_off"]["value"], variants["saturated"]["value"]
         line["value_lidar"] = variants["lidar"]["value"]
         if "repeat" in variants:

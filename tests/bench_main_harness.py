@@ -63,7 +63,7 @@ class StubBench:
 
     def __init__(self, args, model, dev, rank, world, clouds_kind, proposal_layer=None, raw=None):
         self.args, self.rank, self.world = args, rank, world
-        self.out, self.clouds_cpu, self.graphs = {}, None, None
+        self.out, self.clouds_cpu, self.graphs = {k: torch.ones(2) for k in ("backbone_features", "rpn_cls", "rpn_reg")}, None, None
         self.seed0 = bench.shard_seed0(rank, world, 0, args.batch)
 
     def prepare(self):

@@ -15,6 +15,7 @@ cp $R/bench_config5_rpn.json profiles/${T}_final_bench_config5_rpn.json
 cp $R/kernel_stats.txt profiles/${T}_final_kernel_stats.txt
 cp $R/kernel_stats_streams1.txt profiles/${T}_final_kernel_stats_streams1.txt
 cp $R/kernel_stats_train.txt profiles/${T}_final_kernel_stats_train.txt
+cp $R/kernel_stats_split_bf16x6.txt profiles/${T}_final_kernel_stats_split_bf16x6.txt
 cp $R/hbm_traffic.json profiles/${T}_hbm_traffic.json
 cp $R/mfma_util.txt profiles/${T}_mfma_util.txt
 cp $R/opbench.jsonl profiles/${T}_opbench.jsonl

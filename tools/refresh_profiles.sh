@@ -26,6 +26,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python bench.p
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-cpu-baseline --no-roofline --no-variants --streams 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python bench.py --workload train --steps 16 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktr -- python bench.py --workload train-rcnn --steps 16 > /dev/null 2>&1
+PRCNN_MLP_SPLIT=6 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python bench.py --no-cpu-baseline --no-roofline --no-variants --streams 1 > /dev/null 2>&1
+python profiles/summarize_rocprof.py $O/kts "PRCNN_MLP_SPLIT=6 python bench.py --streams 1 (VARIANT: plain-row layers on the split-bf16 six-term kernel; one batch in flight)" > $O/kernel_stats_split_bf16x6.txt
 python profiles/summarize_rocprof.py $O/ktr "python bench.py --workload train-rcnn --steps 16 (RCNN-stage training step, bs4, eager, fused training path)" > $O/kernel_stats_train_rcnn.txt
 python -m pointrcnn_amd.opbench > $O/opbench_raw.jsonl 2> $O/opbench.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/op_FETCH_SIZE -- python -m pointrcnn_amd.opbench > /dev/null 2>&1
