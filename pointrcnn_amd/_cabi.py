@@ -65,7 +65,8 @@ SIGNATURES = {
     "prcnn_mlp_interp": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P]),
     "prcnn_mlp_rows_addinterp": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
     "prcnn_wsplit_bytes": (_Z, [_I, _I]),
-    "prcnn_pack_weight_split": (_I, [_P, _I, _I, _P, _P]),
+    "prcnn_pack_weight_split": (_I, [_P, _I, _I, _I, _P, _P]),
+    "prcnn_mlp_chain_rows_split": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
     "prcnn_mlp_rows_split": (_I, [_P, _I, _L, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _P]),
     "prcnn_mlp_rows_addinterp_split": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
     "prcnn_mlp_chain_supported": (_I, [_I, _I, _P, _I]),
@@ -166,6 +167,9 @@ def lib():
         fn.argtypes = args
     _lib = handle
     return handle
+
+
+EUNSUPPORTED = -3                # PRCNN_EUNSUPPORTED: a valid request this build has no kernel for
 
 
 def check(rc, what=""):

@@ -859,19 +859,23 @@ __device__ __forceinline__ void split3(float x, uint32_t& b0, uint32_t& b1, uint
 // the top halves of two fp32 bit patterns as a bf16 pair (element 0 in the low half)
 __device__ __forceinline__ uint32_t bf16_pair(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
-__global__ void pack_weight_split_kernel(const float* __restrict__ w, int Nout, int K, int KS, int NB, uint4* __restrict__ img) {
+// chain = 0: the layer kernel's image, [column block][k-step][piece][lane], lane (h, j) element e <-> k = 16 ks + 8 h + e
+// chain = 1: the chain kernel's image, [k-step][output block][piece][lane], element e <-> k = 16 ks + 8 (e >> 2) + 4 h + (e & 3)
+__global__ void pack_weight_split_kernel(const float* __restrict__ w, int Nout, int K, int KS, int NB, int chain, uint4* __restrict__ img) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;            // one thread per (column block, k-step, lane)
     if (e >= (long)NB * KS * 64) return;
     const int lane = (int)(e & 63);
-    const long blk = e >> 6;
+    long blk = e >> 6;
     const int ks = (int)(blk % KS), nb = (int)(blk / KS);
-    const int n = nb * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+    const int n = nb * 32 + (lane & 31), hh = lane >> 5;
     uint32_t b[3][8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const float v = (n < Nout && k0 + i < K) ? w[(long)n * K + k0 + i] : 0.f;
+        const int k = chain ? ks * 16 + 8 * (i >> 2) + 4 * hh + (i & 3) : ks * 16 + 8 * hh + i;
+        const float v = (n < Nout && k < K) ? w[(long)n * K + k] : 0.f;
         split3(v, b[0][i], b[1][i], b[2][i]);
     }
+    if (chain) blk = (long)ks * NB + nb;
 #pragma unroll
     for (int p = 0; p < 3; p++)
         img[(blk * 3 + p) * 64 + lane] = make_uint4(bf16_pair(b[p][0], b[p][1]), bf16_pair(b[p][2], b[p][3]),
@@ -1063,6 +1067,7 @@ struct ChainParams {
     const float* wpack2; const float* bias2; int KB2, N2, relu2;
     int nlayers;
     int stack_split;           // mlp_stack2_kernel: most workgroups per row tile (set by dispatch_chain)
+    const void* wsplit1;       // mlp_chain_s_kernel: layer 1's split image (layer 0's is a.wsplit)
 };
 
 #define CH_DPP_FMAX(v, ctrl) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
@@ -1541,6 +1546,141 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == MO
 }
 
 // =====================================================================================================
+// Split-bf16 register-resident chain, plain rows, two layers (the RPN heads: 128 -> 128 -> 76 and 128 -> 128 -> 1) -- the opt-in
+// VARIANT of mlp_chain_fast_kernel<MODE_PLAIN, 4, NB1, 0> (see mlp_layer_s_kernel for the arithmetic: exact three-way bf16 split of
+// both operands, TERMS bf16 MFMA products per fp32 product, fp32 accumulate).  Same transposed formulation as the fp32 chain: the
+// weights are the MFMA A operand, the lane's own row the B operand, the D layout of layer l is the B layout of layer l+1 -- with
+// the 16-wide k-steps of the bf16 MFMA a lane half's eight operand elements are accumulator registers 8 sh .. 8 sh + 7 of block
+// pb, i.e. k = 32 pb + 16 sh + 8 (e >> 2) + 4 h + (e & 3): the chain's weight image (prcnn_pack_weight_split, chain = 1) is packed
+// in that k order, [k-step][output block][piece][lane], so a stage of two k-steps is one contiguous run.  Activations are split in
+// registers (lane-local), weights go L2 -> LDS once per workgroup and stage (two k-steps x NBO blocks x 3 pieces, double
+// buffered) and are read by the four waves with lane-linear ds_read_b128.  bias / ReLU / store / single-channel output are the
+// fp32 chain's own helpers (same D layout).
+// =====================================================================================================
+template <int NBO> struct SStage { static constexpr int U4 = 2 * NBO * 3 * 64; static constexpr int PT = (U4 + 255) / 256; };
+
+template <int NBO>
+__device__ __forceinline__ void sstage_load(const uint4* __restrict__ img, int st, int tid, uint4 (&r)[SStage<NBO>::PT]) {
+#pragma unroll
+    for (int u = 0; u < SStage<NBO>::PT; u++) {
+        const int e = min(tid + 256 * u, SStage<NBO>::U4 - 1);        // clamped, not guarded: straight-line loads (a ragged last
+        r[u] = img[(long)st * SStage<NBO>::U4 + e];                   // round re-reads / re-writes the stage's last element)
+    }
+}
+template <int NBO>
+__device__ __forceinline__ void sstage_store(uint4* ws, int tid, const uint4 (&r)[SStage<NBO>::PT]) {
+#pragma unroll
+    for (int u = 0; u < SStage<NBO>::PT; u++) ws[min(tid + 256 * u, SStage<NBO>::U4 - 1)] = r[u];
+}
+// eight fp32 values (one lane half's k-step) -> the three bf16 operand pieces
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&piece)[3]) {
+    uint32_t b[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) split3(v[i], b[0][i], b[1][i], b[2][i]);
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+        piece[p] = __builtin_bit_cast(bf16x8, make_uint4(bf16_pair(b[p][0], b[p][1]), bf16_pair(b[p][2], b[p][3]),
+                                                        bf16_pair(b[p][4], b[p][5]), bf16_pair(b[p][6], b[p][7])));
+}
+// one k-step of a chain layer: out[ob] += sum over the TERMS piece pairs of W[ob, step] (LDS tiles ksl * NBO + ob) x bp
+template <int NBO, int TERMS>
+__device__ __forceinline__ void schain_step(f32x16 (&out)[NBO], const uint4* ws, int ksl, int lane, const bf16x8 (&bp)[3]) {
+    constexpr int NP = TERMS == 6 ? 3 : 2;
+    bf16x8 w[NBO][NP];
+#pragma unroll
+    for (int ob = 0; ob < NBO; ob++)
+#pragma unroll
+        for (int p = 0; p < NP; p++) w[ob][p] = __builtin_bit_cast(bf16x8, ws[((ksl * NBO + ob) * 3 + p) * 64 + lane]);
+#define SCH_TERM(PA, PB)                                                                                                          \
+    _Pragma("unroll") for (int ob = 0; ob < NBO; ob++) out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ob][PA], bp[PB], out[ob], 0, 0, 0)
+    if constexpr (TERMS == 6) { SCH_TERM(2, 0); SCH_TERM(0, 2); SCH_TERM(1, 1); }
+    SCH_TERM(1, 0); SCH_TERM(0, 1); SCH_TERM(0, 0);
+#undef SCH_TERM
+}
+
+template <int NB1, int TERMS>
+__global__ __launch_bounds__(256, 2) void mlp_chain_s_kernel(const ChainParams Cin) {
+    constexpr int NB0 = 4, KS = 8;                           // K = 128 -> 128 -> N1
+    ChainParams C = Cin;
+    C.a.rows = effective_rows(Cin.a);
+    const MlpParams& P = C.a;
+    const long tile_id = blockIdx.x;
+    if (tile_id * 128 >= P.rows) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const long row = (tile_id * 4 + wave) * 32 + j;
+    const bool valid = row < P.rows;
+    const float* xrow = P.in + (valid ? row : P.rows - 1) * P.ld_in + 4 * h;
+
+    __shared__ __attribute__((aligned(16))) uint4 Ws[2][SStage<NB0>::U4];
+    __shared__ __attribute__((aligned(16))) float s_bias[2][128];
+    if (tid < 128) {
+        s_bias[0][tid] = P.bias ? P.bias[tid] : 0.f;
+        s_bias[1][tid] = (C.bias1 && tid < NB1 * 32) ? C.bias1[tid] : 0.f;
+    }
+    const uint4* img0 = reinterpret_cast<const uint4*>(P.wsplit);
+    const uint4* img1 = reinterpret_cast<const uint4*>(C.wsplit1);
+    const bool out1 = chain_out1_applies<NB1, 0>(C);
+
+    // the lane's row: k-step ks needs x[16 ks + 4 h .. +4) and x[16 ks + 8 + 4 h .. +4); four steps are requested ahead
+    float4 xa[KS], xb[KS];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { xa[ks] = ld4(xrow + 16 * ks); xb[ks] = ld4(xrow + 16 * ks + 8); }
+    uint4 wr[SStage<NB0>::PT];
+    sstage_load<NB0>(img0, 0, tid, wr);
+    sstage_store<NB0>(Ws[0], tid, wr);
+    __syncthreads();
+
+    f32x16 a0[NB0];
+#pragma unroll
+    for (int ob = 0; ob < NB0; ob++) a0[ob] = (f32x16){0};
+#pragma unroll
+    for (int st = 0; st < KS / 2; st++) {
+        if (st + 1 < KS / 2) sstage_load<NB0>(img0, st + 1, tid, wr);
+#pragma unroll
+        for (int ksl = 0; ksl < 2; ksl++) {
+            const int ks = 2 * st + ksl;
+            if (ks + 4 < KS) { xa[ks + 4] = ld4(xrow + 16 * (ks + 4)); xb[ks + 4] = ld4(xrow + 16 * (ks + 4) + 8); }
+            const float v[8] = {xa[ks].x, xa[ks].y, xa[ks].z, xa[ks].w, xb[ks].x, xb[ks].y, xb[ks].z, xb[ks].w};
+            bf16x8 bp[3];
+            split8(v, bp);
+            schain_step<NB0, TERMS>(a0, Ws[st & 1], ksl, lane, bp);
+        }
+        if (st + 1 < KS / 2) sstage_store<NB0>(Ws[(st + 1) & 1], tid, wr);
+        __syncthreads();
+    }
+    bias_act<NB0>(a0, s_bias[0], P.relu, h);
+    if (out1) { chain_out1<NB0>(C, a0, row, valid, lane, h); return; }
+    if constexpr (NB1 > 1) {
+        uint4 w1[SStage<NB1>::PT];
+        uint4* W1s = &Ws[0][0];                              // (a stage of NB1 <= 4 blocks fits a stage of four)
+        sstage_load<NB1>(img1, 0, tid, w1);
+        sstage_store<NB1>(W1s, tid, w1);
+        __syncthreads();
+        f32x16 a1[NB1];
+#pragma unroll
+        for (int ob = 0; ob < NB1; ob++) a1[ob] = (f32x16){0};
+#pragma unroll
+        for (int st = 0; st < NB0 * 2 / 2; st++) {           // NB0 * 2 k-steps, two per stage: stage st = input block st
+            if (st + 1 < NB0) sstage_load<NB1>(img1, st + 1, tid, w1);
+#pragma unroll
+            for (int sh = 0; sh < 2; sh++) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = a0[st][8 * sh + e];
+                bf16x8 bp[3];
+                split8(v, bp);
+                schain_step<NB1, TERMS>(a1, &Ws[st & 1][0], sh, lane, bp);
+            }
+            if (st + 1 < NB0) sstage_store<NB1>(&Ws[(st + 1) & 1][0], tid, w1);
+            __syncthreads();
+        }
+        bias_act<NB1>(a1, s_bias[1], C.relu1, h);
+        chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
+    }
+}
+
+// =====================================================================================================
 // PERSISTENT chain: the fast chain's arithmetic with ALL layers' packed weights resident in LDS for the lifetime of the
 // workgroup (48-128 KB of the CU's 160 KB; one 8-wave workgroup per CU = 2 waves per SIMD sharing one copy).  Each
 // wave then loops over 32-row tiles on its own: no weight staging, no barriers, no workgroup launch per 128 rows, and
@@ -1915,13 +2055,47 @@ PRCNN_API size_t prcnn_wsplit_bytes(int Nout, int K) {
     return (size_t)((Nout + 31) / 32) * ((K + 15) / 16) * 3 * 1024;
 }
 
-PRCNN_API int prcnn_pack_weight_split(const float* w, int Nout, int K, void* wsplit, prcnn_stream_t stream) {
+PRCNN_API int prcnn_pack_weight_split(const float* w, int Nout, int K, int chain, void* wsplit, prcnn_stream_t stream) {
     PRCNN_REQUIRE(w && wsplit && aligned16(wsplit), "prcnn_pack_weight_split: null / misaligned pointer");
-    PRCNN_REQUIRE(Nout > 0 && K > 0, "prcnn_pack_weight_split: bad shape Nout=%d K=%d", Nout, K);
+    PRCNN_REQUIRE(Nout > 0 && K > 0 && (chain == 0 || chain == 1), "prcnn_pack_weight_split: bad shape Nout=%d K=%d chain=%d", Nout, K, chain);
     const int KS = (K + 15) / 16, NB = (Nout + 31) / 32;
     hipLaunchKernelGGL(pack_weight_split_kernel, dim3(prcnn_divup((long)NB * KS * 64, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       Nout, K, KS, NB, reinterpret_cast<uint4*>(wsplit));
+                       Nout, K, KS, NB, chain, reinterpret_cast<uint4*>(wsplit));
     PRCNN_LAUNCH_CHECK("prcnn_pack_weight_split");
+    return PRCNN_OK;
+}
+
+// Two-layer plain-row chain on the split kernels; shapes: K = 128, nout[0] = 128, nout[1] = 1 or 65..128 (the RPN heads).
+// wchain[l]: prcnn_pack_weight_split(chain = 1) images; wpack1: the fp32 pack image of layer 1 (read by the single-channel output).
+// PRCNN_EUNSUPPORTED for any other shape: the caller issues prcnn_mlp_chain_rows.
+PRCNN_API int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t rows, int K, const void* const* wchain, const float* wpack1,
+                                         const float* const* bias, const int* nout, const int* relu, int terms, float* out, int ld_out,
+                                         int col_off, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(in && wchain && bias && nout && relu && out, "prcnn_mlp_chain_rows_split: null pointer");
+    PRCNN_REQUIRE(terms == 3 || terms == 6, "prcnn_mlp_chain_rows_split: terms=%d (3 or 6)", terms);
+    const bool ok = K == 128 && nout[0] == 128 && (nout[1] == 1 || (nout[1] > 64 && nout[1] <= 128)) && aligned16(in) && ld_in % 4 == 0 &&
+                    ld_in >= K && wchain[0] && (nout[1] == 1 ? wpack1 != nullptr : wchain[1] != nullptr);
+    if (!ok) return PRCNN_EUNSUPPORTED;
+    PRCNN_REQUIRE(ld_out >= col_off + nout[1], "prcnn_mlp_chain_rows_split: ld_out=%d < col_off+Nout", ld_out);
+    if (rows == 0) return PRCNN_OK;
+    ChainParams C = {};
+    MlpParams& P = C.a;
+    P.rows = rows; P.K = K; P.in = in; P.ld_in = ld_in; P.bias = bias[0]; P.Nout = nout[0]; P.relu = relu[0];
+    P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.rows_unit = 1;
+    P.wsplit = wchain[0]; P.split_terms = terms;
+    C.wsplit1 = wchain[1]; C.wpack1 = wpack1; C.bias1 = bias[1]; C.N1 = nout[1]; C.relu1 = relu[1]; C.KB1 = 16; C.nlayers = 2;
+    const dim3 grid(prcnn_divup(rows, 128));
+    const hipStream_t s = (hipStream_t)stream;
+#define SCH_LAUNCH(NB1)                                                                                        \
+    do {                                                                                                       \
+        if (terms == 6) hipLaunchKernelGGL((mlp_chain_s_kernel<NB1, 6>), grid, dim3(256), 0, s, C);            \
+        else hipLaunchKernelGGL((mlp_chain_s_kernel<NB1, 3>), grid, dim3(256), 0, s, C);                       \
+    } while (0)
+    if (nout[1] == 1) SCH_LAUNCH(1);
+    else if (nout[1] <= 96) SCH_LAUNCH(3);
+    else SCH_LAUNCH(4);
+#undef SCH_LAUNCH
+    PRCNN_LAUNCH_CHECK("prcnn_mlp_chain_rows_split");
     return PRCNN_OK;
 }
 

@@ -245,15 +245,18 @@ class PackedLinear:
             self.bias[: self.nout] = bias
 
 
-    def wsplit(self):
-        """the pre-split bf16 weight image of the split-bf16 variant (prcnn_pack_weight_split), or None when the layer does not
-        qualify (K a multiple of 32, no rotated input channels)"""
-        if self._wsplit is None and self._w is not None and self.k % 32 == 0:
+    def wsplit(self, chain=0):
+        """the pre-split bf16 weight image of the split-bf16 variant (prcnn_pack_weight_split; chain = 1: the chain kernel's
+        image), or None when the layer does not qualify (K a multiple of 32, no rotated input channels)"""
+        if self._wsplit is None:
+            self._wsplit = {}
+        if chain not in self._wsplit and self._w is not None and self.k % 32 == 0:
             L = _cabi.lib()
-            self._wsplit = torch.empty((L.prcnn_wsplit_bytes(self.nout, self.k),), dtype=torch.uint8, device=self._w.device)
-            _cabi.check(L.prcnn_pack_weight_split(_p(self._w.contiguous()), self.nout, self.k, _p(self._wsplit), _stream()),
+            img = torch.empty((L.prcnn_wsplit_bytes(self.nout, self.k),), dtype=torch.uint8, device=self._w.device)
+            _cabi.check(L.prcnn_pack_weight_split(_p(self._w.contiguous()), self.nout, self.k, int(chain), _p(img), _stream()),
                         "prcnn_pack_weight_split")
-        return self._wsplit
+            self._wsplit[chain] = img
+        return self._wsplit.get(chain)
 
 
 # Split-bf16 VARIANT of the plain-row layers (prcnn_mlp_rows_split): 0 = off (fp32 MFMA, the product's arithmetic), 3 / 6 = the
@@ -309,6 +312,15 @@ def mlp_chain_rows(x, layers, out=None, pool_ns=0, seg=None):
     buf, ld_out, col_off = _out_buf(out, rows_out, layers[-1], x.device)
     a = _chain_args(layers)
     seg_cnt, seg_rows = (None, 0) if seg is None else (seg[0], int(seg[1]))
+    if (MLP_SPLIT_TERMS and not pool_ns and seg is None and a.n == 2 and K == 128 and layers[0].nout == 128 and rows >= 32768
+            and (layers[1].nout == 1 or 64 < layers[1].nout <= 128) and layers[0].wsplit(1) is not None and layers[1].wsplit(1) is not None):
+        if getattr(a, "wchain", None) is None:                 # (host array of the two chain images, kept with the cached args)
+            a.wchain = (ctypes.c_void_p * 2)(layers[0].wsplit(1).data_ptr(), layers[1].wsplit(1).data_ptr())
+        rc = _cabi.lib().prcnn_mlp_chain_rows_split(_p(x), ld_in, rows, K, a.wchain, _p(layers[1].wpack), a.bias, a.nout, a.relu,
+                                                    MLP_SPLIT_TERMS, _p(buf), ld_out, col_off, _stream())
+        if rc != _cabi.EUNSUPPORTED:
+            _cabi.check(rc, "prcnn_mlp_chain_rows_split")
+            return buf
     _cabi.check(_cabi.lib().prcnn_mlp_chain_rows(_p(x), ld_in, rows, K, a.n, a.wpack, a.bias, a.nout, a.relu, _p(buf),
                                                  ld_out, col_off, pool_ns, _p(seg_cnt), seg_rows, _stream()), "prcnn_mlp_chain_rows")
     return buf

@@ -456,3 +456,35 @@ def test_split_bf16_full_rpn_stays_within_the_fp32_contract(dev, monkeypatch):
         np.testing.assert_allclose(a, b, atol=1e-5 * max(1.0, float(np.abs(b).max())), rtol=0)
         differs = differs or not np.array_equal(a, b)
     assert differs, "the split kernel did not run (outputs are bit-identical to the fp32 path)"
+
+
+@pytest.mark.parametrize("n1,relu1", [(76, False), (1, False), (128, True), (96, True)])
+@pytest.mark.parametrize("terms", [6, 3])
+def test_split_bf16_two_layer_chain_against_float64(dev, monkeypatch, n1, relu1, terms):
+    """the heads' two-layer chain (128 -> 128 -> n1) on the split-bf16 chain kernel against a float64 evaluation of the same
+    stack; bound per element: the first layer's error bound pushed through |W2|, plus the second layer's own"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(n1 + terms)
+    rows = 40000 + 17                                     # a ragged last tile
+    x = _scaled_rows(r, rows, 128)
+    w0 = (r.normal(size=(128, 128)) * 0.1).astype(np.float32)
+    b0 = r.normal(size=(128,)).astype(np.float32)
+    w1 = (r.normal(size=(n1, 128)) * 0.1).astype(np.float32)
+    b1 = r.normal(size=(n1,)).astype(np.float32)
+    layers = [lin(dev, w0, b0, True), lin(dev, w1, b1, relu1)]
+    ref32 = ops.mlp_chain_rows(T(x, dev), layers).cpu().numpy()
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", terms)
+    got = ops.mlp_chain_rows(T(x, dev), layers).cpu().numpy().astype(np.float64)
+    assert got.shape == (rows, n1)
+    xd, w0d, w1d = x.astype(np.float64), w0.astype(np.float64), w1.astype(np.float64)
+    h = np.maximum(xd @ w0d.T + b0, 0.0)
+    want = h @ w1d.T + b1
+    if relu1:
+        want = np.maximum(want, 0.0)
+    eps = 2e-6 if terms == 6 else 4e-5
+    s0 = np.abs(xd) @ np.abs(w0d).T + np.abs(b0)
+    bound = eps * (s0 @ np.abs(w1d).T) + eps * (h @ np.abs(w1d).T + np.abs(b1)) + 1e-30
+    assert (np.abs(got - want) <= bound).all(), float((np.abs(got - want) / bound).max())
+    assert not np.array_equal(got.astype(np.float32), ref32), "the split chain did not run"
+    if terms == 6:
+        np.testing.assert_allclose(got, ref32, atol=mlp_tol(ref32), rtol=0)

@@ -39,6 +39,27 @@ def main():
             err = ((y[:4096].double() - ref).abs() / scale).max().item()
             line += "  %s %7.1f us (%5.1f TF) err/scale %.2e" % ({0: "f32", 6: "bf16x6", 3: "bf16x3"}[terms], us, 2.0 * rows * K * N / us * 1e-6, err)
         print(line, flush=True)
+    # the heads: two-layer chains on 524288 rows
+    x = torch.randn((524288, 128), generator=g).to(dev)
+    for n1 in (76, 1):
+        layers = [ops.PackedLinear((torch.randn((128, 128), generator=g) * 0.1).to(dev), torch.randn((128,), generator=g).to(dev), relu=True),
+                  ops.PackedLinear((torch.randn((n1, 128), generator=g) * 0.1).to(dev), torch.randn((n1,), generator=g).to(dev), relu=False)]
+        line = "chain 524288 x 128 -> 128 -> %2d:" % n1
+        ref = None
+        for terms in (0, 6, 3):
+            ops.MLP_SPLIT_TERMS = terms
+            y = ops.mlp_chain_rows(x, layers)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.mlp_chain_rows(x, layers)
+            e1.record()
+            torch.cuda.synchronize()
+            ref = y if ref is None else ref
+            line += "  %s %7.1f us  diff %.2e" % ({0: "f32", 6: "bf16x6", 3: "bf16x3"}[terms], e0.elapsed_time(e1) / 10 * 1e3,
+                                                 ((y - ref).abs().max() / ref.abs().max()).item())
+        print(line, flush=True)
     ops.MLP_SPLIT_TERMS = 0
 
 
