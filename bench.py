@@ -187,6 +187,10 @@ class EventProfiler:
             return 2.0 * (a[2] + 3) * a[5], a[11] * a[12], None, 1, "%d->%d + interpolated addend" % (a[2], a[5])
         if name == "prcnn_mlp_rows_split":              # (fp32-EQUIVALENT flops: 2 K N per row, whatever the number of bf16 terms)
             return 2.0 * a[3] * a[8], a[2], None, 1, "%d->%d (bf16x%d)" % (a[3], a[8], a[6])
+        if name == "prcnn_mlp_chain_rows_split":
+            return chain(a[3], [a[7][0], a[7][1]]), a[2], None, 1, widths(a[3], a[7], 2) + " (bf16x%d)" % a[9]
+        if name == "prcnn_mlp_chain_interp_split":
+            return 2.0 * a[7] * a[11], a[4] * a[5], None, 1, "%d->%d (bf16x%d)" % (a[7], a[11], a[13])
         if name == "prcnn_mlp_rows_addinterp_split":
             return 2.0 * (a[2] + 3) * a[7], a[13] * a[14], None, 1, "%d->%d + interpolated addend (bf16x%d)" % (a[2], a[7], a[5])
         if name == "prcnn_mlp_group":
@@ -934,8 +938,8 @@ def main():
             f32b = InferenceBench(args, model, dev, rank, world, "uniform", proposal_layer, None).warm()
             f32_out = {k: f32b.out[k].clone() for k in ("backbone_features", "rpn_cls", "rpn_reg")}
             f32b.release()
-            split = {"note": "plain-row layers (mlp_rows / mlp_rows_addinterp launches of at least 192 tiles) on mlp_layer_s_kernel; the "
-                             "register-resident chains (SA stacks, FP0, heads) stay fp32-MFMA.  max_diff_vs_f32 = max |out - out_f32| / "
+            split = {"note": "plain-row layers (mlp_rows / mlp_rows_addinterp launches of at least 192 tiles) on mlp_layer_s_kernel, the heads "
+                             "and hoisted FP0 on mlp_chain_s_kernel; the SA stacks and the short FP3 layer stay fp32-MFMA.  max_diff_vs_f32 = max |out - out_f32| / "
                              "max |out_f32| over backbone_features, rpn_cls, rpn_reg of slot 0's batch (contract: 1e-5)"}
             for terms in (6, 3):
                 _ops.MLP_SPLIT_TERMS = terms

@@ -220,6 +220,12 @@ int prcnn_mlp_rows_split(const float* in, int ld_in, int64_t rows, int K, const 
 int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t rows, int K, const void* const* wchain, const float* wpack1,
                                const float* const* bias, const int* nout, const int* relu, int terms, float* out, int ld_out,
                                int col_off, prcnn_stream_t stream);
+/* hoisted FP0 on the split chain kernel: rows relu(interp(known_cl) + act_bias), C2 = 128 and no skip features, through ONE
+ * 128 -> 128 layer (prcnn_mlp_chain_interp with nlayers = 1, C1 = 0, act_bias given); wchain: the chain = 1 image.  Other shapes:
+ * PRCNN_EUNSUPPORTED. */
+int prcnn_mlp_chain_interp_split(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3, int B, int n, int m,
+                                 int C2, const float* act_bias, const void* wchain, const float* bias, int Nout, int relu,
+                                 int terms, float* out, int ld_out, int col_off, prcnn_stream_t stream);
 int prcnn_mlp_rows_addinterp_split(const float* in, int ld_in, int K, const float* wpack, const void* wsplit, int terms,
                                    const float* bias, int Nout, int relu, const float* y_cl, int ld_y, const int32_t* idx3,
                                    const float* w3, int B, int n, int m, float* out, int ld_out, int col_off,

@@ -1598,34 +1598,40 @@ __device__ __forceinline__ void schain_step(f32x16 (&out)[NBO], const uint4* ws,
 #undef SCH_TERM
 }
 
-template <int NB1, int TERMS>
+// MODE_PLAIN: the rows are read as they are; MODE_INTERP (hoisted FP0: act = 2, C1 = 0): row = relu(interp(Y) + act_bias), built in
+// registers from the three neighbours' rows exactly as mlp_chain_fast_kernel builds it.  NB1 = 0: one layer.
+template <int MODE, int NB1, int TERMS>
 __global__ __launch_bounds__(256, 2) void mlp_chain_s_kernel(const ChainParams Cin) {
-    constexpr int NB0 = 4, KS = 8;                           // K = 128 -> 128 -> N1
+    constexpr int NB0 = 4, KS = 8;                           // K = 128 -> 128 (-> N1)
+    constexpr int RD = MODE == MODE_PLAIN ? 4 : 2;           // k-steps of input requested ahead (plain rows stream from HBM)
     ChainParams C = Cin;
     C.a.rows = effective_rows(Cin.a);
     const MlpParams& P = C.a;
-    const long tile_id = blockIdx.x;
+    const long tile_id = tile_of_block(P, blockIdx.x);
     if (tile_id * 128 >= P.rows) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
     const long row = (tile_id * 4 + wave) * 32 + j;
     const bool valid = row < P.rows;
-    const float* xrow = P.in + (valid ? row : P.rows - 1) * P.ld_in + 4 * h;
+    RowMeta<MODE> meta;
+    make_meta<MODE>(P, valid ? row : P.rows - 1, meta);
 
     __shared__ __attribute__((aligned(16))) uint4 Ws[2][SStage<NB0>::U4];
     __shared__ __attribute__((aligned(16))) float s_bias[2][128];
+    __shared__ __attribute__((aligned(16))) float s_b[128];
     if (tid < 128) {
         s_bias[0][tid] = P.bias ? P.bias[tid] : 0.f;
-        s_bias[1][tid] = (C.bias1 && tid < NB1 * 32) ? C.bias1[tid] : 0.f;
+        s_bias[1][tid] = (NB1 > 0 && C.bias1 && tid < NB1 * 32) ? C.bias1[tid] : 0.f;
+        s_b[tid] = MODE != MODE_PLAIN ? P.act_bias[tid] : 0.f;
     }
     const uint4* img0 = reinterpret_cast<const uint4*>(P.wsplit);
     const uint4* img1 = reinterpret_cast<const uint4*>(C.wsplit1);
     const bool out1 = chain_out1_applies<NB1, 0>(C);
 
-    // the lane's row: k-step ks needs x[16 ks + 4 h .. +4) and x[16 ks + 8 + 4 h .. +4); four steps are requested ahead
-    float4 xa[KS], xb[KS];
+    // the lane's row: k-step ks needs elements 16 ks + 4 h .. +4 and 16 ks + 8 + 4 h .. +4
+    Raw<MODE> xa[KS], xb[KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) { xa[ks] = ld4(xrow + 16 * ks); xb[ks] = ld4(xrow + 16 * ks + 8); }
+    for (int ks = 0; ks < RD; ks++) { fast_fetch<MODE>(P, meta, 16 * ks + 4 * h, xa[ks]); fast_fetch<MODE>(P, meta, 16 * ks + 8 + 4 * h, xb[ks]); }
     uint4 wr[SStage<NB0>::PT];
     sstage_load<NB0>(img0, 0, tid, wr);
     sstage_store<NB0>(Ws[0], tid, wr);
@@ -1640,8 +1646,13 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_s_kernel(const ChainParams C
 #pragma unroll
         for (int ksl = 0; ksl < 2; ksl++) {
             const int ks = 2 * st + ksl;
-            if (ks + 4 < KS) { xa[ks + 4] = ld4(xrow + 16 * (ks + 4)); xb[ks + 4] = ld4(xrow + 16 * (ks + 4) + 8); }
-            const float v[8] = {xa[ks].x, xa[ks].y, xa[ks].z, xa[ks].w, xb[ks].x, xb[ks].y, xb[ks].z, xb[ks].w};
+            if (ks + RD < KS) {
+                fast_fetch<MODE>(P, meta, 16 * (ks + RD) + 4 * h, xa[ks + RD]);
+                fast_fetch<MODE>(P, meta, 16 * (ks + RD) + 8 + 4 * h, xb[ks + RD]);
+            }
+            const float4 va = fast_finish<MODE>(meta, 16 * ks + 4 * h, xa[ks], nullptr, s_b);
+            const float4 vb = fast_finish<MODE>(meta, 16 * ks + 8 + 4 * h, xb[ks], nullptr, s_b);
+            const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
             bf16x8 bp[3];
             split8(v, bp);
             schain_step<NB0, TERMS>(a0, Ws[st & 1], ksl, lane, bp);
@@ -1651,6 +1662,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_s_kernel(const ChainParams C
     }
     bias_act<NB0>(a0, s_bias[0], P.relu, h);
     if (out1) { chain_out1<NB0>(C, a0, row, valid, lane, h); return; }
+    if constexpr (NB1 == 0) chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
     if constexpr (NB1 > 1) {
         uint4 w1[SStage<NB1>::PT];
         uint4* W1s = &Ws[0][0];                              // (a stage of NB1 <= 4 blocks fits a stage of four)
@@ -2088,8 +2100,8 @@ PRCNN_API int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t row
     const hipStream_t s = (hipStream_t)stream;
 #define SCH_LAUNCH(NB1)                                                                                        \
     do {                                                                                                       \
-        if (terms == 6) hipLaunchKernelGGL((mlp_chain_s_kernel<NB1, 6>), grid, dim3(256), 0, s, C);            \
-        else hipLaunchKernelGGL((mlp_chain_s_kernel<NB1, 3>), grid, dim3(256), 0, s, C);                       \
+        if (terms == 6) hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_PLAIN, NB1, 6>), grid, dim3(256), 0, s, C); \
+        else hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_PLAIN, NB1, 3>), grid, dim3(256), 0, s, C);            \
     } while (0)
     if (nout[1] == 1) SCH_LAUNCH(1);
     else if (nout[1] <= 96) SCH_LAUNCH(3);
@@ -2786,6 +2798,32 @@ PRCNN_API int prcnn_mlp_chain_interp(const float* known_cl, int ld_known, const 
     if (rc) return rc;
     if (B % 8 == 0 && n % 128 == 0 && getenv("PRCNN_NO_XCD_ORDER") == nullptr) C.a.xcd_tpf = n / 128;
     return dispatch_chain(MODE_INTERP, C, (hipStream_t)stream);
+}
+
+// Hoisted FP0 on the split chain kernel: rows relu(interp(known_cl) + act_bias) (C2 = 128, no skip features) through ONE
+// 128 -> 128 layer.  wchain: prcnn_pack_weight_split(chain = 1).  PRCNN_EUNSUPPORTED for other shapes (issue prcnn_mlp_chain_interp).
+PRCNN_API int prcnn_mlp_chain_interp_split(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3, int B, int n,
+                                           int m, int C2, const float* act_bias, const void* wchain, const float* bias, int Nout,
+                                           int relu, int terms, float* out, int ld_out, int col_off, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(known_cl && idx3 && w3 && act_bias && wchain && out, "prcnn_mlp_chain_interp_split: null pointer");
+    PRCNN_REQUIRE(terms == 3 || terms == 6, "prcnn_mlp_chain_interp_split: terms=%d (3 or 6)", terms);
+    PRCNN_REQUIRE(B >= 0 && n > 0 && m > 0 && ld_known >= C2 && ld_out >= col_off + Nout, "prcnn_mlp_chain_interp_split: bad shape");
+    if (!(C2 == 128 && Nout == 128 && aligned16(known_cl) && ld_known % 4 == 0 && aligned16(act_bias))) return PRCNN_EUNSUPPORTED;
+    if (B == 0) return PRCNN_OK;
+    ChainParams C = {};
+    MlpParams& P = C.a;
+    P.rows = (long)B * n; P.K = C2; P.bias = bias; P.Nout = Nout; P.relu = relu;
+    P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.rows_unit = 1;
+    P.known = known_cl; P.idx3 = idx3; P.w3 = w3; P.ld_known = ld_known; P.n = n; P.m = m; P.C2 = C2; P.C1 = 0;
+    P.vec_a = 1; P.act = 2; P.act_bias = act_bias;
+    P.wsplit = wchain; P.split_terms = terms;
+    C.nlayers = 1;
+    if (B % 8 == 0 && n % 128 == 0 && getenv("PRCNN_NO_XCD_ORDER") == nullptr) P.xcd_tpf = n / 128;
+    const dim3 grid(prcnn_divup(P.rows, 128));
+    if (terms == 6) hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_INTERP, 0, 6>), grid, dim3(256), 0, (hipStream_t)stream, C);
+    else hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_INTERP, 0, 3>), grid, dim3(256), 0, (hipStream_t)stream, C);
+    PRCNN_LAUNCH_CHECK("prcnn_mlp_chain_interp_split");
+    return PRCNN_OK;
 }
 
 // training-mode SharedMLP (forward with batch statistics, dgrad, wgrad): shares the row fetchers and weight image above

@@ -349,6 +349,15 @@ def mlp_chain_interp(known_cl, idx3, w3, skip_cl, layers, out=None, act_bias=Non
     ld_skip = 0 if skip_cl is None else _row_stride(skip_cl)
     buf, ld_out, col_off = _out_buf(out, B * n, layers[-1], known_cl.device)
     a = _chain_args(layers)
+    if (MLP_SPLIT_TERMS and skip_cl is None and act_bias is not None and a.n == 1 and C2 == 128 and layers[0].nout == 128
+            and B * n >= 32768 and layers[0].wsplit(1) is not None):
+        l0 = layers[0]
+        rc = _cabi.lib().prcnn_mlp_chain_interp_split(_p(known_cl), _row_stride(known_cl), _p(idx3), _p(w3), B, n, m, C2, _p(act_bias),
+                                                      _p(l0.wsplit(1)), _p(l0.bias), l0.nout, int(l0.relu), MLP_SPLIT_TERMS, _p(buf),
+                                                      ld_out, col_off, _stream())
+        if rc != _cabi.EUNSUPPORTED:
+            _cabi.check(rc, "prcnn_mlp_chain_interp_split")
+            return buf
     _cabi.check(_cabi.lib().prcnn_mlp_chain_interp(_p(known_cl), _row_stride(known_cl), _p(idx3), _p(w3), _p(skip_cl), ld_skip,
                                                    B, n, m, C2, C1, _p(act_bias), a.n, a.wpack, a.bias, a.nout, a.relu, _p(buf),
                                                    ld_out, col_off, _stream()), "prcnn_mlp_chain_interp")

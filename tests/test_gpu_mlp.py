@@ -488,3 +488,35 @@ def test_split_bf16_two_layer_chain_against_float64(dev, monkeypatch, n1, relu1,
     assert not np.array_equal(got.astype(np.float32), ref32), "the split chain did not run"
     if terms == 6:
         np.testing.assert_allclose(got, ref32, atol=mlp_tol(ref32), rtol=0)
+
+
+@pytest.mark.parametrize("terms", [6, 3])
+def test_split_bf16_hoisted_fp0_chain(dev, monkeypatch, terms):
+    """hoisted FP0 (rows relu(interp(Y) + b0) through one 128 -> 128 layer) on the split chain kernel, B = 8 frames so that the
+    XCD-aware tile order is exercised: against float64 on the SAME interpolated rows (the prologue's fp32 arithmetic is the fp32
+    chain's: the row values are taken from a float64-free restatement in torch) and against the fp32 chain kernel"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(40 + terms)
+    B, n, m = 8, 4096, 1024
+    y = T(r.normal(size=(B, m, 128)).astype(np.float32), dev)
+    idx3 = T(r.integers(0, m, size=(B, n, 3)).astype(np.int32), dev)
+    w3 = r.random(size=(B, n, 3)).astype(np.float32)
+    w3 = T(w3 / w3.sum(-1, keepdims=True), dev)
+    b0 = T(r.normal(size=(128,)).astype(np.float32), dev)
+    w1 = (r.normal(size=(128, 128)) * 0.1).astype(np.float32)
+    b1 = r.normal(size=(128,)).astype(np.float32)
+    l1 = lin(dev, w1, b1, True)
+    ref32 = ops.mlp_chain_interp(y, idx3, w3, None, [l1], act_bias=b0).cpu().numpy()
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", terms)
+    got = ops.mlp_chain_interp(y, idx3, w3, None, [l1], act_bias=b0).cpu().numpy().astype(np.float64)
+    # the interpolated, activated rows in fp32 (same expression order as interp1: (w0 a + w1 b) + w2 c), then float64 for the layer
+    g = torch.gather(y.unsqueeze(1).expand(B, 3, m, 128), 2, idx3.long().permute(0, 2, 1).unsqueeze(-1).expand(B, 3, n, 128))
+    rows = torch.relu((w3[..., 0:1] * g[:, 0] + w3[..., 1:2] * g[:, 1]) + w3[..., 2:3] * g[:, 2] + b0).reshape(-1, 128).cpu().numpy().astype(np.float64)
+    want = np.maximum(rows @ w1.astype(np.float64).T + b1, 0.0)
+    scale = np.abs(rows) @ np.abs(w1).astype(np.float64).T + np.abs(b1)
+    # (the rows themselves may differ from the kernel's by an fp32 rounding of the interpolation: one more 1e-7-class term)
+    bound = ((2e-6 if terms == 6 else 4e-5) + 4e-7) * scale + 1e-30
+    assert (np.abs(got - want) <= bound).all(), float((np.abs(got - want) / bound).max())
+    assert not np.array_equal(got.astype(np.float32), ref32), "the split chain did not run"
+    if terms == 6:
+        np.testing.assert_allclose(got, ref32, atol=mlp_tol(ref32), rtol=0)

@@ -60,6 +60,30 @@ def main():
             line += "  %s %7.1f us  diff %.2e" % ({0: "f32", 6: "bf16x6", 3: "bf16x3"}[terms], e0.elapsed_time(e1) / 10 * 1e3,
                                                  ((y - ref).abs().max() / ref.abs().max()).item())
         print(line, flush=True)
+    # hoisted FP0: interpolated rows through one 128 -> 128 layer
+    B, n, m = 32, 16384, 4096
+    y = torch.randn((B, m, 128), generator=g).to(dev)
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32).to(dev)
+    idx3 = (torch.arange(n, device=dev).view(1, n, 1) // 4 + idx3 % 8).clamp_(max=m - 1).int().contiguous()      # neighbours near n/4: L2-local as in the graph
+    w3 = torch.rand((B, n, 3), generator=g).to(dev)
+    w3 = (w3 / w3.sum(-1, keepdim=True)).contiguous()
+    b0 = torch.randn((128,), generator=g).to(dev)
+    l1 = ops.PackedLinear((torch.randn((128, 128), generator=g) * 0.1).to(dev), torch.randn((128,), generator=g).to(dev), relu=True)
+    line, ref = "FP0 chain 524288 x interp(128) -> 128:", None
+    for terms in (0, 6, 3):
+        ops.MLP_SPLIT_TERMS = terms
+        yy = ops.mlp_chain_interp(y, idx3, w3, None, [l1], act_bias=b0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.mlp_chain_interp(y, idx3, w3, None, [l1], act_bias=b0)
+        e1.record()
+        torch.cuda.synchronize()
+        ref = yy if ref is None else ref
+        line += "  %s %7.1f us  diff %.2e" % ({0: "f32", 6: "bf16x6", 3: "bf16x3"}[terms], e0.elapsed_time(e1) / 10 * 1e3,
+                                             ((yy - ref).abs().max() / ref.abs().max()).item())
+    print(line, flush=True)
     ops.MLP_SPLIT_TERMS = 0
 
 
