@@ -933,7 +933,9 @@ def main():
         # split-bf16 variant of the plain-row layers (FP / SA-hoisted GEMMs): each fp32 product rebuilt from 6 (or 3) bf16 MFMA
         # products of exactly split operands, fp32 accumulate.  NOT this line's arithmetic (dtype stays "f32", value is the
         # fp32-MFMA graph): reported beside it, with its distance from the fp32 outputs on the same batch.
-        if not os.environ.get("PRCNN_BENCH_NO_SPLIT") and not _ops_split.MLP_SPLIT_TERMS:
+        if world > 1:
+            line["variant_split_bf16"] = "measured on the single-GPU line only (python bench.py)"
+        elif not os.environ.get("PRCNN_BENCH_NO_SPLIT") and not _ops_split.MLP_SPLIT_TERMS:
             from pointrcnn_amd import ops as _ops
             f32b = InferenceBench(args, model, dev, rank, world, "uniform", proposal_layer, None).warm()
             f32_out = {k: f32b.out[k].clone() for k in ("backbone_features", "rpn_cls", "rpn_reg")}

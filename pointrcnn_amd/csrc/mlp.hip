@@ -1980,7 +1980,8 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     static const long split_min = getenv("PRCNN_SPLIT_MIN_TILES") ? atol(getenv("PRCNN_SPLIT_MIN_TILES")) : 192;
     if (P.wsplit && mode == MODE_PLAIN && P.K % MLP_BK == 0 && P.vec_a && P.pool_ns == 0 && split_tiles_narrow >= split_min) {
         PRCNN_REQUIRE(aligned16(P.wsplit) && (P.split_terms == 3 || P.split_terms == 6), "prcnn_mlp: bad split image / terms=%d", P.split_terms);
-        const bool wide = P.NB >= 4 && split_tiles_wide >= split_min;
+        static const long split_wide_min = getenv("PRCNN_SPLIT_WIDE_MIN") ? atol(getenv("PRCNN_SPLIT_WIDE_MIN")) : 192;
+        const bool wide = P.NB >= 4 && split_tiles_wide >= split_wide_min;
         dim3 grid(prcnn_divup(P.rows, MLP_BM), prcnn_divup(P.NB, wide ? 4 : 2));
         if (!P.seg_cnt) {
             P.wgm_cols = (int)grid.y;
