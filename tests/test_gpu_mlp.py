@@ -379,7 +379,8 @@ def _scaled_rows(r, rows, K):
 
 
 @pytest.mark.parametrize("rows,K,Nout,relu,bias", [(24576, 32, 128, True, True), (25000, 96, 256, True, True), (12288, 512, 512, False, True),
-                                                   (24576, 64, 64, True, False), (3000, 256, 96, True, True), (200, 64, 64, True, True)])
+                                                   (24576, 64, 64, True, False), (24576 + 77, 64, 96, True, True), (16384, 128, 200, False, True),
+                                                   (12288 + 5, 32, 76, True, True), (3000, 256, 96, True, True), (200, 64, 64, True, True)])
 @pytest.mark.parametrize("terms", [6, 3])
 def test_split_bf16_rows_against_float64(dev, monkeypatch, rows, K, Nout, relu, bias, terms):
     """the split-bf16 layer against a float64 product.  Six terms: every dropped partial product is below 2^-24 |x||w|, so the
