@@ -186,7 +186,7 @@ class EventProfiler:
         if name == "prcnn_mlp_rows_addinterp":
             return 2.0 * (a[2] + 3) * a[5], a[11] * a[12], None, 1, "%d->%d + interpolated addend" % (a[2], a[5])
         if name == "prcnn_mlp_rows_split":              # (fp32-EQUIVALENT flops: 2 K N per row, whatever the number of bf16 terms)
-            return 2.0 * a[3] * a[8], a[2], None, 1, "%d->%d (bf16x%d)" % (a[3], a[8], a[6])
+            return 2.0 * a[3] * a[8], a[2], a[13], a[14], "%d->%d (bf16x%d)" % (a[3], a[8], a[6])
         if name == "prcnn_mlp_chain_rows_split":
             return chain(a[3], [a[7][0], a[7][1]]), a[2], None, 1, widths(a[3], a[7], 2) + " (bf16x%d)" % a[9]
         if name == "prcnn_mlp_chain_interp_split":

@@ -207,6 +207,7 @@ int prcnn_mlp_rows_addinterp(const float* in, int ld_in, int K, const float* wpa
  * everything above 2^-16 |x||w|.  wsplit: prcnn_wsplit_bytes(Nout, K) bytes written by prcnn_pack_weight_split from the
  * (Nout, K) row-major fp32 weight.  The split kernel needs K % 32 == 0 and 16-byte aligned input rows; any other shape runs
  * the fp32 kernel on `wpack`, exactly as prcnn_mlp_rows / prcnn_mlp_rows_addinterp would.  An infinite input yields NaN.
+ * rows_dev / rows_unit / seg_cnt / seg_rows: as for prcnn_mlp_rows (no max-pool in the split variant).
  * prcnn_pack_weight_split: chain = 0 writes the image of the two layer calls, chain = 1 the image of prcnn_mlp_chain_rows_split
  * (same size).  prcnn_mlp_chain_rows_split: the two-layer plain-row chain (prcnn_mlp_chain_rows with nlayers = 2) for K = 128,
  * nout = {128, 1} or {128, 65..128} -- the RPN heads; wchain / bias / nout / relu are HOST arrays of length 2, wchain[l] the
@@ -216,7 +217,8 @@ int prcnn_mlp_rows_addinterp(const float* in, int ld_in, int K, const float* wpa
 size_t prcnn_wsplit_bytes(int Nout, int K);
 int prcnn_pack_weight_split(const float* w, int Nout, int K, int chain, void* wsplit, prcnn_stream_t stream);
 int prcnn_mlp_rows_split(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const void* wsplit, int terms,
-                         const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, prcnn_stream_t stream);
+                         const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, const int32_t* rows_dev,
+                         int rows_unit, const int32_t* seg_cnt, int seg_rows, prcnn_stream_t stream);
 int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t rows, int K, const void* const* wchain, const float* wpack1,
                                const float* const* bias, const int* nout, const int* relu, int terms, float* out, int ld_out,
                                int col_off, prcnn_stream_t stream);

@@ -2113,7 +2113,8 @@ PRCNN_API int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t row
 }
 
 PRCNN_API int prcnn_mlp_rows_split(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const void* wsplit, int terms,
-                                   const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, prcnn_stream_t stream) {
+                                   const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, const int32_t* rows_dev,
+                                   int rows_unit, const int32_t* seg_cnt, int seg_rows, prcnn_stream_t stream) {
     PRCNN_REQUIRE(in && wsplit, "prcnn_mlp_rows_split: null pointer");
     PRCNN_REQUIRE(ld_in >= K && ld_out >= col_off + Nout, "prcnn_mlp_rows_split: bad strides ld_in=%d K=%d ld_out=%d", ld_in, K, ld_out);
     PRCNN_REQUIRE(terms == 3 || terms == 6, "prcnn_mlp_rows_split: terms=%d (3 or 6)", terms);
@@ -2122,7 +2123,10 @@ PRCNN_API int prcnn_mlp_rows_split(const float* in, int ld_in, int64_t rows, int
     P.out = out; P.ld_out = ld_out; P.col_off = col_off;
     P.in = in; P.ld_in = ld_in;
     P.vec_a = aligned16(in) && (ld_in % 4 == 0);
-    P.rows_unit = 1;
+    P.rows_dev = rows_dev; P.rows_unit = rows_unit > 0 ? rows_unit : 1;
+    PRCNN_REQUIRE(!seg_cnt || (seg_rows > 0 && seg_rows % MLP_BM == 0 && rows % seg_rows == 0 && !rows_dev),
+                  "prcnn_mlp_rows_split: seg_rows=%d must be a multiple of %d dividing rows (no rows_dev)", seg_rows, MLP_BM);
+    P.seg_cnt = seg_cnt; P.seg_rows = seg_rows;
     P.wsplit = wsplit; P.split_terms = terms;
     return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
 }

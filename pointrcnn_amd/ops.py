@@ -393,10 +393,11 @@ def mlp_rows(x, lin, out=None, pool_ns=0, rows_dev=None, rows_unit=1, seg=None):
     ld_in = _row_stride(x)
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, lin, x.device)
-    if MLP_SPLIT_TERMS and not pool_ns and rows_dev is None and seg is None and ld_in % 4 == 0 and lin.wsplit() is not None:
+    if MLP_SPLIT_TERMS and not pool_ns and ld_in % 4 == 0 and (seg is None or rows_dev is None) and lin.wsplit() is not None:
         _cabi.check(_cabi.lib().prcnn_mlp_rows_split(_p(x), ld_in, rows, K, _p(lin.wpack), _p(lin.wsplit()), MLP_SPLIT_TERMS,
-                                                     _p(lin.bias), lin.nout, int(lin.relu), _p(buf), ld_out, col_off, _stream()),
-                    "prcnn_mlp_rows_split")
+                                                     _p(lin.bias), lin.nout, int(lin.relu), _p(buf), ld_out, col_off, _p(rows_dev),
+                                                     int(rows_unit), _p(None if seg is None else seg[0]), 0 if seg is None else int(seg[1]),
+                                                     _stream()), "prcnn_mlp_rows_split")
         return buf
     _cabi.check(_cabi.lib().prcnn_mlp_rows(_p(x), ld_in, rows, K, _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu),
                                            _p(buf), ld_out, col_off, pool_ns, _p(rows_dev), int(rows_unit),

@@ -521,3 +521,28 @@ def test_split_bf16_hoisted_fp0_chain(dev, monkeypatch, terms):
     assert not np.array_equal(got.astype(np.float32), ref32), "the split chain did not run"
     if terms == 6:
         np.testing.assert_allclose(got, ref32, atol=mlp_tol(ref32), rtol=0)
+
+
+def test_split_bf16_rows_with_device_row_count_and_live_segments(dev, monkeypatch):
+    """the split layer kernel under a device-side row count and under segment-prefix live rows (the RCNN stage's launches): the same
+    tiles are written as by the fp32 kernel, to the fp32 contract; everything else keeps the caller's bytes"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(91)
+    rows, K, N = 64 * 512, 128, 128
+    x = T(r.normal(size=(rows, K)).astype(np.float32), dev)
+    l = lin(dev, (r.normal(size=(N, K)) * 0.1).astype(np.float32), r.normal(size=(N,)).astype(np.float32), True)
+    cnt = T(r.integers(1, 513, size=(64,)).astype(np.int32), dev)
+    live = T(np.array([100], np.int32), dev)
+
+    def run(**kw):
+        out = torch.full((rows, N), -7.0, device=dev)
+        ops.mlp_rows(x, l, out=(out, 0), **kw)
+        return out.cpu().numpy()
+    ref_seg, ref_dev = run(seg=(cnt, 512)), run(rows_dev=live, rows_unit=128)
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
+    got_seg, got_dev = run(seg=(cnt, 512)), run(rows_dev=live, rows_unit=128)
+    for got, ref in ((got_seg, ref_seg), (got_dev, ref_dev)):
+        assert np.array_equal(got == -7.0, ref == -7.0)                  # the same rows written
+        np.testing.assert_allclose(got, ref, atol=mlp_tol(ref[ref != -7.0]), rtol=0)
+        assert not np.array_equal(got, ref), "the split kernel did not run"
+    assert (got_dev[12800:] == -7.0).all() and (got_dev[:12800] != -7.0).any()
