@@ -8,6 +8,7 @@ cp $R/bench_driver_flags.json profiles/${T}_final_bench_steps20.json
 cp $R/bench_streams1.json profiles/${T}_final_bench_streams1.json
 cp $R/bench_raw_input.json profiles/${T}_final_bench_raw_input.json
 cp $R/bench_rcnn.json profiles/${T}_final_bench_rcnn.json
+cp $R/bench_rcnn_split_bf16x6.json profiles/${T}_final_bench_rcnn_split_bf16x6.json
 cp $R/bench_train.json profiles/${T}_final_bench_train.json
 cp $R/bench_train_rcnn.json profiles/${T}_final_bench_train_rcnn.json
 cp $R/kernel_stats_train_rcnn.txt profiles/${T}_final_kernel_stats_train_rcnn.txt

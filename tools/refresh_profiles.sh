@@ -19,6 +19,7 @@ python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2>> $O/bench_
 python bench.py --streams 1 --no-cpu-baseline --no-variants > $O/bench_streams1.json 2>> $O/bench_default.err
 python bench.py --input raw --no-variants > $O/bench_raw_input.json 2>> $O/bench_default.err
 python bench.py --workload rcnn > $O/bench_rcnn.json 2>> $O/bench_default.err
+PRCNN_MLP_SPLIT=6 python bench.py --workload rcnn > $O/bench_rcnn_split_bf16x6.json 2>> $O/bench_default.err
 python bench.py --workload train > $O/bench_train.json 2>> $O/bench_default.err
 python bench.py --workload train-rcnn > $O/bench_train_rcnn.json 2>> $O/bench_default.err
 python bench.py --npoints 65536 --batch 8 --steps 64 --no-cpu-baseline --no-variants > $O/bench_config5_rpn.json 2>> $O/bench_default.err
