@@ -846,6 +846,9 @@ __global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST, ADDY>::W))
 // Non-finite inputs: an infinity becomes NaN (inf - inf in the split).  Shapes: K a multiple of 32, 16-byte aligned rows.
 // =====================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef SPL_VALU_PER_MFMA
+#define SPL_VALU_PER_MFMA 5                    // split / address instructions placed behind each MFMA of a chunk's second k-step
+#endif
 #define SPL_LDB 80                               // bytes per LDS row of one piece plane: 32 bf16 + 16 bytes of padding
 #define SPL_PLANE (MLP_BM * SPL_LDB)
 
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpPa
 #pragma unroll
         for (int q = 0; q < NM; q++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, SPL_VALU_PER_MFMA, 0);
             if (q % 2 == 1 && q / 2 < 4 * NP) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
