@@ -261,7 +261,9 @@ class PackedLinear:
 
 # Split-bf16 VARIANT of the plain-row layers (prcnn_mlp_rows_split): 0 = off (fp32 MFMA, the product's arithmetic), 3 / 6 = the
 # number of bf16 product terms per fp32 product.  Never on by default; bench.py reports it as a separate variant.
-MLP_SPLIT_TERMS = int(os.environ.get("PRCNN_MLP_SPLIT", "0"))
+MLP_SPLIT_TERMS = int(os.environ.get("PRCNN_MLP_SPLIT") or 0)
+if MLP_SPLIT_TERMS not in (0, 3, 6):
+    raise RuntimeError("PRCNN_MLP_SPLIT=%r: the split-bf16 variant has 3 or 6 terms (0 / unset = off)" % os.environ.get("PRCNN_MLP_SPLIT"))
 
 _MODE_ROWS, _MODE_GROUP, _MODE_INTERP = 0, 1, 2
 _chain_ok = {}
