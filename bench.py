@@ -869,9 +869,10 @@ def main():
                 # Issue-bound model of the serial chain: every sample is one trip of the kernel's sample loop on the critical
                 # wave; a lone wave issues at most one instruction per 4 cycles (wave64 on SIMD-32: two passes + dependency),
                 # so the floor of a frame's chain is (loop instructions) x 4 cycles x samples.  Static instruction counts of the
-                # sample loops from the gfx950 ISA (tools/fps_isa_count.py): level 0 fps_pruned_kernel<16> 513, level 1
-                # fps_pruned_kernel<4> 260, level 2 fps_reg_kernel<64,16> 211 (single wave), level 3 fps_reg_kernel<64,4> 95.
-                instr = (513 * 4095 + 260 * 1023 + 211 * 255 + 95 * 63)
+                # sample loops from the gfx950 ISA (tools/fps_isa_count.py): level 0 fps_slot_kernel<16> 494 (every pair block counted:
+                # an updating wave skips the pairs the sample cannot reach, ~13 instructions each), level 1 fps_pruned_kernel<4> 260,
+                # level 2 fps_reg_kernel<64,16> 211 (single wave), level 3 fps_reg_kernel<64,4> 95.
+                instr = (494 * 4095 + 260 * 1023 + 211 * 255 + 95 * 63)
                 floor_ms = instr * 4 / 2.4e9 * 1e3
                 line["fps_kernel"]["issue_model"] = {
                     "bound": "instruction issue of one wave (serial chain)", "instructions_per_frame_chain": instr,

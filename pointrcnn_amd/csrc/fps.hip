@@ -431,6 +431,186 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
 }
 
 // =====================================================================================================
+// Two-level pruning (fps_slot_kernel): fps_pruned_kernel with SLOT-major point ownership -- slot i of a wave is 64 consecutive
+// Morton points, a pair of slots a 128-point cluster with its own box -- so that the update of a wave the sample reaches into
+// touches only the pairs it can reach (a uniform branch per pair) instead of all 16 slots.  The pairs are tested against the
+// wave's largest distance, which bounds every point's: no per-pair maxima to maintain (round 2's version kept them exact with a
+// DPP reduction per slot and lost more than it skipped).  Same arithmetic and tie rule: bit-identical sample sets.
+// =====================================================================================================
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_slot_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ perm,
+                                                          int N, int npoint, int32_t* __restrict__ idx_out) {
+    constexpr int BLOCK = 1024, NW = 16;
+    typedef typename fvec_t<PPT>::type fvec;
+    __shared__ float slot[2][NW][4];   // x, y, z of every wave's candidate
+    __shared__ unsigned long long cell[3];
+    // original indices of the points a lane holds: only the winner's is ever needed, so they live in LDS (slot-major:
+    // s_po[i * 1024 + tid]) instead of PPT more VGPRs per lane -- at 96 VGPRs the four FPS waves of a SIMD left 128
+    // registers, too few for ANY of the MLP kernels (160-216), i.e. a CU hosting an FPS workgroup was lost to them
+    extern __shared__ int s_po[];
+    __builtin_amdgcn_s_setprio(2);     // the serial chain every batch waits for: its few instructions go first (3 while a wave updates)
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ p = xyz + (size_t)b * N * 3;
+    const int32_t* __restrict__ pm = perm + (size_t)b * N;
+    int32_t* __restrict__ out = idx_out + (size_t)b * npoint;
+
+    fvec px, py, pz, pt;
+    float lox = FPS_BIG, loy = FPS_BIG, loz = FPS_BIG, hix = -FPS_BIG, hiy = -FPS_BIG, hiz = -FPS_BIG;
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        int s = (wave * PPT + i) * 64 + lane;       // position in Morton order, SLOT-major: slot i of a wave = 64 consecutive points
+        bool ok = s < N;
+        int o = ok ? pm[s] : 0x7fffffff;
+        s_po[i * BLOCK + tid] = o;
+        px[i] = ok ? p[o * 3 + 0] : 0.f;
+        py[i] = ok ? p[o * 3 + 1] : 0.f;
+        pz[i] = ok ? p[o * 3 + 2] : 0.f;
+        pt[i] = ok ? 1e10f : -1.0f;
+        if (ok) {
+            lox = fminf(lox, px[i]); hix = fmaxf(hix, px[i]);
+            loy = fminf(loy, py[i]); hiy = fmaxf(hiy, py[i]);
+            loz = fminf(loz, pz[i]); hiz = fmaxf(hiz, pz[i]);
+        }
+    }
+    // the wave's bounding box (uniform); an all-padding wave keeps the empty box (+-1e18: L ~ 3e36 stays finite)
+    lox = wave_min_f32_fused(lox); loy = wave_min_f32_fused(loy); loz = wave_min_f32_fused(loz);
+    hix = wave_max_f32_fused(hix); hiy = wave_max_f32_fused(hiy); hiz = wave_max_f32_fused(hiz);
+
+    // second level: the box of every PAIR of slots (128 consecutive Morton points), kept by lane g = pair index
+    float glx = FPS_BIG, gly = FPS_BIG, glz = FPS_BIG, ghx = -FPS_BIG, ghy = -FPS_BIG, ghz = -FPS_BIG;
+#pragma unroll
+    for (int g = 0; g < PPT / 2; g++) {
+        float ax_ = FPS_BIG, ay_ = FPS_BIG, az_ = FPS_BIG, bx_ = -FPS_BIG, by_ = -FPS_BIG, bz_ = -FPS_BIG;
+#pragma unroll
+        for (int i = 2 * g; i < 2 * g + 2; i++)
+            if (pt[i] >= 0.f) {
+                ax_ = fminf(ax_, px[i]); bx_ = fmaxf(bx_, px[i]);
+                ay_ = fminf(ay_, py[i]); by_ = fmaxf(by_, py[i]);
+                az_ = fminf(az_, pz[i]); bz_ = fmaxf(bz_, pz[i]);
+            }
+        ax_ = wave_min_f32_fused(ax_); ay_ = wave_min_f32_fused(ay_); az_ = wave_min_f32_fused(az_);
+        bx_ = wave_max_f32_fused(bx_); by_ = wave_max_f32_fused(by_); bz_ = wave_max_f32_fused(bz_);
+        if (lane == g) { glx = ax_; gly = ay_; glz = az_; ghx = bx_; ghy = by_; ghz = bz_; }
+    }
+    if (tid == 0 && npoint > 0) out[0] = 0;
+    if (tid < 3) cell[tid] = 0ULL;
+    __syncthreads();
+    float x0 = p[0], y0 = p[1], z0 = p[2];
+    // cached candidate of this wave (uniform): value, original index, coordinates
+    float cval = 1e10f; int corig = 0x7fffffff; float cx = 0.f, cy = 0.f, cz = 0.f;
+    bool first = true;
+    int cb = 1;                                // exchange cell of sample j: j % 3
+    for (int j = 1; j < npoint; j++) {
+        // which pairs of slots can the new sample reach?  Lane g tests pair g's box (a lower bound of the distance to anything in it)
+        // against the WAVE's largest distance -- no pair keeps a maximum of its own: the wave's bounds every point's, so
+        // "bound >= cval" proves no change.  The eight pair boxes together are also a tighter test of the whole wave than its one box.
+        unsigned live = (1u << (PPT / 2)) - 1u;
+        if (!first) {
+            const float hx = fmaxf(fmaxf(glx - x0, x0 - ghx), 0.f), hy = fmaxf(fmaxf(gly - y0, y0 - ghy), 0.f), hz = fmaxf(fmaxf(glz - z0, z0 - ghz), 0.f);
+            const float Lg = __fadd_rn(__fadd_rn(__fmul_rn(hx, hx), __fmul_rn(hy, hy)), __fmul_rn(hz, hz));
+            live = (unsigned)__ballot(Lg < cval) & ((1u << (PPT / 2)) - 1u);
+        }
+        if (live != 0u) {
+            // the sample waits for the updating wave(s): ahead of the three waves that share the SIMD and are still
+            // working through their own bound test / exchange read (oldest-first arbitration otherwise: tools/fps_timing.py
+            // shows the fourth wave of a SIMD taking 2-3x as long for the same instructions)
+            __builtin_amdgcn_s_setprio(3);
+            const f32x2 qx = {x0, x0}, qy = {y0, y0}, qz = {z0, z0};
+#pragma unroll
+            for (int g = 0; g < PPT / 2; g++) {
+                if ((live >> g) & 1u) {                          // wave-uniform
+                    const int i = 2 * g;
+                    f32x2 dx = (f32x2){px[i], px[i + 1]} - qx;
+                    f32x2 dy = (f32x2){py[i], py[i + 1]} - qy;
+                    f32x2 dz = (f32x2){pz[i], pz[i + 1]} - qz;
+                    f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                    pt[i] = __builtin_fminf(pt[i], d.x); pt[i + 1] = __builtin_fminf(pt[i + 1], d.y);
+                }
+            }
+            float best = pt[0];
+#pragma unroll
+            for (int i = 1; i < PPT; i++) best = __builtin_fmaxf(best, pt[i]);
+            const int wmax = wave_max_i32_fused(__float_as_int(best));
+            const float wmaxf = __int_as_float(wmax);
+            // candidates = (lane, slot) with t == wmax; the one with the LOWEST ORIGINAL index wins.  Fast path (a
+            // unique maximum, the overwhelmingly common case).  An updating wave is usually ALONE on its SIMD and issues one
+            // instruction every ~4-5 cycles, so its instruction count is the latency of the whole sample (measured with
+            // tools/fps_timing.py: ~1450 cycles per update, of which a per-slot ballot + scalar select chain took ~600).
+            // Here every lane finds the lowest slot holding ITS maximum and how many slots do (3 VALU per slot, no scalar
+            // chain); one ballot finds the lanes holding the wave maximum; unique lane with a unique slot = fast path.
+            int myslot = 0, mycnt = 0;
+#pragma unroll
+            for (int i = PPT - 1; i >= 0; i--) {
+                const bool e = pt[i] == best;
+                myslot = e ? i : myslot;
+                mycnt += e ? 1 : 0;
+            }
+            const unsigned long long anym = __ballot(best == wmaxf);
+            const int owner0 = __builtin_ctzll(anym);
+            const int total = (__popcll(anym) == 1 && __builtin_amdgcn_readlane(mycnt, owner0) == 1) ? 1 : 2;
+            int istar = __builtin_amdgcn_readlane(myslot, owner0);
+            if (total == 1) {
+                const int owner = owner0;
+                corig = s_po[istar * BLOCK + (wave << 6) + owner];          // own wave's entries: no barrier needed
+                float sx = px[istar], sy = py[istar], sz = pz[istar];
+                cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), owner));
+                cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), owner));
+                cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), owner));
+            } else {                                  // exact ties (duplicated points, lattices): rare, any cost is fine
+                int bo = 0x7fffffff; float bx = 0.f, by = 0.f, bz = 0.f;
+                if (best == wmaxf) {
+#pragma unroll
+                    for (int i = PPT - 1; i >= 0; i--) {
+                        const int oi = s_po[i * BLOCK + tid];
+                        if (pt[i] == wmaxf && oi <= bo) { bo = oi; bx = px[i]; by = py[i]; bz = pz[i]; }
+                    }
+                }
+                corig = wave_min_i32_fused(bo);
+                const int owner = __builtin_ctzll(__ballot(bo == corig));
+                cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), owner));
+                cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), owner));
+                cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), owner));
+            }
+            cval = wmaxf;
+            first = false;
+            __builtin_amdgcn_s_setprio(2);
+        }
+        // Exchange: every wave folds its candidate into ONE 64-bit LDS cell with an atomic max and parks the coordinates in
+        // its slot; after the barrier a wave reads the cell and the winner's slot -- two dependent LDS reads and ~20
+        // instructions, where reading all 16 candidates and reducing them twice by DPP (maximum, then lowest index among
+        // equals) was ~60 instructions per wave and sample.  key = [value, order-preserving | 2^28-1 - original index | wave]:
+        // the largest key is the largest value, ties -> lowest original index.  Cells rotate over three (the next one is
+        // cleared by wave 0 while nobody can still be reading it: its readers passed the previous barrier).
+        if (lane == 0) {
+            float* s = slot[j & 1][wave];
+            s[0] = cx; s[1] = cy; s[2] = cz;
+            const unsigned hi = (unsigned)__float_as_int(cval) ^ 0x80000000u;
+            const unsigned lo = ((0xFFFFFFFu - (unsigned)min(corig, 0xFFFFFFF)) << 4) | (unsigned)wave;
+            // (one lane, one instruction: atomicMax() would be wrapped in the compiler's wave-aggregation loop, ~25 more
+            //  instructions per wave and sample on the critical path)
+            const unsigned long long key = ((unsigned long long)hi << 32) | lo;
+            asm volatile("ds_max_u64 %0, %1" : : "v"((unsigned)(size_t)&cell[cb]), "v"(key) : "memory");
+            if (wave == 0) cell[cb == 2 ? 0 : cb + 1] = 0ULL;
+        }
+        __syncthreads();
+        // the winner's coordinates without a second, dependent LDS round trip: every lane reads one word of the 16 x 4 slot table
+        // (lane = 4 * wave + component, 256 contiguous bytes) TOGETHER with the cell, and the winner's three words are picked out of
+        // the wave's registers by lane index
+        const float sv = (&slot[j & 1][0][0])[lane];
+        const unsigned long long kwin = cell[cb];
+        const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)kwin);
+        const int gorig = (int)(0xFFFFFFFu - (klo >> 4));
+        const int wl = (int)(klo & 15u) * 4;
+        x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl));
+        y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl + 1));
+        z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl + 2));
+        cb = cb == 2 ? 0 : cb + 1;
+        if (tid == 0) out[j] = gorig;
+    }
+}
+
+// =====================================================================================================
 // N > 16384 (BASELINE config 5: 65 536 points per frame): the frame does not fit one workgroup's registers (1024 threads x
 // 16 points), and re-reading it from L2 every iteration (fps_mem_kernel below) costs ~12 us per sample.  Here a frame is
 // owned by S = ceil(N / 16384) workgroups, each keeping its 16384-point slice and running min-distances in VGPRs exactly
@@ -641,7 +821,15 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
         static PrcnnLdsLimit pruned_attr;
         if (!pruned_attr.raise((const void*)fps_pruned_kernel<16>, 16 * 4096))
             return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the pruned kernel");
-        if (N <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4>), dim3(B), dim3(1024), 4 * 4096, s, xyz, perm, N, npoint, idx);
+        // two-level pruning (fps_slot_kernel): pays at 16 points per lane (16 384 -> 4 096: 3.82 -> 3.56 ms), not at 4 or 8 (+4..9 %: the
+        // pair tests and the separate running-maximum pass cost what the skipped slots save); PRCNN_FPS_SLOTS=0 is the A/B switch (same bits)
+        const char* slots_env = getenv("PRCNN_FPS_SLOTS");              // read per call: the tests flip it in-process
+        const bool slots = slots_env == nullptr || atoi(slots_env) != 0;
+        static PrcnnLdsLimit slot_attr;
+        if (slots && N > 8192 && !slot_attr.raise((const void*)fps_slot_kernel<16>, 16 * 4096))
+            return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the slot kernel");
+        if (slots && N > 8192) hipLaunchKernelGGL((fps_slot_kernel<16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);
+        else if (N <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4>), dim3(B), dim3(1024), 4 * 4096, s, xyz, perm, N, npoint, idx);
         else if (N <= 8192) hipLaunchKernelGGL((fps_pruned_kernel<8>), dim3(B), dim3(1024), 8 * 4096, s, xyz, perm, N, npoint, idx);
         else hipLaunchKernelGGL((fps_pruned_kernel<16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);
     }

@@ -196,15 +196,18 @@ def test_op_argument_errors(dev):
         ops.furthest_point_sample(torch.zeros(1, 10, 3, device=dev), 11)          # npoint > N
 
 
-@pytest.mark.parametrize("pruned", [True, False])
-@pytest.mark.parametrize("B,N,npoint", [(2, 16384, 2048), (2, 4096, 1024), (1, 8192, 700), (2, 5000, 333), (1, 2049, 64)])
-def test_fps_pruned_and_plain_variants_are_bit_identical(dev, cpu, B, N, npoint, pruned):
-    """both FPS kernels for 2048 < N <= 16384 -- the spatially pruned one (Morton pre-sort + exact bounding-box skip,
-    csrc/fps.hip; the default) and the plain register-resident one (PRCNN_FPS_PRUNED=0) -- return exactly the oracle's
-    indices, on distinct points, duplicated points (original-index tie-break) and lattices"""
+@pytest.mark.parametrize("pruned", [True, "one-level", False])
+@pytest.mark.parametrize("B,N,npoint", [(2, 16384, 2048), (2, 12000, 1500), (2, 4096, 1024), (1, 8192, 700), (2, 5000, 333), (1, 2049, 64)])
+def test_fps_pruned_and_plain_variants_are_bit_identical(dev, cpu, monkeypatch, B, N, npoint, pruned):
+    """the FPS kernels for 2048 < N <= 16384 -- the spatially pruned ones (Morton pre-sort + exact bounding-box skip, csrc/fps.hip:
+    two-level for N > 8192, the default, and one-level, PRCNN_FPS_SLOTS=0) and the plain register-resident one
+    (PRCNN_FPS_PRUNED=0) -- return exactly the oracle's indices, on distinct points, duplicated points (original-index
+    tie-break) and lattices"""
     from pointrcnn_amd import ops
     old = ops.FPS_PRUNED
-    ops.FPS_PRUNED = pruned
+    ops.FPS_PRUNED = bool(pruned)
+    if pruned == "one-level":
+        monkeypatch.setenv("PRCNN_FPS_SLOTS", "0")
     try:
         clouds = [kitti_cloud(B, N, seed=N)]
         dup = clouds[0].copy()
