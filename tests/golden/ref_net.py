@@ -26,6 +26,22 @@ def available():
     return os.path.isdir(os.path.join(REFERENCE, "lib", "net"))
 
 
+def set_reference(path):
+    """point the loader at another copy of the reference tree (the GPU box: the archive staged by oracle/stage_reference.py,
+    unpacked into a temporary directory); must be called before load()"""
+    global REFERENCE
+    assert _loaded is None or path == REFERENCE, "reference modules already imported from %s" % REFERENCE
+    REFERENCE = path
+
+
+def _host_only():
+    """in the build container (no GPU) `.cuda()` has to be a no-op; on the MI355X nothing is patched: the reference's code runs
+    as it is"""
+    import contextlib
+    import cpu_ops
+    return contextlib.nullcontext() if torch.cuda.is_available() else cpu_ops.cuda_is_cpu()
+
+
 _loaded = None
 
 
@@ -48,8 +64,8 @@ def load(cfg_file="tools/cfgs/default.yaml"):
     yaml.load = _load
     import types
     ns = types.SimpleNamespace(cfg=cfg)
-    import cpu_ops
-    with cpu_ops.cuda_is_cpu():
+    sys.dont_write_bytecode = True            # the reference checkout is read-only
+    with _host_only():
         from lib.net.point_rcnn import PointRCNN
         import lib.net.train_functions as train_functions
         import lib.utils.kitti_utils as kitti_utils
@@ -67,7 +83,7 @@ def build_reference_model(mode="TEST", seed=5, rpn_only=False):
     ns = load()
     ns.cfg.RPN.ENABLED, ns.cfg.RCNN.ENABLED = True, not rpn_only
     ns.cfg.RPN.FIXED = False
-    with cpu_ops.cuda_is_cpu():
+    with _host_only():
         model = ns.PointRCNN(num_classes=2, use_xyz=True, mode=mode)
     cpu_ops.fill_params_by_name(model, seed)
     return model
