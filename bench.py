@@ -163,6 +163,34 @@ def distributed_facts(dist, world):
     return facts
 
 
+def distributed_preflight(dist, world, rank, dev):
+    """first contact with RCCL happens HERE, before anything is timed: every rank reports its device, one all-reduce checks the
+    ring, rank 0 prints what the N > 1 line will rest on (stderr) -- a mis-sized world or a dead link fails fast with a message
+    instead of hanging inside the timed loop"""
+    import socket
+    try:
+        name = torch.cuda.get_device_name(dev)
+    except Exception as e:  # noqa: BLE001
+        name = "unknown (%s)" % type(e).__name__
+    mine = {"rank": rank, "host": socket.gethostname(), "device": str(dev), "name": name, "pid": os.getpid()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    t = torch.full((1,), float(rank + 1), device=dev)
+    dist.all_reduce(t)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    want = world * (world + 1) / 2
+    if abs(float(t.item()) - want) > 1e-6:
+        raise SystemExit("bench.py: all-reduce over %d ranks returned %r, expected %r" % (world, float(t.item()), want))
+    facts = distributed_facts(dist, world)
+    facts["ranks"] = sorted(everyone, key=lambda r: r["rank"])
+    if dev.type == "cuda" and len({(r["host"], r["device"]) for r in everyone}) != world:
+        raise SystemExit("bench.py: %d ranks but only %d distinct devices: %s" % (world, len({(r["host"], r["device"]) for r in everyone}), everyone))
+    if rank == 0:
+        print("[bench] distributed preflight ok: %s" % json.dumps(facts), file=sys.stderr, flush=True)
+    return facts
+
+
 class EventProfiler:
     """Wraps the ctypes library: every prcnn_* launch is bracketed by HIP events recorded on the stream the
     kernel is launched on (torch's current stream).  Used only in the instrumented pass, never in the timed one."""
@@ -342,44 +370,49 @@ def make_cloud_fn(kind):
     return {"uniform": rpn.synthetic_clouds, "lidar": rpn.lidar_like_clouds, "saturated": rpn.saturated_clouds}[kind]
 
 
-_STREAM_CACHE = []
-
-
 class InferenceBench:
-    """the timed inference loop: S in-flight slots, each a captured hipGraph of one step on its own stream"""
+    """the timed inference loop: a client of pointrcnn_amd.pipeline.InferencePipeline (S in-flight slots, each a captured hipGraph
+    of one step on its own stream, results collected in submission order through a bounded queue)"""
 
     def __init__(self, args, model, dev, rank, world, clouds_kind, proposal_layer=None, raw=None):
         self.args, self.model, self.dev, self.proposal_layer, self.raw = args, model, dev, proposal_layer, raw
         self.nstreams = max(1, args.streams)
         make_clouds = make_cloud_fn(clouds_kind)
         self.clouds_cpu = make_clouds(args.batch, args.npoints, seed0=shard_seed0(rank, world, 0, args.batch))
-        self.batches = [{"pts_input": self.clouds_cpu.to(dev)}]
-        for s_ in range(1, self.nstreams):          # every in-flight slot owns its (resident) input batch
-            self.batches.append({"pts_input": make_clouds(args.batch, args.npoints, seed0=shard_seed0(rank, world, s_, args.batch)).to(dev)})
-        # ONE set of streams per process, shared by the headline loop and the variants: torch.cuda.Stream() draws from a pool
-        # of 32 handles, a second bench's 20 streams wrap around it, and that set measured 30 % slower than the first
-        # (12.3 k -> 8.4 k frames/s on the SAME configuration; a third set 5.0 k) -- the stream -> hardware-queue mapping is
-        # only collision-free for the first draw.  Round-2 variant numbers recorded before this fix were low by that factor.
-        while len(_STREAM_CACHE) < self.nstreams:
-            _STREAM_CACHE.append(torch.cuda.Stream())
-        self.streams = _STREAM_CACHE[:self.nstreams]
-        self.graphs, self.out, self.host = None, None, None
+        self.pipe, self.out, self.host, self.graphs = None, None, None, None
+        self._slot_clouds = lambda s_: (self.clouds_cpu if s_ == 0 else                                              # noqa: E731
+                                        make_clouds(args.batch, args.npoints, seed0=shard_seed0(rank, world, s_, args.batch)))
+        self._eager_inputs = None
 
-    def step(self, slot=0):
+    def _example(self):
+        if self.raw is not None:
+            return {k: self.raw["slots"][0]["dev"][k] for k in ("raw", "offsets", "calib", "img_hw")}
+        return {"pts_input": self.clouds_cpu}
+
+    def step_from(self, inputs, slot=0):
+        """one step of the workload on a slot's (static) input tensors: what the pipeline captures"""
         args, model = self.args, self.model
         with torch.no_grad():
             if self.raw is not None:
                 r = self.raw["slots"][slot]
-                xyz, _, _, _, r["status"] = self.raw["ops"].scene_prepare(r["dev"]["raw"], r["dev"]["offsets"], r["max_points"], r["dev"]["calib"],
-                                                                          r["dev"]["img_hw"], self.raw["prep"].scope, args.npoints, r["seed"])
+                xyz, _, _, _, r["status"] = self.raw["ops"].scene_prepare(inputs["raw"], inputs["offsets"], r["max_points"], inputs["calib"],
+                                                                          inputs["img_hw"], self.raw["prep"].scope, args.npoints, r["seed"])
                 o = model({"pts_input": xyz})
             else:
-                o = model(self.batches[slot])
+                o = model(inputs)
             if self.proposal_layer is not None:
                 o["rois"], o["roi_scores_raw"] = self.proposal_layer(o["rpn_cls"][:, :, 0], o["rpn_reg"], o["backbone_xyz"])
             if args.workload == "rcnn":
                 o["pred_boxes3d"], o["raw_scores"], o["keep"], o["num_keep"] = model.detections(o)
             return o
+
+    def step(self, slot=0):
+        """eager step on slot `slot`'s resident inputs, on the current stream (warm-up, instrumented pass)"""
+        if self.pipe is not None:
+            return self.step_from(self.pipe.inputs[slot], slot)
+        if self._eager_inputs is None:
+            self._eager_inputs = {k: v.to(self.dev) for k, v in self._example().items()}
+        return self.step_from(self._eager_inputs, slot)
 
     def warm(self):
         for _ in range(max(1, min(self.args.warmup, 4))):   # packs weights, fills the caching allocator
@@ -388,49 +421,56 @@ class InferenceBench:
         return self
 
     def prepare(self):
+        from pointrcnn_amd.pipeline import InferencePipeline
         args = self.args
         if self.out is None:
             self.warm()
-        if args.graph != "off":
-            try:
-                graphs, gouts = [], []
-                for slot in range(self.nstreams):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.stream(self.streams[slot]):
-                        self.step(slot)
-                    torch.cuda.synchronize()
-                    with torch.cuda.graph(g, stream=self.streams[slot]):
-                        gouts.append(self.step(slot))
-                    graphs.append(g)
-                graphs[0].replay()
-                torch.cuda.synchronize()
-                for k in ("rpn_cls", "rpn_reg"):                 # the replayed graph must reproduce the eager result
-                    assert torch.equal(gouts[0][k], self.out[k]), "graph replay differs from eager (%s)" % k
-                self.graphs, self.out = graphs, gouts[0]
-            except Exception as e:  # noqa: BLE001
-                if args.graph == "on":
-                    raise
-                print("[bench] hipGraph capture unavailable (%s); timing eager launches" % str(e).split("\n")[0], file=sys.stderr)
-                self.graphs = None
-                torch.cuda.synchronize()
+        eager_out = self.out
+        try:
+            self.pipe = InferencePipeline(self.step_from, self._example(), slots=self.nstreams, device=self.dev, graph=args.graph != "off")
+        except Exception as e:  # noqa: BLE001
+            if args.graph == "on":
+                raise
+            print("[bench] hipGraph capture unavailable (%s); timing eager launches" % str(e).split("\n")[0], file=sys.stderr)
+            self.pipe = InferencePipeline(self.step_from, self._example(), slots=self.nstreams, device=self.dev, graph=False)
+        self._eager_inputs = None
+        for s_ in range(1, self.nstreams):            # every in-flight slot owns its (resident) input batch
+            if self.raw is not None:
+                for k in ("raw", "offsets", "calib", "img_hw"):
+                    self.pipe.inputs[s_][k].copy_(self.raw["slots"][s_]["dev"][k])
+            else:
+                self.pipe.inputs[s_]["pts_input"].copy_(self._slot_clouds(s_))
+        torch.cuda.synchronize()
+        self.graphs = self.pipe.graphs if self.pipe.graphed else None
+        self.pipe.submit(None)
+        out0 = self.pipe.result()
+        for k in ("rpn_cls", "rpn_reg"):                 # the replayed graph must reproduce the eager result
+            assert torch.equal(out0[k], eager_out[k]), "graph replay differs from eager (%s)" % k
+        self.out = out0
+        # slot 0's ticket was consumed: re-align ticket numbering so that step k runs on slot k % S
+        for _ in range(1, self.nstreams):
+            self.pipe.submit(None)
+        self.pipe.drain()
         return self
 
     def run(self, k, h2d=False):
-        slot = k % self.nstreams
-        with torch.cuda.stream(self.streams[slot]):
-            if h2d:
-                self.batches[slot]["pts_input"].copy_(self.host[slot], non_blocking=True)
-            if self.raw is not None:
-                self.raw["slots"][slot]["dev"]["raw"].copy_(self.raw["slots"][slot]["host"]["raw"], non_blocking=True)
-            if self.graphs is not None:
-                self.graphs[slot].replay()
-            else:
-                self.step(slot)
+        """step k: collect the oldest result when the pipeline is full (bounded queue), then submit -- with the batch's inputs from
+        pinned host memory when `h2d` (asynchronous copy on the slot's stream), on the resident inputs otherwise"""
+        pipe = self.pipe
+        if pipe.outstanding >= pipe.slots:
+            pipe.result()
+        slot = pipe._next_ticket % pipe.slots
+        if self.raw is not None:
+            pipe.submit({"raw": self.raw["slots"][slot]["host"]["raw"]})
+        elif h2d:
+            pipe.submit({"pts_input": self.host[slot]})
+        else:
+            pipe.submit(None)
 
     def timed(self, steps, warmup, dist=None, h2d=False):
         """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; -> max-over-ranks seconds"""
         if h2d and self.host is None:
-            self.host = [b["pts_input"].cpu().pin_memory() for b in self.batches]
+            self.host = [self.pipe.inputs[s_]["pts_input"].cpu().pin_memory() for s_ in range(self.nstreams)]
         for k in range(warmup):
             self.run(k, h2d)
         torch.cuda.synchronize()
@@ -442,29 +482,30 @@ class InferenceBench:
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        return reduce_elapsed(time.perf_counter() - t0, dist, self.dev)
+        elapsed = reduce_elapsed(time.perf_counter() - t0, dist, self.dev)
+        self.pipe.drain()
+        return elapsed
 
     def timed_single(self, steps, dist=None):
-        """latency mode: ONE batch in flight (slot 0 only), every step waits for the previous one on the same stream"""
+        """latency mode: ONE batch in flight -- submit, wait for its result, submit the next (what a tools/eval_rcnn.py-style loop
+        sees: the FPS serial chain is exposed)"""
+        self.pipe.drain()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        with torch.cuda.stream(self.streams[0]):
-            for _ in range(steps):
-                if self.graphs is not None:
-                    self.graphs[0].replay()
-                else:
-                    self.step(0)
+        for _ in range(steps):
+            self.pipe.submit(None)
+            self.pipe.result()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         return reduce_elapsed(time.perf_counter() - t0, dist, self.dev)
 
     def release(self):
-        self.graphs = None
-        self.batches = None
-        self.out = None
+        if self.pipe is not None:
+            self.pipe.close()
+        self.pipe, self.graphs, self.out, self._eager_inputs = None, None, None, None
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
 
@@ -584,7 +625,7 @@ def run_train(args, dev, rank, world, local_rank, dist):
     fg = int((batches[0]["rpn_cls_label"] > 0).sum().item())
     gemm = stack_gemm_account(lambda: trainer.step(batches[0]), elapsed / args.steps)
     return {
-        "metric": "KITTI frames/sec, RPN training step (16384 pts/frame, bs%d per GPU, DDP over RCCL)" % args.batch,
+        "metric": "KITTI frames/sec, RPN training step (%d pts/frame, bs%d per GPU, DDP over RCCL)" % (args.npoints, args.batch),
         "value": round(whole_job_value(args.batch, world, args.steps, elapsed), 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -691,7 +732,7 @@ def run_train_rcnn(args, dev, rank, world, local_rank, dist):
     nparam = sum(p.numel() for p in trainer.params)
     gemm = stack_gemm_account(lambda: trainer.step(batches[0]), elapsed / args.steps)
     return {
-        "metric": "KITTI frames/sec, RCNN-stage training step (16384 pts/frame, bs%d per GPU, 64 RoIs x 512 pts per frame)" % args.batch,
+        "metric": "KITTI frames/sec, RCNN-stage training step (%d pts/frame, bs%d per GPU, 64 RoIs x 512 pts per frame)" % (args.npoints, args.batch),
         "value": round(whole_job_value(args.batch, world, args.steps, elapsed), 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -733,14 +774,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+        import datetime
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))          # RCCL over xGMI
+        preflight = distributed_preflight(dist, world, rank, dev)
 
     from pointrcnn_amd import _cabi, rpn
     _cabi.lib()
     if args.workload in ("train", "train-rcnn"):
         line = (run_train if args.workload == "train" else run_train_rcnn)(args, dev, rank, world, local_rank, dist)
         if dist is not None:
-            line["distributed"] = distributed_facts(dist, world)
+            line["distributed"] = preflight
         if rank == 0:
             print(json.dumps(line), flush=True)
         if dist is not None:
@@ -784,8 +827,8 @@ def main():
     out, clouds_cpu, graph = bench.out, bench.clouds_cpu, bench.graphs
 
     line = {
-        "metric": ("KITTI frames/sec, RPN inference end-to-end (16384 pts/frame, bs%d per GPU)" % args.batch) if args.workload == "rpn"
-        else ("KITTI frames/sec, full two-stage PointRCNN inference (16384 pts/frame, 100 RoIs/frame, bs%d per GPU)" % args.batch),
+        "metric": ("KITTI frames/sec, RPN inference end-to-end (%d pts/frame, bs%d per GPU)" % (args.npoints, args.batch)) if args.workload == "rpn"
+        else ("KITTI frames/sec, full two-stage PointRCNN inference (%d pts/frame, 100 RoIs/frame, bs%d per GPU)" % (args.npoints, args.batch)),
         "value": round(whole_job_value(args.batch, world, args.steps, elapsed), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -856,7 +899,7 @@ def main():
             if os.path.exists(tpath) and args.batch == 32 and args.npoints == 16384:
                 try:
                     line["roofline"]["traffic"] = json.load(open(tpath))["per_step_bs32"]["mlp"]["hbm_bytes_per_launch_corrected"]
-                    line["roofline"]["traffic_unit"] = "bytes/launch (PMC, profiles/%s)" % tname
+                    line["roofline"]["traffic_unit"] = "bytes/launch; NOT measured in this run: rocprofv3 --pmc passes committed as profiles/%s" % tname
                     break
                 except (KeyError, ValueError):
                     pass
@@ -972,7 +1015,7 @@ def main():
                                    "lidar (range-dependent density, ground band + car clusters, same bounds)": variants["lidar"]}
 
     if dist is not None:
-        line["distributed"] = distributed_facts(dist, world)
+        line["distributed"] = preflight
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

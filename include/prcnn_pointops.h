@@ -605,7 +605,7 @@ int prcnn_interp_rows_grad_ws(const float* G, int ldG, const int32_t* idx3, cons
  * prcnn_proposal_target_sample: ProposalTargetLayer.sample_rois_for_rcnn with sample_bg_inds, aug_roi_by_noise_torch and
  * random_aug_box3d (lib/rpn/proposal_target_layer.py:75-300) for the whole batch in one launch, no host round trip:
  *   roi_boxes3d (B, M, 7), gt_boxes3d (B, G, gt_cols >= 7) with all-zero rows padding the end (G <= 128);
- *   cfg6 (HOST pointer): RCNN.REG_FG_THRESH, CLS_FG_THRESH, CLS_BG_THRESH, CLS_BG_THRESH_LO, FG_RATIO, HARD_BG_RATIO;
+ *   cfg6 (HOST pointer, six DOUBLES -- the reference's sampler does its slot arithmetic in Python doubles): RCNN.REG_FG_THRESH, CLS_FG_THRESH, CLS_BG_THRESH, CLS_BG_THRESH_LO, FG_RATIO, HARD_BG_RATIO;
  *   aug_times = RCNN.ROI_FG_AUG_TIMES; aug_method 0 = 'multiple', 1 = 'single' (RCNN.REG_AUG_METHOD);
  *   -> rois, gt_of_rois (B, R, 7), roi_iou (B, R), src (B, R) the input RoI behind every slot, max_overlaps / gt_assignment
  *   (B, M), counts (B, 4) = fg / hard-bg / easy-bg candidates and fg slots, status (B): 0 ok, 1 = neither foreground nor
@@ -619,7 +619,7 @@ int prcnn_boxes_iou3d(const float* a, int Na, const float* b, int Nb, float* out
  * 2 atan2f(a, b). */
 int prcnn_ref_trig(const float* a, const float* b, int n, int fn, float* out, prcnn_stream_t stream);
 int prcnn_proposal_target_sample(const float* roi_boxes3d, const float* gt_boxes3d, int B, int M, int G, int gt_cols, int roi_per_image,
-                                 const float* cfg6, int aug_times, int aug_method, uint32_t seed, float* rois, float* gt_of_rois,
+                                 const double* cfg6, int aug_times, int aug_method, uint32_t seed, float* rois, float* gt_of_rois,
                                  float* roi_iou, int32_t* src, float* max_overlaps, int32_t* gt_assignment, int32_t* counts,
                                  int32_t* status, prcnn_stream_t stream);
 

@@ -318,8 +318,8 @@ class _Cpu:
         o = {"rois": np.zeros((B, R, 7), np.float32), "gt_of_rois": np.zeros((B, R, 7), np.float32), "roi_iou": np.zeros((B, R), np.float32),
              "src": np.zeros((B, R), np.int32), "max_overlaps": np.zeros((B, M), np.float32), "gt_assignment": np.zeros((B, M), np.int32),
              "counts": np.zeros((B, 4), np.int32), "status": np.zeros((B,), np.int32)}
-        c = np.asarray(cfgv, np.float32)
-        self.lib.prcnn_cpu_proposal_target_sample(_p(roi, _F), _p(gt, _F), B, M, G, gc, R, _p(c, _F), int(aug_times),
+        c = np.ascontiguousarray(cfgv, np.float64)
+        self.lib.prcnn_cpu_proposal_target_sample(_p(roi, _F), _p(gt, _F), B, M, G, gc, R, _p(c, ctypes.POINTER(ctypes.c_double)), int(aug_times),
                                                   {"multiple": 0, "single": 1}[aug_method], ctypes.c_uint32(seed), trig_mode,
                                                   _p(o["rois"], _F), _p(o["gt_of_rois"], _F), _p(o["roi_iou"], _F), _p(o["src"], _I),
                                                   _p(o["max_overlaps"], _F), _p(o["gt_assignment"], _I), _p(o["counts"], _I),

@@ -1276,12 +1276,14 @@ static int pt_cand_cmp(const void* x, const void* y) {
  * counts (B,4): fg candidates, hard-bg candidates, easy-bg candidates, fg slots; status (B): 0 ok, 1 = neither foreground nor
  * background candidates (the reference raises), 2 = no ground-truth box */
 PRCNN_EXPORT void prcnn_cpu_proposal_target_sample(const float* roi_boxes3d, const float* gt_boxes3d, int B, int M, int G, int gt_cols,
-                                                   int R, const float* cfgv, int aug_times, int aug_method, uint32_t seed, int trig_mode,
+                                                   int R, const double* cfgv, int aug_times, int aug_method, uint32_t seed, int trig_mode,
                                                    float* rois, float* gt_of_rois, float* roi_iou, int32_t* src, float* max_overlaps,
                                                    int32_t* gt_assignment, int32_t* counts, int32_t* status) {
-    const float reg_fg = cfgv[0], cls_fg = cfgv[1], cls_bg = cfgv[2], cls_bg_lo = cfgv[3], fg_ratio = cfgv[4], hard_ratio = cfgv[5];
+    /* thresholds meet float32 overlaps; the two ratios stay double (Python arithmetic: int(10 * 0.7) = 7, with 0.7f it would be 6) */
+    const float reg_fg = (float)cfgv[0], cls_fg = (float)cfgv[1], cls_bg = (float)cfgv[2], cls_bg_lo = (float)cfgv[3];
+    const double fg_ratio = cfgv[4], hard_ratio = cfgv[5];
     const float fg_thresh = reg_fg < cls_fg ? reg_fg : cls_fg;
-    const int fg_per_image = (int)nearbyint((double)fg_ratio * (double)R);                  /* np.round: half to even */
+    const int fg_per_image = (int)nearbyint(fg_ratio * (double)R);                  /* np.round: half to even */
     pt_cand* cand = (pt_cand*)malloc(sizeof(pt_cand) * (size_t)(M > 0 ? M : 1));
     int* fg = (int*)malloc(sizeof(int) * (size_t)(M > 0 ? M : 1) * 3);
     int *hard = fg + M, *easy = fg + 2 * M;
@@ -1339,7 +1341,7 @@ PRCNN_EXPORT void prcnn_cpu_proposal_target_sample(const float* roi_boxes3d, con
         counts[b * 4 + 3] = n_fg_slots;
         if (n_bg_slots > 0) {                                                   /* sample_bg_inds (:190-220) */
             int n_hard = 0;
-            if (nhard > 0 && neasy > 0) n_hard = (int)((double)n_bg_slots * (double)hard_ratio);     /* int(bg * HARD_BG_RATIO) */
+            if (nhard > 0 && neasy > 0) n_hard = (int)((double)n_bg_slots * hard_ratio);     /* int(bg * HARD_BG_RATIO) */
             else if (nhard > 0) n_hard = n_bg_slots;
             for (int t = 0; t < n_bg_slots; t++) {
                 if (t < n_hard) o_src[n_fg_slots + t] = hard[pt_below(pt_rand(seed, 12, (uint32_t)b, (uint32_t)t), nhard)];

@@ -67,7 +67,8 @@ struct PtParams {
     const float* roi;        // (B, M, 7)
     const float* gt;         // (B, G, gt_cols)
     int B, M, G, gt_cols, R;
-    float reg_fg, cls_fg, cls_bg, cls_bg_lo, hard_ratio;
+    float reg_fg, cls_fg, cls_bg, cls_bg_lo;
+    double hard_ratio;
     int fg_per_image, aug_times, aug_method;
     unsigned seed;
     float* rois; float* gt_of_rois; float* roi_iou; int32_t* src;      // (B,R,7) (B,R,7) (B,R) (B,R)
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(PT_THREADS) void proposal_target_kernel(const PtPar
         else P.status[b] = 1;
         s_slots[0] = fs; s_slots[1] = bs;
         int nh = 0;
-        if (nhard > 0 && neasy > 0) nh = (int)((double)bs * (double)P.hard_ratio);
+        if (nhard > 0 && neasy > 0) nh = (int)((double)bs * P.hard_ratio);
         else if (nhard > 0) nh = bs;
         s_hard_slots = nh;
         P.counts[b * 4 + 3] = fs;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(PT_THREADS) void proposal_target_kernel(const PtPar
 }
 
 PRCNN_API int prcnn_proposal_target_sample(const float* roi_boxes3d, const float* gt_boxes3d, int B, int M, int G, int gt_cols,
-                                           int roi_per_image, const float* cfg6, int aug_times, int aug_method, uint32_t seed,
+                                           int roi_per_image, const double* cfg6, int aug_times, int aug_method, uint32_t seed,
                                            float* rois, float* gt_of_rois, float* roi_iou, int32_t* src, float* max_overlaps,
                                            int32_t* gt_assignment, int32_t* counts, int32_t* status, prcnn_stream_t stream) {
     PRCNN_REQUIRE(B >= 0 && M > 0 && G > 0 && G <= PT_MAX_GT && gt_cols >= 7 && roi_per_image > 0,
@@ -270,13 +271,20 @@ PRCNN_API int prcnn_proposal_target_sample(const float* roi_boxes3d, const float
                   "prcnn_proposal_target_sample: null pointer");
     PtParams P;
     P.roi = roi_boxes3d; P.gt = gt_boxes3d; P.B = B; P.M = M; P.G = G; P.gt_cols = gt_cols; P.R = roi_per_image;
-    P.reg_fg = cfg6[0]; P.cls_fg = cfg6[1]; P.cls_bg = cfg6[2]; P.cls_bg_lo = cfg6[3]; P.hard_ratio = cfg6[5];
-    P.fg_per_image = (int)nearbyint((double)cfg6[4] * (double)roi_per_image);                 // np.round
+    // thresholds meet float32 overlaps (torch casts the Python scalar to the tensor's dtype); the two ratios stay DOUBLE: the reference
+    // computes np.round(FG_RATIO * ROI_PER_IMAGE) and int(bg_rois_per_this_image * HARD_BG_RATIO) in Python doubles (0.7f * 10 -> 6, 0.7 * 10 -> 7)
+    P.reg_fg = (float)cfg6[0]; P.cls_fg = (float)cfg6[1]; P.cls_bg = (float)cfg6[2]; P.cls_bg_lo = (float)cfg6[3]; P.hard_ratio = cfg6[5];
+    P.fg_per_image = (int)nearbyint(cfg6[4] * (double)roi_per_image);                 // np.round
     P.aug_times = aug_times; P.aug_method = aug_method; P.seed = seed;
     P.rois = rois; P.gt_of_rois = gt_of_rois; P.roi_iou = roi_iou; P.src = src; P.max_overlaps = max_overlaps;
     P.gt_assignment = gt_assignment; P.counts = counts; P.status = status;
     hipLaunchKernelGGL(pt_overlaps_kernel, dim3(prcnn_divup(M, 4), B), dim3(64), 0, (hipStream_t)stream, P);
-    hipLaunchKernelGGL(proposal_target_kernel, dim3(B), dim3(PT_THREADS), (size_t)M * 4 * sizeof(int), (hipStream_t)stream, P);
+    // keys / fg / hard / easy lists: 16 bytes per RoI of dynamic LDS (128 KB at the 8192-RoI cap) next to ~12 KB static
+    const size_t lds = (size_t)M * 4 * sizeof(int);
+    static PrcnnLdsLimit attr;
+    PRCNN_REQUIRE(lds <= 48 * 1024 || attr.raise((const void*)proposal_target_kernel, 8192 * 4 * (int)sizeof(int)),
+                  "prcnn_proposal_target_sample: cannot raise the dynamic LDS limit for M=%d", M);
+    hipLaunchKernelGGL(proposal_target_kernel, dim3(B), dim3(PT_THREADS), lds, (hipStream_t)stream, P);
     PRCNN_LAUNCH_CHECK("prcnn_proposal_target_sample");
     return PRCNN_OK;
 }

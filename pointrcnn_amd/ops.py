@@ -655,7 +655,7 @@ def proposal_target_sample(roi_boxes3d, gt_boxes3d, roi_per_image=64, thresholds
          "roi_iou": torch.empty((B, R), dtype=_F32, device=dev), "src": torch.empty((B, R), dtype=_INT, device=dev),
          "max_overlaps": torch.empty((B, M), dtype=_F32, device=dev), "gt_assignment": torch.empty((B, M), dtype=_INT, device=dev),
          "counts": torch.empty((B, 4), dtype=_INT, device=dev), "status": torch.empty((B,), dtype=_INT, device=dev)}
-    cfg6 = (ctypes.c_float * 6)(*[float(v) for v in tuple(thresholds) + (fg_ratio, hard_bg_ratio)])
+    cfg6 = (ctypes.c_double * 6)(*[float(v) for v in tuple(thresholds) + (fg_ratio, hard_bg_ratio)])
     _cabi.check(_cabi.lib().prcnn_proposal_target_sample(_p(roi_boxes3d), _p(gt_boxes3d), B, M, G, gc, R, ctypes.cast(cfg6, ctypes.c_void_p),
                                                          int(aug_times), {"multiple": 0, "single": 1}[aug_method], seed & 0xFFFFFFFF,
                                                          _p(o["rois"]), _p(o["gt_of_rois"]), _p(o["roi_iou"]), _p(o["src"]),

@@ -52,9 +52,14 @@ def _alpha(boxes):
 
 
 class ProposalTargetLayer(nn.Module):
-    def __init__(self, cfg=ProposalTargetConfig, seed=0):
+    def __init__(self, cfg=ProposalTargetConfig, seed=None):
+        """seed None (default): every call keys the sampler's counter-based random table with a fresh draw from torch's global
+        (host) generator -- as the reference's sampler, which draws from the numpy / torch global RNGs, it follows
+        torch.manual_seed, differs between DDP ranks seeded differently and resumes with the generator state; an int: a
+        deterministic counter (seed, seed + 1, ...) for tests.  (No registered buffer: the module must keep the reference's
+        state-dict keys.)"""
         super().__init__()
-        self.cfg, self.seed = cfg, int(seed)
+        self.cfg, self.seed = cfg, None if seed is None else int(seed)
 
     def forward(self, input_dict):
         cfg = self.cfg
@@ -97,7 +102,9 @@ class ProposalTargetLayer(nn.Module):
         """(B,M,7), (B,G,7) -> batch_rois (B,R,7), batch_gt_of_rois (B,R,7), batch_roi_iou (B,R); `self.last` keeps the sampler's
         other outputs (source RoI of every slot, candidate counts, status) on the device"""
         cfg = self.cfg
-        if seed is None:
+        if seed is None and self.seed is None:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())          # host generator: no device round trip
+        elif seed is None:
             seed, self.seed = self.seed, self.seed + 1
         o = ops.proposal_target_sample(roi_boxes3d.contiguous(), gt_boxes3d.contiguous(), cfg.ROI_PER_IMAGE,
                                        (cfg.REG_FG_THRESH, cfg.CLS_FG_THRESH, cfg.CLS_BG_THRESH, cfg.CLS_BG_THRESH_LO), cfg.FG_RATIO,

@@ -84,21 +84,47 @@ class Pointnet2MSG(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def prefetch_samples(self, pointcloud):
+    def prefetch_samples(self, pointcloud, ready=None):
         """Draw the sample sets of a FUTURE forward pass now, on the side stream, underneath whatever the current stream is
         doing (the rest of this training step).  The furthest-point-sampling chain depends on the input coordinates only and is
         a serial 4.5 ms chain on one workgroup per frame: drawn inside the step it is the first thing every level waits for;
         drawn one step ahead -- the next batch is known to any prefetching data loader -- it costs 16 of 256 CUs for a few
-        milliseconds.  The next forward() on the SAME tensor (pointer, shape, version) picks the result up; any other input
-        drops it.  pointcloud: the (B, N, 3+C) tensor the next forward will be called with (must already be resident)."""
+        milliseconds.  The next forward() on the SAME tensor object (identity, shape, version) picks the result up; any other
+        input drops it.
+        pointcloud: the (B, N, 3+C) tensor the next forward will be called with.  Its producer must be visible to the side
+        stream: pass `ready` (an event recorded after the copy / kernel that wrote it, on whatever stream that was -- an
+        asynchronous H2D copy on a loader stream, typically); with ready=None the tensor must already be MATERIALISED, i.e.
+        every write to it was enqueued on the current stream before the work the side stream is allowed to overtake -- then an
+        event recorded on the current stream right here orders the side stream behind those writes and nothing else.
+        The xyz slice of a (B, N, 3+C) cloud with C > 0 is a copy kernel: it is enqueued on the SIDE stream, after that event
+        (round-3 advisor finding: on the current stream it would have queued behind this step's forward while the side stream
+        read its output)."""
+        cur = torch.cuda.current_stream(pointcloud.device)
+        if ready is None:
+            ready = torch.cuda.Event()
+            ready.record(cur)
         with torch.no_grad():
-            xyz, _ = self._break_up_pc(pointcloud)
+            side = self._side_stream(pointcloud.device, cur)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                xyz, _ = self._break_up_pc(pointcloud)
             side, ahead = self._sample_ahead(xyz, wait_current=False)
-        self._prefetched = (self._pc_key(pointcloud), side, ahead, xyz)
+        # the key holds the tensor ITSELF: an identity test at pick-up cannot be fooled by a new tensor landing at a dropped
+        # batch's address (same pointer, shape, version 0)
+        self._prefetched = (pointcloud, self._pc_key(pointcloud), side, ahead, xyz)
 
     @staticmethod
     def _pc_key(pc):
         return (pc.data_ptr(), tuple(pc.shape), tuple(pc.stride()), pc._version)
+
+    @staticmethod
+    def _side_stream(device, cur):
+        key = (device.index, cur.cuda_stream)          # the default stream's handle is 0 on EVERY device
+        with _SIDE_LOCK:                               # DataParallel-style callers run one thread per device
+            side = _SIDE_STREAMS.get(key)
+            if side is None:
+                side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        return side
 
     def _sample_ahead(self, xyz, wait_current=True):
         """The furthest-point-sampling chain of ALL levels on a side stream.  Level k's sample set depends on level k-1's
@@ -107,11 +133,7 @@ class Pointnet2MSG(nn.Module):
         levels' samples can be drawn underneath the set-abstraction work of the levels before them.
         -> per level (new_xyz, ready-event); the tensors are held by the caller until the end of the forward pass."""
         cur = torch.cuda.current_stream(xyz.device)
-        key = (xyz.device.index, cur.cuda_stream)      # the default stream's handle is 0 on EVERY device
-        with _SIDE_LOCK:                               # DataParallel-style callers run one thread per device
-            side = _SIDE_STREAMS.get(key)
-            if side is None:
-                side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=xyz.device)
+        side = self._side_stream(xyz.device, cur)
         if wait_current:
             side.wait_stream(cur)
         ahead, x = [], xyz
@@ -129,8 +151,10 @@ class Pointnet2MSG(nn.Module):
         l_xyz, l_features = [xyz], [features]
         want = FPS_AHEAD == "1" or (FPS_AHEAD == "auto" and torch.is_grad_enabled())
         pre, self._prefetched = self._prefetched, None
-        if pre is not None and pre[0] == self._pc_key(pointcloud):
-            side, ahead = pre[1], pre[2]                 # drawn during the previous step (prefetch_samples)
+        if pre is not None and pre[0] is pointcloud and pre[1] == self._pc_key(pointcloud):
+            side, ahead = pre[2], pre[3]                 # drawn during the previous step (prefetch_samples)
+            if pre[4].data_ptr() != xyz.data_ptr():      # C > 0: the side stream sliced its own xyz copy; keep it alive for this stream
+                pre[4].record_stream(torch.cuda.current_stream(xyz.device))
         else:
             side, ahead = self._sample_ahead(xyz) if (want and xyz.is_cuda) else (None, None)
         if ahead is not None:

@@ -159,3 +159,41 @@ def test_proposal_target_layer_mirror_forward(cpu, dev):
     # with augmentation on: same keys, finite
     out2 = ProposalTargetLayer(ProposalTargetConfig, seed=3)(inp)
     assert set(out2) == set(out) and all(torch.isfinite(v.float()).all() for v in out2.values())
+
+
+def _hard_slots(o, b):
+    fs = int(o["counts"][b, 3])
+    mo = o["max_overlaps"][b][o["src"][b][fs:]]
+    return fs, int((mo >= 0.05).sum())
+
+
+def test_slot_arithmetic_is_python_double_arithmetic(cpu):
+    """round-3 advisor finding: int(bg_rois_per_this_image * HARD_BG_RATIO) (proposal_target_layer.py:159) is Python double arithmetic --
+    10 * 0.7 = 7, whereas 10 * 0.7f = 6.9999998 -> 6.  The ratios therefore cross the boundary as doubles."""
+    roi, gt = rpt.scenes(1)
+    o = cpu.proposal_target_sample(roi, gt, roi_per_image=20, cfgv=(0.55, 0.6, 0.45, 0.05, 0.5, 0.7), seed=3)
+    c = o["counts"][0]
+    assert c[0] >= 10 and c[1] >= 7 and c[2] >= 3, "frame 0 of this scene has all three candidate kinds"
+    assert _hard_slots(o, 0) == (10, 7)
+    o = cpu.proposal_target_sample(roi, gt, roi_per_image=20, cfgv=(0.55, 0.6, 0.45, 0.05, 0.35, 0.7), seed=3)     # np.round(7.0) = 7 foreground slots
+    fs, nh = _hard_slots(o, 0)
+    assert fs == 7 and nh == int(13 * 0.7)
+
+
+@pytest.mark.gpu
+def test_hip_sampler_slot_arithmetic_and_large_roi_lists(cpu, dev):
+    from pointrcnn_amd import ops
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)        # noqa: E731
+    roi, gt = rpt.scenes(1)
+    got = ops.proposal_target_sample(t(roi), t(gt), roi_per_image=20, fg_ratio=0.5, hard_bg_ratio=0.7, seed=3)
+    want = cpu.proposal_target_sample(roi, gt, roi_per_image=20, cfgv=(0.55, 0.6, 0.45, 0.05, 0.5, 0.7), seed=3)
+    for k in want:
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    assert _hard_slots(want, 0) == (10, 7)
+    # the documented cap: 8192 RoIs per frame = 128 KB of dynamic LDS (the limit is raised for the kernel), and a size in between
+    for M in (5000, 8192):
+        roi, gt = rpt.scenes(11, B=2, M=M, G=12)
+        got = ops.proposal_target_sample(t(roi), t(gt), seed=5)
+        want = cpu.proposal_target_sample(roi, gt, seed=5)
+        for k in want:
+            assert np.array_equal(got[k].cpu().numpy(), want[k]), (M, k)
