@@ -47,6 +47,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+_T0 = time.perf_counter()
+
+
+def trace(msg):
+    """stage markers on stderr (PRCNN_BENCH_TRACE=1): where a run that dies without a JSON line got to"""
+    if os.environ.get("PRCNN_BENCH_TRACE"):
+        print("[bench %7.2fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32-input MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -214,11 +223,11 @@ class EventProfiler:
         if name == "prcnn_mlp_rows_addinterp":
             return 2.0 * (a[2] + 3) * a[5], a[11] * a[12], None, 1, "%d->%d + interpolated addend" % (a[2], a[5])
         if name == "prcnn_mlp_rows_split":              # (fp32-EQUIVALENT flops: 2 K N per row, whatever the number of bf16 terms)
-            return 2.0 * a[3] * a[8], a[2], a[13], a[14], "%d->%d (bf16x%d)" % (a[3], a[8], a[6])
+            return 2.0 * a[3] * a[8], a[2], a[14], a[15], "%d->%d (bf16x%d)" % (a[3], a[8], a[6])
         if name == "prcnn_mlp_chain_rows_split":
             return chain(a[3], [a[7][0], a[7][1]]), a[2], None, 1, widths(a[3], a[7], 2) + " (bf16x%d)" % a[9]
         if name == "prcnn_mlp_chain_interp_split":
-            return 2.0 * a[7] * a[11], a[4] * a[5], None, 1, "%d->%d (bf16x%d)" % (a[7], a[11], a[13])
+            return 2.0 * a[7] * a[12], a[4] * a[5], None, 1, "%d->%d (bf16x%d)" % (a[7], a[12], a[14])
         if name == "prcnn_mlp_rows_addinterp_split":
             return 2.0 * (a[2] + 3) * a[7], a[13] * a[14], None, 1, "%d->%d + interpolated addend (bf16x%d)" % (a[2], a[7], a[5])
         if name == "prcnn_mlp_group":
@@ -358,8 +367,8 @@ def cpu_baseline(model, clouds_cpu, gpu_out):
             "reference_roipool3d": ref_roipool, "host_cores_available": cores, "gpu_vs_oracle_rel_err_frame0": err}
     if res is not None:
         line.update({"value": res["frames_per_s"], "cores": res["cores"],
-                     "sample": "%d frames (16384 pts each) of the same RPN graph, %d worker processes x %d threads, median of %d runs "
-                               "after 1 warm-up (%s s)" % (res["frames"], res["workers"], res["threads_per_worker"], len(res["runs_s"]),
+                     "sample": "%d frames (%d pts each) of the same RPN graph, %d worker processes x %d threads, median of %d runs "
+                               "after 1 warm-up (%s s)" % (res["frames"], clouds_cpu.shape[1], res["workers"], res["threads_per_worker"], len(res["runs_s"]),
                                                           res["runs_s"]),
                      "cpu_seconds_by_op": res["cpu_seconds_by_op"]})
     return line
@@ -385,9 +394,18 @@ class InferenceBench:
         self._eager_inputs = None
 
     def _example(self):
+        """per-slot initial inputs: every in-flight slot owns its (resident) batch and is captured on it"""
+        if os.environ.get("PRCNN_BENCH_SAME_EXAMPLE"):          # dev A/B: every slot captured on slot 0's batch
+            if self.raw is not None:
+                return {k: self.raw["slots"][0]["dev"][k] for k in ("raw", "offsets", "calib", "img_hw")}
+            return {"pts_input": self.clouds_cpu}
         if self.raw is not None:
-            return {k: self.raw["slots"][0]["dev"][k] for k in ("raw", "offsets", "calib", "img_hw")}
-        return {"pts_input": self.clouds_cpu}
+            return [{k: self.raw["slots"][s_]["dev"][k] for k in ("raw", "offsets", "calib", "img_hw")} for s_ in range(self.nstreams)]
+        return [{"pts_input": self._slot_clouds(s_)} for s_ in range(self.nstreams)]
+
+    def _example0(self):
+        ex = self._example()
+        return ex[0] if isinstance(ex, list) else ex
 
     def step_from(self, inputs, slot=0):
         """one step of the workload on a slot's (static) input tensors: what the pipeline captures"""
@@ -411,7 +429,7 @@ class InferenceBench:
         if self.pipe is not None:
             return self.step_from(self.pipe.inputs[slot], slot)
         if self._eager_inputs is None:
-            self._eager_inputs = {k: v.to(self.dev) for k, v in self._example().items()}
+            self._eager_inputs = {k: v.to(self.dev) for k, v in self._example0().items()}
         return self.step_from(self._eager_inputs, slot)
 
     def warm(self):
@@ -434,16 +452,19 @@ class InferenceBench:
             print("[bench] hipGraph capture unavailable (%s); timing eager launches" % str(e).split("\n")[0], file=sys.stderr)
             self.pipe = InferencePipeline(self.step_from, self._example(), slots=self.nstreams, device=self.dev, graph=False)
         self._eager_inputs = None
-        for s_ in range(1, self.nstreams):            # every in-flight slot owns its (resident) input batch
-            if self.raw is not None:
-                for k in ("raw", "offsets", "calib", "img_hw"):
-                    self.pipe.inputs[s_][k].copy_(self.raw["slots"][s_]["dev"][k])
-            else:
-                self.pipe.inputs[s_]["pts_input"].copy_(self._slot_clouds(s_))
+        trace("pipeline built")
+        if os.environ.get("PRCNN_BENCH_SAME_EXAMPLE"):
+            for s_ in range(1, self.nstreams):
+                if self.raw is not None:
+                    for k in ("raw", "offsets", "calib", "img_hw"):
+                        self.pipe.inputs[s_][k].copy_(self.raw["slots"][s_]["dev"][k])
+                else:
+                    self.pipe.inputs[s_]["pts_input"].copy_(self._slot_clouds(s_))
         torch.cuda.synchronize()
         self.graphs = self.pipe.graphs if self.pipe.graphed else None
         self.pipe.submit(None)
         out0 = self.pipe.result()
+        trace("slot 0 replayed")
         for k in ("rpn_cls", "rpn_reg"):                 # the replayed graph must reproduce the eager result
             assert torch.equal(out0[k], eager_out[k]), "graph replay differs from eager (%s)" % k
         self.out = out0
@@ -822,8 +843,11 @@ def main():
         from pointrcnn_amd.proposal_layer import ProposalConfig, ProposalLayer
         proposal_layer = ProposalLayer("TEST", cfg=type("Cfg", (ProposalConfig,), {"NMS_TYPE": args.proposals}))
 
+    trace("model built; preparing %d slots" % nstreams)
     bench = InferenceBench(args, model, dev, rank, world, args.clouds, proposal_layer, raw).prepare()
+    trace("slots captured; timed loop")
     elapsed = bench.timed(args.steps, args.warmup, dist, h2d=args.h2d)
+    trace("timed loop done: %.3f ms/step" % (1e3 * elapsed / args.steps))
     out, clouds_cpu, graph = bench.out, bench.clouds_cpu, bench.graphs
 
     line = {
@@ -854,7 +878,9 @@ def main():
     plain = args.workload == "rpn" and args.input == "clouds" and not args.h2d
     if plain and not args.no_variants:
         # SURVEY 8(d)(i) counts the H2D copy: same graphs, every batch's clouds copied from pinned host memory on the batch's stream
+        trace("h2d-inclusive loop")
         e2 = bench.timed(args.steps, min(args.warmup, nstreams), dist, h2d=True)
+        trace("latency-mode loop")
         line["value_h2d_inclusive"] = round(whole_job_value(args.batch, world, args.steps, e2), 2)
         # a latency-sensitive caller keeps ONE batch in flight: then the FPS serial chain (1 workgroup per frame) is exposed
         lsteps = min(args.steps, 48)
@@ -863,8 +889,9 @@ def main():
         line["latency_mode_ms_per_batch"] = round(1e3 * e3 / lsteps, 3)
 
     fam = None
-    if rank == 0 and not args.no_roofline and args.workload == "rpn":
+    if rank == 0 and not args.no_roofline:
         nprof = min(3, args.steps)
+        trace("instrumented pass")
         if args.dump_launches:
             instrumented_pass(args, bench, 1, dump=sys.stderr)
         fam = instrumented_pass(args, bench, nprof)
@@ -874,7 +901,7 @@ def main():
         # exact) remove most of the reference graph's MLP work (14.95 GFLOP/frame, padding rows included),
         # so the reference-graph rate -- reported next to it -- is a throughput figure, not a utilisation, and may exceed
         # the peak.
-        ref_flops = rpn.rpn_flops_per_frame() * args.batch * nprof if args.npoints == 16384 else None
+        ref_flops = rpn.rpn_flops_per_frame() * args.batch * nprof if (args.npoints == 16384 and args.workload == "rpn") else None
         achieved = mlp["flops"] / secs / 1e12 if secs > 0 else 0.0
         line["roofline"] = {"kernel": "mlp_chain_* + mlp_layer_kernel (fused gather/interp + fp32 MFMA + bias/ReLU/max-pool)",
                             "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
@@ -925,8 +952,16 @@ def main():
                             "each), so the per-step FPS time IS one frame's chain; frac = floor / measured.  The lever left is the "
                             "instruction count per sample, not the issue rate"}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "rpn" and args.input == "clouds":
-        line["cpu_baseline"] = cpu_baseline(model, clouds_cpu, out)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.input == "clouds":
+        trace("cpu baseline")
+        # two-stage workload: the RPN stage of the same graph on the host (its backbone is ~85 % of the two-stage step) and the
+        # reference's own CPU code for the stage-2 pooling next to it; the RCNN stage's MLPs have no CPU path in the reference
+        line["cpu_baseline"] = cpu_baseline(model.rpn if args.workload == "rcnn" else model, clouds_cpu, out)
+        if args.workload == "rcnn":
+            line["cpu_baseline"]["what"] = ("RPN STAGE ONLY of the two-stage graph (backbone + heads; the proposal layer, roipool3d and the "
+                                            "RCNN stage are not in `value`; the reference's roipool3d_cpu is timed in reference_roipool3d): "
+                                            + line["cpu_baseline"]["what"])
+        trace("cpu baseline done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and raw is not None:
         # the input builder's CPU oracle (one thread) on the first frames of slot 0, and a bit-for-bit check of the GPU rows
         import numpy as np
@@ -960,6 +995,7 @@ def main():
             todo = (("repeat", "uniform", True),) + todo + (("repeat2", "uniform", True),)
         for name, kind, dedup in todo:
             pm.GROUP_DEDUP = dedup
+            trace("variant %s" % name)
             vb = InferenceBench(args, model, dev, rank, world, kind, proposal_layer, None).warm()
             f2 = None
             if rank == 0 and not args.no_roofline:          # (eager pass before the graphs of this variant exist)
@@ -989,6 +1025,7 @@ def main():
                              "max |out_f32| over backbone_features, rpn_cls, rpn_reg of slot 0's batch (contract: 1e-5)"}
             for terms in (6, 3):
                 _ops.MLP_SPLIT_TERMS = terms
+                trace("variant split-bf16x%d" % terms)
                 try:
                     vb = InferenceBench(args, model, dev, rank, world, "uniform", proposal_layer, None).warm()
                     diff = max(float((vb.out[k] - f32_out[k]).abs().max() / f32_out[k].abs().max()) for k in f32_out)

@@ -46,7 +46,7 @@ typedef void* prcnn_stream_t; /* hipStream_t */
 #define PRCNN_EHIP (-2)         /* HIP runtime / launch failure */
 #define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-int prcnn_abi_version(void);   /* 6: + prcnn_fps_status, training-mode SharedMLP (prcnn_train_*), prcnn_boxes_iou3d, prcnn_proposal_target_sample, prcnn_ref_trig (box trigonometry = the reference's host libm, bit for bit); 5: + prcnn_gt_aug_edit;
+int prcnn_abi_version(void);   /* 7: split-bf16 chain entry points take the fp32 pack images too (fp32 recomputation of rows with non-finite values); 6: + prcnn_fps_status, training-mode SharedMLP (prcnn_train_*), prcnn_boxes_iou3d, prcnn_proposal_target_sample, prcnn_ref_trig (box trigonometry = the reference's host libm, bit for bit); 5: + prcnn_gt_aug_edit;
                                  * 4: + prcnn_host_* (host twins of the reference's *_cpu entry points), prcnn_build_id,
                                  * prcnn_fps_order (upstream tie order), prcnn_rpn_labels,
                                  * prcnn_ball_query2_grid takes xyz (dense-frame scan fallback);
@@ -206,28 +206,32 @@ int prcnn_mlp_rows_addinterp(const float* in, int ld_in, int K, const float* wpa
  * bf16 MFMA products with fp32 accumulation: terms = 6 keeps everything above 2^-24 |x||w| (fp32-grade results), terms = 3
  * everything above 2^-16 |x||w|.  wsplit: prcnn_wsplit_bytes(Nout, K) bytes written by prcnn_pack_weight_split from the
  * (Nout, K) row-major fp32 weight.  The split kernel needs K % 32 == 0 and 16-byte aligned input rows; any other shape runs
- * the fp32 kernel on `wpack`, exactly as prcnn_mlp_rows / prcnn_mlp_rows_addinterp would.  An infinite input yields NaN.
- * rows_dev / rows_unit / seg_cnt / seg_rows: as for prcnn_mlp_rows (no max-pool in the split variant).
+ * the fp32 kernel on `wpack`, exactly as prcnn_mlp_rows / prcnn_mlp_rows_addinterp would.  Non-finite values: a wave that finds
+ * a non-finite accumulator (an infinite or NaN input value, an overflowing product) recomputes its rows with fp32 MFMAs on
+ * `wpack` -- those outputs are the fp32 kernels' own (inf stays inf, NaN only where IEEE arithmetic gives NaN).
+ * pool_ns / rows_dev / rows_unit / seg_cnt / seg_rows: as for prcnn_mlp_rows.  A supported shape runs the split kernel whatever
+ * its row count (the arithmetic of a layer does not depend on the batch size).
  * prcnn_pack_weight_split: chain = 0 writes the image of the two layer calls, chain = 1 the image of prcnn_mlp_chain_rows_split
  * (same size).  prcnn_mlp_chain_rows_split: the two-layer plain-row chain (prcnn_mlp_chain_rows with nlayers = 2) for K = 128,
  * nout = {128, 1} or {128, 65..128} -- the RPN heads; wchain / bias / nout / relu are HOST arrays of length 2, wchain[l] the
- * chain = 1 image of layer l (wchain[1] unused when nout[1] == 1: that output is a dot product on wpack1, the fp32
- * prcnn_pack_weight image of layer 1).  Any other shape: PRCNN_EUNSUPPORTED, issue prcnn_mlp_chain_rows.
+ * chain = 1 image of layer l (wchain[1] unused when nout[1] == 1: that output is a dot product on wpack[1]); wpack: HOST array
+ * of the two layers' fp32 prcnn_pack_weight images (the single-channel output and the fp32 recomputation of rows with
+ * non-finite values read them).  Any other shape: PRCNN_EUNSUPPORTED, issue prcnn_mlp_chain_rows.
  * (The reference computes these layers as fp32 cuDNN convolutions, [U] pytorch_utils.py SharedMLP) */
 size_t prcnn_wsplit_bytes(int Nout, int K);
 int prcnn_pack_weight_split(const float* w, int Nout, int K, int chain, void* wsplit, prcnn_stream_t stream);
 int prcnn_mlp_rows_split(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const void* wsplit, int terms,
-                         const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, const int32_t* rows_dev,
-                         int rows_unit, const int32_t* seg_cnt, int seg_rows, prcnn_stream_t stream);
-int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t rows, int K, const void* const* wchain, const float* wpack1,
+                         const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, int pool_ns,
+                         const int32_t* rows_dev, int rows_unit, const int32_t* seg_cnt, int seg_rows, prcnn_stream_t stream);
+int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t rows, int K, const void* const* wchain, const float* const* wpack,
                                const float* const* bias, const int* nout, const int* relu, int terms, float* out, int ld_out,
                                int col_off, prcnn_stream_t stream);
 /* hoisted FP0 on the split chain kernel: rows relu(interp(known_cl) + act_bias), C2 = 128 and no skip features, through ONE
- * 128 -> 128 layer (prcnn_mlp_chain_interp with nlayers = 1, C1 = 0, act_bias given); wchain: the chain = 1 image.  Other shapes:
- * PRCNN_EUNSUPPORTED. */
+ * 128 -> 128 layer (prcnn_mlp_chain_interp with nlayers = 1, C1 = 0, act_bias given); wchain: the chain = 1 image, wpack: the
+ * layer's fp32 prcnn_pack_weight image (rows with non-finite values).  Other shapes: PRCNN_EUNSUPPORTED. */
 int prcnn_mlp_chain_interp_split(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3, int B, int n, int m,
-                                 int C2, const float* act_bias, const void* wchain, const float* bias, int Nout, int relu,
-                                 int terms, float* out, int ld_out, int col_off, prcnn_stream_t stream);
+                                 int C2, const float* act_bias, const void* wchain, const float* wpack, const float* bias, int Nout,
+                                 int relu, int terms, float* out, int ld_out, int col_off, prcnn_stream_t stream);
 int prcnn_mlp_rows_addinterp_split(const float* in, int ld_in, int K, const float* wpack, const void* wsplit, int terms,
                                    const float* bias, int Nout, int relu, const float* y_cl, int ld_y, const int32_t* idx3,
                                    const float* w3, int B, int n, int m, float* out, int ld_out, int col_off,

@@ -66,9 +66,9 @@ SIGNATURES = {
     "prcnn_mlp_rows_addinterp": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
     "prcnn_wsplit_bytes": (_Z, [_I, _I]),
     "prcnn_pack_weight_split": (_I, [_P, _I, _I, _I, _P, _P]),
-    "prcnn_mlp_chain_interp_split": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
+    "prcnn_mlp_chain_interp_split": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
     "prcnn_mlp_chain_rows_split": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
-    "prcnn_mlp_rows_split": (_I, [_P, _I, _L, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P]),
+    "prcnn_mlp_rows_split": (_I, [_P, _I, _L, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P]),
     "prcnn_mlp_rows_addinterp_split": (_I, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
     "prcnn_mlp_chain_supported": (_I, [_I, _I, _P, _I]),
     "prcnn_mlp_chain_rows": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P]),

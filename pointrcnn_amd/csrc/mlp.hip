@@ -843,7 +843,12 @@ __global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST, ADDY>::W))
 // ds_read_b128 lane group land on 16 distinct 16-byte bank slots); the weights come pre-split (prcnn_pack_weight_split: per
 // (32-column block, 16-wide k-step, piece) the 64 lanes' 16-byte B operands, contiguous) and stream from L2 through a two-step
 // register ring, as in mlp_layer_b_kernel.  Accumulator layout = mlp_layer_b_kernel's: the epilogue is shared.
-// Non-finite inputs: an infinity becomes NaN (inf - inf in the split).  Shapes: K a multiple of 32, 16-byte aligned rows.
+// Non-finite inputs: the split of an infinity is (inf, NaN, NaN) and a NaN piece poisons every product of its row, where the fp32
+// kernels return what IEEE arithmetic returns (inf * w = +-inf, NaN only from inf - inf, inf * 0 or a NaN operand).  So a wave whose
+// accumulators hold a non-finite value after the main loop (one fma per accumulator register to find out) recomputes its 64-row x
+// 32 WNB-column block with fp32 MFMAs straight from global memory -- split_redo_f32, mlp_layer_b_kernel's k order, no LDS, no
+// barrier: the block then holds exactly the fp32 kernel's bits.  Finite products that overflow take the same path (same result).
+// Shapes: K a multiple of 32, 16-byte aligned rows.
 // =====================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef SPL_VALU_PER_MFMA
@@ -883,6 +888,62 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, int Nout, 
     for (int p = 0; p < 3; p++)
         img[(blk * 3 + p) * 64 + lane] = make_uint4(bf16_pair(b[p][0], b[p][1]), bf16_pair(b[p][2], b[p][3]),
                                                     bf16_pair(b[p][4], b[p][5]), bf16_pair(b[p][6], b[p][7]));
+}
+
+// true (wave-uniform) when any of the wave's accumulator registers is not finite: x * 0 is NaN for x = +-inf / NaN, 0 otherwise
+template <int NR>
+__device__ __forceinline__ bool wave_has_nonfinite(const f32x16 (&acc)[NR]) {
+    float chk = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) chk = __builtin_fmaf(acc[r][e], 0.f, chk);
+    return __builtin_amdgcn_ballot_w64(chk != chk) != 0;
+}
+
+// the wave's 64 x (32 WNB) block again, with fp32 MFMAs and operands read straight from global memory (rare path: a non-finite
+// operand).  Same products in the same order as mlp_layer_b_kernel: k-block by k-block, the four k-pairs of a block one after the
+// other -- bit-identical to the fp32 layer kernel.
+template <int WNB>
+__device__ __forceinline__ void split_redo_f32(const MlpParams& P, f32x16 (&acc)[2][WNB], long row0, int wm, int wn, int nb0, int lane) {
+    const int h = lane >> 5, j = lane & 31;
+    const float* ar[2];
+    const float* bp[WNB];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        long g = row0 + wm * 64 + r * 32 + j;
+        if (g >= P.rows) g = P.rows - 1;                 // clamped, never stored
+        ar[r] = P.in + g * P.ld_in + 4 * h;
+    }
+#pragma unroll
+    for (int n = 0; n < WNB; n++) bp[n] = P.wpack + ((long)min(nb0 + wn * WNB + n, P.NB - 1) * P.KB) * 256 + lane * 4;
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int n = 0; n < WNB; n++) acc[r][n] = (f32x16){0};
+    for (int kb = 0; kb < P.KB; kb++) {
+        float4 a[2], b[WNB];
+#pragma unroll
+        for (int r = 0; r < 2; r++) a[r] = ld4(ar[r] + kb * 8);
+#pragma unroll
+        for (int n = 0; n < WNB; n++) b[n] = ld4(bp[n] + (long)kb * 256);
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, b[n].x, acc[r][n], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].y, b[n].y, acc[r][n], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].z, b[n].z, acc[r][n], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int n = 0; n < WNB; n++) acc[r][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].w, b[n].w, acc[r][n], 0, 0, 0);
+    }
 }
 
 template <int WNB, int TERMS, bool ADDY>
@@ -1046,6 +1107,11 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpPa
         }
         if (sum == 123.456f) P.out[tid] = sum;
         if (PRCNN_ABL & 16) return;
+    }
+    if (!(PRCNN_ABL & (16 | 128))) {
+        // non-finite operands (see the header): this wave's block again on the fp32 pipe
+        const bool bad = wave_has_nonfinite<2 * WNB>(reinterpret_cast<const f32x16 (&)[2 * WNB]>(acc));
+        if (bad && n_active) split_redo_f32<WNB>(P, acc, row0, wm, wn, nb0, lane);
     }
     layer_epilogue<MODE_PLAIN, WNB, ADDY>(P, acc, reinterpret_cast<float*>(Ls), nullptr, tid, row0, nb0, n_active, false);
 }
@@ -1601,6 +1667,56 @@ __device__ __forceinline__ void schain_step(f32x16 (&out)[NBO], const uint4* ws,
 #undef SCH_TERM
 }
 
+// The wave's 32 rows through the whole chain again on the fp32 pipe (rare path: a non-finite value among the rows' inputs, see
+// mlp_layer_s_kernel's header).  Weights straight from the fp32 pack images in global memory (a.wpack, wpack1), the lane's own
+// row as the B operand, layer 1 fed from layer 0's accumulators -- the fp32 chain kernels' products in their k order, no LDS
+// staging, no barrier (the other waves of the workgroup are past theirs).  Stores go to the same addresses as the split path's,
+// later in program order.
+template <int MODE, int NB1>
+__device__ __forceinline__ void schain_redo_f32(const ChainParams& C, long row, bool valid, int lane, int h, const float* s_b,
+                                                const float (*s_bias)[128], bool out1) {
+    constexpr int NB0 = 4, KB = 16;
+    const MlpParams& P = C.a;
+    RowMeta<MODE> meta;
+    make_meta<MODE>(P, valid ? row : P.rows - 1, meta);
+    f32x16 a0[NB0];
+#pragma unroll
+    for (int ob = 0; ob < NB0; ob++) a0[ob] = (f32x16){0};
+    for (int kb = 0; kb < KB; kb++) {
+        Raw<MODE> x;
+        fast_fetch<MODE>(P, meta, 8 * kb + 4 * h, x);
+        const float4 v = fast_finish<MODE>(meta, 8 * kb + 4 * h, x, nullptr, s_b);
+#pragma unroll
+        for (int ob = 0; ob < NB0; ob++) {
+            const float4 w = ldw(P.wpack, KB, ob, kb, lane);
+            a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, v.x, a0[ob], 0, 0, 0);
+            a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, v.y, a0[ob], 0, 0, 0);
+            a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, v.z, a0[ob], 0, 0, 0);
+            a0[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, v.w, a0[ob], 0, 0, 0);
+        }
+    }
+    bias_act<NB0>(a0, s_bias[0], P.relu, h);
+    if (out1) { chain_out1<NB0>(C, a0, row, valid, lane, h); return; }
+    if constexpr (NB1 == 0) chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
+    if constexpr (NB1 > 1) {
+        f32x16 a1[NB1];
+#pragma unroll
+        for (int ob = 0; ob < NB1; ob++) a1[ob] = (f32x16){0};
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++)                       // (register indices must be compile-time)
+#pragma unroll
+            for (int ob = 0; ob < NB1; ob++) {
+                const float4 w = ldw(C.wpack1, KB, ob, kb, lane);
+                a1[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a0[kb >> 2][4 * (kb & 3) + 0], a1[ob], 0, 0, 0);
+                a1[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a0[kb >> 2][4 * (kb & 3) + 1], a1[ob], 0, 0, 0);
+                a1[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a0[kb >> 2][4 * (kb & 3) + 2], a1[ob], 0, 0, 0);
+                a1[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, a0[kb >> 2][4 * (kb & 3) + 3], a1[ob], 0, 0, 0);
+            }
+        bias_act<NB1>(a1, s_bias[1], C.relu1, h);
+        chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
+    }
+}
+
 // MODE_PLAIN: the rows are read as they are; MODE_INTERP (hoisted FP0: act = 2, C1 = 0): row = relu(interp(Y) + act_bias), built in
 // registers from the three neighbours' rows exactly as mlp_chain_fast_kernel builds it.  NB1 = 0: one layer.
 template <int MODE, int NB1, int TERMS>
@@ -1663,9 +1779,19 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_s_kernel(const ChainParams C
         if (st + 1 < KS / 2) sstage_store<NB0>(Ws[(st + 1) & 1], tid, wr);
         __syncthreads();
     }
+    // a non-finite input value (its split holds NaN pieces, which reach every output of the row): the wave redoes its rows on the
+    // fp32 pipe once the split path is through its barriers
+    const bool bad = P.wpack != nullptr && wave_has_nonfinite<NB0>(a0);
     bias_act<NB0>(a0, s_bias[0], P.relu, h);
-    if (out1) { chain_out1<NB0>(C, a0, row, valid, lane, h); return; }
-    if constexpr (NB1 == 0) chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
+    if (out1) {
+        chain_out1<NB0>(C, a0, row, valid, lane, h);
+        if (bad) schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, s_bias, true);
+        return;
+    }
+    if constexpr (NB1 == 0) {
+        if (!bad) chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
+        else schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, s_bias, false);
+    }
     if constexpr (NB1 > 1) {
         uint4 w1[SStage<NB1>::PT];
         uint4* W1s = &Ws[0][0];                              // (a stage of NB1 <= 4 blocks fits a stage of four)
@@ -1691,7 +1817,8 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_s_kernel(const ChainParams C
             __syncthreads();
         }
         bias_act<NB1>(a1, s_bias[1], C.relu1, h);
-        chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
+        if (!bad) chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
+        else schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, s_bias, false);
     }
 }
 
@@ -1977,11 +2104,13 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     if (P.rows == 0) return PRCNN_OK;
     P.KB = (P.K + 7) / 8;
     P.NB = (P.Nout + 31) / 32;
-    // split-bf16 variant: 128 x 128 tiles while they give most CUs a workgroup (two are resident per CU), else 128 x 64; a launch
-    // with fewer than 192 of those (FP3's 2048 rows) stays on the fp32 kernels below, which have forms for few rows
+    // split-bf16 variant: 128 x 128 tiles while they give most CUs a workgroup (two are resident per CU), else 128 x 64.  Every
+    // launch of a supported shape takes it, however few its rows: which arithmetic a layer is computed in must not depend on the
+    // batch size (a frame's result is the same bits in a batch of 1 and of 32).  PRCNN_SPLIT_MIN_TILES (dev A/B) sends launches of
+    // fewer tiles to the fp32 kernels, which have forms for few rows.
     const long split_tiles_wide = (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4), split_tiles_narrow = (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 2);
-    static const long split_min = getenv("PRCNN_SPLIT_MIN_TILES") ? atol(getenv("PRCNN_SPLIT_MIN_TILES")) : 192;
-    if (P.wsplit && mode == MODE_PLAIN && P.K % MLP_BK == 0 && P.vec_a && P.pool_ns == 0 && split_tiles_narrow >= split_min) {
+    static const long split_min = getenv("PRCNN_SPLIT_MIN_TILES") ? atol(getenv("PRCNN_SPLIT_MIN_TILES")) : 0;
+    if (P.wsplit && mode == MODE_PLAIN && P.K % MLP_BK == 0 && P.vec_a && split_tiles_narrow >= split_min) {
         PRCNN_REQUIRE(aligned16(P.wsplit) && (P.split_terms == 3 || P.split_terms == 6), "prcnn_mlp: bad split image / terms=%d", P.split_terms);
         static const long split_wide_min = getenv("PRCNN_SPLIT_WIDE_MIN") ? atol(getenv("PRCNN_SPLIT_WIDE_MIN")) : 192;
         const bool wide = P.NB >= 4 && split_tiles_wide >= split_wide_min;
@@ -2084,13 +2213,15 @@ PRCNN_API int prcnn_pack_weight_split(const float* w, int Nout, int K, int chain
 // Two-layer plain-row chain on the split kernels; shapes: K = 128, nout[0] = 128, nout[1] = 1 or 65..128 (the RPN heads).
 // wchain[l]: prcnn_pack_weight_split(chain = 1) images; wpack1: the fp32 pack image of layer 1 (read by the single-channel output).
 // PRCNN_EUNSUPPORTED for any other shape: the caller issues prcnn_mlp_chain_rows.
-PRCNN_API int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t rows, int K, const void* const* wchain, const float* wpack1,
+PRCNN_API int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t rows, int K, const void* const* wchain, const float* const* wpack,
                                          const float* const* bias, const int* nout, const int* relu, int terms, float* out, int ld_out,
                                          int col_off, prcnn_stream_t stream) {
-    PRCNN_REQUIRE(in && wchain && bias && nout && relu && out, "prcnn_mlp_chain_rows_split: null pointer");
+    PRCNN_REQUIRE(in && wchain && wpack && bias && nout && relu && out, "prcnn_mlp_chain_rows_split: null pointer");
     PRCNN_REQUIRE(terms == 3 || terms == 6, "prcnn_mlp_chain_rows_split: terms=%d (3 or 6)", terms);
+    PRCNN_REQUIRE(wpack[0] && wpack[1] && aligned16(wpack[0]) && aligned16(wpack[1]), "prcnn_mlp_chain_rows_split: the fp32 pack images of both layers are needed (non-finite rows, single-channel output)");
+    const float* wpack1 = wpack[1];
     const bool ok = K == 128 && nout[0] == 128 && (nout[1] == 1 || (nout[1] > 64 && nout[1] <= 128)) && aligned16(in) && ld_in % 4 == 0 &&
-                    ld_in >= K && wchain[0] && (nout[1] == 1 ? wpack1 != nullptr : wchain[1] != nullptr);
+                    ld_in >= K && wchain[0] && (nout[1] == 1 || wchain[1] != nullptr);
     if (!ok) return PRCNN_EUNSUPPORTED;
     PRCNN_REQUIRE(ld_out >= col_off + nout[1], "prcnn_mlp_chain_rows_split: ld_out=%d < col_off+Nout", ld_out);
     if (rows == 0) return PRCNN_OK;
@@ -2098,7 +2229,7 @@ PRCNN_API int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t row
     MlpParams& P = C.a;
     P.rows = rows; P.K = K; P.in = in; P.ld_in = ld_in; P.bias = bias[0]; P.Nout = nout[0]; P.relu = relu[0];
     P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.rows_unit = 1;
-    P.wsplit = wchain[0]; P.split_terms = terms;
+    P.wsplit = wchain[0]; P.split_terms = terms; P.wpack = wpack[0];
     C.wsplit1 = wchain[1]; C.wpack1 = wpack1; C.bias1 = bias[1]; C.N1 = nout[1]; C.relu1 = relu[1]; C.KB1 = 16; C.nlayers = 2;
     const dim3 grid(prcnn_divup(rows, 128));
     const hipStream_t s = (hipStream_t)stream;
@@ -2116,19 +2247,19 @@ PRCNN_API int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t row
 }
 
 PRCNN_API int prcnn_mlp_rows_split(const float* in, int ld_in, int64_t rows, int K, const float* wpack, const void* wsplit, int terms,
-                                   const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, const int32_t* rows_dev,
-                                   int rows_unit, const int32_t* seg_cnt, int seg_rows, prcnn_stream_t stream) {
+                                   const float* bias, int Nout, int relu, float* out, int ld_out, int col_off, int pool_ns,
+                                   const int32_t* rows_dev, int rows_unit, const int32_t* seg_cnt, int seg_rows, prcnn_stream_t stream) {
     PRCNN_REQUIRE(in && wsplit, "prcnn_mlp_rows_split: null pointer");
     PRCNN_REQUIRE(ld_in >= K && ld_out >= col_off + Nout, "prcnn_mlp_rows_split: bad strides ld_in=%d K=%d ld_out=%d", ld_in, K, ld_out);
     PRCNN_REQUIRE(terms == 3 || terms == 6, "prcnn_mlp_rows_split: terms=%d (3 or 6)", terms);
     MlpParams P = {};
     P.rows = rows; P.K = K; P.wpack = wpack; P.bias = bias; P.Nout = Nout; P.relu = relu;
-    P.out = out; P.ld_out = ld_out; P.col_off = col_off;
+    P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.pool_ns = pool_ns;
     P.in = in; P.ld_in = ld_in;
     P.vec_a = aligned16(in) && (ld_in % 4 == 0);
     P.rows_dev = rows_dev; P.rows_unit = rows_unit > 0 ? rows_unit : 1;
-    PRCNN_REQUIRE(!seg_cnt || (seg_rows > 0 && seg_rows % MLP_BM == 0 && rows % seg_rows == 0 && !rows_dev),
-                  "prcnn_mlp_rows_split: seg_rows=%d must be a multiple of %d dividing rows (no rows_dev)", seg_rows, MLP_BM);
+    PRCNN_REQUIRE(!seg_cnt || (seg_rows > 0 && seg_rows % MLP_BM == 0 && rows % seg_rows == 0 && pool_ns == 0 && !rows_dev),
+                  "prcnn_mlp_rows_split: seg_rows=%d must be a multiple of %d dividing rows (no pooling, no rows_dev)", seg_rows, MLP_BM);
     P.seg_cnt = seg_cnt; P.seg_rows = seg_rows;
     P.wsplit = wsplit; P.split_terms = terms;
     return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
@@ -2811,9 +2942,9 @@ PRCNN_API int prcnn_mlp_chain_interp(const float* known_cl, int ld_known, const 
 // Hoisted FP0 on the split chain kernel: rows relu(interp(known_cl) + act_bias) (C2 = 128, no skip features) through ONE
 // 128 -> 128 layer.  wchain: prcnn_pack_weight_split(chain = 1).  PRCNN_EUNSUPPORTED for other shapes (issue prcnn_mlp_chain_interp).
 PRCNN_API int prcnn_mlp_chain_interp_split(const float* known_cl, int ld_known, const int32_t* idx3, const float* w3, int B, int n,
-                                           int m, int C2, const float* act_bias, const void* wchain, const float* bias, int Nout,
-                                           int relu, int terms, float* out, int ld_out, int col_off, prcnn_stream_t stream) {
-    PRCNN_REQUIRE(known_cl && idx3 && w3 && act_bias && wchain && out, "prcnn_mlp_chain_interp_split: null pointer");
+                                           int m, int C2, const float* act_bias, const void* wchain, const float* wpack, const float* bias,
+                                           int Nout, int relu, int terms, float* out, int ld_out, int col_off, prcnn_stream_t stream) {
+    PRCNN_REQUIRE(known_cl && idx3 && w3 && act_bias && wchain && wpack && aligned16(wpack) && out, "prcnn_mlp_chain_interp_split: null / misaligned pointer");
     PRCNN_REQUIRE(terms == 3 || terms == 6, "prcnn_mlp_chain_interp_split: terms=%d (3 or 6)", terms);
     PRCNN_REQUIRE(B >= 0 && n > 0 && m > 0 && ld_known >= C2 && ld_out >= col_off + Nout, "prcnn_mlp_chain_interp_split: bad shape");
     if (!(C2 == 128 && Nout == 128 && aligned16(known_cl) && ld_known % 4 == 0 && aligned16(act_bias))) return PRCNN_EUNSUPPORTED;
@@ -2824,7 +2955,7 @@ PRCNN_API int prcnn_mlp_chain_interp_split(const float* known_cl, int ld_known, 
     P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.rows_unit = 1;
     P.known = known_cl; P.idx3 = idx3; P.w3 = w3; P.ld_known = ld_known; P.n = n; P.m = m; P.C2 = C2; P.C1 = 0;
     P.vec_a = 1; P.act = 2; P.act_bias = act_bias;
-    P.wsplit = wchain; P.split_terms = terms;
+    P.wsplit = wchain; P.split_terms = terms; P.wpack = wpack;
     C.nlayers = 1;
     if (B % 8 == 0 && n % 128 == 0 && getenv("PRCNN_NO_XCD_ORDER") == nullptr) P.xcd_tpf = n / 128;
     const dim3 grid(prcnn_divup(P.rows, 128));

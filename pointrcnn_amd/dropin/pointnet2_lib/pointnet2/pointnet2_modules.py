@@ -55,6 +55,8 @@ def _run_mlp_tail(x_rows, layers, start, out, pool_ns):
 def _flatten_frames(x):
     """(B, N, C) rows with a uniform row stride -> (1, B*N, C) view (frames become one long cloud; indices b*N + p)"""
     B, N, C = x.shape
+    if C == 1 and x.stride(2) != 1:       # a size-1 dimension carries whatever stride its history left it (a (B, 1, N) intensity plane)
+        x = x.as_strided((B, N, 1), (x.stride(0), x.stride(1), 1), x.storage_offset())
     assert x.stride(2) == 1 and (B == 1 or x.stride(0) == N * x.stride(1)), "rows must have one uniform stride"
     return x.as_strided((1, B * N, C), (B * N * x.stride(1), x.stride(1), 1), x.storage_offset())
 

@@ -30,7 +30,11 @@ def _fold_bn(conv, bn):
 def _rows_view(x_cl):
     """x_cl: (..., C) view with unit last stride -> tensor usable as uniformly strided rows (copy if needed)."""
     if x_cl.stride(-1) != 1:
-        return x_cl.contiguous()
+        if x_cl.shape[-1] != 1:
+            return x_cl.contiguous()
+        # a single channel: the size-1 last dimension keeps whatever stride its history left it (torch calls the tensor contiguous
+        # and .contiguous() returns it unchanged) -- give it the unit stride the kernels' callers test for
+        x_cl = x_cl.as_strided(x_cl.shape, tuple(x_cl.stride()[:-1]) + (1,), x_cl.storage_offset())
     ld = None
     expect = None
     for size, stride in zip(reversed(x_cl.shape[:-1]), reversed(x_cl.stride()[:-1])):

@@ -314,11 +314,11 @@ def mlp_chain_rows(x, layers, out=None, pool_ns=0, seg=None):
     buf, ld_out, col_off = _out_buf(out, rows_out, layers[-1], x.device)
     a = _chain_args(layers)
     seg_cnt, seg_rows = (None, 0) if seg is None else (seg[0], int(seg[1]))
-    if (MLP_SPLIT_TERMS and not pool_ns and seg is None and a.n == 2 and K == 128 and layers[0].nout == 128 and rows >= 32768
+    if (MLP_SPLIT_TERMS and not pool_ns and seg is None and a.n == 2 and K == 128 and layers[0].nout == 128
             and (layers[1].nout == 1 or 64 < layers[1].nout <= 128) and layers[0].wsplit(1) is not None and layers[1].wsplit(1) is not None):
         if getattr(a, "wchain", None) is None:                 # (host array of the two chain images, kept with the cached args)
             a.wchain = (ctypes.c_void_p * 2)(layers[0].wsplit(1).data_ptr(), layers[1].wsplit(1).data_ptr())
-        rc = _cabi.lib().prcnn_mlp_chain_rows_split(_p(x), ld_in, rows, K, a.wchain, _p(layers[1].wpack), a.bias, a.nout, a.relu,
+        rc = _cabi.lib().prcnn_mlp_chain_rows_split(_p(x), ld_in, rows, K, a.wchain, a.wpack, a.bias, a.nout, a.relu,
                                                     MLP_SPLIT_TERMS, _p(buf), ld_out, col_off, _stream())
         if rc != _cabi.EUNSUPPORTED:
             _cabi.check(rc, "prcnn_mlp_chain_rows_split")
@@ -352,10 +352,10 @@ def mlp_chain_interp(known_cl, idx3, w3, skip_cl, layers, out=None, act_bias=Non
     buf, ld_out, col_off = _out_buf(out, B * n, layers[-1], known_cl.device)
     a = _chain_args(layers)
     if (MLP_SPLIT_TERMS and skip_cl is None and act_bias is not None and a.n == 1 and C2 == 128 and layers[0].nout == 128
-            and B * n >= 32768 and layers[0].wsplit(1) is not None):
+            and layers[0].wsplit(1) is not None):
         l0 = layers[0]
         rc = _cabi.lib().prcnn_mlp_chain_interp_split(_p(known_cl), _row_stride(known_cl), _p(idx3), _p(w3), B, n, m, C2, _p(act_bias),
-                                                      _p(l0.wsplit(1)), _p(l0.bias), l0.nout, int(l0.relu), MLP_SPLIT_TERMS, _p(buf),
+                                                      _p(l0.wsplit(1)), _p(l0.wpack), _p(l0.bias), l0.nout, int(l0.relu), MLP_SPLIT_TERMS, _p(buf),
                                                       ld_out, col_off, _stream())
         if rc != _cabi.EUNSUPPORTED:
             _cabi.check(rc, "prcnn_mlp_chain_interp_split")
@@ -395,9 +395,9 @@ def mlp_rows(x, lin, out=None, pool_ns=0, rows_dev=None, rows_unit=1, seg=None):
     ld_in = _row_stride(x)
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, lin, x.device)
-    if MLP_SPLIT_TERMS and not pool_ns and ld_in % 4 == 0 and (seg is None or rows_dev is None) and lin.wsplit() is not None:
+    if MLP_SPLIT_TERMS and ld_in % 4 == 0 and (seg is None or (rows_dev is None and not pool_ns)) and lin.wsplit() is not None:
         _cabi.check(_cabi.lib().prcnn_mlp_rows_split(_p(x), ld_in, rows, K, _p(lin.wpack), _p(lin.wsplit()), MLP_SPLIT_TERMS,
-                                                     _p(lin.bias), lin.nout, int(lin.relu), _p(buf), ld_out, col_off, _p(rows_dev),
+                                                     _p(lin.bias), lin.nout, int(lin.relu), _p(buf), ld_out, col_off, int(pool_ns), _p(rows_dev),
                                                      int(rows_unit), _p(None if seg is None else seg[0]), 0 if seg is None else int(seg[1]),
                                                      _stream()), "prcnn_mlp_rows_split")
         return buf

@@ -84,7 +84,14 @@ class InferencePipeline:
         times eagerly per slot (lazy initialisation, weight packing, allocator pool) and then captured; everything it launches
         must go to torch's current stream (every C-ABI call of this package does).
         example_inputs: dict name -> tensor giving shape and dtype of every input (contents are the slot's initial data, so a
-        pipeline can also be replayed on resident inputs: submit(None))."""
+        pipeline can also be replayed on resident inputs: submit(None)); or a sequence of `slots` such dicts, one per slot (every
+        slot is then warmed up and captured on its own data)."""
+        per_slot = None
+        if isinstance(example_inputs, (list, tuple)):
+            per_slot = list(example_inputs)
+            if len(per_slot) != int(slots):
+                raise ValueError("InferencePipeline: %d example dicts for %d slots" % (len(per_slot), int(slots)))
+            example_inputs = per_slot[0]
         some = next(iter(example_inputs.values()))
         if device is not None:
             self.device = torch.device(device)
@@ -103,7 +110,8 @@ class InferencePipeline:
             warnings.warn("InferencePipeline: %d slots but GPU_MAX_HW_QUEUES=%s: streams that share a hardware queue serialise "
                           "(set it before the first HIP call)" % (self.slots, os.environ.get("GPU_MAX_HW_QUEUES", "4 (default)")))
         self.streams = shared_streams(self.device, self.slots) if self.on_gpu else [None] * self.slots
-        self.inputs = [{k: v.detach().to(self.device, copy=True) for k, v in example_inputs.items()} for _ in range(self.slots)]
+        self.inputs = [{k: v.detach().to(self.device, copy=True) for k, v in (per_slot[s_] if per_slot else example_inputs).items()}
+                       for s_ in range(self.slots)]
         self.outputs = [None] * self.slots
         self.graphs = [None] * self.slots
         self.events = [torch.cuda.Event() if self.on_gpu else None for _ in range(self.slots)]

@@ -381,12 +381,14 @@ def _scaled_rows(r, rows, K):
 @pytest.mark.parametrize("rows,K,Nout,relu,bias", [(24576, 32, 128, True, True), (25000, 96, 256, True, True), (12288, 512, 512, False, True),
                                                    (24576, 64, 64, True, False), (24576 + 77, 64, 96, True, True), (16384, 128, 200, False, True),
                                                    (12288 + 5, 32, 76, True, True), (3000, 256, 96, True, True), (200, 64, 64, True, True)])
+@pytest.mark.own_arithmetic
 @pytest.mark.parametrize("terms", [6, 3])
 def test_split_bf16_rows_against_float64(dev, monkeypatch, rows, K, Nout, relu, bias, terms):
     """the split-bf16 layer against a float64 product.  Six terms: every dropped partial product is below 2^-24 |x||w|, so the
     result must sit within the fp32 kernel's own contract (1e-5 of the scale) -- checked here against the tighter, per-element
     bound 2e-6 * (|x| . |w| + |b|).  Three terms: below 2^-16 |x||w| per product, bound 4e-5 * (|x| . |w| + |b|).  The last two
-    shapes are too small for the split kernel (fewer than 192 tiles): they must run, on the fp32 kernel."""
+    shapes are launches of a few tiles: they take the split kernel like any other (the arithmetic of a layer does not depend on
+    its row count)."""
     from pointrcnn_amd import ops
     r = np.random.default_rng(rows + K + terms)
     a = _scaled_rows(r, rows, K)
@@ -404,6 +406,7 @@ def test_split_bf16_rows_against_float64(dev, monkeypatch, rows, K, Nout, relu, 
         np.testing.assert_allclose(got, want, atol=mlp_tol(want), rtol=0)
 
 
+@pytest.mark.own_arithmetic
 def test_split_bf16_identity_and_exact_pieces(dev, monkeypatch):
     """A = identity with an asymmetric W whose entries need all 24 significand bits: with six terms the three pieces of W are
     reassembled exactly (x = 1 has one piece), so the output IS W^T bit for bit -- catches a wrong lane / k mapping of the bf16
@@ -422,6 +425,7 @@ def test_split_bf16_identity_and_exact_pieces(dev, monkeypatch):
     assert (got[:, :4] == -7.0).all() and (got[:, 4 + Nout:] == -7.0).all()
 
 
+@pytest.mark.own_arithmetic
 def test_split_bf16_addinterp_equals_fp32_layer(dev, monkeypatch):
     """hoisted FP first layer with the interpolated addend: the split variant against the fp32 kernel on the same inputs"""
     from pointrcnn_amd import ops
@@ -439,6 +443,7 @@ def test_split_bf16_addinterp_equals_fp32_layer(dev, monkeypatch):
     np.testing.assert_allclose(got, want, atol=mlp_tol(want), rtol=0)
 
 
+@pytest.mark.own_arithmetic
 def test_split_bf16_full_rpn_stays_within_the_fp32_contract(dev, monkeypatch):
     """the whole RPN graph (default.yaml, 4 frames of 16384 points) with the plain-row layers on the six-term split kernel: sample
     sets and neighbour lists are untouched (index operators see the same coordinates), features and head outputs stay within the
@@ -459,6 +464,7 @@ def test_split_bf16_full_rpn_stays_within_the_fp32_contract(dev, monkeypatch):
     assert differs, "the split kernel did not run (outputs are bit-identical to the fp32 path)"
 
 
+@pytest.mark.own_arithmetic
 @pytest.mark.parametrize("n1,relu1", [(76, False), (1, False), (128, True), (96, True)])
 @pytest.mark.parametrize("terms", [6, 3])
 def test_split_bf16_two_layer_chain_against_float64(dev, monkeypatch, n1, relu1, terms):
@@ -491,6 +497,7 @@ def test_split_bf16_two_layer_chain_against_float64(dev, monkeypatch, n1, relu1,
         np.testing.assert_allclose(got, ref32, atol=mlp_tol(ref32), rtol=0)
 
 
+@pytest.mark.own_arithmetic
 @pytest.mark.parametrize("terms", [6, 3])
 def test_split_bf16_hoisted_fp0_chain(dev, monkeypatch, terms):
     """hoisted FP0 (rows relu(interp(Y) + b0) through one 128 -> 128 layer) on the split chain kernel, B = 8 frames so that the
@@ -523,6 +530,7 @@ def test_split_bf16_hoisted_fp0_chain(dev, monkeypatch, terms):
         np.testing.assert_allclose(got, ref32, atol=mlp_tol(ref32), rtol=0)
 
 
+@pytest.mark.own_arithmetic
 def test_split_bf16_rows_with_device_row_count_and_live_segments(dev, monkeypatch):
     """the split layer kernel under a device-side row count and under segment-prefix live rows (the RCNN stage's launches): the same
     tiles are written as by the fp32 kernel, to the fp32 contract; everything else keeps the caller's bytes"""
@@ -546,3 +554,131 @@ def test_split_bf16_rows_with_device_row_count_and_live_segments(dev, monkeypatc
         np.testing.assert_allclose(got, ref, atol=mlp_tol(ref[ref != -7.0]), rtol=0)
         assert not np.array_equal(got, ref), "the split kernel did not run"
     assert (got_dev[12800:] == -7.0).all() and (got_dev[:12800] != -7.0).any()
+
+
+def _same_class(got, ref):
+    """the non-finite entries agree: NaN where NaN, +inf where +inf, -inf where -inf"""
+    return (np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isposinf(got), np.isposinf(ref))
+            and np.array_equal(np.isneginf(got), np.isneginf(ref)))
+
+
+@pytest.mark.own_arithmetic
+@pytest.mark.parametrize("Nout,relu,pool", [(256, False, 0), (64, True, 0), (128, False, 16)])
+def test_split_bf16_layer_nonfinite_rows_are_the_fp32_kernels_rows(dev, monkeypatch, Nout, relu, pool):
+    """The split of an infinity is (inf, NaN, NaN): left alone it would turn a row that the fp32 kernels return as +-inf into NaN
+    (and inf x 0 pieces into NaN where fp32 has inf).  A wave that sees a non-finite accumulator redoes its 64-row block with fp32
+    MFMAs in mlp_layer_b_kernel's k order: those blocks are the fp32 kernel's BITS, every other block stays a split result within
+    the contract.  Rows with +inf, -inf, NaN, +inf and -inf together, and a finite product that overflows."""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(500 + Nout)
+    rows, K = 24576 + 64, 128
+    a = r.normal(size=(rows, K)).astype(np.float32)
+    w = (r.normal(size=(Nout, K)) * 0.2).astype(np.float32)
+    w[3, :] = np.abs(w[3, :])                                 # one all-positive weight row: +inf and -inf in a row give NaN there too
+    w[5, 7] = 0.0                                             # inf x 0 = NaN in the fp32 product as well
+    w[9, 9] = w[9, 10] = 1.0                                  # 2e38 + 2e38 overflows in column 9 of row 20000 (finite operands)
+    b = r.normal(size=(Nout,)).astype(np.float32)
+    bad = {3: [(5, np.inf)], 700: [(0, -np.inf)], 5000: [(127, np.nan)], 9000: [(1, np.inf), (2, -np.inf)], 12000: [(7, np.inf)],
+           20000: [(9, 2e38), (10, 2e38)], rows - 1: [(64, np.inf)]}
+    for row, ents in bad.items():
+        for c, v in ents:
+            a[row, c] = v
+    l = lin(dev, w, b, relu)
+    ref = ops.mlp_rows(T(a, dev), l, pool_ns=pool).cpu().numpy()
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
+    got = ops.mlp_rows(T(a, dev), l, pool_ns=pool).cpu().numpy()
+    assert np.isinf(ref).any() and (relu or pool or np.isnan(ref).any())
+    assert _same_class(got, ref)
+    unit = 64 // pool if pool else 64                         # output rows of a wave's 64-row block
+    redone, partly = np.zeros(got.shape[0], bool), np.zeros(got.shape[0], bool)
+    for row in bad:
+        q = row // 64
+        # (the overflowing row makes ONE column non-finite: only the wave that owns that column block redoes its part of the rows)
+        (partly if row == 20000 else redone)[q * unit:(q + 1) * unit] = True
+    assert np.array_equal(got[redone], ref[redone], equal_nan=True), "a redone block is not the fp32 kernel's bits"
+    fin = np.isfinite(ref[partly])
+    assert np.abs(got[partly][fin] - ref[partly][fin]).max() <= mlp_tol(ref[partly][fin])
+    rest_g, rest_r = got[~(redone | partly)], ref[~(redone | partly)]
+    assert np.isfinite(rest_r).all()
+    np.testing.assert_allclose(rest_g, rest_r, atol=mlp_tol(rest_r), rtol=0)
+    assert not np.array_equal(rest_g, rest_r), "the split kernel did not run"
+
+
+@pytest.mark.own_arithmetic
+def test_split_bf16_addinterp_nonfinite_rows(dev, monkeypatch):
+    """hoisted FP first layer: non-finite skip features (the matrix product) and a non-finite interpolated addend row (added in
+    the shared fp32 epilogue): the same entries are NaN / +inf / -inf as in the fp32 kernel, finite entries within the contract"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(611)
+    B, n, m, C1, Nout = 2, 8192, 2048, 96, 256
+    skip = r.normal(size=(B, n, C1)).astype(np.float32)
+    skip[0, 17, 3] = np.inf
+    skip[1, 4000, 95] = -np.inf
+    skip[1, 8191, 0] = np.nan
+    y = r.normal(size=(B, m, Nout)).astype(np.float32)
+    y[0, 5, 100] = np.inf
+    idx3 = r.integers(0, m, size=(B, n, 3)).astype(np.int32)
+    idx3[0, 300] = (5, 6, 7)
+    w3 = r.random(size=(B, n, 3)).astype(np.float32)
+    w3 = w3 / w3.sum(-1, keepdims=True)
+    l = lin(dev, (r.normal(size=(Nout, C1)) * 0.2).astype(np.float32), r.normal(size=(Nout,)).astype(np.float32), False)
+    args = (T(skip, dev), l, T(y, dev), T(idx3, dev), T(w3, dev))
+    ref = ops.mlp_rows_addinterp(*args).cpu().numpy()
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
+    got = ops.mlp_rows_addinterp(*args).cpu().numpy()
+    assert np.isinf(ref).any() and np.isnan(ref).any() and _same_class(got, ref)
+    fin = np.isfinite(ref)
+    assert np.abs(got[fin] - ref[fin]).max() <= mlp_tol(ref[fin])
+
+
+@pytest.mark.own_arithmetic
+@pytest.mark.parametrize("n1,relu1", [(76, False), (1, False), (128, True)])
+def test_split_bf16_chain_nonfinite_rows(dev, monkeypatch, n1, relu1):
+    """the heads' chain with +inf / -inf / NaN among the input rows: the wave redoes its 32 rows on the fp32 pipe (the fp32 chain's
+    products in its k order) -- the same entries are non-finite as in the fp32 chain, their finite neighbours and every other tile
+    within the contract.  (After the first layer's ReLU an infinity survives, a NaN does not: max(NaN, 0) = 0 in both kernels.)"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(700 + n1)
+    rows = 40000 + 17
+    x = r.normal(size=(rows, 128)).astype(np.float32)
+    bad = {0: (3, np.inf), 33: (127, -np.inf), 4100: (64, np.nan), 20000: (1, np.inf), rows - 1: (5, -np.inf)}
+    for row, (c, v) in bad.items():
+        x[row, c] = v
+    w0 = (r.normal(size=(128, 128)) * 0.1).astype(np.float32)
+    w1 = (r.normal(size=(n1, 128)) * 0.1).astype(np.float32)
+    layers = [lin(dev, w0, r.normal(size=(128,)).astype(np.float32), True), lin(dev, w1, r.normal(size=(n1,)).astype(np.float32), relu1)]
+    ref = ops.mlp_chain_rows(T(x, dev), layers).cpu().numpy()
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
+    got = ops.mlp_chain_rows(T(x, dev), layers).cpu().numpy()
+    assert (~np.isfinite(ref)).any() and _same_class(got, ref)
+    fin = np.isfinite(ref)
+    assert np.abs(got[fin] - ref[fin]).max() <= mlp_tol(ref[fin])
+    clean = np.ones(rows, bool)
+    for row in bad:
+        clean[(row // 32) * 32:(row // 32 + 1) * 32] = False
+    assert not np.array_equal(got[clean], ref[clean]), "the split chain did not run"
+
+
+@pytest.mark.own_arithmetic
+def test_split_bf16_hoisted_fp0_nonfinite_rows(dev, monkeypatch):
+    """hoisted FP0 with an infinite known-point row: every row interpolating from it is relu(inf + b) = inf going into the layer"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(801)
+    B, n, m = 8, 4096, 1024
+    y = r.normal(size=(B, m, 128)).astype(np.float32)
+    y[2, 10, 7] = np.inf
+    y[5, 1000, 100] = -np.inf                              # relu(-inf + b) = 0: finite
+    idx3 = r.integers(0, m, size=(B, n, 3)).astype(np.int32)
+    idx3[2, 50] = (10, 11, 12)
+    idx3[5, 60] = (1000, 3, 4)
+    w3 = r.random(size=(B, n, 3)).astype(np.float32)
+    w3 = w3 / w3.sum(-1, keepdims=True)
+    b0 = T(r.normal(size=(128,)).astype(np.float32), dev)
+    l1 = lin(dev, (r.normal(size=(128, 128)) * 0.1).astype(np.float32), r.normal(size=(128,)).astype(np.float32), False)
+    args = (T(y, dev), T(idx3, dev), T(w3, dev), None, [l1])
+    ref = ops.mlp_chain_interp(*args, act_bias=b0).cpu().numpy()
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
+    got = ops.mlp_chain_interp(*args, act_bias=b0).cpu().numpy()
+    assert np.isinf(ref).any() and _same_class(got, ref)
+    fin = np.isfinite(ref)
+    assert np.abs(got[fin] - ref[fin]).max() <= mlp_tol(ref[fin])

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import kitti_cloud, mlp_tol, unit_cloud
+from util import assert_same_result, kitti_cloud, mlp_tol, unit_cloud
 
 pytestmark = pytest.mark.gpu
 
@@ -225,7 +225,7 @@ def test_rpn_backward_composed_path(dev):
 
 @pytest.mark.parametrize("div", [1, 4, 32])
 @pytest.mark.parametrize("cloud", ["sparse", "dense", "mixed"])
-def test_sa_padding_free_grouping_is_bit_identical(dev, cloud, div):
+def test_sa_padding_free_grouping_is_bit_identical(dev, cloud, div, mlp_mode):
     """PRCNN_GROUP_DEDUP (csrc/dedup.hip): sparse groups (<= nsample/div hits) run as their real rows only, dense
     groups with all their rows -- the level's output must not change by one bit.  sparse cloud: nearly every group has
     one hit; dense: all full; mixed: both lists populated (and the MSG level's two radii split differently).
@@ -254,7 +254,7 @@ def test_sa_padding_free_grouping_is_bit_identical(dev, cloud, div):
                     outs[flag] = mod(xyz, feat)[1].clone()
             finally:
                 pm.GROUP_DEDUP, pm.DEDUP_SPARSE_DIV = True, keep
-        assert torch.equal(outs[False], outs[True]), (cloud, mlps)
+        assert_same_result(outs[False], outs[True], mlp_mode, (cloud, mlps))
 
 
 @pytest.mark.parametrize("ns", [16, 12, 32])
@@ -290,7 +290,7 @@ def test_group_compact_lists(dev, smax, ns):
     assert torch.equal(sp.nxn.view(-1, 3)[:cd], new_xyz.view(-1, 3)[sp.listn[:cd].long()])
 
 
-def test_rcnn_roi_duplicate_elimination_is_bit_identical(dev, cpu):
+def test_rcnn_roi_duplicate_elimination_is_bit_identical(dev, cpu, mlp_mode):
     """PRCNN_ROI_DEDUP: an RoI with fewer than 512 points is padded with copies of its first rows; the fused stage skips the
     copies in the per-point layers and never gathers them in the first SA level.  RoIs from empty to > 512 points: the
     stage's outputs must not change by one bit, and `distinct` must be the oracle's point count."""
@@ -318,7 +318,7 @@ def test_rcnn_roi_duplicate_elimination_is_bit_identical(dev, cpu):
         finally:
             rcnn.ROI_DEDUP = True
     for k in ("rcnn_cls", "rcnn_reg", "pooled_empty_flag"):
-        assert torch.equal(outs[False][k], outs[True][k]), k
+        assert_same_result(outs[False][k], outs[True][k], mlp_mode, k)
     # distinct == min(points inside the enlarged box, 512), 1 for the empty RoI
     pool_boxes = rcnn.enlarge_box3d(rois.view(-1, 7), 1.0).view(B, M, 7)
     feat_cl = data["rpn_features"]

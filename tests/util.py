@@ -168,3 +168,17 @@ def scene_invariants(out_rect, out_int, valid_rect, valid_int, npoints):
     else:
         assert mult.min() >= 1 and mult.max() <= 2 and mult.sum() == npoints    # everything, topped up without replacement
     return mult
+
+
+def assert_same_result(a, b, mlp_mode, what=""):
+    """a, b: outputs (torch tensors) of two code paths that compute the same function.  "f32": the kernel variants perform the
+    same fp32 operations in the same order -- the outputs are the same BITS.  "split6": the two paths may send a layer to
+    different kernel families (an fp32 register-resident chain on one side, split-bf16 layer kernels on the other), so the bar
+    is the parity contract of the MLP outputs: 1e-5 of the output scale."""
+    import torch
+    if mlp_mode == "f32" or not a.is_floating_point():
+        assert torch.equal(a, b), what
+        return
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= 1e-5 * scale, (what, err, scale)
