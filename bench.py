@@ -374,6 +374,21 @@ def cpu_baseline(model, clouds_cpu, gpu_out):
     return line
 
 
+def arithmetic_label(terms):
+    """`dtype` of the line: the arithmetic the fused inference MLPs compute in"""
+    if terms == 0:
+        return "f32 (fp32 MFMA: v_mfma_f32_32x32x2_f32; PRCNN_MLP_SPLIT=0)"
+    return ("f32 via split-bf16x%d MFMA (every fp32 operand cut exactly into 3 bf16 pieces, %d bf16 MFMA products per fp32 product, fp32 "
+            "accumulate: %s; grouped SA stacks on fp32 MFMA; PRCNN_MLP_SPLIT=0 selects fp32 MFMA throughout)" %
+            (terms, terms, "fp32-grade, measured error 2.9e-7 of sum|x||w| vs 3.0e-7 for the fp32-MFMA kernel" if terms == 6 else
+             "error 1e-5 of sum|x||w|: outside the 1e-5 output contract, dev only"))
+
+
+def rel_diff(a, b, keys=("backbone_features", "rpn_cls", "rpn_reg")):
+    """max over the keys of max |a - b| / max |b|"""
+    return max(float((a[k] - b[k]).abs().max() / b[k].abs().max()) for k in keys)
+
+
 def make_cloud_fn(kind):
     from pointrcnn_amd import rpn
     return {"uniform": rpn.synthetic_clouds, "lidar": rpn.lidar_like_clouds, "saturated": rpn.saturated_clouds}[kind]
@@ -579,6 +594,88 @@ def stack_gemm_account(step, seconds_per_step):
             "frac_of_fp32_mfma_peak_over_the_whole_step": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
 
 
+def train_roofline(step, gemm):
+    """roofline object of a training line: the hand-written SharedMLP stacks (prcnn_train_stack_fwd / _bwd: MFMA forward, dgrad, wgrad
+    + the BatchNorm reductions, packing and pooling launched inside those calls) are the dominant family; achieved = the executed GEMM
+    flops of the step (stack_gemm_account) / the GPU time of those library calls, HIP events on the launch stream around every call"""
+    from pointrcnn_amd import _cabi
+    if gemm is None:
+        return None
+    step()
+    torch.cuda.synchronize()
+    prof = EventProfiler(_cabi._lib)
+    real = _cabi._lib
+    _cabi._lib = prof
+    nrep = 2
+    try:
+        for _ in range(nrep):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        _cabi._lib = real
+    fam = {}
+    for name, s_, e_, _ in prof.records:
+        d = fam.setdefault(name[len("prcnn_"):], [0.0, 0])
+        d[0] += s_.elapsed_time(e_) / nrep
+        d[1] += 1
+    stack_ms = sum(v[0] for k, v in fam.items() if k.startswith("train_stack_"))
+    lib_ms = sum(v[0] for v in fam.values())
+    if stack_ms <= 0:
+        return None
+    achieved = gemm["executed_GFLOP_per_step"] / stack_ms            # GFLOP / ms = TFLOP/s
+    return {"kernel": "train_fwd_kernel / train_dgrad_kernel / train_wgrad(_lds)_kernel (fp32 MFMA) + BatchNorm reductions, pack, pool inside "
+                      "prcnn_train_stack_fwd / prcnn_train_stack_bwd",
+            "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "flops_per_step": gemm["executed_GFLOP_per_step"] * 1e9, "stack_calls_ms_per_step": round(stack_ms, 3),
+            "all_library_calls_ms_per_step": round(lib_ms, 3),
+            "by_call_ms_per_step": {k: {"ms": round(v[0], 3), "calls": v[1] // nrep} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:12]},
+            "note": "achieved = executed GEMM flops (forward + input gradient + weight gradient on the live rows) / GPU time of the stack "
+                    "library calls (which also hold the BatchNorm statistics / backward reductions, weight packing, pooling and the split "
+                    "wgrad reduction -- not GEMM flops); HIP events on the launch stream, eager step"}
+
+
+def train_cpu_baseline(model_rpn, clouds_cpu, gpu_frames_per_s):
+    """the RPN training step on the host cores (oracle/rpn_train_cpu.py: C-oracle index operators + torch-CPU autograd for everything
+    that carries gradients, one frame per worker process), on a bounded sample; run as a subprocess before... no HIP state in it"""
+    import pickle
+    import subprocess
+    import tempfile
+    import numpy as np
+    from oracle import rpn_cpu
+    spec = rpn_cpu.extract_rpn_weights(model_rpn)
+    cores = os.cpu_count() or 1
+    nframes = int(max(4, min(cores // 2, 64)))          # (a training frame keeps ~6 GB of activations: fewer, fatter workers)
+    if nframes > clouds_cpu.shape[0]:
+        from pointrcnn_amd import rpn as _rpn
+        clouds_cpu = torch.cat([clouds_cpu, _rpn.synthetic_clouds(nframes - clouds_cpu.shape[0], clouds_cpu.shape[1], seed0=91000)])
+    res = None
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "spec.pkl"), "wb") as f:
+            pickle.dump(spec, f)
+        np.save(os.path.join(td, "clouds.npy"), clouds_cpu[:nframes].cpu().numpy())
+        env = dict(os.environ)
+        env.pop("OMP_NUM_THREADS", None)
+        try:
+            p = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--train", "--spec", os.path.join(td, "spec.pkl"), "--clouds",
+                                os.path.join(td, "clouds.npy"), "--repeats", "2", "--budget-s", "30"], cwd=ROOT, env=env,
+                               capture_output=True, text=True, timeout=900)
+            res = json.loads(p.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001
+            print("[bench] train cpu_baseline subprocess failed: %s" % e, file=sys.stderr)
+    line = {"value": None, "unit": "frames/s", "cores": cores, "kind": "port",
+            "what": "RPN training step per frame on the host: index operators = C oracle, gradient-carrying part (grouping, SharedMLP + "
+                    "training-mode BatchNorm + ReLU on nsample-padded rows, max-pool, interpolation, heads, backward, SGD update) = torch-CPU "
+                    "autograd; proxy loss; the reference has no CPU path for training (oracle/rpn_train_cpu.py)"}
+    if res is not None:
+        line.update({"value": res["frames_per_s"], "cores": res["cores"],
+                     "sample": "%d frames (%d pts each), %d worker processes x %d threads, median of %d runs after 1 warm-up (%s s)" %
+                               (res["frames"], clouds_cpu.shape[1], res["workers"], res["threads_per_worker"], len(res["runs_s"]), res["runs_s"]),
+                     "cpu_seconds_by_op": res["cpu_seconds_by_op"],
+                     "gpu_over_cpu": round(gpu_frames_per_s / res["frames_per_s"], 1) if res["frames_per_s"] else None})
+    return line
+
+
 def run_train(args, dev, rank, world, local_rank, dist):
     """BASELINE config 4: RPN training iterations under DDP; -> the JSON line"""
     from pointrcnn_amd import ops, rpn, train_functions as tf
@@ -645,7 +742,13 @@ def run_train(args, dev, rank, world, local_rank, dist):
     torch.cuda.synchronize()
     fg = int((batches[0]["rpn_cls_label"] > 0).sum().item())
     gemm = stack_gemm_account(lambda: trainer.step(batches[0]), elapsed / args.steps)
+    extra = {}
+    if rank == 0 and not args.no_roofline:
+        extra["roofline"] = train_roofline(lambda: trainer.step(batches[0]), gemm)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        extra["cpu_baseline"] = train_cpu_baseline(model, batches[0]["pts_input"].cpu(), whole_job_value(args.batch, world, args.steps, elapsed))
     return {
+        **extra,
         "metric": "KITTI frames/sec, RPN training step (%d pts/frame, bs%d per GPU, DDP over RCCL)" % (args.npoints, args.batch),
         "value": round(whole_job_value(args.batch, world, args.steps, elapsed), 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
@@ -752,7 +855,20 @@ def run_train_rcnn(args, dev, rank, world, local_rank, dist):
     last = model.rcnn_net.proposal_target_layer.last
     nparam = sum(p.numel() for p in trainer.params)
     gemm = stack_gemm_account(lambda: trainer.step(batches[0]), elapsed / args.steps)
+    extra = {}
+    if rank == 0 and not args.no_roofline:
+        extra["roofline"] = train_roofline(lambda: trainer.step(batches[0]), gemm)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded sample of the step on the host: its fixed-RPN forward (the step's first half) through the inference CPU baseline and the
+        # reference's own roipool3d_cpu; the RCNN stage's forward / backward has no CPU path in the reference and no port here
+        model.rpn.eval()
+        with torch.no_grad():
+            rpn_out = model.rpn({"pts_input": batches[0]["pts_input"]})
+        extra["cpu_baseline"] = cpu_baseline(model.rpn, batches[0]["pts_input"].cpu(), rpn_out)
+        extra["cpu_baseline"]["what"] = ("FIXED-RPN FORWARD of the step only (+ the reference's roipool3d_cpu in reference_roipool3d); the RCNN "
+                                         "stage's forward / backward is not in `value`: " + extra["cpu_baseline"]["what"])
     return {
+        **extra,
         "metric": "KITTI frames/sec, RCNN-stage training step (%d pts/frame, bs%d per GPU, 64 RoIs x 512 pts per frame)" % (args.npoints, args.batch),
         "value": round(whole_job_value(args.batch, world, args.steps, elapsed), 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
@@ -873,8 +989,7 @@ def main():
                    "roi_dedup": os.environ.get("PRCNN_ROI_DEDUP", "1") != "0"},
     }
     from pointrcnn_amd import ops as _ops_split
-    if _ops_split.MLP_SPLIT_TERMS:                          # PRCNN_MLP_SPLIT set for the whole run (dev / profiling): say so, this is NOT the f32 line
-        line["dtype"] = "f32 + split-bf16x%d plain-row layers (PRCNN_MLP_SPLIT)" % _ops_split.MLP_SPLIT_TERMS
+    line["dtype"] = arithmetic_label(_ops_split.MLP_SPLIT_TERMS)
     plain = args.workload == "rpn" and args.input == "clouds" and not args.h2d
     if plain and not args.no_variants:
         # SURVEY 8(d)(i) counts the H2D copy: same graphs, every batch's clouds copied from pinned host memory on the batch's stream
@@ -917,6 +1032,22 @@ def main():
         by_launch = fam.pop("mlp_by_launch", None)
         if by_launch:
             line["roofline"]["by_kernel"] = by_launch
+        if _ops_split.MLP_SPLIT_TERMS and by_launch:
+            # split-bf16 arithmetic: `achieved` / `frac` are fp32-EQUIVALENT flops (2 K N per row) against the fp32-MFMA peak -- what
+            # the layers would need on the fp32 matrix pipe; the bf16 pipe itself executes `terms` products per fp32 product
+            t_ = _ops_split.MLP_SPLIT_TERMS
+            sp = [r for r in by_launch if r["launch"].endswith("_split")]
+            sp_us, sp_gf = sum(r["us"] for r in sp), sum(r["GFLOP"] for r in sp)
+            line["roofline"]["kernel"] = ("mlp_layer_s_kernel / mlp_chain_s_kernel (split-bf16x%d MFMA, fp32 accumulate) + fp32-MFMA grouped SA stacks "
+                                          "(fused gather/interp + bias/ReLU/max-pool)" % t_)
+            line["roofline"]["note"] = ("achieved/frac = executed fp32-EQUIVALENT flops (2 K N per row, after exact first-layer hoisting and padding-free "
+                                        "grouping) / MLP-family GPU time, against the fp32-MFMA dense peak; bf16_pipe prices the split launches' "
+                                        "bf16 products (x%d) against the bf16 dense peak" % t_)
+            line["roofline"]["bf16_pipe"] = {"launches": len(sp), "us_per_step": round(sp_us, 1), "fp32_equivalent_GFLOP_per_step": round(sp_gf, 2),
+                                             "bf16_TFLOPs_executed": round(sp_gf * t_ * 1e3 / sp_us / 1e3, 1) if sp_us > 0 else None,
+                                             "peak_bf16_TFLOPs": 2500.0,
+                                             "frac_of_bf16_peak": round(sp_gf * t_ / sp_us / 2500.0, 4) if sp_us > 0 else None,
+                                             "fp32_mfma_launches_us_per_step": round(sum(r["us"] for r in by_launch) - sp_us, 1)}
         line["kernels"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "launches_per_step": v["launches"] // nprof}
                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         # HBM bytes per launch of the same kernel family from the PMC passes committed under profiles/ (rocprofv3
@@ -989,7 +1120,7 @@ def main():
         #   value_saturated  -- clouds whose every ball is full: nothing to remove, the split is pure overhead (worst case)
         from pointnet2_lib.pointnet2 import pointnet2_modules as pm
         bench.release()
-        vsteps, variants = min(args.steps, 96), {}
+        vsteps, variants, arith_diff = min(args.steps, 96), {}, {}
         todo = (("dedup_off", "uniform", False), ("saturated", "saturated", True), ("lidar", "lidar", True))
         if os.environ.get("PRCNN_BENCH_VARIANT_SELFCHECK"):     # dev: the headline configuration again, as a variant
             todo = (("repeat", "uniform", True),) + todo + (("repeat2", "uniform", True),)
@@ -997,6 +1128,14 @@ def main():
             pm.GROUP_DEDUP = dedup
             trace("variant %s" % name)
             vb = InferenceBench(args, model, dev, rank, world, kind, proposal_layer, None).warm()
+            if dedup and _ops_split.MLP_SPLIT_TERMS and world == 1:      # distance of this arithmetic from the fp32-MFMA graph on this kind of cloud
+                mine = {k: vb.out[k].clone() for k in ("backbone_features", "rpn_cls", "rpn_reg")}
+                keep_terms, _ops_split.MLP_SPLIT_TERMS = _ops_split.MLP_SPLIT_TERMS, 0
+                try:
+                    arith_diff[kind] = float("%.3g" % rel_diff(mine, vb.step(0)))
+                finally:
+                    _ops_split.MLP_SPLIT_TERMS = keep_terms
+                del mine
             f2 = None
             if rank == 0 and not args.no_roofline:          # (eager pass before the graphs of this variant exist)
                 f2 = instrumented_pass(args, vb, 1).get("mlp")
@@ -1010,37 +1149,45 @@ def main():
                                            "mlp_TFLOPs_executed": round(f2["flops"] / (f2["ms"] * 1e-3) / 1e12, 2) if f2["ms"] > 0 else None})
             vb.release()
         pm.GROUP_DEDUP = os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"
-        # split-bf16 variant of the plain-row layers (FP / SA-hoisted GEMMs): each fp32 product rebuilt from 6 (or 3) bf16 MFMA
-        # products of exactly split operands, fp32 accumulate.  NOT this line's arithmetic (dtype stays "f32", value is the
-        # fp32-MFMA graph): reported beside it, with its distance from the fp32 outputs on the same batch.
+        # The other arithmetics of the SAME command, beside the line's own (`dtype`): the fp32-MFMA graph (PRCNN_MLP_SPLIT=0) and the
+        # three-term split (dev only: outside the contract).  max_diff_vs_f32_mfma = max |out - out_f32| / max |out_f32| over
+        # backbone_features, rpn_cls, rpn_reg of slot 0's batch (contract: 1e-5), on uniform, lidar and saturated clouds.
         if world > 1:
-            line["variant_split_bf16"] = "measured on the single-GPU line only (python bench.py)"
-        elif not os.environ.get("PRCNN_BENCH_NO_SPLIT") and not _ops_split.MLP_SPLIT_TERMS:
+            line["arithmetics"] = "measured on the single-GPU line only (python bench.py)"
+        elif not os.environ.get("PRCNN_BENCH_NO_SPLIT"):
             from pointrcnn_amd import ops as _ops
-            f32b = InferenceBench(args, model, dev, rank, world, "uniform", proposal_layer, None).warm()
-            f32_out = {k: f32b.out[k].clone() for k in ("backbone_features", "rpn_cls", "rpn_reg")}
-            f32b.release()
-            split = {"note": "plain-row layers (mlp_rows / mlp_rows_addinterp launches of at least 192 tiles) on mlp_layer_s_kernel, the heads "
-                             "and hoisted FP0 on mlp_chain_s_kernel; the SA stacks and the short FP3 layer stay fp32-MFMA.  max_diff_vs_f32 = max |out - out_f32| / "
-                             "max |out_f32| over backbone_features, rpn_cls, rpn_reg of slot 0's batch (contract: 1e-5)"}
-            for terms in (6, 3):
+            mine_terms = _ops.MLP_SPLIT_TERMS
+            outs, arith = {}, {"note": "value / ms_per_step of the same timed loop under each arithmetic of the fused inference MLPs; mlp_* from an "
+                                       "instrumented eager pass (fp32-EQUIVALENT flops: 2 K N per row whatever the number of bf16 terms)"}
+            for terms in (mine_terms,) + tuple(t for t in (0, 6, 3) if t != mine_terms):
                 _ops.MLP_SPLIT_TERMS = terms
-                trace("variant split-bf16x%d" % terms)
+                name = "f32_mfma" if terms == 0 else "split_bf16x%d" % terms
+                trace("arithmetic %s" % name)
                 try:
                     vb = InferenceBench(args, model, dev, rank, world, "uniform", proposal_layer, None).warm()
-                    diff = max(float((vb.out[k] - f32_out[k]).abs().max() / f32_out[k].abs().max()) for k in f32_out)
+                    outs[terms] = {k: vb.out[k].clone() for k in ("backbone_features", "rpn_cls", "rpn_reg")}
+                    if terms == mine_terms:                       # (its timed loop is the line's own)
+                        vb.release()
+                        continue
                     f2 = instrumented_pass(args, vb, 1).get("mlp") if (rank == 0 and not args.no_roofline) else None
                     vb.prepare()
                     ev = vb.timed(vsteps, nstreams, dist)
-                    split["bf16x%d" % terms] = {"value": round(whole_job_value(args.batch, world, vsteps, ev), 2), "steps": vsteps,
-                                                 "ms_per_step": round(1e3 * ev / vsteps, 3), "max_diff_vs_f32": float("%.3g" % diff)}
+                    arith[name] = {"value": round(whole_job_value(args.batch, world, vsteps, ev), 2), "steps": vsteps, "ms_per_step": round(1e3 * ev / vsteps, 3)}
                     if f2:
-                        split["bf16x%d" % terms].update({"mlp_ms_per_step": round(f2["ms"], 3),
-                                                          "mlp_fp32_equivalent_TFLOPs": round(f2["flops"] / (f2["ms"] * 1e-3) / 1e12, 2)})
+                        arith[name].update({"mlp_ms_per_step": round(f2["ms"], 3),
+                                            "mlp_fp32_equivalent_TFLOPs": round(f2["flops"] / (f2["ms"] * 1e-3) / 1e12, 2)})
                     vb.release()
                 finally:
-                    _ops.MLP_SPLIT_TERMS = 0
-            line["variant_split_bf16"] = split
+                    _ops.MLP_SPLIT_TERMS = mine_terms
+            for terms, o in outs.items():
+                if terms != 0 and 0 in outs:
+                    d = {"uniform": float("%.3g" % rel_diff(o, outs[0]))}
+                    if terms == mine_terms:
+                        d.update(arith_diff)
+                    (arith.setdefault("split_bf16x%d" % terms, {}))["max_diff_vs_f32_mfma"] = d
+            line["arithmetics"] = arith
+            if "f32_mfma" in arith:
+                line["value_f32_mfma"] = arith["f32_mfma"]["value"]
         line["value_dedup_off"], line["value_saturated"] = variants["dedup_off"]["value"], variants["saturated"]["value"]
         line["value_lidar"] = variants["lidar"]["value"]
         if "repeat" in variants:

@@ -47,6 +47,16 @@ def _frame(xyz):
     return float(out["rpn_cls"].sum()), float(np.abs(out["rpn_reg"]).sum()), timings
 
 
+def _train_frame(xyz):
+    """--train: forward + proxy loss + backward + SGD update of one frame (oracle/rpn_train_cpu.py)"""
+    from oracle import rpn_train_cpu
+    if "params" not in _STATE:
+        _STATE["params"] = rpn_train_cpu.make_params(_STATE["spec"])
+    timings = {}
+    loss = rpn_train_cpu.rpn_train_frame(_STATE["cpu"], xyz, _STATE["params"], timings=timings)
+    return loss, 0.0, timings
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--spec", required=True)
@@ -54,7 +64,9 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="worker processes (default: min(frames, cores))")
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--budget-s", type=float, default=40.0, help="stop repeating once this much wall time is spent (>= 2 timed runs)")
+    ap.add_argument("--train", action="store_true", help="time the TRAINING step of every frame (forward, backward, update) instead of inference")
     a = ap.parse_args()
+    frame_fn = _train_frame if a.train else _frame
     clouds = np.load(a.clouds)
     cores = os.cpu_count() or 1
     workers = a.workers or max(1, min(clouds.shape[0], cores))
@@ -62,11 +74,11 @@ def main():
     frames = [np.ascontiguousarray(f) for f in clouds]
     t_start = time.perf_counter()
     with mp.get_context("fork").Pool(workers, initializer=_init, initargs=(a.spec, threads)) as pool:
-        first = pool.map(_frame, frames, chunksize=1)                      # warm-up (library loads, BLAS thread pools)
+        first = pool.map(frame_fn, frames, chunksize=1)                    # warm-up (library loads, BLAS thread pools)
         runs = []
         for _ in range(a.repeats):
             t0 = time.perf_counter()
-            res = pool.map(_frame, frames, chunksize=1)
+            res = pool.map(frame_fn, frames, chunksize=1)
             runs.append(time.perf_counter() - t0)
             if time.perf_counter() - t_start > a.budget_s and len(runs) >= 2:
                 break

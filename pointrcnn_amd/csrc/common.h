@@ -23,6 +23,20 @@ int prcnn_fail(int code, const char* fmt, ...);
 
 static inline int prcnn_divup(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Counters and small workspaces the kernels depend on are cleared by a KERNEL on the launch stream, not by hipMemsetAsync: a
+// captured hipMemsetAsync becomes a memset node of the hipGraph, and round 4 traced a memory fault in group_compact_kernel
+// (list offsets taken from a counter that was not zero when the kernel ran) to replays of graphs holding such nodes
+// (tools/graph_fault_probe2.py, rocgdb); a kernel node is ordered like every other launch of the step.
+static __global__ void prcnn_fill_words_kernel(uint32_t* __restrict__ p, uint32_t v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+static inline hipError_t prcnn_fill_words(void* p, uint32_t v, size_t nwords, hipStream_t s) {
+    if (nwords == 0) return hipSuccess;
+    hipLaunchKernelGGL(prcnn_fill_words_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, (uint32_t*)p, v, nwords);
+    return hipGetLastError();
+}
+
 // hipFuncSetAttribute applies to the function ON THE CURRENT DEVICE only, and one process may drive several devices from
 // several threads (the reference's nn.DataParallel convention, SURVEY 8(b) "Threading").  The "already raised" state is
 // therefore one bit per device, updated atomically; two threads racing on the same device both set the (idempotent)

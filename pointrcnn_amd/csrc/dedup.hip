@@ -163,7 +163,7 @@ PRCNN_API int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int 
     PRCNN_REQUIRE(sparse_max >= 1 && sparse_max <= nsample, "prcnn_group_compact: sparse_max=%d (1..nsample)", sparse_max);
     PRCNN_REQUIRE(counts, "prcnn_group_compact: null counts");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(counts, 0, 3 * sizeof(int32_t), s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_group_compact: memset failed");
+    if (prcnn_fill_words(counts, 0u, 3, s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_group_compact: clearing the counters failed");
     if (B == 0 || M == 0) return PRCNN_OK;
     PRCNN_REQUIRE((long)B * N < 2147483647L && (long)B * M * sparse_max < 2147483647L, "prcnn_group_compact: 32-bit row index overflow");
     PRCNN_REQUIRE(idx && new_xyz && ridx && rnx && slist && soff && scnt, "prcnn_group_compact: null pointer");

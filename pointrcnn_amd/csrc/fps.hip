@@ -850,7 +850,7 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
         static const bool use_mem = getenv("PRCNN_FPS_MEM") != nullptr;       // A/B switch: the L2 re-read kernel (same bits)
         if (!use_mem && S <= FPS_MULTI_MAX_SPLIT && ((uintptr_t)tmp & 7) == 0) {
             const size_t slot_bytes = (size_t)B * 2 * S * 5 * sizeof(unsigned long long);
-            if (hipMemsetAsync(tmp, 0xFF, slot_bytes, s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot clear the exchange slots");
+            if (prcnn_fill_words(tmp, 0xFFFFFFFFu, slot_bytes / 4, s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot clear the exchange slots");
             if (int st = prcnn_fps_status()) return st;               // an earlier launch of this kind timed out: say so now
             hipLaunchKernelGGL(fps_multi_kernel, dim3(B * S), dim3(1024), 0, s, xyz, N, npoint, S, reinterpret_cast<unsigned long long*>(tmp), idx,
                                fps_timeout_word());

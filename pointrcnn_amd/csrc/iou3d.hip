@@ -164,7 +164,7 @@ PRCNN_API int prcnn_nms(const float* boxes, int N, float thresh, int kind, int m
     PRCNN_REQUIRE(kind == PRCNN_NMS_ROTATED || kind == PRCNN_NMS_NORMAL, "prcnn_nms: bad kind %d", kind);
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) {
-        if (hipMemsetAsync(num_keep, 0, sizeof(int32_t), s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_nms: memset failed");
+        if (prcnn_fill_words(num_keep, 0u, 1, s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_nms: memset failed");
         return PRCNN_OK;
     }
     PRCNN_REQUIRE(boxes && keep && workspace, "prcnn_nms: null pointer");

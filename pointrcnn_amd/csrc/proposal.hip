@@ -713,9 +713,9 @@ PRCNN_API int prcnn_proposal_layer(const float* scores, const float* boxes3d, in
     PRCNN_REQUIRE(out_boxes && out_scores, "%s: null output", op);
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) {
-        if (hipMemsetAsync(out_boxes, 0, (size_t)B * post * 7 * 4, s) != hipSuccess ||
-            hipMemsetAsync(out_scores, 0, (size_t)B * post * 4, s) != hipSuccess ||
-            (out_count && hipMemsetAsync(out_count, 0, (size_t)B * 4, s) != hipSuccess))
+        if (prcnn_fill_words(out_boxes, 0u, (size_t)B * post * 7, s) != hipSuccess ||
+            prcnn_fill_words(out_scores, 0u, (size_t)B * post, s) != hipSuccess ||
+            (out_count && prcnn_fill_words(out_count, 0u, (size_t)B, s) != hipSuccess))
             return prcnn_fail(PRCNN_EHIP, "%s: memset failed", op);
         return PRCNN_OK;
     }
@@ -764,7 +764,7 @@ PRCNN_API int prcnn_nms_batched(const float* boxes3d, const float* scores, const
     PRCNN_REQUIRE(num_keep, "%s: null num_keep", op);
     hipStream_t s = (hipStream_t)stream;
     if (M == 0) {
-        if (hipMemsetAsync(num_keep, 0, (size_t)B * 4, s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "%s: memset failed", op);
+        if (prcnn_fill_words(num_keep, 0u, (size_t)B, s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "%s: memset failed", op);
         return PRCNN_OK;
     }
     if (max_keep == 0 || max_keep > M) max_keep = M;

@@ -287,7 +287,7 @@ PRCNN_API int prcnn_scene_prepare(const float* raw, const int64_t* offsets, int 
     P.counters = reinterpret_cast<int32_t*>(w);
     P.list = reinterpret_cast<uint2*>(w + (((size_t)B * 2 * sizeof(int32_t) + 63) / 64) * 64);
     P.out_xyz = out_xyz; P.out_int = out_intensity; P.out_src = out_src; P.nvalid = nvalid; P.status = status;
-    if (hipMemsetAsync(P.counters, 0, (size_t)B * 2 * sizeof(int32_t), s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_scene_prepare: memset failed");
+    if (prcnn_fill_words(P.counters, 0u, (size_t)B * 2, s) != hipSuccess) return prcnn_fail(PRCNN_EHIP, "prcnn_scene_prepare: memset failed");
     if (max_points_per_frame > 0) {
         hipLaunchKernelGGL(scene_flag_kernel, dim3(prcnn_divup(max_points_per_frame, SCENE_THREADS), B), dim3(SCENE_THREADS), 0, s, P);
         PRCNN_LAUNCH_CHECK("prcnn_scene_prepare(flags)");

@@ -259,11 +259,19 @@ class PackedLinear:
         return self._wsplit.get(chain)
 
 
-# Split-bf16 VARIANT of the plain-row layers (prcnn_mlp_rows_split): 0 = off (fp32 MFMA, the product's arithmetic), 3 / 6 = the
-# number of bf16 product terms per fp32 product.  Never on by default; bench.py reports it as a separate variant.
-MLP_SPLIT_TERMS = int(os.environ.get("PRCNN_MLP_SPLIT") or 0)
+# Arithmetic of the fused inference MLPs' plain-row layers, heads and hoisted FP0 (everything that reaches prcnn_mlp_rows*,
+# the two-layer head chains and the interpolating chain):
+#   6 (default) -- split-bf16, six terms: every fp32 operand cut EXACTLY into three bf16 pieces, six bf16 MFMA products per fp32
+#                  product, fp32 accumulate; drops partial products below 2^-24 |x||w|: fp32-grade results (measured 2.9e-7 of
+#                  sum |x||w| against float64, the fp32-MFMA kernel 3.0e-7), rows with non-finite values recomputed on the fp32
+#                  pipe.  Qualified by the whole GPU suite, which runs every test under both arithmetics (tests/conftest.py
+#                  `mlp_mode`), and by bench.py's max_diff_vs_f32_mfma on uniform, lidar and saturated clouds (contract 1e-5).
+#   0           -- fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout: PRCNN_MLP_SPLIT=0.
+#   3           -- three terms (drops below 2^-16 |x||w|): OUTSIDE the 1e-5 contract, dev / trade-off measurements only.
+# The choice never depends on row counts (a frame's bits are the same in a batch of 1 and of 32).  Training kernels are fp32 MFMA.
+MLP_SPLIT_TERMS = int(os.environ.get("PRCNN_MLP_SPLIT", "6") or 0)
 if MLP_SPLIT_TERMS not in (0, 3, 6):
-    raise RuntimeError("PRCNN_MLP_SPLIT=%r: the split-bf16 variant has 3 or 6 terms (0 / unset = off)" % os.environ.get("PRCNN_MLP_SPLIT"))
+    raise RuntimeError("PRCNN_MLP_SPLIT=%r: 6 (default) / 3 split-bf16 terms, 0 = fp32 MFMA" % os.environ.get("PRCNN_MLP_SPLIT"))
 
 _MODE_ROWS, _MODE_GROUP, _MODE_INTERP = 0, 1, 2
 _chain_ok = {}

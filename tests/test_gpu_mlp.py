@@ -650,7 +650,8 @@ def test_split_bf16_chain_nonfinite_rows(dev, monkeypatch, n1, relu1):
     ref = ops.mlp_chain_rows(T(x, dev), layers).cpu().numpy()
     monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
     got = ops.mlp_chain_rows(T(x, dev), layers).cpu().numpy()
-    assert (~np.isfinite(ref)).any() and _same_class(got, ref)
+    # (two ReLU layers: +inf hidden units of both signs of weight sum to NaN, which the output ReLU returns as 0 -- all finite)
+    assert (relu1 or (~np.isfinite(ref)).any()) and _same_class(got, ref)
     fin = np.isfinite(ref)
     assert np.abs(got[fin] - ref[fin]).max() <= mlp_tol(ref[fin])
     clean = np.ones(rows, bool)

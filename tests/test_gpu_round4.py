@@ -82,3 +82,40 @@ def test_roipool3d_shapes_of_save_rpn_feature_and_training(dev, cpu, M, N, S):
     wp, we = cpu.roipool3d(xyz, big, feat, S)
     assert np.array_equal(empty.cpu().numpy(), we) and we[0, -1] == 1
     assert np.array_equal(pooled.cpu().numpy(), wp)
+
+
+def test_graphs_captured_on_one_batch_replay_on_another_at_bs32(dev, monkeypatch):
+    """Round-4 regression.  bench.py's engine with every slot captured on slot 0's batch (PRCNN_BENCH_SAME_EXAMPLE) and the other
+    slots' inputs replaced afterwards died with a GPU memory fault in group_compact_kernel at bs32 from the second set-abstraction
+    level on (rocgdb; tools/graph_fault_probe2.py): the counters its list offsets come from were cleared by hipMemsetAsync, which a
+    capture turns into a memset node of the hipGraph, and were not zero when the kernel ran in a replay.  They are cleared by a
+    kernel now (common.h prcnn_fill_words).  Here: that exact path, 3 slots, and slot 1's replay == the eager step on its batch."""
+    import argparse
+    import bench
+    from pointrcnn_amd import rpn
+    from pointrcnn_amd.proposal_layer import ProposalLayer
+    monkeypatch.setenv("PRCNN_BENCH_SAME_EXAMPLE", "1")
+    torch.manual_seed(1234)
+    model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
+    pl = ProposalLayer("TEST")
+    args = argparse.Namespace(streams=3, batch=32, npoints=16384, warmup=2, graph="on", workload="rpn")
+    ib = bench.InferenceBench(args, model, dev, 0, 1, "uniform", pl, None).prepare()
+    try:
+        assert ib.pipe.graphed
+        other = rpn.synthetic_clouds(32, 16384, seed0=bench.shard_seed0(0, 1, 1, 32)).to(dev)
+        with torch.no_grad():
+            want = ib.step_from({"pts_input": other}, 0)
+            want = {k: want[k].clone() for k in ("rpn_cls", "rpn_reg", "rois")}
+        assert torch.equal(ib.pipe.inputs[1]["pts_input"], other)
+        for _ in range(2):                                   # replayed twice: the counters of the first replay are the second's stale bytes
+            t = ib.pipe.submit(None)
+            while t % 3 != 1:
+                ib.pipe.result()
+                t = ib.pipe.submit(None)
+            while ib.pipe.outstanding > 1:
+                ib.pipe.result()
+            got = ib.pipe.result()
+            for k in want:
+                assert torch.equal(got[k], want[k]), k
+    finally:
+        ib.release()
