@@ -1052,7 +1052,7 @@ def main():
                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         # HBM bytes per launch of the same kernel family from the PMC passes committed under profiles/ (rocprofv3
         # --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied there); null when absent.
-        for tname in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        for tname in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and args.batch == 32 and args.npoints == 16384:
                 try:

@@ -19,7 +19,8 @@ ds = list(per.values())
 first = ([i - 1 for i, d in enumerate(ds) if ("fps_pruned_kernel<16>" in d["name"] or "fps_slot_kernel<16>" in d["name"])] or
          [i for i, d in enumerate(ds) if "fps_reg_kernel<1024" in d["name"]])[-1]
 print("# MFMA pipe utilisation of the MLP launches of one bs32 RPN step (rocprofv3 PMC, single stream, eager)")
-print("# util = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES); MOPS_F32 x 512 = fp32 MFMA FLOPs issued")
+print("# util = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES); MOPS_F32 x 512 = fp32 MFMA FLOPs issued (the split-bf16 kernels issue")
+print("# bf16 MFMAs, which this counter does not see: their GFLOP column is 0; their pipe-busy share is in util)")
 print("%-46s %14s %14s %8s %12s" % ("kernel", "MFMA_BUSY", "BUSY_CU", "util", "MFMA GFLOP"))
 tb = tc = 0.0
 for d in ds[first:]:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh'
-# Outputs land in gpurun_out/refresh/; copy the summaries into profiles/ afterwards (tools/collect_profiles.sh).
+# Outputs land in gpurun_out/refresh/; copy the summaries into profiles/ afterwards (tools/collect_profiles.sh r04).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
@@ -12,23 +12,23 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_FETCH_SI
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_WRITE_SIZE -- $B > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/pmc_mfma -- $B > /dev/null 2>&1
 python profiles/derive_hbm_traffic.py $O/pmc_ $O/hbm_traffic.json > $O/hbm_traffic.txt 2>&1
-cp $O/hbm_traffic.json profiles/r03_hbm_traffic.json
+cp $O/hbm_traffic.json profiles/r04_hbm_traffic.json
 python profiles/derive_mfma_util.py $O/pmc_mfma > $O/mfma_util.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2>> $O/bench_default.err
 python bench.py --streams 1 --no-cpu-baseline --no-variants > $O/bench_streams1.json 2>> $O/bench_default.err
 python bench.py --input raw --no-variants > $O/bench_raw_input.json 2>> $O/bench_default.err
 python bench.py --workload rcnn > $O/bench_rcnn.json 2>> $O/bench_default.err
-PRCNN_MLP_SPLIT=6 python bench.py --workload rcnn > $O/bench_rcnn_split_bf16x6.json 2>> $O/bench_default.err
+PRCNN_MLP_SPLIT=0 python bench.py --workload rcnn --no-cpu-baseline > $O/bench_rcnn_f32_mfma.json 2>> $O/bench_default.err
 python bench.py --workload train > $O/bench_train.json 2>> $O/bench_default.err
 python bench.py --workload train-rcnn > $O/bench_train_rcnn.json 2>> $O/bench_default.err
-python bench.py --npoints 65536 --batch 8 --steps 64 --no-cpu-baseline --no-variants > $O/bench_config5_rpn.json 2>> $O/bench_default.err
+python bench.py --npoints 65536 --batch 8 --steps 64 --no-variants > $O/bench_config5_rpn.json 2>> $O/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python bench.py --no-cpu-baseline --no-roofline --no-variants > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-cpu-baseline --no-roofline --no-variants --streams 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python bench.py --workload train --steps 16 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktr -- python bench.py --workload train-rcnn --steps 16 > /dev/null 2>&1
-PRCNN_MLP_SPLIT=6 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python bench.py --no-cpu-baseline --no-roofline --no-variants --streams 1 > /dev/null 2>&1
-python profiles/summarize_rocprof.py $O/kts "PRCNN_MLP_SPLIT=6 python bench.py --streams 1 (VARIANT: plain-row layers on the split-bf16 six-term kernel; one batch in flight)" > $O/kernel_stats_split_bf16x6.txt
+PRCNN_MLP_SPLIT=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python bench.py --no-cpu-baseline --no-roofline --no-variants > /dev/null 2>&1
+python profiles/summarize_rocprof.py $O/kts "PRCNN_MLP_SPLIT=0 python bench.py (fp32-MFMA arithmetic throughout; 20 batches in flight, hipGraph replay)" > $O/kernel_stats_f32_mfma.txt
 python profiles/summarize_rocprof.py $O/ktr "python bench.py --workload train-rcnn --steps 16 (RCNN-stage training step, bs4, eager, fused training path)" > $O/kernel_stats_train_rcnn.txt
 python -m pointrcnn_amd.opbench > $O/opbench_raw.jsonl 2> $O/opbench.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/op_FETCH_SIZE -- python -m pointrcnn_amd.opbench > /dev/null 2>&1
