@@ -1044,9 +1044,9 @@ def main():
                                         "grouping) / MLP-family GPU time, against the fp32-MFMA dense peak; bf16_pipe prices the split launches' "
                                         "bf16 products (x%d) against the bf16 dense peak" % t_)
             line["roofline"]["bf16_pipe"] = {"launches": len(sp), "us_per_step": round(sp_us, 1), "fp32_equivalent_GFLOP_per_step": round(sp_gf, 2),
-                                             "bf16_TFLOPs_executed": round(sp_gf * t_ * 1e3 / sp_us / 1e3, 1) if sp_us > 0 else None,
+                                             "bf16_TFLOPs_executed": round(sp_gf * t_ / sp_us * 1e3, 1) if sp_us > 0 else None,      # GFLOP / us = PFLOP/s
                                              "peak_bf16_TFLOPs": 2500.0,
-                                             "frac_of_bf16_peak": round(sp_gf * t_ / sp_us / 2500.0, 4) if sp_us > 0 else None,
+                                             "frac_of_bf16_peak": round(sp_gf * t_ / sp_us * 1e3 / 2500.0, 4) if sp_us > 0 else None,
                                              "fp32_mfma_launches_us_per_step": round(sum(r["us"] for r in by_launch) - sp_us, 1)}
         line["kernels"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "launches_per_step": v["launches"] // nprof}
                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}

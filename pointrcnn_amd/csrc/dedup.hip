@@ -40,6 +40,7 @@ struct CompactParams {
 };
 
 constexpr int COMPACT_THREADS = 1024;
+constexpr int DEDUP_GRID_CAP = 8192;           // workgroups of the grid-stride scatter kernels (32 per CU)
 
 // NS > 0: nsample known at compile time (a multiple of 4) -- the group's index row is fetched with 16-byte loads, all in
 // flight at once, instead of a dependent scalar walk
@@ -132,28 +133,28 @@ __global__ __launch_bounds__(COMPACT_THREADS) void group_compact_kernel(CompactP
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, int ld_src, const int32_t* __restrict__ list,
                                                            const int32_t* __restrict__ count, int C, float* __restrict__ dst, int ld_dst,
                                                            int col_off) {
-    const int n = *count;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    const long r = e / C;
-    if (r >= n) return;
-    const int c = (int)(e - r * C);
-    dst[(size_t)list[r] * ld_dst + col_off + c] = src[(size_t)r * ld_src + c];
+    const long total = (long)(*count) * C;             // grid-stride: the grid is capped, not sized for the list's capacity
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / C;
+        const int c = (int)(e - r * C);
+        dst[(size_t)list[r] * ld_dst + col_off + c] = src[(size_t)r * ld_src + c];
+    }
 }
 
 __global__ __launch_bounds__(256) void segmax_scatter_kernel(const float* __restrict__ src, int ld_src, const int32_t* __restrict__ list,
                                                              const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
                                                              const int32_t* __restrict__ count, int C, float* __restrict__ dst,
                                                              int ld_dst, int col_off) {
-    const int n = *count;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    const long j = e / C;
-    if (j >= n) return;
-    const int c = (int)(e - j * C);
-    const float* p = src + (size_t)off[j] * ld_src + c;
-    const int rows = cnt[j];
-    float m = p[0];
-    for (int r = 1; r < rows; r++) m = fmaxf(m, p[(size_t)r * ld_src]);
-    dst[(size_t)list[j] * ld_dst + col_off + c] = m;
+    const long total = (long)(*count) * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long j = e / C;
+        const int c = (int)(e - j * C);
+        const float* p = src + (size_t)off[j] * ld_src + c;
+        const int rows = cnt[j];
+        float m = p[0];
+        for (int r = 1; r < rows; r++) m = fmaxf(m, p[(size_t)r * ld_src]);
+        dst[(size_t)list[j] * ld_dst + col_off + c] = m;
+    }
 }
 
 PRCNN_API int prcnn_group_compact(const int32_t* idx, const float* new_xyz, int B, int N, int M, int nsample, int sparse_max,
@@ -188,7 +189,8 @@ PRCNN_API int prcnn_segmax_scatter(const float* src, int ld_src, const int32_t* 
     PRCNN_REQUIRE(max_groups >= 0 && C > 0 && ld_src >= C && ld_dst >= col_off + C, "prcnn_segmax_scatter: bad shape");
     if (max_groups == 0) return PRCNN_OK;
     PRCNN_REQUIRE(src && list && off && cnt && count && dst, "prcnn_segmax_scatter: null pointer");
-    hipLaunchKernelGGL(segmax_scatter_kernel, dim3(prcnn_divup((long)max_groups * C, 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+    // (capacity-sized grids retired one empty workgroup per 256 elements of CAPACITY: 40 us per launch on the RCNN stage's lists)
+    hipLaunchKernelGGL(segmax_scatter_kernel, dim3(min(prcnn_divup((long)max_groups * C, 256), DEDUP_GRID_CAP)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
                        list, off, cnt, count, C, dst, ld_dst, col_off);
     PRCNN_LAUNCH_CHECK("prcnn_segmax_scatter");
     return PRCNN_OK;
@@ -199,7 +201,7 @@ PRCNN_API int prcnn_scatter_rows(const float* src, int ld_src, const int32_t* li
     PRCNN_REQUIRE(max_rows >= 0 && C > 0 && ld_src >= C && ld_dst >= col_off + C, "prcnn_scatter_rows: bad shape");
     if (max_rows == 0) return PRCNN_OK;
     PRCNN_REQUIRE(src && list && count && dst, "prcnn_scatter_rows: null pointer");
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(prcnn_divup((long)max_rows * C, 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, list,
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(min(prcnn_divup((long)max_rows * C, 256), DEDUP_GRID_CAP)), dim3(256), 0, (hipStream_t)stream, src, ld_src, list,
                        count, C, dst, ld_dst, col_off);
     PRCNN_LAUNCH_CHECK("prcnn_scatter_rows");
     return PRCNN_OK;
