@@ -1044,6 +1044,37 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpPa
     load_b(1, 1);
     load_chunk(0, raA);
     load_chunk(min(1, nchunks - 1), raB);
+    // Hoisted-FP addend, built FIRST (as mlp_layer_b_kernel does): the interpolated tile -- per 16-byte piece three gathers, ~400
+    // instructions per thread -- goes straight into the accumulators through the still idle operand LDS while the B ring and the first
+    // two A chunks requested above are in flight; in the epilogue its gathers were exposed behind a main loop of K / 32 chunks (three
+    // for FP1's 96-wide skip features).  PRCNN_ADDY_PHASE=0 keeps it in the epilogue (A/B switch; last-bit different summation order).
+    bool addy_done = false;
+    if constexpr (ADDY) {
+        const bool stageable = P.addY && P.addy_phase != 0 && (P.Nout % 4 == 0) && (P.ldY % 4 == 0) && aligned16(P.addY);
+        if (stageable) {                                     // workgroup-uniform
+            float* T = reinterpret_cast<float*>(Ls);
+#pragma unroll
+            for (int pass = 0; pass < WNB; pass++) {
+                if (pass > 0) __syncthreads();
+                addy_stage_half(P, tid, row0, nb0, pass, T, 72);
+                __syncthreads();
+#pragma unroll
+                for (int nn = 0; nn < WNB; nn++) {
+                    const int blk = wn * WNB + nn;
+                    if ((blk >> 1) != pass) continue;
+                    const int tc = (blk & 1) * 32 + j;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        acc[0][nn][r] = T[(wm * 64 + rin) * 72 + tc];
+                        acc[1][nn][r] = T[(wm * 64 + 32 + rin) * 72 + tc];
+                    }
+                }
+            }
+            __syncthreads();
+            addy_done = true;
+        }
+    }
     store_chunk(0, raA);
     __syncthreads();
     read_a(0, 0, a0);
@@ -1110,10 +1141,14 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpPa
     }
     if (!(PRCNN_ABL & (16 | 128))) {
         // non-finite operands (see the header): this wave's block again on the fp32 pipe
-        const bool bad = wave_has_nonfinite<2 * WNB>(reinterpret_cast<const f32x16 (&)[2 * WNB]>(acc));
+        // (workgroup-uniform when the addend sits in the accumulators: the epilogue then stages it again for all four waves; a
+        //  non-finite ADDEND takes this path too and comes out as the fp32 kernel's sum)
+        bool bad = wave_has_nonfinite<2 * WNB>(reinterpret_cast<const f32x16 (&)[2 * WNB]>(acc));
+        if (ADDY && addy_done) bad = __syncthreads_or(bad) != 0;
         if (bad && n_active) split_redo_f32<WNB>(P, acc, row0, wm, wn, nb0, lane);
+        if (bad) addy_done = false;
     }
-    layer_epilogue<MODE_PLAIN, WNB, ADDY>(P, acc, reinterpret_cast<float*>(Ls), nullptr, tid, row0, nb0, n_active, false);
+    layer_epilogue<MODE_PLAIN, WNB, ADDY>(P, acc, reinterpret_cast<float*>(Ls), nullptr, tid, row0, nb0, n_active, addy_done);
 }
 
 // =====================================================================================================
@@ -2279,7 +2314,8 @@ PRCNN_API int prcnn_mlp_rows_addinterp_split(const float* in, int ld_in, int K, 
     P.in = in; P.ld_in = ld_in;
     P.vec_a = aligned16(in) && (ld_in % 4 == 0);
     P.addY = y_cl; P.ldY = ld_y; P.idx3 = idx3; P.w3 = w3; P.n = n; P.m = m;
-    P.addy_phase = 0;
+    static const int addy_phase = getenv("PRCNN_ADDY_PHASE") ? atoi(getenv("PRCNN_ADDY_PHASE")) : 2;      // A/B switch: 0 = all in the epilogue
+    P.addy_phase = addy_phase;
     P.rows_unit = 1;
     P.wsplit = wsplit; P.split_terms = terms;
     return launch_mlp(MODE_PLAIN, P, (hipStream_t)stream);
