@@ -2,12 +2,12 @@
 
 What tools/eval_rcnn.py:459-520 does per batch -- `inputs = torch.from_numpy(pts_input).cuda(non_blocking=True)`, `model(input_data)`,
 read the outputs -- keeps ONE batch in flight on one stream.  On this path that exposes the furthest-point-sampling chain: a serial
-4.5 ms chain on one workgroup per frame (32 of 256 CUs for a bs32 batch), during which the rest of the chip idles (4.3-4.5 k
+4.5 ms chain on one workgroup per frame (32 of 256 CUs for a bs32 batch), during which the rest of the chip idles (4.8 k
 frames/s).  Batches are independent, so the engine keeps `slots` of them in flight: slot s owns a HIP stream (and, with
 GPU_MAX_HW_QUEUES >= slots, a hardware queue), static device input buffers, and a hipGraph of one whole step captured on that
-stream.  `submit()` copies a batch's inputs into the slot's buffers ON THE SLOT'S STREAM (pinned host memory -> asynchronous H2D
-that overlaps the other slots' kernels) and replays the graph; results come back in submission order.  One batch's FPS then runs
-underneath other batches' MLP kernels (13 k frames/s on the same graph).
+stream.  `submit()` copies a batch's inputs into the slot's buffers (pinned host memory -> asynchronous H2D on a copy stream shared by the
+slots, first come first served, overlapping the slots' kernels; the slot's stream waits for its copy) and replays the graph; results come back in submission order.  One batch's FPS then runs
+underneath other batches' MLP kernels (15.7 k frames/s on the same graph).
 
     pipe = InferencePipeline(lambda inp, slot: model(inp), {"pts_input": example}, slots=20)
     for out in pipe.map(batches):          # batches: iterable of {"pts_input": pinned host or device tensor}
@@ -24,6 +24,11 @@ Contract
     submitted (`result(clone=True)` copies it out on the slot's stream);
   * a failing submit (bad input shape / dtype, a step that raises in eager mode) leaves the pipeline usable: the slot is free
     again, no ticket was consumed, the tickets in flight are untouched;
+  * a batch's inputs travel on ONE copy stream shared by the slots (per device), in submission order, and the slot's stream waits
+    for its copy's event: 20 slots each copying on their own stream share the DMA engines chunk by chunk, so after a cold start all
+    20 copies finish together, late, and every batch's sampling chain starts late with them (bench.py, 20-step runs with host inputs:
+    12.8 k instead of 15.7 k frames/s); first come, first served lets slot 0 start after one copy.  `copy_stream=False` keeps the
+    copies on the slots' streams;
   * thread-safe (one lock around submit / result); several pipelines may coexist (they share one process-wide set of streams:
     torch's pool holds 32 stream handles and a second set of 20 wraps around it -- measured 30 % slower than the first).
 
@@ -41,6 +46,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import torch  # noqa: E402
 
 _STREAMS = {}                 # device index -> list of streams shared by every pipeline of the process
+_COPY_STREAMS = {}            # device index -> the input-copy stream shared by every pipeline of the process
 _STREAMS_LOCK = threading.Lock()
 
 
@@ -55,6 +61,14 @@ def shared_streams(device, n):
         while len(pool) < n:
             pool.append(torch.cuda.Stream(device=device))
         return pool[:n]
+
+
+def shared_copy_stream(device):
+    with _STREAMS_LOCK:
+        cs = _COPY_STREAMS.get(device.index)
+        if cs is None:
+            cs = _COPY_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        return cs
 
 
 def _flatten(out):
@@ -79,7 +93,7 @@ def _clone(out):
 
 
 class InferencePipeline:
-    def __init__(self, step_fn, example_inputs, slots=20, device=None, graph=True, warmup=2):
+    def __init__(self, step_fn, example_inputs, slots=20, device=None, graph=True, warmup=2, copy_stream=True):
         """step_fn(inputs: dict of the slot's static tensors, slot: int) -> tensor / dict / tuple of tensors.  It is run `warmup`
         times eagerly per slot (lazy initialisation, weight packing, allocator pool) and then captured; everything it launches
         must go to torch's current stream (every C-ABI call of this package does).
@@ -115,6 +129,10 @@ class InferencePipeline:
         self.outputs = [None] * self.slots
         self.graphs = [None] * self.slots
         self.events = [torch.cuda.Event() if self.on_gpu else None for _ in range(self.slots)]
+        if os.environ.get("PRCNN_PIPELINE_COPY_STREAM") == "0":      # dev A/B switch
+            copy_stream = False
+        self.copy_stream = shared_copy_stream(self.device) if (self.on_gpu and copy_stream) else None
+        self.copy_events = [torch.cuda.Event() if self.copy_stream is not None else None for _ in range(self.slots)]
         self._lock = threading.RLock()
         self._next_ticket = 0          # ticket the next submit() gets
         self._next_result = 0          # oldest outstanding ticket
@@ -162,15 +180,26 @@ class InferencePipeline:
             if not isinstance(v, torch.Tensor) or tuple(v.shape) != tuple(dst.shape) or v.dtype != dst.dtype:
                 raise ValueError("InferencePipeline.submit: input %r must be a %s tensor of shape %s, got %s" %
                                  (k, dst.dtype, tuple(dst.shape), "%s %s" % (v.dtype, tuple(v.shape)) if isinstance(v, torch.Tensor) else type(v)))
+        if self.copy_stream is not None:
+            cs = self.copy_stream
+            cs.wait_event(self.events[s])          # the slot's previous replay has read its inputs (no-op before the first one)
+            if ready is not None:
+                cs.wait_event(ready)
+            with torch.cuda.stream(cs):
+                for k, v in batch.items():
+                    self.inputs[s][k].copy_(v, non_blocking=True)
+            self.copy_events[s].record(cs)
+            self.streams[s].wait_event(self.copy_events[s])
+            return
         if self.on_gpu and ready is not None:
             self.streams[s].wait_event(ready)
         for k, v in batch.items():
             self.inputs[s][k].copy_(v, non_blocking=True)
 
     def submit(self, batch=None, ready=None):
-        """enqueue one batch; -> ticket.  batch: dict name -> tensor (pinned host memory: asynchronous H2D on the slot's stream;
-        device tensors: D2D, `ready` = event after their producer if that ran on another stream), or None = replay on the data
-        already resident in the slot's input buffers."""
+        """enqueue one batch; -> ticket.  batch: dict name -> tensor (pinned host memory: asynchronous H2D on the shared copy stream,
+        the slot's stream waits for it; device tensors: D2D, `ready` = event after their producer if that ran on another stream),
+        or None = replay on the data already resident in the slot's input buffers."""
         with self._lock:
             if self._closed:
                 raise RuntimeError("InferencePipeline is closed")
@@ -249,6 +278,8 @@ class InferencePipeline:
         with self._lock:
             self._closed = True
             if self.on_gpu:
+                if self.copy_stream is not None:
+                    self.copy_stream.synchronize()
                 for s in self.streams:
                     s.synchronize()
             self.graphs = [None] * self.slots

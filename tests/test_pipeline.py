@@ -57,6 +57,18 @@ def test_resident_replay_and_clone():
     assert torch.equal(a["y"], b["y"]) and a["y"].data_ptr() != b["y"].data_ptr()
 
 
+def test_per_slot_examples_are_each_slots_resident_data():
+    """example_inputs as a sequence: slot s is warmed up / captured on -- and keeps resident -- its own batch"""
+    from pointrcnn_amd.pipeline import InferencePipeline
+    step = lambda inp, slot: {"y": inp["x"] + 0.5}                            # noqa: E731
+    ex = [{"x": torch.full((4,), float(10 * s))} for s in range(3)]
+    pipe = InferencePipeline(step, ex, slots=3, device="cpu")
+    got = [float(o["y"][0]) for o in pipe.map(None for _ in range(6))]        # two rounds on the resident inputs
+    assert got == [0.5, 10.5, 20.5, 0.5, 10.5, 20.5]
+    with pytest.raises(ValueError):
+        InferencePipeline(step, ex[:2], slots=3, device="cpu")
+
+
 def test_bad_batch_consumes_no_ticket_and_leaves_the_pipeline_usable():
     pipe, calls = _pipe(2)
     pipe.submit({"x": torch.ones(4)})
