@@ -16,6 +16,7 @@ cp $R/bench_config5_rpn.json profiles/${T}_final_bench_config5_rpn.json
 cp $R/kernel_stats.txt profiles/${T}_final_kernel_stats.txt
 cp $R/kernel_stats_streams1.txt profiles/${T}_final_kernel_stats_streams1.txt
 cp $R/kernel_stats_train.txt profiles/${T}_final_kernel_stats_train.txt
+[ -f $R/kernel_stats_rcnn.txt ] && cp $R/kernel_stats_rcnn.txt profiles/${T}_final_kernel_stats_rcnn.txt
 cp $R/kernel_stats_f32_mfma.txt profiles/${T}_final_kernel_stats_f32_mfma.txt
 cp $R/hbm_traffic.json profiles/${T}_hbm_traffic.json
 cp $R/mfma_util.txt profiles/${T}_mfma_util.txt

@@ -27,6 +27,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python bench.p
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python bench.py --no-cpu-baseline --no-roofline --no-variants --streams 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python bench.py --workload train --steps 16 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktr -- python bench.py --workload train-rcnn --steps 16 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktc -- python bench.py --workload rcnn --steps 160 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+python profiles/summarize_rocprof.py $O/ktc "python bench.py --workload rcnn --steps 160 (config 3: two-stage detector, 10 batches in flight, hipGraph replay)" > $O/kernel_stats_rcnn.txt
 PRCNN_MLP_SPLIT=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python bench.py --no-cpu-baseline --no-roofline --no-variants > /dev/null 2>&1
 python profiles/summarize_rocprof.py $O/kts "PRCNN_MLP_SPLIT=0 python bench.py (fp32-MFMA arithmetic throughout; 20 batches in flight, hipGraph replay)" > $O/kernel_stats_f32_mfma.txt
 python profiles/summarize_rocprof.py $O/ktr "python bench.py --workload train-rcnn --steps 16 (RCNN-stage training step, bs4, eager, fused training path)" > $O/kernel_stats_train_rcnn.txt
