@@ -189,7 +189,8 @@ PRCNN_API int prcnn_segmax_scatter(const float* src, int ld_src, const int32_t* 
     PRCNN_REQUIRE(max_groups >= 0 && C > 0 && ld_src >= C && ld_dst >= col_off + C, "prcnn_segmax_scatter: bad shape");
     if (max_groups == 0) return PRCNN_OK;
     PRCNN_REQUIRE(src && list && off && cnt && count && dst, "prcnn_segmax_scatter: null pointer");
-    // (capacity-sized grids retired one empty workgroup per 256 elements of CAPACITY: 40 us per launch on the RCNN stage's lists)
+    // (capped grid + stride instead of one workgroup per 256 elements of CAPACITY; on the RCNN stage's lists the launch is its
+    //  traffic, ~37 us, either way)
     hipLaunchKernelGGL(segmax_scatter_kernel, dim3(min(prcnn_divup((long)max_groups * C, 256), DEDUP_GRID_CAP)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
                        list, off, cnt, count, C, dst, ld_dst, col_off);
     PRCNN_LAUNCH_CHECK("prcnn_segmax_scatter");
