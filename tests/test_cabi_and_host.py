@@ -76,6 +76,21 @@ def test_product_has_no_cpu_fallback_and_never_touches_the_oracle():
                 assert "libprcnn_oracle" not in src and "oracle/" not in src.replace("oracle/prcnn_oracle.c", ""), f
 
 
+def test_graph_capturable_paths_clear_their_counters_with_kernels():
+    """Round 4: a captured hipMemsetAsync is a memset NODE of the hipGraph, and graphs holding such nodes faulted in replay (the
+    counters group_compact_kernel takes its list offsets from were not zero).  Every clear on an inference /
+    input path is prcnn_fill_words (a kernel node); hipMemsetAsync survives only in the training-gradient launchers, which are
+    not captured."""
+    csrc = os.path.join(ROOT, "pointrcnn_amd", "csrc")
+    allowed = {"mlp_train.h", "gather.hip"}            # dknown / dfeat / three_interp_grad workspaces: backward passes
+    for f in sorted(os.listdir(csrc)):
+        src = open(os.path.join(csrc, f)).read()
+        code = "\n".join(ln.split("//")[0] for ln in src.splitlines())
+        if "hipMemsetAsync(" in code:
+            assert f in allowed, "%s clears memory with hipMemsetAsync on a graph-capturable path" % f
+    assert "prcnn_fill_words(counts" in open(os.path.join(csrc, "dedup.hip")).read()
+
+
 def test_dropin_module_names_and_state_dict_keys():
     import pointrcnn_amd
     pointrcnn_amd.install()
