@@ -10,7 +10,7 @@ O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-variants --graph off --streams 1"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_FETCH_SIZE -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_WRITE_SIZE -- $B > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/pmc_mfma -- $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $O/pmc_mfma -- $B > /dev/null 2>&1
 python profiles/derive_hbm_traffic.py $O/pmc_ $O/hbm_traffic.json > $O/hbm_traffic.txt 2>&1
 cp $O/hbm_traffic.json profiles/r04_hbm_traffic.json
 python profiles/derive_mfma_util.py $O/pmc_mfma > $O/mfma_util.txt 2>&1
