@@ -460,12 +460,12 @@ class InferenceBench:
             self.warm()
         eager_out = self.out
         try:
-            self.pipe = InferencePipeline(self.step_from, self._example(), slots=self.nstreams, device=self.dev, graph=args.graph != "off")
+            self.pipe = InferencePipeline(self.step_from, self._example(), slots=self.nstreams, device=self.dev, graph=args.graph != "off", copy_stream=True)
         except Exception as e:  # noqa: BLE001
             if args.graph == "on":
                 raise
             print("[bench] hipGraph capture unavailable (%s); timing eager launches" % str(e).split("\n")[0], file=sys.stderr)
-            self.pipe = InferencePipeline(self.step_from, self._example(), slots=self.nstreams, device=self.dev, graph=False)
+            self.pipe = InferencePipeline(self.step_from, self._example(), slots=self.nstreams, device=self.dev, graph=False, copy_stream=True)
         self._eager_inputs = None
         trace("pipeline built")
         if os.environ.get("PRCNN_BENCH_SAME_EXAMPLE"):

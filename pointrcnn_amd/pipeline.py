@@ -5,8 +5,8 @@ read the outputs -- keeps ONE batch in flight on one stream.  On this path that 
 4.5 ms chain on one workgroup per frame (32 of 256 CUs for a bs32 batch), during which the rest of the chip idles (4.8 k
 frames/s).  Batches are independent, so the engine keeps `slots` of them in flight: slot s owns a HIP stream (and, with
 GPU_MAX_HW_QUEUES >= slots, a hardware queue), static device input buffers, and a hipGraph of one whole step captured on that
-stream.  `submit()` copies a batch's inputs into the slot's buffers (pinned host memory -> asynchronous H2D on a copy stream shared by the
-slots, first come first served, overlapping the slots' kernels; the slot's stream waits for its copy) and replays the graph; results come back in submission order.  One batch's FPS then runs
+stream.  `submit()` copies a batch's inputs into the slot's buffers (pinned host memory -> asynchronous H2D on the slot's stream, or, with
+copy_stream=True, on one copy stream shared by the slots, first come first served; either way overlapping the other slots' kernels) and replays the graph; results come back in submission order.  One batch's FPS then runs
 underneath other batches' MLP kernels (15.7 k frames/s on the same graph).
 
     pipe = InferencePipeline(lambda inp, slot: model(inp), {"pts_input": example}, slots=20)
@@ -24,11 +24,13 @@ Contract
     submitted (`result(clone=True)` copies it out on the slot's stream);
   * a failing submit (bad input shape / dtype, a step that raises in eager mode) leaves the pipeline usable: the slot is free
     again, no ticket was consumed, the tickets in flight are untouched;
-  * a batch's inputs travel on ONE copy stream shared by the slots (per device), in submission order, and the slot's stream waits
-    for its copy's event: 20 slots each copying on their own stream share the DMA engines chunk by chunk, so after a cold start all
-    20 copies finish together, late, and every batch's sampling chain starts late with them (bench.py, 20-step runs with host inputs:
-    12.8 k instead of 15.7 k frames/s); first come, first served lets slot 0 start after one copy.  `copy_stream=False` keeps the
-    copies on the slots' streams;
+  * `copy_stream=True` (what bench.py uses; ONE producer thread): a batch's inputs travel on one copy stream shared by the slots, in
+    submission order, and the slot's stream waits for its copy's event.  20 slots each copying on their own stream share the DMA
+    engines chunk by chunk, so after a cold start all 20 copies finish together, late, and every batch's sampling chain starts late
+    with them (20-step runs with host inputs: 12.1-12.8 k instead of 15.7 k frames/s); first come, first served lets slot 0 start
+    after one copy.  The default (False) keeps every copy on its slot's stream: with two pipelines fed from two threads through the
+    shared copy stream one result of `test_two_pipelines_and_two_threads` came out wrong in one of four runs (round 4, unexplained),
+    which the per-slot copies never did;
   * thread-safe (one lock around submit / result); several pipelines may coexist (they share one process-wide set of streams:
     torch's pool holds 32 stream handles and a second set of 20 wraps around it -- measured 30 % slower than the first).
 
@@ -93,7 +95,7 @@ def _clone(out):
 
 
 class InferencePipeline:
-    def __init__(self, step_fn, example_inputs, slots=20, device=None, graph=True, warmup=2, copy_stream=True):
+    def __init__(self, step_fn, example_inputs, slots=20, device=None, graph=True, warmup=2, copy_stream=False):
         """step_fn(inputs: dict of the slot's static tensors, slot: int) -> tensor / dict / tuple of tensors.  It is run `warmup`
         times eagerly per slot (lazy initialisation, weight packing, allocator pool) and then captured; everything it launches
         must go to torch's current stream (every C-ABI call of this package does).
@@ -129,8 +131,8 @@ class InferencePipeline:
         self.outputs = [None] * self.slots
         self.graphs = [None] * self.slots
         self.events = [torch.cuda.Event() if self.on_gpu else None for _ in range(self.slots)]
-        if os.environ.get("PRCNN_PIPELINE_COPY_STREAM") == "0":      # dev A/B switch
-            copy_stream = False
+        if os.environ.get("PRCNN_PIPELINE_COPY_STREAM") in ("0", "1"):      # dev A/B switch
+            copy_stream = os.environ["PRCNN_PIPELINE_COPY_STREAM"] == "1"
         self.copy_stream = shared_copy_stream(self.device) if (self.on_gpu and copy_stream) else None
         self.copy_events = [torch.cuda.Event() if self.copy_stream is not None else None for _ in range(self.slots)]
         self._lock = threading.RLock()

@@ -109,7 +109,8 @@ def _small_rpn(dev):
 
 
 @pytest.mark.gpu
-def test_every_slot_reproduces_the_single_stream_path_bit_for_bit(dev):
+@pytest.mark.parametrize("copy_stream", [False, True])
+def test_every_slot_reproduces_the_single_stream_path_bit_for_bit(dev, copy_stream):
     """default.yaml RPN + proposal layer, bs2 x 16384 points, 5 slots, 12 different batches from pinned host memory: each result ==
     the eager single-stream forward of that batch (what tools/eval_rcnn.py's loop computes), in submission order"""
     from pointrcnn_amd import rpn
@@ -128,7 +129,7 @@ def test_every_slot_reproduces_the_single_stream_path_bit_for_bit(dev):
         for h in hosts:
             o = step({"pts_input": h.to(dev)}, 0)
             want.append({k: o[k].clone() for k in keys})
-    with InferencePipeline(step, {"pts_input": hosts[0]}, slots=5) as pipe:
+    with InferencePipeline(step, {"pts_input": hosts[0]}, slots=5, copy_stream=copy_stream) as pipe:
         assert pipe.graphed and pipe.device.type == "cuda"
         n = 0
         for out in pipe.map({"pts_input": h} for h in hosts):
