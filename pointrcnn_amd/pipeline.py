@@ -21,17 +21,27 @@ Contract
   * at most `slots` tickets are outstanding: `submit()` on a full pipeline raises PipelineFull (collect a result first; `map`
     does the interleaving);
   * the dict returned for ticket t aliases slot (t % slots)'s static output tensors: it is valid until ticket t + slots is
-    submitted (`result(clone=True)` copies it out on the slot's stream);
+    submitted (`result(clone=True)` copies it out on the slot's stream).  "Valid" is a statement about STREAM ORDER, and the
+    pipeline enforces its half of it: `result()` notes the HIP stream the collecting thread is on, and the submit that reuses the
+    slot makes the slot's stream (and the copy stream) wait for everything that stream was given up to then -- so device work the
+    consumer ENQUEUED on the outputs before ticket t + slots was submitted (a `.clone()`, a kernel, a D2H copy) reads ticket t's
+    data even if it has not run yet.  Work the consumer enqueues later, or on a stream other than its current one at `result()`
+    time, is the consumer's to order (round 4 did not enforce this: `map()` re-submitted on the slot right after the yield, and a
+    consumer-side `.clone()` still queued on the thread's default stream read the NEXT ticket's values -- the wrong result of
+    `test_two_pipelines_and_two_threads`; regression: tests/test_pipeline.py::test_consumer_work_enqueued_before_the_slot_is_reused_reads_its_own_ticket).
+    Eager slots (graph=False) rebind their outputs every step: `result()` calls `record_stream` on them for the consumer's stream,
+    so the allocator does not hand their blocks to the slot's next step while the consumer's reads are pending;
   * a failing submit (bad input shape / dtype, a step that raises in eager mode) leaves the pipeline usable: the slot is free
     again, no ticket was consumed, the tickets in flight are untouched;
   * `copy_stream=True` (what bench.py uses; ONE producer thread): a batch's inputs travel on one copy stream shared by the slots, in
     submission order, and the slot's stream waits for its copy's event.  20 slots each copying on their own stream share the DMA
     engines chunk by chunk, so after a cold start all 20 copies finish together, late, and every batch's sampling chain starts late
     with them (20-step runs with host inputs: 12.1-12.8 k instead of 15.7 k frames/s); first come, first served lets slot 0 start
-    after one copy.  The default (False) keeps every copy on its slot's stream: with two pipelines fed from two threads through the
-    shared copy stream one result of `test_two_pipelines_and_two_threads` came out wrong in one of four runs (round 4, unexplained),
-    which the per-slot copies never did;
-  * thread-safe (one lock around submit / result); several pipelines may coexist (they share one process-wide set of streams:
+    after one copy.  The default (False) keeps every copy on its slot's stream.  Both modes are covered by the two-threads test
+    (the round-4 failure seen with the copy stream was the consumer race described above, which the copy stream's timing exposed);
+  * thread-safe: one state lock around the bookkeeping of submit / result, collectors serialised among themselves; `result()` does
+    NOT hold the state lock while it waits for the ticket's event, so a producer thread keeps submitting while a consumer thread
+    blocks; several pipelines may coexist (they share one process-wide set of streams:
     torch's pool holds 32 stream handles and a second set of 20 wraps around it -- measured 30 % slower than the first).
 
 `device="cpu"` runs the same ticket / slot bookkeeping with eager steps and no streams: the host logic is testable without a GPU
@@ -43,9 +53,14 @@ import warnings
 
 # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise.  Only
 # effective when set before the HIP runtime starts, i.e. before the first CUDA call of the process.
+_QUEUES_PRESET = "GPU_MAX_HW_QUEUES" in os.environ      # the user's own setting: taken as effective
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import torch  # noqa: E402
+
+# a setdefault made after the HIP runtime started (a model moved to the GPU before this import: the usual order for a library
+# user) changes nothing: the process then runs on the default 4 queues whatever the environment says now
+_QUEUES_TOO_LATE = (not _QUEUES_PRESET) and torch.cuda.is_initialized()
 
 _STREAMS = {}                 # device index -> list of streams shared by every pipeline of the process
 _COPY_STREAMS = {}            # device index -> the input-copy stream shared by every pipeline of the process
@@ -122,9 +137,12 @@ class InferencePipeline:
         assert self.slots >= 1
         self.step_fn = step_fn
         self.graphed = bool(graph) and self.on_gpu
-        if self.on_gpu and self.slots > int(os.environ.get("GPU_MAX_HW_QUEUES", "4")):
-            warnings.warn("InferencePipeline: %d slots but GPU_MAX_HW_QUEUES=%s: streams that share a hardware queue serialise "
-                          "(set it before the first HIP call)" % (self.slots, os.environ.get("GPU_MAX_HW_QUEUES", "4 (default)")))
+        queues = 4 if _QUEUES_TOO_LATE else int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        if self.on_gpu and self.slots > queues:
+            warnings.warn("InferencePipeline: %d slots but %s: streams that share a hardware queue serialise "
+                          "(export GPU_MAX_HW_QUEUES before the first HIP call of the process)" %
+                          (self.slots, "HIP was initialised before pointrcnn_amd.pipeline was imported, so the default 4 hardware "
+                           "queues are in use" if _QUEUES_TOO_LATE else "GPU_MAX_HW_QUEUES=%d" % queues))
         self.streams = shared_streams(self.device, self.slots) if self.on_gpu else [None] * self.slots
         self.inputs = [{k: v.detach().to(self.device, copy=True) for k, v in (per_slot[s_] if per_slot else example_inputs).items()}
                        for s_ in range(self.slots)]
@@ -135,7 +153,11 @@ class InferencePipeline:
             copy_stream = os.environ["PRCNN_PIPELINE_COPY_STREAM"] == "1"
         self.copy_stream = shared_copy_stream(self.device) if (self.on_gpu and copy_stream) else None
         self.copy_events = [torch.cuda.Event() if self.copy_stream is not None else None for _ in range(self.slots)]
-        self._lock = threading.RLock()
+        self._lock = threading.RLock()           # ticket / slot bookkeeping
+        self._collect_lock = threading.RLock()   # one collector at a time (results are handed out in order)
+        self._consumer = [None] * self.slots     # slot -> HIP stream its last result was handed to (see `result`)
+        self._order_consumers = True             # False = round 4's behaviour (the negative control of the regression test)
+        self._consumer_events = [torch.cuda.Event() if self.on_gpu else None for _ in range(self.slots)]
         self._next_ticket = 0          # ticket the next submit() gets
         self._next_result = 0          # oldest outstanding ticket
         self._failed = {}              # ticket -> exception raised by its (eager) step
@@ -170,8 +192,21 @@ class InferencePipeline:
     def outstanding(self):
         return self._next_ticket - self._next_result
 
-    def _load(self, s, batch, ready):
-        """copy a batch into slot s's static inputs on the slot's stream (validates first: nothing is enqueued for a bad batch)"""
+    def _wait_for_consumer(self, s):
+        """slot s is about to be overwritten: whatever the consumer of its last result has enqueued so far on the stream it
+        collected on runs first (module docstring, third contract item).  Costs one stream query when that stream is idle."""
+        cs, self._consumer[s] = self._consumer[s], None
+        if not self._order_consumers:
+            return
+        if cs is None or cs == self.streams[s] or cs.query():
+            return
+        ev = self._consumer_events[s]
+        ev.record(cs)
+        self.streams[s].wait_event(ev)
+        if self.copy_stream is not None:
+            self.copy_stream.wait_event(ev)
+
+    def _validate(self, s, batch):
         if batch is None:
             return
         unknown = set(batch) - set(self.inputs[s])
@@ -182,6 +217,11 @@ class InferencePipeline:
             if not isinstance(v, torch.Tensor) or tuple(v.shape) != tuple(dst.shape) or v.dtype != dst.dtype:
                 raise ValueError("InferencePipeline.submit: input %r must be a %s tensor of shape %s, got %s" %
                                  (k, dst.dtype, tuple(dst.shape), "%s %s" % (v.dtype, tuple(v.shape)) if isinstance(v, torch.Tensor) else type(v)))
+
+    def _load(self, s, batch, ready):
+        """copy a (validated) batch into slot s's static inputs: on the copy stream, or on the slot's stream"""
+        if batch is None:
+            return
         if self.copy_stream is not None:
             cs = self.copy_stream
             cs.wait_event(self.events[s])          # the slot's previous replay has read its inputs (no-op before the first one)
@@ -210,6 +250,7 @@ class InferencePipeline:
             t = self._next_ticket
             s = t % self.slots
             if not self.on_gpu:
+                self._validate(s, batch)
                 self._load(s, batch, None)
                 try:
                     with torch.no_grad():
@@ -219,8 +260,10 @@ class InferencePipeline:
                 self._next_ticket = t + 1
                 return t
             stream = self.streams[s]
+            self._validate(s, batch)                          # raises before anything of this ticket is enqueued
+            self._wait_for_consumer(s)
             with torch.cuda.stream(stream):
-                self._load(s, batch, ready)                   # raises before anything of this ticket is enqueued
+                self._load(s, batch, ready)
                 if self.graphed:
                     self.graphs[s].replay()
                 else:
@@ -235,27 +278,41 @@ class InferencePipeline:
 
     # ---- collection -----------------------------------------------------------------------------------------------
     def result(self, clone=False):
-        """outputs of the oldest outstanding ticket (blocks on that ticket's event only); raises the step's exception if its
-        eager step failed -- the ticket is consumed either way"""
-        with self._lock:
-            if self.outstanding <= 0:
-                raise RuntimeError("InferencePipeline.result: nothing outstanding")
-            t = self._next_result
-            s = t % self.slots
+        """outputs of the oldest outstanding ticket (blocks on that ticket's event only, without holding the state lock: other
+        threads keep submitting meanwhile); raises the step's exception if its eager step failed -- the ticket is consumed either
+        way.  The calling thread's current HIP stream is noted as the consumer of the slot (module docstring)."""
+        with self._collect_lock:
+            with self._lock:
+                if self.outstanding <= 0:
+                    raise RuntimeError("InferencePipeline.result: nothing outstanding")
+                t = self._next_result
+                s = t % self.slots
+                ev, cloned = self.events[s], None
             if self.on_gpu:
-                self.events[s].synchronize()
-            self._next_result = t + 1
-            err = self._failed.pop(t, None)
+                ev.synchronize()                   # the ticket stays outstanding while we wait: its slot cannot be resubmitted
+            with self._lock:
+                err = self._failed.pop(t, None)
+                out = self.outputs[s]
+                if err is None and self.on_gpu:
+                    if clone:                      # enqueued on the slot's stream: ahead of any later replay of the slot
+                        with torch.cuda.stream(self.streams[s]):
+                            out = _clone(out)
+                        cloned = torch.cuda.Event()
+                        cloned.record(self.streams[s])
+                    else:
+                        cs = torch.cuda.current_stream(self.device)
+                        self._consumer[s] = cs
+                        if not self.graphed and cs != self.streams[s] and self._order_consumers:
+                            for x in _flatten(out):
+                                if x.is_cuda:
+                                    x.record_stream(cs)
+                elif err is None and clone:
+                    out = _clone(out)
+                self._next_result = t + 1
             if err is not None:
                 raise err
-            out = self.outputs[s]
-            if clone:
-                if self.on_gpu:
-                    with torch.cuda.stream(self.streams[s]):
-                        out = _clone(out)
-                    self.streams[s].synchronize()
-                else:
-                    out = _clone(out)
+            if cloned is not None:
+                cloned.synchronize()
             return out
 
     def map(self, batches, clone=False):
@@ -269,7 +326,7 @@ class InferencePipeline:
 
     def drain(self):
         """wait for everything in flight and drop the results"""
-        with self._lock:
+        with self._collect_lock:
             while self.outstanding > 0:
                 try:
                     self.result()

@@ -146,18 +146,108 @@ def test_sa_module_fused_training_equals_composed_torch_path(dev, C, dedup, monk
     monkeypatch.setattr(pm, "TRAIN_DEDUP", dedup)
     nx_a, out_a = fused(xyz, fa)
     pm.TRAIN_FUSED = False
-    try:
-        nx_b, out_b = comp(xyz, fb)
-    finally:
-        pm.TRAIN_FUSED = True
-    assert torch.equal(nx_a, nx_b)
-    _close(out_a, out_b, 1e-5, "pooled features")
-    gout = torch.randn(out_b.shape, generator=g).to(dev)
-    out_a.backward(gout)
-    out_b.backward(gout)
+    # the composed side through ATen's own convolution / batch-norm kernels: MIOpen picks its convolution algorithm from run-time
+    # measurements, and one of its choices for the 3-channel first layer moved this comparison by 1e-4 once in round 4
+    # (tools/train_flake_probe.py measures both sides against float64; the fused side is additionally held to a float64 reference
+    # 50 times over in test_sa_module_fused_training_equals_float64_reference_50_times)
+    with torch.backends.cudnn.flags(enabled=False):
+        try:
+            nx_b, out_b = comp(xyz, fb)
+        finally:
+            pm.TRAIN_FUSED = True
+        assert torch.equal(nx_a, nx_b)
+        _close(out_a, out_b, 1e-5, "pooled features")
+        gout = torch.randn(out_b.shape, generator=g).to(dev)
+        out_a.backward(gout)
+        out_b.backward(gout)
     if feat is not None:
         _close_pooled(fa.grad, fb.grad, "feature gradient")
     _compare_modules(fused, comp, pooled=True)
+
+
+def sa_reference_f64(module, xyz, feat, gout):
+    """The reference's SA-module training step restated in float64 on the CPU with torch autograd -- no MIOpen, no rocBLAS, no HIP
+    arithmetic in the loop: grouped rows [xyz[idx] - new_xyz | feat[idx]] (upstream QueryAndGroup order; the fp32 difference is the
+    kernels' own input) -> per layer y = rows W^T, BatchNorm with batch statistics (biased variance, running stats with momentum and
+    the unbiased variance), ReLU -> max over nsample (lib/net/pointnet2_msg.py:20-34).  Sampling and ball-query indices come from
+    the device operators (index ops, bit-exact against the oracle elsewhere).
+    -> out (B,C,M) f64, feature gradient or None, {parameter name: gradient}, {buffer name: value after the step}"""
+    from pointrcnn_amd import ops
+    with torch.no_grad():
+        new_xyz = ops.gather_rows(xyz.contiguous(), ops.furthest_point_sample(xyz.contiguous(), module.npoint))
+        idxs = [ops.ball_query(g.radius, g.nsample, xyz.contiguous(), new_xyz.contiguous()) for g in module.groupers]
+    names = {id(p): n for n, p in module.named_parameters()}
+    bnames = {id(b): n for n, b in module.named_buffers()}
+    x32, c32 = xyz.cpu(), new_xyz.cpu()
+    f64 = None if feat is None else feat.detach().double().cpu().requires_grad_(True)
+    B = xyz.shape[0]
+    bi = torch.arange(B)[:, None, None]
+    leaves, buffers, outs = {}, {}, []
+    for g, mlp, idx in zip(module.groupers, module.mlps, idxs):
+        idx = idx.long().cpu()
+        M, ns = idx.shape[1:]
+        rows = (x32[bi, idx] - c32[:, :, None, :]).double()
+        if f64 is not None:
+            rows = torch.cat([rows, f64.transpose(1, 2)[bi, idx]], dim=3)
+        x = rows.reshape(B * M * ns, -1)
+        for layer in mlp.layers():
+            bn = layer.bn.bn
+            W = layer.conv.weight.detach().double().cpu().flatten(1).requires_grad_(True)
+            gamma, beta = bn.weight.detach().double().cpu().requires_grad_(True), bn.bias.detach().double().cpu().requires_grad_(True)
+            leaves[names[id(layer.conv.weight)]], leaves[names[id(bn.weight)]], leaves[names[id(bn.bias)]] = W, gamma, beta
+            y = x @ W.t()
+            mean, var = y.mean(0), y.var(0, unbiased=False)
+            n = y.shape[0]
+            buffers[bnames[id(bn.running_mean)]] = ((1 - bn.momentum) * bn.running_mean.double().cpu() + bn.momentum * mean).detach()
+            buffers[bnames[id(bn.running_var)]] = ((1 - bn.momentum) * bn.running_var.double().cpu() + bn.momentum * var * n / (n - 1)).detach()
+            x = torch.relu((y - mean) / torch.sqrt(var + bn.eps) * gamma + beta)
+        outs.append(x.view(B, M, ns, -1).max(dim=2)[0])
+    out = torch.cat(outs, dim=2).transpose(1, 2)
+    out.backward(gout.double().cpu())
+    return out.detach(), (None if f64 is None else f64.grad), {n: t.grad for n, t in leaves.items()}, buffers
+
+
+@pytest.mark.own_arithmetic
+@pytest.mark.parametrize("dedup", [True, False])
+@pytest.mark.parametrize("C", [0, 8, 96])
+def test_sa_module_fused_training_equals_float64_reference_50_times(dev, C, dedup, monkeypatch):
+    """the fused training path against a float64 CPU autograd restatement (no MIOpen on the other side), the
+    same step 50 times on fresh copies of the module -- every repetition inside the written bars (forward 1e-5 * scale; gradients
+    and the feature gradient 1e-5 in the median and 5e-3 in norm, the pooled bar: near-ties of the max may route single entries
+    differently; running statistics 1e-5), and every repetition's gradients BIT-IDENTICAL to the first one's (the path is
+    deterministic by construction: fixed summation orders, no float atomics on this route)."""
+    B, N = 3, 1500
+    pm, m0, _ = _modules("sa", dev, 5 + C, npoint=200, radii=[0.15, 0.3], nsamples=[16, 32],
+                         mlps=[[C, 16, 16, 32], [C, 32, 48, 64]], use_xyz=True, bn=True)
+    g = torch.Generator().manual_seed(C)
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    feat = None if C == 0 else torch.randn(B, C, N, generator=g).to(dev)
+    monkeypatch.setattr(pm, "TRAIN_DEDUP", dedup)
+    gout = torch.randn((B, 96, 200), generator=g).to(dev)
+    out64, fgrad64, grads64, buffers64 = sa_reference_f64(m0, xyz, feat, gout)
+    first = None
+    for rep in range(50):
+        m = copy.deepcopy(m0)
+        fa = None if feat is None else feat.clone().requires_grad_(True)
+        assert m._train_ok(xyz, fa)
+        _, out = m(xyz, fa)
+        out.backward(gout)
+        grads = {n: p.grad for n, p in m.named_parameters()}
+        if rep == 0:
+            _close(out, out64, 1e-5, "pooled features")
+            if fa is not None:
+                _close_pooled(fa.grad, fgrad64, "feature gradient")
+            for n in grads:
+                _close_pooled(grads[n], grads64[n], n)
+            for n, b in m.named_buffers():
+                if b.dtype.is_floating_point:
+                    _close(b, buffers64[n], 1e-5, n)
+            first = (out.clone(), None if fa is None else fa.grad.clone(), {n: v.clone() for n, v in grads.items()})
+        else:
+            assert torch.equal(out, first[0]), rep
+            assert fa is None or torch.equal(fa.grad, first[1]), rep
+            for n in grads:
+                assert torch.equal(grads[n], first[2][n]), (rep, n)
 
 
 @pytest.mark.parametrize("C1", [0, 32])

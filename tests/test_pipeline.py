@@ -148,8 +148,56 @@ def test_every_slot_reproduces_the_single_stream_path_bit_for_bit(dev, copy_stre
         assert all(torch.equal(out[k], want[7][k]) for k in keys)
 
 
+def _delay_kernel(ms=40.0):
+    """keep the current stream busy for ~ms (torch's spin kernel counts device clock ticks whose rate differs between chips: calibrated)"""
+    if not hasattr(_delay_kernel, "ticks_per_ms"):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000)
+        a.record()
+        torch.cuda._sleep(1_000_000)
+        b.record()
+        b.synchronize()
+        _delay_kernel.ticks_per_ms = 1_000_000 / max(a.elapsed_time(b), 1e-3)
+    torch.cuda._sleep(int(ms * _delay_kernel.ticks_per_ms))
+
+
 @pytest.mark.gpu
-def test_two_pipelines_and_two_threads(dev):
+@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("copy_stream", [False, True])
+def test_consumer_work_enqueued_before_the_slot_is_reused_reads_its_own_ticket(dev, graph, copy_stream):
+    """The round-4 wrong result, made deterministic: the consumer's `.clone()` of ticket t's outputs sits behind 40 ms of other work
+    on the consumer's stream while `map()` already re-submits on the same slot.  The pipeline makes the slot (and the copy stream)
+    wait for what the consumer has enqueued (pipeline.py `_wait_for_consumer`, `record_stream` for eager slots), so every clone
+    holds its own ticket's values.  Negative control (graphed slots, where the overwrite is deterministic): with that ordering
+    switched off -- round 4's behaviour -- the same loop reads later tickets' values."""
+    from pointrcnn_amd.pipeline import InferencePipeline
+    step = lambda inp, slot: {"y": inp["x"] * 2 + 1}                          # noqa: E731
+    hosts = [torch.full((1 << 22,), float(i)).pin_memory() for i in range(8)]
+
+    def run(order):
+        pipe = InferencePipeline(step, {"x": hosts[0]}, slots=2, graph=graph, copy_stream=copy_stream)
+        pipe._order_consumers = order
+        side, got = torch.cuda.Stream(), []
+        with torch.cuda.stream(side):
+            for o in pipe.map({"x": h} for h in hosts):
+                _delay_kernel()
+                got.append(o["y"].clone())
+                del o
+        side.synchronize()
+        pipe.close()
+        return [i for i, g in enumerate(got) if not bool((g == 2.0 * i + 1).all())]
+    assert run(True) == []
+    if graph:
+        assert run(False) != [], "the negative control no longer reproduces the race: this test proves nothing"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("copy_stream", [False, True])
+def test_two_pipelines_and_two_threads(dev, copy_stream):
+    """two pipelines (graphed and eager slots on shared streams, per-slot copies or the shared copy stream), two threads, each
+    consumer cloning its results on its thread's default stream right before `map` reuses the slot; 50 rounds (round 4: one wrong
+    tensor per run at pa's ticket 2, the one slot whose stream the eager pipeline does not share, i.e. whose next replay starts at
+    once)"""
     from pointrcnn_amd import rpn
     from pointrcnn_amd.pipeline import InferencePipeline
     model = _small_rpn(dev)
@@ -157,16 +205,17 @@ def test_two_pipelines_and_two_threads(dev):
     hosts = [rpn.synthetic_clouds(1, 16384, seed0=4000 + i).pin_memory() for i in range(8)]
     with torch.no_grad():
         want = [model({"pts_input": h.to(dev)})["rpn_reg"].clone() for h in hosts]
-    pa = InferencePipeline(step, {"pts_input": hosts[0]}, slots=3)
-    pb = InferencePipeline(step, {"pts_input": hosts[0]}, slots=2, graph=False)       # eager slots next to graphed ones
+    pa = InferencePipeline(step, {"pts_input": hosts[0]}, slots=3, copy_stream=copy_stream)
+    pb = InferencePipeline(step, {"pts_input": hosts[0]}, slots=2, graph=False, copy_stream=copy_stream)    # eager slots next to graphed ones
     errs = []
 
     def worker(pipe, order):
         try:
             torch.cuda.set_device(dev)
-            got = [o["rpn_reg"].clone() for o in pipe.map({"pts_input": hosts[i]} for i in order)]
-            for i, g in zip(order, got):
-                assert torch.equal(g, want[i]), i
+            for rep in range(50):
+                got = [o["rpn_reg"].clone() for o in pipe.map({"pts_input": hosts[i]} for i in order)]
+                for i, g in zip(order, got):
+                    assert torch.equal(g, want[i]), (rep, i)
         except Exception as e:  # noqa: BLE001
             errs.append(e)
     ths = [threading.Thread(target=worker, args=(pa, [0, 1, 2, 3, 4, 5, 6, 7])), threading.Thread(target=worker, args=(pb, [7, 5, 3, 1, 6]))]
@@ -176,6 +225,40 @@ def test_two_pipelines_and_two_threads(dev):
         t.join()
     pa.close(); pb.close()
     assert not errs, errs
+
+
+@pytest.mark.gpu
+def test_a_producer_keeps_submitting_while_a_consumer_waits_for_a_result(dev):
+    """result() must not hold the state lock while it blocks on the ticket's event: with the oldest ticket stuck behind
+    a 300 ms kernel, a second thread's submit() returns long before that ticket completes"""
+    import time
+    from pointrcnn_amd.pipeline import InferencePipeline
+
+    def step(inp, slot):
+        if slot == 0:
+            _delay_kernel(300.0)
+        return inp["x"] + 1
+    _delay_kernel(1.0)                                                        # calibrate outside the pipeline's streams
+    torch.cuda.synchronize()
+    pipe = InferencePipeline(step, {"x": torch.zeros(16, device=dev)}, slots=2, graph=False, warmup=1)
+    torch.cuda.synchronize()
+    pipe.submit(None)                                                         # ticket 0: 300 ms
+    waited, submitted = {}, {}
+
+    def consumer():
+        torch.cuda.set_device(dev)
+        t0 = time.perf_counter()
+        pipe.result()
+        waited["s"] = time.perf_counter() - t0
+    th = threading.Thread(target=consumer)
+    th.start()
+    time.sleep(0.05)                                                          # the consumer is inside result() now
+    t0 = time.perf_counter()
+    pipe.submit(None)                                                         # ticket 1 on slot 1
+    submitted["s"] = time.perf_counter() - t0
+    th.join()
+    pipe.drain(); pipe.close()
+    assert waited["s"] > 0.15 and submitted["s"] < 0.1, (waited, submitted)
 
 
 @pytest.mark.gpu
