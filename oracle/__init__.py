@@ -31,9 +31,6 @@ def build(force=False):
     from . import build_ref
     if build_ref.have_reference() and (force or not os.path.exists(ref_so)):
         build_ref.build(verbose=False)
-    from . import stage_reference       # the reference's Python tree as one archive for the GPU box (tests only)
-    if stage_reference.have_reference() and (force or not os.path.exists(stage_reference.ARCHIVE)):
-        stage_reference.stage()
     return so
 
 

@@ -4,7 +4,8 @@
 unchanged lib/net + lib/rpn + lib/utils Python on the HIP kernels there.  Like oracle/_ref/libprcnn_ref.so (the reference's
 native sources compiled for the host), this is a BUILT ARTEFACT of the checker: one archive under oracle/_ref/ (git-ignored,
 never committed, not gpurun-ignored so that it travels with the snapshot).  Nothing in the product reads it; the test unpacks
-it into a temporary directory and sets sys.path exactly as tools/_init_path.py:1-4 does.
+it into a temporary directory and sets sys.path exactly as tools/_init_path.py:1-4 does.  Staging is an explicit step
+(`__graft_entry__.build()` runs it in the build container; `python -m oracle.stage_reference`), not a side effect of oracle.build().
 
     python -m oracle.stage_reference            # -> oracle/_ref/reference_py.tar.gz
 """
@@ -15,8 +16,10 @@ import tarfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 REFERENCE = os.environ.get("PRCNN_REFERENCE", "/root/reference")
 ARCHIVE = os.path.join(HERE, "_ref", "reference_py.tar.gz")
-# what the network-level route needs: the library package, the config files and the path helper of tools/
-WANTED = (("lib", (".py",)), ("tools/cfgs", (".yaml",)), ("tools", ("_init_path.py",)))
+# what the network-level route and the end-to-end run of tools/eval_rcnn.py need: the library package, the config files, the
+# scripts of tools/ with their two helper packages (train_utils: checkpoint save / load; kitti_object_eval_python: the AP evaluator)
+WANTED = (("lib", (".py",)), ("tools/cfgs", (".yaml",)), ("tools", (".py",)), ("tools/train_utils", (".py",)),
+          ("tools/kitti_object_eval_python", (".py",)))
 
 
 def have_reference():
@@ -28,7 +31,7 @@ def members():
     for sub, suffixes in WANTED:
         top = os.path.join(REFERENCE, sub)
         for d, dirs, files in os.walk(top):
-            dirs[:] = sorted(x for x in dirs if x != "__pycache__" and (sub != "tools" or d != top))
+            dirs[:] = sorted(x for x in dirs if x != "__pycache__" and sub == "lib")      # only lib/ is taken recursively
             for f in sorted(files):
                 if f.endswith(suffixes):
                     out.append(os.path.relpath(os.path.join(d, f), REFERENCE))
@@ -65,8 +68,28 @@ def locate(tmpdir=None):
         return REFERENCE
     if os.path.exists(ARCHIVE) and tmpdir is not None:
         with tarfile.open(ARCHIVE, "r:gz") as tar:
-            tar.extractall(tmpdir)
+            tar.extractall(tmpdir, filter="data")      # plain files under tmpdir only: no links, devices, absolute or .. paths
         return str(tmpdir)
+    return None
+
+
+def writable_copy(dest):
+    """the same tree as a WRITABLE copy under `dest` (tools/eval_rcnn.py writes next to itself: `cp *.py backup_files/`, `../data`,
+    `../output`): unpacked from the archive, or copied file by file from the read-only checkout; -> dest, or None"""
+    dest = str(dest)
+    if have_reference():
+        import shutil
+        for rel in members():
+            os.makedirs(os.path.dirname(os.path.join(dest, rel)), exist_ok=True)
+            shutil.copyfile(os.path.join(REFERENCE, rel), os.path.join(dest, rel))
+        return dest
+    if os.path.exists(ARCHIVE):
+        with tarfile.open(ARCHIVE, "r:gz") as tar:
+            tar.extractall(dest, filter="data")
+        for d, _, files in os.walk(dest):
+            for f in files:
+                os.chmod(os.path.join(d, f), 0o644)
+        return dest
     return None
 
 

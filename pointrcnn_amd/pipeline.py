@@ -157,6 +157,7 @@ class InferencePipeline:
         self._collect_lock = threading.RLock()   # one collector at a time (results are handed out in order)
         self._consumer = [None] * self.slots     # slot -> HIP stream its last result was handed to (see `result`)
         self._order_consumers = True             # False = round 4's behaviour (the negative control of the regression test)
+        self.consumer_waits = 0                  # submits that found the slot's consumer stream still busy and waited for it
         self._consumer_events = [torch.cuda.Event() if self.on_gpu else None for _ in range(self.slots)]
         self._next_ticket = 0          # ticket the next submit() gets
         self._next_result = 0          # oldest outstanding ticket
@@ -200,6 +201,7 @@ class InferencePipeline:
             return
         if cs is None or cs == self.streams[s] or cs.query():
             return
+        self.consumer_waits += 1
         ev = self._consumer_events[s]
         ev.record(cs)
         self.streams[s].wait_event(ev)

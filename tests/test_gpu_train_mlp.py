@@ -214,8 +214,9 @@ def test_sa_module_fused_training_equals_float64_reference_50_times(dev, C, dedu
     """the fused training path against a float64 CPU autograd restatement (no MIOpen on the other side), the
     same step 50 times on fresh copies of the module -- every repetition inside the written bars (forward 1e-5 * scale; gradients
     and the feature gradient 1e-5 in the median and 5e-3 in norm, the pooled bar: near-ties of the max may route single entries
-    differently; running statistics 1e-5), and every repetition's gradients BIT-IDENTICAL to the first one's (the path is
-    deterministic by construction: fixed summation orders, no float atomics on this route)."""
+    differently; running statistics 1e-5), and every repetition's output and parameter gradients BIT-IDENTICAL to the first one's
+    (fixed summation orders); the feature gradient too on the padding-free rows (gather form), within 1e-5 on the padded rows (their
+    scatter accumulates with float atomics)."""
     B, N = 3, 1500
     pm, m0, _ = _modules("sa", dev, 5 + C, npoint=200, radii=[0.15, 0.3], nsamples=[16, 32],
                          mlps=[[C, 16, 16, 32], [C, 32, 48, 64]], use_xyz=True, bn=True)
@@ -245,7 +246,10 @@ def test_sa_module_fused_training_equals_float64_reference_50_times(dev, C, dedu
             first = (out.clone(), None if fa is None else fa.grad.clone(), {n: v.clone() for n, v in grads.items()})
         else:
             assert torch.equal(out, first[0]), rep
-            assert fa is None or torch.equal(fa.grad, first[1]), rep
+            if fa is not None and dedup:
+                assert torch.equal(fa.grad, first[1]), rep
+            elif fa is not None:                   # the padded-rows route scatters the feature gradient with float atomics
+                _close(fa.grad, first[1], 1e-5, "feature gradient, repetition %d" % rep)
             for n in grads:
                 assert torch.equal(grads[n], first[2][n]), (rep, n)
 

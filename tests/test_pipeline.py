@@ -168,8 +168,9 @@ def test_consumer_work_enqueued_before_the_slot_is_reused_reads_its_own_ticket(d
     """The round-4 wrong result, made deterministic: the consumer's `.clone()` of ticket t's outputs sits behind 40 ms of other work
     on the consumer's stream while `map()` already re-submits on the same slot.  The pipeline makes the slot (and the copy stream)
     wait for what the consumer has enqueued (pipeline.py `_wait_for_consumer`, `record_stream` for eager slots), so every clone
-    holds its own ticket's values.  Negative control (graphed slots, where the overwrite is deterministic): with that ordering
-    switched off -- round 4's behaviour -- the same loop reads later tickets' values."""
+    holds its own ticket's values, and the pipeline reports that it had to wait (consumer_waits).  Negative control (graphed slots
+    with per-slot copies, where the overwrite is deterministic): with that ordering switched off -- round 4's behaviour -- the same
+    loop reads later tickets' values."""
     from pointrcnn_amd.pipeline import InferencePipeline
     step = lambda inp, slot: {"y": inp["x"] * 2 + 1}                          # noqa: E731
     hosts = [torch.full((1 << 22,), float(i)).pin_memory() for i in range(8)]
@@ -184,11 +185,15 @@ def test_consumer_work_enqueued_before_the_slot_is_reused_reads_its_own_ticket(d
                 got.append(o["y"].clone())
                 del o
         side.synchronize()
+        waits = pipe.consumer_waits
         pipe.close()
-        return [i for i, g in enumerate(got) if not bool((g == 2.0 * i + 1).all())]
-    assert run(True) == []
-    if graph:
-        assert run(False) != [], "the negative control no longer reproduces the race: this test proves nothing"
+        return [(i, float(g[0])) for i, g in enumerate(got) if not bool((g == 2.0 * i + 1).all())], waits
+    wrong, waits = run(True)
+    assert wrong == [], wrong
+    assert waits == len(hosts) - 2, waits          # every re-submission found its consumer busy and was ordered behind it
+    if graph and not copy_stream:
+        wrong, waits = run(False)
+        assert waits == 0 and wrong != [], "the negative control no longer reproduces the race: this test proves nothing"
 
 
 @pytest.mark.gpu

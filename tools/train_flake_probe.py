@@ -44,7 +44,7 @@ def main(reps=50):
                         o.backward(gout)
                 finally:
                     pm.TRAIN_FUSED = True
-                grads = {n: p.grad.double().cpu() for n, p in m.named_parameters()}
+                grads = {n: p.grad.double().cpu().reshape(g64[n].shape) for n, p in m.named_parameters()}
                 for n, v in grads.items():
                     d = (v - g64[n]).abs().reshape(-1)
                     sc = float(g64[n].abs().max())
