@@ -48,6 +48,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 _T0 = time.perf_counter()
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md); the split-bf16 kernels' pipe
 
 
 def trace(msg):
@@ -98,6 +99,7 @@ def parse(argv=None):
     ap.add_argument("--raw-points", type=int, default=118000, help="raw points per synthetic scan for --input raw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc subprocess passes behind roofline.traffic")
     ap.add_argument("--dump-launches", action="store_true", help="print every library launch of one instrumented step to stderr "
                     "(name, live rows, executed GFLOP, us, TFLOP/s)")
     args = ap.parse_args(argv)
@@ -211,36 +213,46 @@ class EventProfiler:
 
     @staticmethod
     def _work(name, a):
-        """(flops per row, rows, rows_dev pointer, rows per device count) of one call.  EXECUTED work: first-layer
-        hoisting and padding-free grouping make it smaller than the reference graph's count."""
-        def chain(k0, nout):
+        """(fp32-equivalent flops per row, rows, rows_dev pointer, rows per device count, label, bf16 terms, MFMA flops per row ON THE
+        PIPE THE LAUNCH USES) of one call.  EXECUTED work: first-layer hoisting and padding-free grouping make it smaller than the
+        reference graph's count.  MFMA flops: what the matrix pipe is given -- output widths in whole 32-column blocks (a 76-wide
+        layer runs as 96 columns, the cls head's single output channel is a VALU dot product: 0), times the number of bf16 products
+        per fp32 product for the split kernels -- the quantity SQ_INSTS_VALU_MFMA_MOPS_{F32,BF16} x 512 counts."""
+        def pad(n):
+            return 0 if n == 1 else -(-int(n) // 32) * 32
+        def chain(k0, nout, padded=False):
             widths = [k0] + list(nout)
-            return 2.0 * sum(x * y for x, y in zip(widths[:-1], widths[1:]))
+            return 2.0 * sum(x * (pad(y) if padded else y) for x, y in zip(widths[:-1], widths[1:]))
         def widths(k0, nout, n):
             return "->".join(str(int(v)) for v in [k0] + [nout[i] for i in range(n)])
         if name == "prcnn_mlp_rows":
-            return 2.0 * a[3] * a[6], a[2], a[12], a[13], "%d->%d" % (a[3], a[6])
+            return 2.0 * a[3] * a[6], a[2], a[12], a[13], "%d->%d" % (a[3], a[6]), 0, 2.0 * a[3] * pad(a[6])
         if name == "prcnn_mlp_rows_addinterp":
-            return 2.0 * (a[2] + 3) * a[5], a[11] * a[12], None, 1, "%d->%d + interpolated addend" % (a[2], a[5])
+            return 2.0 * (a[2] + 3) * a[5], a[11] * a[12], None, 1, "%d->%d + interpolated addend" % (a[2], a[5]), 0, 2.0 * a[2] * pad(a[5])
         if name == "prcnn_mlp_rows_split":              # (fp32-EQUIVALENT flops: 2 K N per row, whatever the number of bf16 terms)
-            return 2.0 * a[3] * a[8], a[2], a[14], a[15], "%d->%d (bf16x%d)" % (a[3], a[8], a[6])
+            return 2.0 * a[3] * a[8], a[2], a[14], a[15], "%d->%d (bf16x%d)" % (a[3], a[8], a[6]), a[6], 2.0 * a[3] * pad(a[8]) * a[6]
         if name == "prcnn_mlp_chain_rows_split":
-            return chain(a[3], [a[7][0], a[7][1]]), a[2], None, 1, widths(a[3], a[7], 2) + " (bf16x%d)" % a[9]
+            return (chain(a[3], [a[7][0], a[7][1]]), a[2], None, 1, widths(a[3], a[7], 2) + " (bf16x%d)" % a[9], a[9],
+                    chain(a[3], [a[7][0], a[7][1]], True) * a[9])
         if name == "prcnn_mlp_chain_interp_split":
-            return 2.0 * a[7] * a[12], a[4] * a[5], None, 1, "%d->%d (bf16x%d)" % (a[7], a[12], a[14])
+            return 2.0 * a[7] * a[12], a[4] * a[5], None, 1, "%d->%d (bf16x%d)" % (a[7], a[12], a[14]), a[14], 2.0 * a[7] * pad(a[12]) * a[14]
         if name == "prcnn_mlp_rows_addinterp_split":
-            return 2.0 * (a[2] + 3) * a[7], a[13] * a[14], None, 1, "%d->%d + interpolated addend (bf16x%d)" % (a[2], a[7], a[5])
+            return (2.0 * (a[2] + 3) * a[7], a[13] * a[14], None, 1, "%d->%d + interpolated addend (bf16x%d)" % (a[2], a[7], a[5]), a[5],
+                    2.0 * a[2] * pad(a[7]) * a[5])
         if name == "prcnn_mlp_group":
-            return 2.0 * (a[9] + (0 if a[10] else 3)) * a[14], a[5] * a[7] * a[8], a[20], a[8], "%d->%d" % (a[9] + (0 if a[10] else 3), a[14])
+            k = a[9] + (0 if a[10] else 3)
+            return 2.0 * k * a[14], a[5] * a[7] * a[8], a[20], a[8], "%d->%d" % (k, a[14]), 0, 2.0 * k * pad(a[14])
         if name == "prcnn_mlp_interp":
-            return 2.0 * (a[9] + a[10]) * a[14], a[6] * a[7], None, 1, "%d->%d" % (a[9] + a[10], a[14])
+            return 2.0 * (a[9] + a[10]) * a[14], a[6] * a[7], None, 1, "%d->%d" % (a[9] + a[10], a[14]), 0, 2.0 * (a[9] + a[10]) * pad(a[14])
         if name == "prcnn_mlp_chain_rows":
-            return chain(a[3], a[7]), a[2], None, 1, widths(a[3], a[7], a[4])
+            return chain(a[3], a[7]), a[2], None, 1, widths(a[3], a[7], a[4]), 0, chain(a[3], [a[7][i] for i in range(a[4])], True)
         if name == "prcnn_mlp_chain_group":
-            return chain(a[9] + (0 if a[10] else 3), a[15]), a[5] * a[7] * a[8], a[21], a[8], widths(a[9] + (0 if a[10] else 3), a[15], a[12])
+            k = a[9] + (0 if a[10] else 3)
+            return chain(k, a[15]), a[5] * a[7] * a[8], a[21], a[8], widths(k, a[15], a[12]), 0, chain(k, [a[15][i] for i in range(a[12])], True)
         if name == "prcnn_mlp_chain_interp":
-            return chain(a[9] + a[10], a[15]), a[6] * a[7], None, 1, widths(a[9] + a[10], a[15], a[12])
-        return 0.0, 0, None, 1, ""
+            return (chain(a[9] + a[10], a[15]), a[6] * a[7], None, 1, widths(a[9] + a[10], a[15], a[12]), 0,
+                    chain(a[9] + a[10], [a[15][i] for i in range(a[12])], True))
+        return 0.0, 0, None, 1, "", 0, 0.0
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
@@ -268,10 +280,10 @@ class EventProfiler:
             # scale, minus what the dense list (its own launches) carries
             undedup[sp.counts.data_ptr()] = sp.G * sp.ns - c[1] * sp.ns
         fam = {}
-        self.mlp_launches = []        # (entry point, live rows, flops per row, us) of every MLP-family launch, in launch order
-        for name, s, e, (per_row, rows, ptr, unit, label) in self.records:
+        self.mlp_launches = []        # (entry point, live rows, flops per row, us, label, bf16 terms, MFMA flops per row, rows without padding-free grouping) of every MLP-family launch, in launch order
+        for name, s, e, (per_row, rows, ptr, unit, label, terms, pipe_per_row) in self.records:
             key = "mlp" if name.startswith("prcnn_mlp_") else name[len("prcnn_"):]
-            d = fam.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0, "rows": 0, "rows_launched": 0})
+            d = fam.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0, "rows": 0, "rows_launched": 0, "pipe_seconds_at_peak": 0.0})
             ptr = getattr(ptr, "value", ptr)
             live = min(rows, dev_counts[ptr] * unit) if ptr else rows
             if dump is not None:
@@ -279,7 +291,10 @@ class EventProfiler:
                 print("%-28s rows %8d / %8d  flop/row %8.0f  %7.2f GFLOP %8.1f us %6.1f TF/s" %
                       (name, live, rows, per_row, per_row * live / 1e9, us, per_row * live / us / 1e6 if us > 0 else 0), file=dump)
             if key == "mlp":
-                self.mlp_launches.append((name[len("prcnn_"):], live, per_row, s.elapsed_time(e) * 1e3, label))
+                self.mlp_launches.append((name[len("prcnn_"):], live, per_row, s.elapsed_time(e) * 1e3, label, terms, pipe_per_row,
+                                          undedup[ptr] if ptr in undedup else live))
+                # time the launch's MFMA work would take at the dense peak of the pipe it runs on
+                d["pipe_seconds_at_peak"] += pipe_per_row * live / ((BF16_MFMA_PEAK_TFLOPS if terms else FP32_MFMA_PEAK_TFLOPS) * 1e12)
             d["ms"] += s.elapsed_time(e)
             d["launches"] += 1
             d["flops"] += per_row * live
@@ -546,18 +561,45 @@ class InferenceBench:
         torch.cuda.empty_cache()
 
 
-def instrumented_pass(args, bench, nprof, dump=None):
-    """per-op-family GPU time + EXECUTED MLP flops of `nprof` eager steps (HIP events on the launch stream)"""
+def event_pair_overhead_us(n=200):
+    """what an empty HIP event pair on the current stream measures: subtracted from every bracketed launch"""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        b.record()
+    torch.cuda.synchronize()
+    v = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+    return v[len(v) // 2]
+
+
+def instrumented_pass(args, bench, nprof, dump=None, loaded=False):
+    """per-op-family GPU time + EXECUTED MLP flops of `nprof` eager steps (HIP events on the launch stream).
+    loaded=True: the pass runs in the TIMED configuration -- the other slots' captured steps keep replaying on their streams while the
+    instrumented eager step runs on the current stream, so a launch's duration is what it is with 19 other batches on the chip (FPS
+    workgroups holding CUs, other batches' layers sharing the rest), not what it is alone."""
     from pointrcnn_amd import _cabi, ops as _ops
     bench.step(0)                           # one unprofiled eager step first (allocator / lazy state after the graph replays)
     torch.cuda.synchronize()
     prof = EventProfiler(_cabi._lib)
     real = _cabi._lib
+    pipe = getattr(bench, "pipe", None)
+    background = loaded and pipe is not None and pipe.graphed and pipe.slots > 1
     _cabi._lib, _ops._split_log = prof, prof.splits
     try:
         for _ in range(nprof):
+            if background:
+                # enough queued replays to outlast one eager step (an eager step under load takes a few FPS chains; a slot's replay
+                # is one chain + its share of the chip): 6 rounds on every other slot, topped up before every step
+                for _r in range(6):
+                    for s_ in range(1, pipe.slots):
+                        with torch.cuda.stream(pipe.streams[s_]):
+                            pipe.graphs[s_].replay()
             bench.step(0)
+            if background:
+                torch.cuda.synchronize()
         fam = prof.summary(dump)
+        fam["event_pair_overhead_us"] = event_pair_overhead_us()
         # per-launch table, averaged over the nprof repeats (the launch sequence of a step is static)
         per_step = len(prof.mlp_launches) // max(1, nprof)
         if per_step and per_step * nprof == len(prof.mlp_launches):
@@ -565,13 +607,61 @@ def instrumented_pass(args, bench, nprof, dump=None):
             for i in range(per_step):
                 reps = prof.mlp_launches[i::per_step]
                 us = sum(r[3] for r in reps) / len(reps)
-                gflop = reps[0][1] * reps[0][2] / 1e9
-                table.append({"launch": reps[0][0], "widths": reps[0][4], "rows": reps[0][1], "flop_per_row": reps[0][2], "us": round(us, 1), "GFLOP": round(gflop, 3),
-                              "frac_of_peak": round(gflop * 1e3 / us / FP32_MFMA_PEAK_TFLOPS, 3) if us > 0 else None})
+                name, rows, per_row, _, label, terms, pipe_per_row, rows_ref = reps[0]
+                gflop, pipe_gflop = rows * per_row / 1e9, rows * pipe_per_row / 1e9
+                peak = BF16_MFMA_PEAK_TFLOPS if terms else FP32_MFMA_PEAK_TFLOPS
+                table.append({"launch": name, "widths": label, "rows": rows, "rows_in_the_reference_graph": rows_ref, "us": round(us, 1),
+                              "fp32_equivalent_GFLOP": round(gflop, 3), "fp32_equivalent_TFLOPs": round(gflop * 1e3 / us, 1) if us > 0 else None,
+                              "pipe": "bf16 MFMA x%d" % terms if terms else "fp32 MFMA", "mfma_GFLOP_on_pipe": round(pipe_gflop, 3),
+                              "pipe_peak_TFLOPs": peak,
+                              "frac_of_pipe_peak": round(min(1.0, pipe_gflop * 1e3 / us / peak), 4) if us > 0 else None})
             fam["mlp_by_launch"] = table
         return fam
     finally:
         _cabi._lib, _ops._split_log = real, None
+        if background:
+            torch.cuda.synchronize()
+
+
+def measure_hbm_traffic(args, timeout_s=240):
+    """roofline.traffic, measured in this run: HBM bytes per launch of the MLP family from two rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in SEPARATE runs, kernel trace only -- the recipe of /opt/skills/guides/MI355X_MICROARCH.md, gfx950 correction
+    included) of a short single-stream eager run of this script, as subprocesses.  -> fields for the roofline object; traffic is null
+    (with the reason) when rocprofv3 is missing or a pass fails -- never a number from another run."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"traffic": None, "traffic_note": "rocprofv3 not found on this box"}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", str(args.batch), "--npoints", str(args.npoints),
+           "--clouds", args.clouds, "--proposals", args.proposals, "--no-cpu-baseline", "--no-roofline", "--no-variants", "--no-traffic",
+           "--graph", "off", "--streams", "1"]
+    t0 = time.perf_counter()
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                p = subprocess.run([exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(td, "pmc_" + c), "--"] + cmd,
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+                if p.returncode != 0:
+                    return {"traffic": None, "traffic_note": "rocprofv3 --pmc %s pass failed (rc %d): %s" % (c, p.returncode, (p.stderr or "")[-300:])}
+            spec = importlib.util.spec_from_file_location("derive_hbm_traffic", os.path.join(ROOT, "profiles", "derive_hbm_traffic.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            res = mod.derive(os.path.join(td, "pmc_"))
+    except Exception as e:  # noqa: BLE001  (a missing counter, a timeout: the line must still be printed)
+        return {"traffic": None, "traffic_note": "hbm traffic passes failed: %s: %s" % (type(e).__name__, str(e)[:300])}
+    mlp = res.get("mlp")
+    if not mlp:
+        return {"traffic": None, "traffic_note": "no MLP-family dispatch in the counter collection"}
+    return {"traffic": mlp["hbm_bytes_per_launch_corrected"], "traffic_unit": "HBM bytes per launch of the MLP family, measured in this run",
+            "traffic_detail": {"launches_per_step": mlp["launches_per_step"], "hbm_bytes_per_step": mlp["hbm_bytes_per_step_corrected"],
+                               "FETCH_SIZE_KiB": mlp["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": mlp["WRITE_SIZE_KiB"], "correction": mod.CORRECTION,
+                               "command": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE} --kernel-trace -- python bench.py --steps 2 --warmup 1 --graph off "
+                                          "--streams 1 (two separate subprocess passes, %.0f s)" % (time.perf_counter() - t0),
+                               "all_families_hbm_bytes_per_step": {k: v["hbm_bytes_per_step_corrected"] for k, v in res.items()}}}
 
 
 def stack_gemm_account(step, seconds_per_step):
@@ -1009,58 +1099,92 @@ def main():
         trace("instrumented pass")
         if args.dump_launches:
             instrumented_pass(args, bench, 1, dump=sys.stderr)
-        fam = instrumented_pass(args, bench, nprof)
-        mlp = fam.get("mlp", {"ms": 0.0, "launches": 1, "flops": 0.0, "rows": 0, "rows_launched": 0})
-        secs = mlp["ms"] * 1e-3
-        # The roofline is priced on the flops the kernels EXECUTE: first-layer hoisting and padding-free grouping (both
-        # exact) remove most of the reference graph's MLP work (14.95 GFLOP/frame, padding rows included),
-        # so the reference-graph rate -- reported next to it -- is a throughput figure, not a utilisation, and may exceed
-        # the peak.
-        ref_flops = rpn.rpn_flops_per_frame() * args.batch * nprof if (args.npoints == 16384 and args.workload == "rpn") else None
-        achieved = mlp["flops"] / secs / 1e12 if secs > 0 else 0.0
-        line["roofline"] = {"kernel": "mlp_chain_* + mlp_layer_kernel (fused gather/interp + fp32 MFMA + bias/ReLU/max-pool)",
-                            "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                            "launches_per_step": mlp["launches"] // nprof,
-                            "avg_launch_us": round(1e3 * mlp["ms"] / max(1, mlp["launches"]), 2),
-                            "flops_per_step": mlp["flops"] / nprof, "rows_per_step": mlp["rows"] // nprof,
-                            "rows_per_step_without_dedup": mlp.get("rows_undedup", mlp["rows_launched"]) // nprof,
-                            "reference_graph_flops_per_step": ref_flops / nprof if ref_flops else None,
-                            "reference_graph_TFLOPs": round(ref_flops / secs / 1e12, 3) if ref_flops and secs > 0 else None,
-                            "note": "achieved/frac = executed flops (after exact first-layer hoisting and padding-free grouping) / "
-                                    "MLP-family GPU time; reference_graph_TFLOPs = the reference's dense flop count over the same time"}
+        fam = instrumented_pass(args, bench, nprof)                     # one batch on the chip (single stream)
         by_launch = fam.pop("mlp_by_launch", None)
+        ovh = fam.pop("event_pair_overhead_us", 0.0)
+        zero = {"ms": 0.0, "launches": 1, "flops": 0.0, "rows": 0, "rows_launched": 0, "pipe_seconds_at_peak": 0.0}
+        mlp = fam.get("mlp", zero)
+        trace("instrumented pass in the timed configuration")
+        fam_l = instrumented_pass(args, bench, nprof, loaded=True)      # the timed configuration: the other slots keep replaying
+        by_launch_l = fam_l.pop("mlp_by_launch", None)
+        ovh_l = fam_l.pop("event_pair_overhead_us", ovh)
+        mlp_l = fam_l.get("mlp", zero)
+
+        def family(m, overhead_us):
+            """Sum of the family's bracketed launch durations minus what an empty event pair measures; frac = the time its MFMA work
+            takes at the dense peak OF THE PIPE EACH LAUNCH USES (2.5 PFLOP/s bf16 for the split launches, 157.3 TFLOP/s for the
+            fp32-MFMA launches) / that time == the time-weighted mean of the launches' pipe fractions"""
+            secs = max(1e-9, m["ms"] * 1e-3 - m["launches"] * overhead_us * 1e-6)
+            return secs, m["pipe_seconds_at_peak"] / secs
+        secs, frac_alone = family(mlp, ovh)
+        secs_l, frac_loaded = family(mlp_l, ovh_l)
+        loaded_ok = getattr(bench, "pipe", None) is not None and bench.pipe.graphed and bench.pipe.slots > 1
+        # SURVEY 8(d): the algorithmic figure is the REFERENCE GRAPH's dense count (14.95 GFLOP/frame at 16 384 points).  Two exact
+        # rewrites -- first-layer hoisting and padding-free grouping -- remove most of it before anything is multiplied, so the
+        # reference-graph rate is a THROUGHPUT figure (it may exceed any peak); utilisation is priced on what the pipe is given.
+        ref_flops = rpn.rpn_flops_per_frame() * args.batch * nprof if (args.npoints == 16384 and args.workload == "rpn") else None
+        eq = mlp_l if loaded_ok else mlp
+        eq_secs = secs_l if loaded_ok else secs
+        line["roofline"] = {
+            "kernel": "fused per-point MLP family: mlp_layer_s_kernel / mlp_chain_s_kernel (bf16 MFMA, exact 3-way operand split, %d products per "
+                      "fp32 product, fp32 accumulate) + fp32-MFMA grouped SA chains (sa_xyz_chain / mlp_chain_fast / mlp_stack2); fused gather / "
+                      "interpolation / bias / ReLU / max-pool" % _ops_split.MLP_SPLIT_TERMS if _ops_split.MLP_SPLIT_TERMS else
+                      "fused per-point MLP family on fp32 MFMA (mlp_layer_b / mlp_chain_fast / sa_xyz_chain / mlp_stack2; PRCNN_MLP_SPLIT=0)",
+            "bound": "mfma", "unit": "TFLOP/s",
+            "definition": "frac = sum over the family's launches of (MFMA flops given to the pipe / dense peak of THAT pipe) / sum of the launches' "
+                          "durations, durations from HIP events on the launch stream with the other %d slots' captured steps replaying (the timed "
+                          "configuration), minus the empty-event-pair time per launch; achieved = frac x peak, peak = the bf16 dense peak when the "
+                          "split launches hold most of the time, else the fp32-MFMA peak.  profiles/recompute_roofline.py derives the same number "
+                          "from the rocprofv3 kernel trace of the timed loop and the MFMA instruction counters" % (nstreams - 1),
+            "frac": round(frac_loaded if loaded_ok else frac_alone, 4),
+            "frac_single_stream": round(frac_alone, 4),
+            "family_us_per_step": round(1e6 * eq_secs / nprof, 1), "family_us_per_step_single_stream": round(1e6 * secs / nprof, 1),
+            "launches_per_step": mlp["launches"] // nprof, "event_pair_overhead_us": round(ovh, 2),
+            "algorithmic_GFLOP_per_step_reference_graph": round(ref_flops / nprof / 1e9, 1) if ref_flops else None,
+            "executed_fp32_equivalent_GFLOP_per_step": round(mlp["flops"] / nprof / 1e9, 2),
+            "mfma_GFLOP_per_step_on_the_pipes": None,
+            "fp32_equivalent_TFLOPs": round(eq["flops"] / eq_secs / 1e12, 2),
+            "fp32_equivalent_vs_fp32_mfma_peak": round(eq["flops"] / eq_secs / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "fp32_equivalent_vs_fp32_mfma_peak_single_stream": round(mlp["flops"] / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "reference_graph_TFLOPs": round(ref_flops / eq_secs / 1e12, 1) if ref_flops else None,
+            "rows_per_step": mlp["rows"] // nprof, "rows_per_step_without_dedup": mlp.get("rows_undedup", mlp["rows_launched"]) // nprof,
+            "flops_per_step": mlp["flops"] / nprof,
+            "traffic": None,
+            "note": "fp32_equivalent_* = executed 2 K N flops per live row (after the exact rewrites) over the same time, against the 157.3 TFLOP/s "
+                    "fp32-MFMA peak: what the layers would need on the fp32 matrix pipe -- a separately named figure, not the roofline fraction; "
+                    "reference_graph_TFLOPs = SURVEY 8(d)'s dense count over the same time (a throughput, not a utilisation)"}
         if by_launch:
-            line["roofline"]["by_kernel"] = by_launch
-        if _ops_split.MLP_SPLIT_TERMS and by_launch:
-            # split-bf16 arithmetic: `achieved` / `frac` are fp32-EQUIVALENT flops (2 K N per row) against the fp32-MFMA peak -- what
-            # the layers would need on the fp32 matrix pipe; the bf16 pipe itself executes `terms` products per fp32 product
-            t_ = _ops_split.MLP_SPLIT_TERMS
-            sp = [r for r in by_launch if r["launch"].endswith("_split")]
-            sp_us, sp_gf = sum(r["us"] for r in sp), sum(r["GFLOP"] for r in sp)
-            line["roofline"]["kernel"] = ("mlp_layer_s_kernel / mlp_chain_s_kernel (split-bf16x%d MFMA, fp32 accumulate) + fp32-MFMA grouped SA stacks "
-                                          "(fused gather/interp + bias/ReLU/max-pool)" % t_)
-            line["roofline"]["note"] = ("achieved/frac = executed fp32-EQUIVALENT flops (2 K N per row, after exact first-layer hoisting and padding-free "
-                                        "grouping) / MLP-family GPU time, against the fp32-MFMA dense peak; bf16_pipe prices the split launches' "
-                                        "bf16 products (x%d) against the bf16 dense peak" % t_)
-            line["roofline"]["bf16_pipe"] = {"launches": len(sp), "us_per_step": round(sp_us, 1), "fp32_equivalent_GFLOP_per_step": round(sp_gf, 2),
-                                             "bf16_TFLOPs_executed": round(sp_gf * t_ / sp_us * 1e3, 1) if sp_us > 0 else None,      # GFLOP / us = PFLOP/s
-                                             "peak_bf16_TFLOPs": 2500.0,
-                                             "frac_of_bf16_peak": round(sp_gf * t_ / sp_us * 1e3 / 2500.0, 4) if sp_us > 0 else None,
-                                             "fp32_mfma_launches_us_per_step": round(sum(r["us"] for r in by_launch) - sp_us, 1)}
+            tab = by_launch_l if (loaded_ok and by_launch_l and len(by_launch_l) == len(by_launch)) else by_launch
+            for row, alone in zip(tab, by_launch):
+                row["us_single_stream"] = alone["us"]
+            line["roofline"]["by_kernel"] = tab
+            bf = [r for r in tab if r["pipe"].startswith("bf16")]
+            f3 = [r for r in tab if not r["pipe"].startswith("bf16")]
+            pipes = {}
+            for nm, rows_, peak in (("bf16", bf, BF16_MFMA_PEAK_TFLOPS), ("fp32", f3, FP32_MFMA_PEAK_TFLOPS)):
+                us = sum(r["us"] for r in rows_) - ovh_l * len(rows_)
+                gf = sum(r["mfma_GFLOP_on_pipe"] for r in rows_)
+                pipes[nm] = {"launches": len(rows_), "us_per_step": round(us, 1), "mfma_GFLOP_per_step": round(gf, 2),
+                             "TFLOPs": round(gf * 1e3 / us, 1) if us > 0 else None, "peak_TFLOPs": peak,
+                             "frac_of_pipe_peak": round(gf * 1e3 / us / peak, 4) if us > 0 else None}
+            line["roofline"]["by_pipe"] = pipes
+            line["roofline"]["mfma_GFLOP_per_step_on_the_pipes"] = {k: v["mfma_GFLOP_per_step"] for k, v in pipes.items()}
+            dominant = "bf16" if pipes["bf16"]["us_per_step"] >= pipes["fp32"]["us_per_step"] else "fp32"
+        else:
+            dominant = "bf16" if _ops_split.MLP_SPLIT_TERMS else "fp32"
+        line["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS if dominant == "bf16" else FP32_MFMA_PEAK_TFLOPS
+        line["roofline"]["achieved"] = round(line["roofline"]["frac"] * line["roofline"]["peak"], 2)
+        fam_timed = fam_l if loaded_ok else fam
+        line["kernels_timed_configuration"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "launches_per_step": v["launches"] // nprof}
+                                               for k, v in sorted(fam_timed.items(), key=lambda kv: -kv[1]["ms"])} if loaded_ok else None
         line["kernels"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "launches_per_step": v["launches"] // nprof}
                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
-        # HBM bytes per launch of the same kernel family from the PMC passes committed under profiles/ (rocprofv3
-        # --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied there); null when absent.
-        for tname in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath) and args.batch == 32 and args.npoints == 16384:
-                try:
-                    line["roofline"]["traffic"] = json.load(open(tpath))["per_step_bs32"]["mlp"]["hbm_bytes_per_launch_corrected"]
-                    line["roofline"]["traffic_unit"] = "bytes/launch; NOT measured in this run: rocprofv3 --pmc passes committed as profiles/%s" % tname
-                    break
-                except (KeyError, ValueError):
-                    pass
+        # HBM bytes per launch of the family, MEASURED IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate runs, as
+        # MI355X_MICROARCH.md prescribes) of a short single-stream eager run of this same script as subprocesses; null when rocprofv3
+        # is unavailable, fails or --no-traffic is given
+        if world == 1 and not args.no_traffic and args.workload == "rpn" and args.input == "clouds":
+            trace("hbm traffic passes")
+            line["roofline"].update(measure_hbm_traffic(args))
         if "fps" in fam:      # the longest single kernel is latency/VALU-bound, neither HBM nor MFMA: report its rate
             evals = args.batch * sum(n * m for n, m in zip([args.npoints] + rpn.RPNConfig.SA_NPOINTS[:-1], rpn.RPNConfig.SA_NPOINTS))
             line["fps_kernel"] = {"ms_per_step": round(fam["fps"]["ms"] / nprof, 3), "distance_evals_per_step": evals,
@@ -1082,6 +1206,26 @@ def main():
                     "note": "1 instruction / 4 cycles at 2.4 GHz; all frames of a batch run their chains concurrently (one workgroup "
                             "each), so the per-step FPS time IS one frame's chain; frac = floor / measured.  The lever left is the "
                             "instruction count per sample, not the issue rate"}
+            # first-class roofline entry of the kernel that holds most of the kernel time (it is bound by neither HBM nor MFMA)
+            tot = sum(v["ms"] for v in fam_timed.values())
+            cus = min(256, args.batch)
+            valu_peak = 256 * 4 * 16 * 2 * 2.4e9 / 10 / 1e9            # G evals/s: 256 CUs x 4 SIMDs x 16 lanes x 2 (packed fp32) x 2.4 GHz / 10 VALU ops per evaluation
+            line["roofline_fps"] = {
+                "kernel": "furthest-point-sampling chain (fps_sort + fps_slot_kernel<16> / fps_pruned_kernel<4> / fps_reg_kernel), one workgroup per frame",
+                "bound": "instruction issue of one wave per sample (serial chain); neither HBM nor MFMA",
+                "achieved": line["fps_kernel"]["Gevals_per_s"], "unit": "G distance-evaluations/s (algorithmic: N x npoint per level, SURVEY 8(d): 71.6 M per frame)",
+                "ms_per_step": line["fps_kernel"]["ms_per_step"],
+                "ms_per_step_timed_configuration": round(fam_timed["fps"]["ms"] / nprof, 3) if "fps" in fam_timed else None,
+                "share_of_kernel_time": round(fam_timed["fps"]["ms"] / tot, 4) if ("fps" in fam_timed and tot > 0) else None,
+                "cu_occupancy": "%d of 256 CUs (one workgroup per frame of the batch)" % cus,
+                "frac": line["fps_kernel"].get("issue_model", {}).get("frac"),
+                "frac_definition": "issue-model floor of one frame's chain (static loop instruction counts x 4 cycles x samples at 2.4 GHz) / measured chain time",
+                "valu_model": {"peak_Gevals_per_s_whole_chip": round(valu_peak, 0), "peak_Gevals_per_s_on_the_occupied_CUs": round(valu_peak * cus / 256, 0),
+                               "frac_of_whole_chip": round(line["fps_kernel"]["Gevals_per_s"] / valu_peak, 4),
+                               "frac_of_occupied_CUs": round(line["fps_kernel"]["Gevals_per_s"] / (valu_peak * cus / 256), 4),
+                               "note": "10 VALU operations per evaluation (3 subtractions, 3 products, 2 sums, minimum, maximum-select) at the packed "
+                                       "fp32 rate; algorithmic evaluations: the exact box pruning skips ~3/4 of them, so the fraction of the occupied "
+                                       "CUs can exceed what the executed instructions alone would give"}}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.input == "clouds":
         trace("cpu baseline")

@@ -24,10 +24,20 @@
  *     device (the reference's nn.DataParallel convention).  The only process-wide state is a per-(kernel, device)
  *     "dynamic-LDS limit already raised" bit, updated atomically (csrc/common.h PrcnnLdsLimit).
  *
- * Arithmetic contract (shared bit-for-bit with oracle/prcnn_oracle.c, trig_mode 1):
- *   squared distances are ((dx*dx + dy*dy) + dz*dz) with individually rounded fp32 operations (no
- *   FMA); box angles use cos/sin evaluated in double and rounded once to fp32; polygon vertices are
- *   ordered by a division-only monotone surrogate of atan2.
+ * Arithmetic contract (shared bit-for-bit with oracle/prcnn_oracle.c):
+ *   - squared distances are ((dx*dx + dy*dy) + dz*dz) with individually rounded fp32 operations (no FMA; the library is built
+ *     with -ffp-contract=off);
+ *   - box trigonometry of roipool3d / pts_in_boxes3d / labels / GT-aug / overlap / IoU / NMS / proposal NMS / RoI sampling is the
+ *     REFERENCE'S HOST ARITHMETIC (oracle trig_mode 2): glibc 2.35's float sinf / cosf / atan2f restated operation by operation
+ *     (csrc/ref_trig.h; prcnn_ref_trig exposes it), because the reference calls cos / sin / atan2 on floats
+ *     (iou3d_kernel.cu:56,104-106,135-136; roipool3d.cpp:89); polygon vertices are ordered by that atan2f, as the reference's
+ *     bubble sort orders them (iou3d_kernel.cu:188-196).  Results are bit-identical to the reference's own sources compiled for
+ *     the host (oracle/_ref, oracle trig_mode 0), near-threshold pairs and on-the-face points included
+ *     (tests/test_gpu_parity_residuals.py);
+ *   - decode_bbox_target and the canonical transform of roipool3d keep cos / sin evaluated in double and rounded once to fp32
+ *     (oracle trig_mode 1): their reference is torch's vectorised cos / sin, pinned to 2.4e-7, not glibc's scalar routines;
+ *   - MLP layers: fp32 accumulation on the matrix pipe, either fp32 MFMA or the exact three-way bf16 split with six products per
+ *     fp32 product (fp32-grade: |err| <= ~3e-7 * sum_k |x_k||w_k| per output element, measured against float64, for both).
  */
 #ifndef PRCNN_POINTOPS_H
 #define PRCNN_POINTOPS_H

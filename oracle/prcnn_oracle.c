@@ -15,7 +15,7 @@
  * PARITY PINNING STATUS
  *   roipool3d / pts_in_boxes3d : PINNED -- checked bit-for-bit against the
  *       reference's own lib/utils/roipool3d/src/roipool3d.cpp compiled in
- *       place (oracle/_ref, tests/test_oracle_vs_ref.py) and via golden
+ *       place (oracle/_ref, tests/test_oracle.py) and via golden
  *       fixtures generated from it (tests/golden/).
  *   iou3d (overlap / iou / nms): PINNED -- checked against the reference's
  *       lib/utils/iou3d/src/iou3d_kernel.cu device functions compiled for the

@@ -3,8 +3,9 @@
 // Replaces iou3d_cuda.{boxes_overlap_bev_gpu, boxes_iou_bev_gpu, nms_gpu, nms_normal_gpu}
 // (lib/utils/iou3d/src/iou3d.cpp:31,52,73,123 -> iou3d_kernel.cu:223-387).  The geometry follows the
 // reference's clipping algorithm step for step (iou3d_kernel.cu:34-221: edge-edge intersections, contained
-// corners, centroid, angular sort, shoelace) under the canonical arithmetic contract shared with
-// oracle/prcnn_oracle.c (trig_mode 1), so results are bit-identical to the oracle.
+// corners, centroid, angular sort, shoelace) in the reference's own host arithmetic -- glibc's float sinf / cosf / atan2f restated
+// bit for bit (ref_trig.h; oracle/prcnn_oracle.c trig_mode 2) -- so results are bit-identical to the oracle AND to the reference's
+// sources compiled for the host (oracle/_ref).
 //
 // What is different from the reference's execution plan:
 //   * per-box work (cos/sin, centre, rotated corners) is done ONCE per box into LDS, not once per pair;

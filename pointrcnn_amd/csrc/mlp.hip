@@ -832,7 +832,8 @@ __global__ __launch_bounds__(MLP_THREADS, (LayerBOcc<MODE, WNB, FAST, ADDY>::W))
 }
 
 // =====================================================================================================
-// Split-bf16 plain layer (an explicitly requested VARIANT, never the default arithmetic): every fp32 operand is cut into three
+// Split-bf16 plain layer (the DEFAULT arithmetic of the plain-row layers since round 4, TERMS = 6; PRCNN_MLP_SPLIT=0 selects the
+// fp32-MFMA kernels above, TERMS = 3 is an explicitly requested variant outside the 1e-5 contract): every fp32 operand is cut into three
 // bf16 pieces x = x0 + x1 + x2 -- EXACTLY: x0 = the top 16 bits of x, x1 = the top 16 bits of x - x0, x2 = x - x0 - x1, which
 // has at most 8 significant bits left -- and the product is rebuilt from bf16 MFMAs (v_mfma_f32_32x32x16_bf16, fp32
 // accumulate, 16x the fp32-MFMA rate):

@@ -12,7 +12,7 @@ BASELINE config-5 dense case (65 536 pts, 512 RoIs, batch 8), prints one JSON li
                       (`served_from_cache`) instead of reporting a fraction above 1 (the round-2 file listed 0.92 of 8 TB/s for
                       grouping_operation: 7.4 TB/s of algorithmic bytes, 1.3 TB/s of HBM traffic);
       PMC bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction) are merged into the committed
-      file by profiles/derive_opbench_pmc.py when those passes were run;
+      file by profiles/join_op_traffic.py when those passes were run;
     search ops (fps / ball_query / three_nn / nms): distance (pair) evaluations per second;
     fused MLP: algorithmic FLOP/s vs 157.3 TFLOP/s dense fp32 MFMA.
 Algorithmic work per unit follows SURVEY.md 8(d).

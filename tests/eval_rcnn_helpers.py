@@ -44,7 +44,9 @@ def make_ckpt(out, seed):
     _rcnn_mode_cfg()
     from lib.net.point_rcnn import PointRCNN
     import tools.train_utils.train_utils as train_utils
-    model = PointRCNN(num_classes=2, use_xyz=True, mode="TEST")
+    import contextlib
+    with (contextlib.nullcontext() if torch.cuda.is_available() else cpu_ops.cuda_is_cpu()):      # ProposalLayer.__init__ calls .cuda()
+        model = PointRCNN(num_classes=2, use_xyz=True, mode="TEST")
     cpu_ops.fill_params_by_name(model, int(seed))
     assert out.endswith(".pth")
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
