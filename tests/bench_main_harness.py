@@ -8,7 +8,9 @@ replaced, in THIS process only:
   * dist.init_process_group("nccl", device_id=...) -> the same call with backend "gloo";
   * the library loader and the two workloads' compute: InferenceBench / run_train become stubs that keep the real
     barrier + reduce_elapsed sequence and sleep (rank + 1) * 5 ms per step, so the slow rank is rank 1;
-  * bench.self_launch_command -> the same command line pointing at this harness instead of bench.py.
+  * bench.self_launch_command -> the same command line pointing at this harness instead of bench.py;
+  * PRCNN_HARNESS_REAL_PIPELINE=1: InferenceBench is NOT replaced -- bench.py's own client code drives the real
+    pointrcnn_amd.pipeline.InferencePipeline (device "cpu": slots, tickets, bounded queue, in-order results) around a toy model.
 Everything else -- main()'s control flow -- is bench.py's own code."""
 import os
 import sys
@@ -116,12 +118,27 @@ class _Model:
         return self
 
 
-bench.InferenceBench = StubBench
+class _TinyRPN(torch.nn.Module):
+    """stand-in model for PRCNN_HARNESS_REAL_PIPELINE=1: the REAL bench.InferenceBench and pointrcnn_amd.pipeline.InferencePipeline
+    (device "cpu": ticket / slot bookkeeping with eager steps) run under torch.distributed.run; only the network is a toy that
+    takes (rank + 1) * 3 ms per step and returns the keys InferenceBench checks"""
+
+    def forward(self, inp):
+        x = inp["pts_input"]
+        time.sleep(0.003 * (_rank() + 1))
+        f = x.sum(2, keepdim=True)
+        return {"rpn_cls": f * 0.5, "rpn_reg": f.expand(-1, -1, 4).contiguous() + 1.0, "backbone_features": f.transpose(1, 2), "backbone_xyz": x}
+
+
+if os.environ.get("PRCNN_HARNESS_REAL_PIPELINE") == "1":
+    torch.Tensor.pin_memory = lambda self, *a, **k: self          # no CUDA runtime here: "pinned" host tensors are plain ones
+else:
+    bench.InferenceBench = StubBench
 bench.run_train = _stub_train
 bench.run_train_rcnn = _stub_train
 from pointrcnn_amd import rpn  # noqa: E402
 
-rpn.RPN = lambda *a, **k: _Model()
+rpn.RPN = (lambda *a, **k: _TinyRPN()) if os.environ.get("PRCNN_HARNESS_REAL_PIPELINE") == "1" else (lambda *a, **k: _Model())
 rpn.randomize_bn_stats = lambda m, seed=0: m
 
 if __name__ == "__main__":

@@ -68,3 +68,23 @@ def test_main_refuses_a_world_size_that_disagrees_with_gpus():
     env = dict(_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, HARNESS, "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in r.stderr
+
+
+def test_inference_pipeline_bookkeeping_under_torch_distributed_run():
+    """bench.py's REAL InferenceBench + pointrcnn_amd.pipeline.InferencePipeline (device "cpu": the slot / ticket /
+    bounded-queue logic, eager steps) under `python -m torch.distributed.run`, world 2, gloo: 3 slots, more steps than slots (slots are
+    reused, results collected in order), H2D-style submits and the one-batch-in-flight loop included (the variants' loops); rank 1's
+    model is the slow one and sets the time"""
+    steps = 7
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), HARNESS, "--gpus", "2", "--steps", str(steps), "--warmup", "2", "--batch", "4", "--npoints", "256",
+           "--streams", "3", "--proposals", "off", "--graph", "off", "--no-roofline", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(_env(), PRCNN_HARNESS_REAL_PIPELINE="1", PRCNN_BENCH_NO_SPLIT="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["config"]["streams"] == 3 and line["config"]["launch"] == "eager"
+    assert line["ms_per_step"] >= 5.5                                  # rank 1: 6 ms per step
+    assert abs(line["value"] - 4 * 2 * 1e3 / line["ms_per_step"]) <= 0.01 * line["value"]
+    assert line["value_h2d_inclusive"] > 0 and line["value_latency_mode"] > 0
