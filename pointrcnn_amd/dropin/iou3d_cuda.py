@@ -16,17 +16,29 @@ def _check_input(t, name):
         raise RuntimeError("%s must be contiguous " % name)
 
 
+def _rows5(boxes, name):
+    """The pybind functions take `boxes.size(0)` rows of five contiguous floats from the data pointer, whatever the tensor's other
+    dimensions (iou3d.cpp:80-81,40-41): tools/eval_rcnn.py:617-619 hands nms_gpu an (N, 1, 5) tensor -- scores of shape (N, 1) index
+    the boxes in iou3d_utils.py:64-66.  Same acceptance here: any contiguous tensor of N x 5 elements is N rows."""
+    n = boxes.shape[0] if boxes.dim() else 0
+    if boxes.dim() == 2 and boxes.shape[1] == 5:
+        return boxes
+    if boxes.numel() != n * 5:
+        raise RuntimeError("%s must hold size(0) x 5 floats [x1, y1, x2, y2, ry], got shape %s" % (name, tuple(boxes.shape)))
+    return boxes.view(n, 5)
+
+
 def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
     for t, n in ((boxes_a, "boxes_a"), (boxes_b, "boxes_b"), (ans_overlap, "ans_overlap")):
         _check_input(t, n)
-    ops.boxes_overlap_bev(boxes_a, boxes_b, out=ans_overlap)
+    ops.boxes_overlap_bev(_rows5(boxes_a, "boxes_a"), _rows5(boxes_b, "boxes_b"), out=ans_overlap)
     return 1
 
 
 def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
     for t, n in ((boxes_a, "boxes_a"), (boxes_b, "boxes_b"), (ans_iou, "ans_iou")):
         _check_input(t, n)
-    ops.boxes_iou_bev(boxes_a, boxes_b, out=ans_iou)
+    ops.boxes_iou_bev(_rows5(boxes_a, "boxes_a"), _rows5(boxes_b, "boxes_b"), out=ans_iou)
     return 1
 
 
@@ -34,7 +46,7 @@ def _nms(boxes, keep, thresh, rotated):
     _check_input(boxes, "boxes")
     if not keep.is_contiguous():
         raise RuntimeError("keep must be contiguous ")
-    keep_dev, num = ops.nms_sorted(boxes, thresh, rotated=rotated)
+    keep_dev, num = ops.nms_sorted(_rows5(boxes, "boxes"), thresh, rotated=rotated)
     n = int(num.item())
     if n:
         keep[:n].copy_(keep_dev[:n])

@@ -6,6 +6,7 @@
 Inputs (all under profiles/):
   <tag>_final_kernel_stats.txt   rocprofv3 --kernel-trace --stats of the TIMED configuration (`python bench.py`: 20 batches in flight,
                                  hipGraph replay): per kernel name, calls and total duration
+  <tag>_final_kernel_stats_streams1.txt   the same with --streams 1 (one batch on the chip: what bench.py's HIP events time)
   <tag>_mfma_util.txt            rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_{F32,BF16} per launch of one bs32 step: MFMA flops the matrix
                                  pipe was given, by pipe (x 512 flops per counted operation)
   <tag>_final_bench.json         the bench line whose roofline.frac is being checked
@@ -51,10 +52,7 @@ def mfma_flops(path):
     return f32, bf16
 
 
-def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
-    ks = kernel_stats(os.path.join(HERE, tag + "_final_kernel_stats.txt"))
-    f32, bf16 = mfma_flops(os.path.join(HERE, tag + "_mfma_util.txt"))
+def one(ks, f32, bf16, what):
     # steps in the trace = launches of a kernel that runs once per step (level-0 FPS)
     once = [c for n, (c, _) in ks.items() if "fps_slot_kernel<16>" in n or "fps_pruned_kernel<16>" in n]
     steps = once[0] if once else None
@@ -64,20 +62,28 @@ def main():
     us_per_step = fam_us / steps
     at_peak_us = (f32 / FP32_PEAK + bf16 / BF16_PEAK) * 1e3          # GFLOP / (TFLOP/s) = ms -> us
     frac = at_peak_us / us_per_step
-    print("steps in the trace          %d" % steps)
-    print("family kernel time          %.1f us per step (timed configuration, rocprofv3 kernel trace)" % us_per_step)
-    print("MFMA work                   %.1f GFLOP fp32 pipe + %.1f GFLOP bf16 pipe per step (PMC counters)" % (f32, bf16))
-    print("time at the pipes' peaks    %.1f us" % at_peak_us)
-    print("roofline.frac recomputed    %.4f" % frac)
+    print("%s: %d steps in the trace, family kernel time %.1f us per step, time at the pipes' peaks %.1f us -> frac %.4f" %
+          (what, steps, us_per_step, at_peak_us, frac))
+    return frac
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    f32, bf16 = mfma_flops(os.path.join(HERE, tag + "_mfma_util.txt"))
+    print("MFMA work per step (PMC counters): %.1f GFLOP on the fp32 pipe + %.1f GFLOP on the bf16 pipe" % (f32, bf16))
+    timed = one(kernel_stats(os.path.join(HERE, tag + "_final_kernel_stats.txt")), f32, bf16, "timed configuration (20 batches in flight)")
+    alone = None
+    p1 = os.path.join(HERE, tag + "_final_kernel_stats_streams1.txt")
+    if os.path.exists(p1):
+        alone = one(kernel_stats(p1), f32, bf16, "one batch on the chip (--streams 1)            ")
     bj = os.path.join(HERE, tag + "_final_bench.json")
     if os.path.exists(bj):
         line = json.loads(open(bj).read().strip().splitlines()[-1])
         got = line["roofline"]["frac"]
-        print("roofline.frac of the line   %.4f   (ratio %.3f; bench.py measures the durations with HIP events in the same configuration)" %
-              (got, got / frac))
-        if "family_us_per_step" in line["roofline"]:
-            print("line's family time          %.1f us per step" % line["roofline"]["family_us_per_step"])
-        return 0 if abs(got / frac - 1.0) <= 0.05 else 1
+        print("roofline.frac of the bench line (HIP events, one batch on the chip): %.4f" % got)
+        if alone:
+            print("  ratio to the single-stream trace %.3f, to the timed configuration %.3f" % (got / alone, got / timed))
+            return 0 if abs(got / alone - 1.0) <= 0.05 else 1
     return 0
 
 

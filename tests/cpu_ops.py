@@ -86,26 +86,32 @@ def oracle_ops(trig_mode=2):
         pooled_empty_flag.copy_(_t(empty))
         return 1
 
-    def nms(kind):
-        def f(boxes, keep, thresh):
-            k = cpu.nms(_np(boxes), thresh, kind, trig_mode)
-            keep[: len(k)] = _t(k)
-            return len(k)
-        return f
+    # iou3d: the ENTRY POINTS of the drop-in module run as they are (argument checks, the (N, 1, 5) acceptance, the copy into the
+    # caller's CPU `keep`); what is routed to the oracle is the tensor-level layer underneath them, and the is_cuda test of CHECK_INPUT
+    def nms_sorted(boxes_sorted, thresh, rotated=True, max_keep=0):
+        assert boxes_sorted.dim() == 2 and boxes_sorted.shape[1] == 5, tuple(boxes_sorted.shape)
+        k = cpu.nms(_np(boxes_sorted), thresh, "rotated" if rotated else "normal", trig_mode)
+        keep = torch.zeros((max(boxes_sorted.shape[0], 1),), dtype=torch.int64)
+        keep[: len(k)] = _t(k)
+        return keep, torch.tensor([len(k)], dtype=torch.int32)
 
-    def overlap(boxes_a, boxes_b, out):
-        out.copy_(_t(cpu.boxes_overlap_bev(_np(boxes_a), _np(boxes_b), trig_mode)))
-        return 1
+    def overlap(boxes_a, boxes_b, out=None):
+        r = _t(cpu.boxes_overlap_bev(_np(boxes_a), _np(boxes_b), trig_mode))
+        return r if out is None else out.copy_(r)
 
-    def iou(boxes_a, boxes_b, out):
-        out.copy_(_t(cpu.boxes_iou_bev(_np(boxes_a), _np(boxes_b), trig_mode)))
-        return 1
+    def iou(boxes_a, boxes_b, out=None):
+        r = _t(cpu.boxes_iou_bev(_np(boxes_a), _np(boxes_b), trig_mode))
+        return r if out is None else out.copy_(r)
+
+    def check_input(t, name):
+        if not t.is_contiguous():
+            raise RuntimeError("%s must be contiguous " % name)
 
     patch(roipool3d_cuda, "forward", rp_forward)
-    patch(iou3d_cuda, "nms_gpu", nms("rotated"))
-    patch(iou3d_cuda, "nms_normal_gpu", nms("normal"))
-    patch(iou3d_cuda, "boxes_overlap_bev_gpu", overlap)
-    patch(iou3d_cuda, "boxes_iou_bev_gpu", iou)
+    patch(ops, "nms_sorted", nms_sorted)
+    patch(ops, "boxes_overlap_bev", overlap)
+    patch(ops, "boxes_iou_bev", iou)
+    patch(iou3d_cuda, "_check_input", check_input)
     try:
         yield cpu
     finally:
