@@ -49,6 +49,75 @@ __device__ __forceinline__ int row0_max_i32_fused(int v) {          // first 16 
     return __builtin_amdgcn_readlane(v, 15);
 }
 
+// Wave maximum of `best` AND, per lane, the bit mask of the slots holding the lane's own maximum (bit i = pt[i] == best), in one
+// hand-scheduled block (round 5).  A slot costs two VALU: v_cmp_eq into VCC, then v_addc_co acc = acc + acc + VCC, i.e. (acc << 1) | hit
+// -- where "lowest slot holding the maximum" + "how many slots hold it" cost three per slot each way before (compare, select the slot
+// number, count).  The slot steps are issued BETWEEN the six DPP steps of the maximum, whose VALU-write -> DPP-read hazard (two wait
+// states) they cover: no s_nop.  The owner lane's mask is read out with one v_readlane; its lowest set bit is the slot, its population
+// count says whether the maximum is unique in the lane.  An updating wave issues ~one instruction per 4-5 cycles, so this is latency
+// of every sample (fps_slot_kernel<16>: -24 VALU, -6 s_nop per update).
+#define FPS_EQ(p) "v_cmp_eq_f32 vcc, " p ", %[best]\n\tv_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+#define FPS_DPPS(ctrl) "v_max_i32_dpp %[t], %[t], %[t] " ctrl "\n\t"
+template <int PPT> struct WaveMaxEq;
+template <> struct WaveMaxEq<16> {
+    template <class V> static __device__ __forceinline__ int run(const V& pt, float best, unsigned& eqbits) {
+        int t; unsigned acc;
+        asm volatile("v_mov_b32 %[t], %[best]\n\tv_mov_b32 %[acc], 0\n\t"
+                     FPS_EQ("%[p15]") FPS_DPPS("row_shr:1 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p14]") FPS_DPPS("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p13]") FPS_DPPS("row_shr:4 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p12]") FPS_DPPS("row_shr:8 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p11]") FPS_DPPS("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                     FPS_EQ("%[p10]") FPS_DPPS("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     FPS_EQ("%[p9]") FPS_EQ("%[p8]") FPS_EQ("%[p7]") FPS_EQ("%[p6]") FPS_EQ("%[p5]")
+                     FPS_EQ("%[p4]") FPS_EQ("%[p3]") FPS_EQ("%[p2]") FPS_EQ("%[p1]") FPS_EQ("%[p0]")
+                     : [t] "=&v"(t), [acc] "=&v"(acc)
+                     : [best] "v"(best), [p0] "v"(pt[0]), [p1] "v"(pt[1]), [p2] "v"(pt[2]), [p3] "v"(pt[3]), [p4] "v"(pt[4]), [p5] "v"(pt[5]),
+                       [p6] "v"(pt[6]), [p7] "v"(pt[7]), [p8] "v"(pt[8]), [p9] "v"(pt[9]), [p10] "v"(pt[10]), [p11] "v"(pt[11]),
+                       [p12] "v"(pt[12]), [p13] "v"(pt[13]), [p14] "v"(pt[14]), [p15] "v"(pt[15])
+                     : "vcc");
+        eqbits = acc;
+        return __builtin_amdgcn_readlane(t, 63);          // (twenty VALU after the last DPP step)
+    }
+};
+template <> struct WaveMaxEq<8> {
+    template <class V> static __device__ __forceinline__ int run(const V& pt, float best, unsigned& eqbits) {
+        int t; unsigned acc;
+        asm volatile("v_mov_b32 %[t], %[best]\n\tv_mov_b32 %[acc], 0\n\t"
+                     FPS_EQ("%[p7]") FPS_DPPS("row_shr:1 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p6]") FPS_DPPS("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p5]") FPS_DPPS("row_shr:4 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p4]") FPS_DPPS("row_shr:8 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p3]") FPS_DPPS("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                     FPS_EQ("%[p2]") FPS_DPPS("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     FPS_EQ("%[p1]") FPS_EQ("%[p0]")
+                     : [t] "=&v"(t), [acc] "=&v"(acc)
+                     : [best] "v"(best), [p0] "v"(pt[0]), [p1] "v"(pt[1]), [p2] "v"(pt[2]), [p3] "v"(pt[3]), [p4] "v"(pt[4]), [p5] "v"(pt[5]),
+                       [p6] "v"(pt[6]), [p7] "v"(pt[7])
+                     : "vcc");
+        eqbits = acc;
+        return __builtin_amdgcn_readlane(t, 63);
+    }
+};
+template <> struct WaveMaxEq<4> {
+    template <class V> static __device__ __forceinline__ int run(const V& pt, float best, unsigned& eqbits) {
+        int t; unsigned acc;
+        asm volatile("v_mov_b32 %[t], %[best]\n\tv_mov_b32 %[acc], 0\n\t"
+                     FPS_EQ("%[p3]") FPS_DPPS("row_shr:1 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p2]") FPS_DPPS("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p1]") FPS_DPPS("row_shr:4 row_mask:0xf bank_mask:0xf")
+                     FPS_EQ("%[p0]") FPS_DPPS("row_shr:8 row_mask:0xf bank_mask:0xf")
+                     "s_nop 1\n\t" FPS_DPPS("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                     "s_nop 1\n\t" FPS_DPPS("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     "s_nop 1\n\t"
+                     : [t] "=&v"(t), [acc] "=&v"(acc)
+                     : [best] "v"(best), [p0] "v"(pt[0]), [p1] "v"(pt[1]), [p2] "v"(pt[2]), [p3] "v"(pt[3])
+                     : "vcc");
+        eqbits = acc;
+        return __builtin_amdgcn_readlane(t, 63);
+    }
+};
+
 template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict__ xyz, int N, int npoint,
                                                         int32_t* __restrict__ idx_out) {
@@ -343,7 +412,8 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
                 pt[0] = t; best = t;
             }
             FPS_T(unsigned long long u1 = __builtin_readcyclecounter(); t_u1 += u1 - u0;)
-            const int wmax = wave_max_i32_fused(__float_as_int(best));
+            unsigned eqbits;
+            const int wmax = WaveMaxEq<PPT>::run(pt, best, eqbits);
             const float wmaxf = __int_as_float(wmax);
             FPS_T(unsigned long long u2 = __builtin_readcyclecounter(); t_u2 += u2 - u1;)
             // candidates = (lane, slot) with t == wmax; the one with the LOWEST ORIGINAL index wins.  Fast path (a
@@ -352,17 +422,11 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
             // tools/fps_timing.py: ~1450 cycles per update, of which a per-slot ballot + scalar select chain took ~600).
             // Here every lane finds the lowest slot holding ITS maximum and how many slots do (3 VALU per slot, no scalar
             // chain); one ballot finds the lanes holding the wave maximum; unique lane with a unique slot = fast path.
-            int myslot = 0, mycnt = 0;
-#pragma unroll
-            for (int i = PPT - 1; i >= 0; i--) {
-                const bool e = pt[i] == best;
-                myslot = e ? i : myslot;
-                mycnt += e ? 1 : 0;
-            }
             const unsigned long long anym = __ballot(best == wmaxf);
             const int owner0 = __builtin_ctzll(anym);
-            const int total = (__popcll(anym) == 1 && __builtin_amdgcn_readlane(mycnt, owner0) == 1) ? 1 : 2;
-            int istar = __builtin_amdgcn_readlane(myslot, owner0);
+            const unsigned ownbits = (unsigned)__builtin_amdgcn_readlane((int)eqbits, owner0);       // the owner lane's slots holding the maximum
+            const int total = (__popcll(anym) == 1 && __popc(ownbits) == 1) ? 1 : 2;
+            int istar = __builtin_ctz(ownbits);
             FPS_T(unsigned long long u3 = __builtin_readcyclecounter(); t_u3 += u3 - u2;)
             if (total == 1) {
                 const int owner = owner0;
@@ -531,7 +595,8 @@ __global__ __launch_bounds__(1024) void fps_slot_kernel(const float* __restrict_
             float best = pt[0];
 #pragma unroll
             for (int i = 1; i < PPT; i++) best = __builtin_fmaxf(best, pt[i]);
-            const int wmax = wave_max_i32_fused(__float_as_int(best));
+            unsigned eqbits;
+            const int wmax = WaveMaxEq<PPT>::run(pt, best, eqbits);
             const float wmaxf = __int_as_float(wmax);
             // candidates = (lane, slot) with t == wmax; the one with the LOWEST ORIGINAL index wins.  Fast path (a
             // unique maximum, the overwhelmingly common case).  An updating wave is usually ALONE on its SIMD and issues one
@@ -539,17 +604,11 @@ __global__ __launch_bounds__(1024) void fps_slot_kernel(const float* __restrict_
             // tools/fps_timing.py: ~1450 cycles per update, of which a per-slot ballot + scalar select chain took ~600).
             // Here every lane finds the lowest slot holding ITS maximum and how many slots do (3 VALU per slot, no scalar
             // chain); one ballot finds the lanes holding the wave maximum; unique lane with a unique slot = fast path.
-            int myslot = 0, mycnt = 0;
-#pragma unroll
-            for (int i = PPT - 1; i >= 0; i--) {
-                const bool e = pt[i] == best;
-                myslot = e ? i : myslot;
-                mycnt += e ? 1 : 0;
-            }
             const unsigned long long anym = __ballot(best == wmaxf);
             const int owner0 = __builtin_ctzll(anym);
-            const int total = (__popcll(anym) == 1 && __builtin_amdgcn_readlane(mycnt, owner0) == 1) ? 1 : 2;
-            int istar = __builtin_amdgcn_readlane(myslot, owner0);
+            const unsigned ownbits = (unsigned)__builtin_amdgcn_readlane((int)eqbits, owner0);       // the owner lane's slots holding the maximum
+            const int total = (__popcll(anym) == 1 && __popc(ownbits) == 1) ? 1 : 2;
+            int istar = __builtin_ctz(ownbits);
             if (total == 1) {
                 const int owner = owner0;
                 corig = s_po[istar * BLOCK + (wave << 6) + owner];          // own wave's entries: no barrier needed

@@ -5,7 +5,7 @@
 // reference's clipping algorithm step for step (iou3d_kernel.cu:34-221: edge-edge intersections, contained
 // corners, centroid, angular sort, shoelace) in the reference's own host arithmetic -- glibc's float sinf / cosf / atan2f restated
 // bit for bit (ref_trig.h; oracle/prcnn_oracle.c trig_mode 2) -- so results are bit-identical to the oracle AND to the reference's
-// sources compiled for the host (oracle/_ref).
+// sources compiled for the host (the test suite's reference build).
 //
 // What is different from the reference's execution plan:
 //   * per-box work (cos/sin, centre, rotated corners) is done ONCE per box into LDS, not once per pair;

@@ -33,7 +33,7 @@ def main():
                     best = span
         if best is None:
             continue
-        ins = [l.strip().split()[0] for l in body[best[0]:best[1] + 1] if l.startswith("\t") and not l.strip().startswith((";", "."))]
+        ins = [l.strip().split()[0] for l in body[best[0]:best[1] + 1] if l.startswith("\t") and l.strip() and not l.strip().startswith((";", "."))]
         cls = {"valu": 0, "salu": 0, "lds": 0, "vmem": 0, "barrier": 0, "other": 0}
         for op in ins:
             if op.startswith("v_"): cls["valu"] += 1
