@@ -947,28 +947,27 @@ __device__ __forceinline__ void split_redo_f32(const MlpParams& P, f32x16 (&acc)
     }
 }
 
+// One 128-row tile of the split layer: the body of mlp_layer_s_kernel.  (bx, by) = the workgroup's grid position, or, in the
+// bounded-grid form, the position the tile loop stands in for; tid = the thread's index, passed in so that the tile loop can hand in
+// an opaque copy per tile (see mlp_layer_s_kernel).
 template <int WNB, int TERMS, bool ADDY>
-__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpParams Pin) {
-    MlpParams P = Pin;
-    P.rows = effective_rows(Pin);
+__device__ __forceinline__ void layer_s_tile(const MlpParams& P, const long bx, const int by, const int tid, unsigned char* __restrict__ Ls) {
     constexpr int QN = 2 * WNB;
     constexpr int NP = TERMS == 6 ? 3 : 2;               // pieces in use
     long tile_id;
     int nb0;
     if (P.wgm_cols > 0) {
-        const long bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+        const long bid = bx, xcd = bid & 7, slot = bid >> 3;
         const long rl = slot / P.wgm_cols;
         tile_id = rl * 8 + xcd;
         nb0 = (int)(slot - rl * P.wgm_cols) * QN;
     } else {
-        tile_id = tile_of_block(P, blockIdx.x);
-        nb0 = blockIdx.y * QN;
+        tile_id = tile_of_block(P, bx);
+        nb0 = by * QN;
     }
     if (tile_id * MLP_BM >= P.rows) return;
     if (tile_dead(P, tile_id * MLP_BM)) return;
-    __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * 3 * SPL_PLANE];
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, j = lane & 31;
@@ -1150,6 +1149,31 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpPa
         if (bad) addy_done = false;
     }
     layer_epilogue<MODE_PLAIN, WNB, ADDY>(P, acc, reinterpret_cast<float*>(Ls), nullptr, tid, row0, nb0, n_active, addy_done);
+}
+
+// LOOP = false: one workgroup per tile (the grid covers the launch's row count).
+// LOOP = true (round 5): the BOUNDED-GRID form for launches sized for the capacity of a compacted list (device-side row count: the
+// RCNN stage's lists hold 0.4-0.6 M live rows of 6.5-26 M): a fixed number of workgroups walk the LIVE tiles, where the one-tile form
+// retired one empty workgroup per 128 rows of CAPACITY (90-100 us of pure dispatch per launch, seven launches per two-stage step).
+// A plain loop around the body cost 20-48 VGPRs (round 4: the optimiser keeps every lane-derived address of the body live across
+// the back edge); here each trip derives everything from an OPAQUE copy of the thread index (a volatile v_mov the optimiser cannot
+// hoist or merge), so nothing but the loop counter lives across tiles and the body is allocated as in the one-tile form.
+template <int WNB, int TERMS, bool ADDY, bool LOOP>
+__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpParams Pin) {
+    MlpParams P = Pin;
+    P.rows = effective_rows(Pin);
+    __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * 3 * SPL_PLANE];
+    if constexpr (LOOP) {
+        const long nbid = ((P.rows + MLP_BM - 1) / MLP_BM + 7) / 8 * 8 * P.wgm_cols;       // 1-D XCD-aware order only (launch_mlp)
+        for (long bid = blockIdx.x; bid < nbid; bid += gridDim.x) {
+            int tid;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"(threadIdx.x));
+            layer_s_tile<WNB, TERMS, ADDY>(P, bid, 0, tid, Ls);
+            __syncthreads();                             // the next tile's LDS writes vs this tile's last reads
+        }
+    } else {
+        layer_s_tile<WNB, TERMS, ADDY>(P, blockIdx.x, blockIdx.y, threadIdx.x, Ls);
+    }
 }
 
 // =====================================================================================================
@@ -2155,10 +2179,16 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
             P.wgm_cols = (int)grid.y;
             grid = dim3((unsigned)(prcnn_divup(grid.x, 8) * 8 * grid.y), 1);
         }
+        // a launch sized for the CAPACITY of a compacted list (device-side row count): 2048 workgroups (four rounds of the 512 resident
+        // ones, a multiple of the 8 XCDs) walk the live tiles instead of one workgroup per tile of capacity; PRCNN_BOUNDED_GRID=0: A/B
+        static const bool bounded_on = !(getenv("PRCNN_BOUNDED_GRID") && atoi(getenv("PRCNN_BOUNDED_GRID")) == 0);
+        const bool bounded = bounded_on && P.rows_dev && !P.seg_cnt && !P.addY && grid.x > 2048u;
+        if (bounded) grid = dim3(2048u, 1);
 #define SPL_LAUNCH(W, T)                                                                                                  \
     do {                                                                                                                  \
-        if (P.addY) hipLaunchKernelGGL((mlp_layer_s_kernel<W, T, true>), grid, dim3(MLP_THREADS), 0, s, P);               \
-        else hipLaunchKernelGGL((mlp_layer_s_kernel<W, T, false>), grid, dim3(MLP_THREADS), 0, s, P);                     \
+        if (P.addY) hipLaunchKernelGGL((mlp_layer_s_kernel<W, T, true, false>), grid, dim3(MLP_THREADS), 0, s, P);        \
+        else if (bounded) hipLaunchKernelGGL((mlp_layer_s_kernel<W, T, false, true>), grid, dim3(MLP_THREADS), 0, s, P);  \
+        else hipLaunchKernelGGL((mlp_layer_s_kernel<W, T, false, false>), grid, dim3(MLP_THREADS), 0, s, P);              \
     } while (0)
         if (wide) { if (P.split_terms == 6) SPL_LAUNCH(2, 6); else SPL_LAUNCH(2, 3); }
         else { if (P.split_terms == 6) SPL_LAUNCH(1, 6); else SPL_LAUNCH(1, 3); }
