@@ -1165,34 +1165,39 @@ def main():
                                   "Gevals_per_s": round(evals / (fam["fps"]["ms"] / nprof * 1e-3) / 1e9, 1),
                                   "note": "serial chain, 1 workgroup/frame (32 of 256 CUs); hidden by --streams"}
             if args.npoints == 16384 and list(rpn.RPNConfig.SA_NPOINTS) == [4096, 1024, 256, 64]:
-                # Issue-bound model of the serial chain: every sample is one trip of the kernel's sample loop on the critical
-                # wave; a lone wave issues at most one instruction per 4 cycles (wave64 on SIMD-32: two passes + dependency),
-                # so the floor of a frame's chain is (loop instructions) x 4 cycles x samples.  Static instruction counts of the
-                # sample loops from the gfx950 ISA (tools/fps_isa_count.py): level 0 fps_slot_kernel<16> 494 (every pair block counted:
-                # an updating wave skips the pairs the sample cannot reach, ~13 instructions each), level 1 fps_pruned_kernel<4> 260,
-                # level 2 fps_reg_kernel<64,16> 211 (single wave), level 3 fps_reg_kernel<64,4> 95.
-                instr = (494 * 4095 + 260 * 1023 + 211 * 255 + 95 * 63)
+                # Issue-bound model of the serial chain (round 5: DYNAMIC instruction counts).  Every sample is one trip of the kernel's sample
+                # loop on the wave that finishes last -- an updating wave on its fast path; a lone wave issues at most one instruction per
+                # 4 cycles, so the floor of a frame's chain is (instructions on that path) x 4 cycles x samples.  Counts from the gfx950 ISA
+                # (hipcc -S, block by block): level 0 fps_slot_kernel<16,16>: 168 + 14 per reachable pair of slots, 3.2 pairs per update
+                # measured (tools/fps_timing.py) = 213 (bound test 19, pair dispatch 23, maximum 8, slot masks + wave maximum 42, owner
+                # search + selects 26, candidate 9, publish 11, barrier + collect 19, loop 11; the tie path, 190 instructions, runs only on
+                # exactly equal distances; a wave that does not update issues 62); level 1 fps_pruned_kernel<4>: 170; level 2
+                # fps_reg_kernel<64,16> (one wave, no exchange) 211; level 3 fps_reg_kernel<64,4> 95.  Rounds 3-4 priced the STATIC loop
+                # (494: all eight pair blocks and the tie path), which the round-5 kernel undercuts.
+                instr = (213 * 4095 + 170 * 1023 + 211 * 255 + 95 * 63)
                 floor_ms = instr * 4 / 2.4e9 * 1e3
                 line["fps_kernel"]["issue_model"] = {
                     "bound": "instruction issue of one wave (serial chain)", "instructions_per_frame_chain": instr,
                     "floor_ms_per_frame_chain": round(floor_ms, 3), "achieved_ms_per_frame_chain": round(fam["fps"]["ms"] / nprof, 3),
-                    "frac": round(floor_ms / (fam["fps"]["ms"] / nprof), 3),
-                    "note": "1 instruction / 4 cycles at 2.4 GHz; all frames of a batch run their chains concurrently (one workgroup "
-                            "each), so the per-step FPS time IS one frame's chain; frac = floor / measured.  The lever left is the "
-                            "instruction count per sample, not the issue rate"}
+                    "frac": round(min(1.0, floor_ms / (fam["fps"]["ms"] / nprof)), 3),
+                    "note": "dynamic instructions of the critical wave x 4 cycles at 2.4 GHz; all frames of a batch run their chains "
+                            "concurrently (one workgroup each), so the per-step FPS time IS one frame's chain; frac = floor / measured.  "
+                            "What separates the two: a dependent instruction issues after ~6 cycles, not 4 (measured: the one-accumulator "
+                            "slot-mask chain against the two-accumulator one), two LDS round trips and one barrier per sample, and four "
+                            "waves sharing a SIMD's VALU while all sixteen run the bound test"}
             # first-class roofline entry of the kernel that holds most of the kernel time (it is bound by neither HBM nor MFMA)
             tot = sum(v["ms"] for v in fam_timed.values())
             cus = min(256, args.batch)
             valu_peak = 256 * 4 * 16 * 2 * 2.4e9 / 10 / 1e9            # G evals/s: 256 CUs x 4 SIMDs x 16 lanes x 2 (packed fp32) x 2.4 GHz / 10 VALU ops per evaluation
             line["roofline_fps"] = {
-                "kernel": "furthest-point-sampling chain (fps_sort + fps_slot_kernel<16> / fps_pruned_kernel<4> / fps_reg_kernel), one workgroup per frame",
+                "kernel": "furthest-point-sampling chain (fps_sort + fps_slot_kernel<16,16> / fps_pruned_kernel<4> / fps_reg_kernel), one workgroup per frame",
                 "bound": "instruction issue of one wave per sample (serial chain); neither HBM nor MFMA",
                 "achieved": line["fps_kernel"]["Gevals_per_s"], "unit": "G distance-evaluations/s (algorithmic: N x npoint per level, SURVEY 8(d): 71.6 M per frame)",
                 "ms_per_step": line["fps_kernel"]["ms_per_step"],
                 "share_of_kernel_time_single_stream": round(fam_timed["fps"]["ms"] / tot, 4) if ("fps" in fam_timed and tot > 0) else None,
                 "cu_occupancy": "%d of 256 CUs (one workgroup per frame of the batch)" % cus,
                 "frac": line["fps_kernel"].get("issue_model", {}).get("frac"),
-                "frac_definition": "issue-model floor of one frame's chain (static loop instruction counts x 4 cycles x samples at 2.4 GHz) / measured chain time",
+                "frac_definition": "issue-model floor of one frame's chain (dynamic instruction count of the critical wave x 4 cycles x samples at 2.4 GHz) / measured chain time",
                 "valu_model": {"peak_Gevals_per_s_whole_chip": round(valu_peak, 0), "peak_Gevals_per_s_on_the_occupied_CUs": round(valu_peak * cus / 256, 0),
                                "frac_of_whole_chip": round(line["fps_kernel"]["Gevals_per_s"] / valu_peak, 4),
                                "frac_of_occupied_CUs": round(line["fps_kernel"]["Gevals_per_s"] / (valu_peak * cus / 256), 4),

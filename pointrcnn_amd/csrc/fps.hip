@@ -77,7 +77,7 @@ template <> struct WaveMaxEq<16> {
                        [p12] "v"(pt[12]), [p13] "v"(pt[13]), [p14] "v"(pt[14]), [p15] "v"(pt[15])
                      : "vcc");
         eqbits = acc;
-        return __builtin_amdgcn_readlane(t, 63);          // (twenty VALU after the last DPP step)
+        return t;                                         // lane 63 holds the wave maximum (twenty VALU after the last DPP step)
     }
 };
 template <> struct WaveMaxEq<8> {
@@ -96,7 +96,7 @@ template <> struct WaveMaxEq<8> {
                        [p6] "v"(pt[6]), [p7] "v"(pt[7])
                      : "vcc");
         eqbits = acc;
-        return __builtin_amdgcn_readlane(t, 63);
+        return t;
     }
 };
 template <> struct WaveMaxEq<4> {
@@ -114,9 +114,35 @@ template <> struct WaveMaxEq<4> {
                      : [best] "v"(best), [p0] "v"(pt[0]), [p1] "v"(pt[1]), [p2] "v"(pt[2]), [p3] "v"(pt[3])
                      : "vcc");
         eqbits = acc;
-        return __builtin_amdgcn_readlane(t, 63);
+        return t;
     }
 };
+
+// WaveMaxEq<16> with TWO accumulators and the compare results in two SGPR pairs instead of VCC (round 5): a v_addc then reads a
+// compare issued two to three instructions earlier and an accumulator written two instructions earlier -- the one-accumulator form is
+// a chain of 32 instructions each waiting for its predecessor's result (measured ~6 cycles per instruction on a lone wave against 4
+// for independent ones).  a0 collects slots 15..8, a1 slots 7..0.
+#define FPS_EQ2(pa, pb) "v_cmp_eq_f32_e64 %[sa], " pa ", %[best]\n\tv_cmp_eq_f32_e64 %[sb], " pb ", %[best]\n\t"
+#define FPS_AC2 "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[sa]\n\tv_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[sb]\n\t"
+template <class V> __device__ __forceinline__ int wave_max_eq2_16(const V& pt, float best, unsigned& eqbits) {
+    int t; unsigned a0, a1; unsigned long long sa, sb;
+    asm volatile("v_mov_b32 %[t], %[best]\n\tv_mov_b32 %[a0], 0\n\tv_mov_b32 %[a1], 0\n\t"
+                 FPS_EQ2("%[p15]", "%[p7]") FPS_DPPS("row_shr:1 row_mask:0xf bank_mask:0xf") FPS_AC2
+                 FPS_EQ2("%[p14]", "%[p6]") FPS_DPPS("row_shr:2 row_mask:0xf bank_mask:0xf") FPS_AC2
+                 FPS_EQ2("%[p13]", "%[p5]") FPS_DPPS("row_shr:4 row_mask:0xf bank_mask:0xf") FPS_AC2
+                 FPS_EQ2("%[p12]", "%[p4]") FPS_DPPS("row_shr:8 row_mask:0xf bank_mask:0xf") FPS_AC2
+                 FPS_EQ2("%[p11]", "%[p3]") FPS_DPPS("row_bcast:15 row_mask:0xa bank_mask:0xf") FPS_AC2
+                 FPS_EQ2("%[p10]", "%[p2]") FPS_DPPS("row_bcast:31 row_mask:0xc bank_mask:0xf") FPS_AC2
+                 FPS_EQ2("%[p9]", "%[p1]") FPS_AC2
+                 FPS_EQ2("%[p8]", "%[p0]") FPS_AC2
+                 : [t] "=&v"(t), [a0] "=&v"(a0), [a1] "=&v"(a1), [sa] "=&s"(sa), [sb] "=&s"(sb)
+                 : [best] "v"(best), [p0] "v"(pt[0]), [p1] "v"(pt[1]), [p2] "v"(pt[2]), [p3] "v"(pt[3]), [p4] "v"(pt[4]), [p5] "v"(pt[5]),
+                   [p6] "v"(pt[6]), [p7] "v"(pt[7]), [p8] "v"(pt[8]), [p9] "v"(pt[9]), [p10] "v"(pt[10]), [p11] "v"(pt[11]),
+                   [p12] "v"(pt[12]), [p13] "v"(pt[13]), [p14] "v"(pt[14]), [p15] "v"(pt[15])
+                 : "vcc");
+    eqbits = (a0 << 8) | a1;
+    return t;
+}
 
 template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict__ xyz, int N, int npoint,
@@ -227,6 +253,14 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict_
 // =====================================================================================================
 // finite stand-in for infinity (this file is built with -ffinite-math-only); FPS_BIG^2 * 3 still fits fp32
 #define FPS_BIG 1.0e18f
+// FPS_V: build-time A/B switches of two round-5 changes to the sample loop (bit 1: early priority for the winner's wave and its Morton
+// neighbours, bit 2: two-accumulator slot masks + tree maximum + one-compare uniqueness test); default: both on
+#ifndef FPS_V
+#define FPS_V 6
+#endif
+#ifndef FPS_PAIR_ASM
+#define FPS_PAIR_ASM 1          // 0: the compiler's order of the pair update (A/B switch of the build)
+#endif
 
 __device__ __forceinline__ unsigned morton_spread10(unsigned v) {       // 10 bits -> every third bit
     v &= 0x3ffu;
@@ -317,12 +351,58 @@ __device__ __forceinline__ int row0_min_i32_fused(int v) {
     return __builtin_amdgcn_readlane(v, 15);
 }
 
+// ---- the per-sample exchange of the workgroup kernels (fps_pruned_kernel, fps_slot_kernel) ----
+// Exchange table, three rotating buffers of 64 words: words 0-15 / 16-31 / 32-47 = x / y / z of the 16 waves' candidates, words
+// 48-49 = the 64-bit cell the candidates are folded into with ONE ds_max_u64 per wave: key = [value, order-preserving | 2^28-1 -
+// original index | wave], the largest key is the largest value, ties -> lowest original index (reading all 16 candidates and
+// reducing them twice by DPP was ~60 instructions per wave and sample).  The buffer of sample j is j % 3; wave 0 clears the next
+// one's cell while nobody can still be reading it (its readers passed the previous barrier).  Round 5: ONE ds_read_b32 per lane
+// after the barrier fetches the whole buffer, so cell and coordinates arrive together (rounds 3-4 read a 16 x 4 slot table and the
+// cell with two loads that were meant to fly together, but the register allocator reused the cell's upper half as the second
+// address: two dependent LDS round trips on the critical path of every sample; found by reading the ISA).
+#define FPS_XT_DECL __shared__ __attribute__((aligned(256))) unsigned xt[3][64]
+// The candidate a wave publishes is kept in the form the publish needs -- coordinates and the 64-bit key in VGPRs (fps_cand_t,
+// rebuilt only when the wave updates) -- so that a wave that did not update re-publishes with five instructions (address, two
+// coordinate stores, the atomic, wave 0's clear) instead of rebuilding key and operands from scalars every sample (~17).
+struct fps_cand_t { float x, y, z; unsigned long long key; };
+__device__ __forceinline__ void fps_cand_set(fps_cand_t& c, int wave, float cx, float cy, float cz, float cval, int corig) {
+    const unsigned hi = (unsigned)__float_as_int(cval) ^ 0x80000000u;
+    const unsigned lo = ((0xFFFFFFFu - (unsigned)min(corig, 0xFFFFFFF)) << 4) | (unsigned)wave;
+    c.x = cx; c.y = cy; c.z = cz; c.key = ((unsigned long long)hi << 32) | lo;
+    asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.key));          // uniform values, but they stay in vector registers
+}
+__device__ __forceinline__ void fps_xt_publish(unsigned (*xt)[64], int cb, int wave, const fps_cand_t& c) {
+    unsigned* t = xt[cb];
+    t[wave] = __float_as_uint(c.x); t[16 + wave] = __float_as_uint(c.y); t[32 + wave] = __float_as_uint(c.z);
+    // (one lane, one instruction: atomicMax() would be wrapped in the compiler's wave-aggregation loop, ~25 more instructions per
+    //  wave and sample on the critical path)
+    asm volatile("ds_max_u64 %0, %1 offset:192" : : "v"((unsigned)(size_t)&t[0]), "v"(c.key) : "memory");
+    if (wave == 0) *(unsigned long long*)&xt[cb == 2 ? 0 : cb + 1][48] = 0ULL;
+}
+// after the barrier: lane L reads word L of the sample's buffer; the cell's low word (original index | wave) is lane 48's, the
+// winner's coordinates are lanes w, 16 + w, 32 + w's.  Returns the winner's original index.
+__device__ __forceinline__ int fps_xt_collect(unsigned (*xt)[64], int cb, int lane, float& x0, float& y0, float& z0, int& wl) {
+    const int tv = (int)xt[cb][lane];
+    const unsigned klo = (unsigned)__builtin_amdgcn_readlane(tv, 48);
+    wl = (int)(klo & 15u);
+    x0 = __int_as_float(__builtin_amdgcn_readlane(tv, wl));
+    y0 = __int_as_float(__builtin_amdgcn_readlane(tv, wl | 16));
+    z0 = __int_as_float(__builtin_amdgcn_readlane(tv, wl | 32));
+    return (int)(0xFFFFFFFu - (klo >> 4));
+}
+
 #ifdef PRCNN_FPS_TIMING            // dev build (tools/fps_timing.py): per-wave cycle sums of the loop's phases, frame 0
-__device__ unsigned long long prcnn_fps_dbg[16 * 8 + 16];
+__device__ unsigned long long prcnn_fps_dbg[16 * 8 + 16 + 16 * 16];      // pruned kernel: [0, 144); slot kernel: 16 words per wave from 144
 PRCNN_API int prcnn_fps_timing_read(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(prcnn_fps_dbg), sizeof(prcnn_fps_dbg)) == hipSuccess ? 0 : -1;
 }
 #define FPS_T(...) __VA_ARGS__
+// the slot kernel takes time stamps on ONE wave per build (PRCNN_FPS_TIMING_WAVE; -1 = every wave): sixteen waves reading the clock at
+// the same points serialise on the scalar cache and measure each other
+#ifndef PRCNN_FPS_TIMING_WAVE
+#define PRCNN_FPS_TIMING_WAVE -1
+#endif
+#define FPS_NOW(w) ((PRCNN_FPS_TIMING_WAVE < 0 || (w) == PRCNN_FPS_TIMING_WAVE) ? __builtin_readcyclecounter() : 0ULL)
 #else
 #define FPS_T(...)
 #endif
@@ -332,8 +412,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
                                                           int N, int npoint, int32_t* __restrict__ idx_out) {
     constexpr int BLOCK = 1024, NW = 16;
     typedef typename fvec_t<PPT>::type fvec;
-    __shared__ float slot[2][NW][4];   // x, y, z of every wave's candidate
-    __shared__ unsigned long long cell[3];
+    FPS_XT_DECL;
     // original indices of the points a lane holds: only the winner's is ever needed, so they live in LDS (slot-major:
     // s_po[i * 1024 + tid]) instead of PPT more VGPRs per lane -- at 96 VGPRs the four FPS waves of a SIMD left 128
     // registers, too few for ANY of the MLP kernels (160-216), i.e. a CU hosting an FPS workgroup was lost to them
@@ -368,11 +447,12 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
     hix = wave_max_f32_fused(hix); hiy = wave_max_f32_fused(hiy); hiz = wave_max_f32_fused(hiz);
 
     if (tid == 0 && npoint > 0) out[0] = 0;
-    if (tid < 3) cell[tid] = 0ULL;
+    if (tid < 192) (&xt[0][0])[tid] = 0u;
     __syncthreads();
     float x0 = p[0], y0 = p[1], z0 = p[2];
     // cached candidate of this wave (uniform): value, original index, coordinates
     float cval = 1e10f; int corig = 0x7fffffff; float cx = 0.f, cy = 0.f, cz = 0.f;
+    fps_cand_t cand; fps_cand_set(cand, wave, cx, cy, cz, cval, corig);
     bool first = true;
 
     FPS_T(unsigned long long t_upd = 0, t_wait = 0, t_red = 0, n_upd = 0, t_u1 = 0, t_u2 = 0, t_u3 = 0, t_u4 = 0; unsigned long long t0 = __builtin_readcyclecounter();)
@@ -413,7 +493,14 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
             }
             FPS_T(unsigned long long u1 = __builtin_readcyclecounter(); t_u1 += u1 - u0;)
             unsigned eqbits;
-            const int wmax = WaveMaxEq<PPT>::run(pt, best, eqbits);
+            const int wvec = WaveMaxEq<PPT>::run(pt, best, eqbits);          // lane 63 = the wave maximum
+            // every lane fetches the original index of ITS OWN candidate (lowest slot holding the lane's maximum) as soon as the slot
+            // masks exist; the owner's word is read out below, after the scalar search and the coordinate selects, so the LDS round
+            // trip is hidden (rounds 3-4 read s_po at the owner's address inside the fast path, after the search: an exposed round
+            // trip per update -- a load whose only use sits in a branch is sunk into it; the sched_barriers keep the order written)
+            const int myorig = s_po[__builtin_ctz(eqbits) * BLOCK + tid];
+            __builtin_amdgcn_sched_barrier(0);
+            const int wmax = __builtin_amdgcn_readlane(wvec, 63);
             const float wmaxf = __int_as_float(wmax);
             FPS_T(unsigned long long u2 = __builtin_readcyclecounter(); t_u2 += u2 - u1;)
             // candidates = (lane, slot) with t == wmax; the one with the LOWEST ORIGINAL index wins.  Fast path (a
@@ -427,14 +514,15 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
             const unsigned ownbits = (unsigned)__builtin_amdgcn_readlane((int)eqbits, owner0);       // the owner lane's slots holding the maximum
             const int total = (__popcll(anym) == 1 && __popc(ownbits) == 1) ? 1 : 2;
             int istar = __builtin_ctz(ownbits);
+            // the fast path's selects, taken before the branch (wasted on the rare tie path) so that they too run under the load
+            const float fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[istar]), owner0));
+            const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[istar]), owner0));
+            const float fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[istar]), owner0));
+            __builtin_amdgcn_sched_barrier(0);
+            const int corig_fast = __builtin_amdgcn_readlane(myorig, owner0);
             FPS_T(unsigned long long u3 = __builtin_readcyclecounter(); t_u3 += u3 - u2;)
             if (total == 1) {
-                const int owner = owner0;
-                corig = s_po[istar * BLOCK + (wave << 6) + owner];          // own wave's entries: no barrier needed
-                float sx = px[istar], sy = py[istar], sz = pz[istar];
-                cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), owner));
-                cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), owner));
-                cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), owner));
+                corig = corig_fast; cx = fx; cy = fy; cz = fz;
             } else {                                  // exact ties (duplicated points, lattices): rare, any cost is fine
                 int bo = 0x7fffffff; float bx = 0.f, by = 0.f, bz = 0.f;
                 if (best == wmaxf) {
@@ -452,40 +540,23 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
             }
             cval = wmaxf;
             first = false;
+            fps_cand_set(cand, wave, cx, cy, cz, cval, corig);
             __builtin_amdgcn_s_setprio(2);
             FPS_T(t_u4 += __builtin_readcyclecounter() - u3;)
         }
+#if FPS_V & 2
+        else __builtin_amdgcn_s_setprio(2);
+#endif
         FPS_T(unsigned long long t1 = __builtin_readcyclecounter(); t_upd += t1 - t0; n_upd += update ? 1 : 0;)
-        // Exchange: every wave folds its candidate into ONE 64-bit LDS cell with an atomic max and parks the coordinates in
-        // its slot; after the barrier a wave reads the cell and the winner's slot -- two dependent LDS reads and ~20
-        // instructions, where reading all 16 candidates and reducing them twice by DPP (maximum, then lowest index among
-        // equals) was ~60 instructions per wave and sample.  key = [value, order-preserving | 2^28-1 - original index | wave]:
-        // the largest key is the largest value, ties -> lowest original index.  Cells rotate over three (the next one is
-        // cleared by wave 0 while nobody can still be reading it: its readers passed the previous barrier).
-        if (lane == 0) {
-            float* s = slot[j & 1][wave];
-            s[0] = cx; s[1] = cy; s[2] = cz;
-            const unsigned hi = (unsigned)__float_as_int(cval) ^ 0x80000000u;
-            const unsigned lo = ((0xFFFFFFFu - (unsigned)min(corig, 0xFFFFFFF)) << 4) | (unsigned)wave;
-            // (one lane, one instruction: atomicMax() would be wrapped in the compiler's wave-aggregation loop, ~25 more
-            //  instructions per wave and sample on the critical path)
-            const unsigned long long key = ((unsigned long long)hi << 32) | lo;
-            asm volatile("ds_max_u64 %0, %1" : : "v"((unsigned)(size_t)&cell[cb]), "v"(key) : "memory");
-            if (wave == 0) cell[cb == 2 ? 0 : cb + 1] = 0ULL;
-        }
+        // Exchange (fps_xt_publish / fps_xt_collect above): candidates folded into the sample's cell, one barrier, one LDS read
+        if (lane == 0) fps_xt_publish(xt, cb, wave, cand);
         __syncthreads();
         FPS_T(unsigned long long t2 = __builtin_readcyclecounter(); t_wait += t2 - t1;)
-        // the winner's coordinates without a second, dependent LDS round trip: every lane reads one word of the 16 x 4 slot table
-        // (lane = 4 * wave + component, 256 contiguous bytes) TOGETHER with the cell, and the winner's three words are picked out of
-        // the wave's registers by lane index
-        const float sv = (&slot[j & 1][0][0])[lane];
-        const unsigned long long kwin = cell[cb];
-        const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)kwin);
-        const int gorig = (int)(0xFFFFFFFu - (klo >> 4));
-        const int wl = (int)(klo & 15u) * 4;
-        x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl));
-        y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl + 1));
-        z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl + 2));
+        int wwin;
+        const int gorig = fps_xt_collect(xt, cb, lane, x0, y0, z0, wwin);
+#if FPS_V & 2
+        if ((unsigned)(__builtin_amdgcn_readfirstlane(wave) - wwin + 1) <= 2u) __builtin_amdgcn_s_setprio(3);          // see fps_slot_kernel
+#endif
         cb = cb == 2 ? 0 : cb + 1;
         if (tid == 0) out[j] = gorig;
         FPS_T(t0 = __builtin_readcyclecounter(); t_red += t0 - t2;)
@@ -501,13 +572,12 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
 // wave's largest distance, which bounds every point's: no per-pair maxima to maintain (round 2's version kept them exact with a
 // DPP reduction per slot and lost more than it skipped).  Same arithmetic and tie rule: bit-identical sample sets.
 // =====================================================================================================
-template <int PPT>
-__global__ __launch_bounds__(1024) void fps_slot_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ perm,
+template <int PPT, int NW>
+__global__ __launch_bounds__(NW * 64) void fps_slot_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ perm,
                                                           int N, int npoint, int32_t* __restrict__ idx_out) {
-    constexpr int BLOCK = 1024, NW = 16;
+    constexpr int BLOCK = NW * 64;          // NW waves x 64 lanes x PPT points (16 x 16 for 16 384 points; 8 x 8 for the 4 096-point level: 716 vs 659 us, not used)
     typedef typename fvec_t<PPT>::type fvec;
-    __shared__ float slot[2][NW][4];   // x, y, z of every wave's candidate
-    __shared__ unsigned long long cell[3];
+    FPS_XT_DECL;
     // original indices of the points a lane holds: only the winner's is ever needed, so they live in LDS (slot-major:
     // s_po[i * 1024 + tid]) instead of PPT more VGPRs per lane -- at 96 VGPRs the four FPS waves of a SIMD left 128
     // registers, too few for ANY of the MLP kernels (160-216), i.e. a CU hosting an FPS workgroup was lost to them
@@ -558,12 +628,14 @@ __global__ __launch_bounds__(1024) void fps_slot_kernel(const float* __restrict_
         if (lane == g) { glx = ax_; gly = ay_; glz = az_; ghx = bx_; ghy = by_; ghz = bz_; }
     }
     if (tid == 0 && npoint > 0) out[0] = 0;
-    if (tid < 3) cell[tid] = 0ULL;
+    if (tid < 192) (&xt[0][0])[tid] = 0u;
     __syncthreads();
     float x0 = p[0], y0 = p[1], z0 = p[2];
     // cached candidate of this wave (uniform): value, original index, coordinates
     float cval = 1e10f; int corig = 0x7fffffff; float cx = 0.f, cy = 0.f, cz = 0.f;
+    fps_cand_t cand; fps_cand_set(cand, wave, cx, cy, cz, cval, corig);
     bool first = true;
+    FPS_T(unsigned long long q_test = 0, q_dist = 0, q_max = 0, q_search = 0, q_pub = 0, q_coll = 0, q_nupd = 0, q_npair = 0; unsigned long long q0 = FPS_NOW(wave); const unsigned long long q_begin = q0;)
     int cb = 1;                                // exchange cell of sample j: j % 3
     for (int j = 1; j < npoint; j++) {
         // which pairs of slots can the new sample reach?  Lane g tests pair g's box (a lower bound of the distance to anything in it)
@@ -575,7 +647,9 @@ __global__ __launch_bounds__(1024) void fps_slot_kernel(const float* __restrict_
             const float Lg = __fadd_rn(__fadd_rn(__fmul_rn(hx, hx), __fmul_rn(hy, hy)), __fmul_rn(hz, hz));
             live = (unsigned)__ballot(Lg < cval) & ((1u << (PPT / 2)) - 1u);
         }
+        FPS_T(unsigned long long q1 = FPS_NOW(wave); q_test += q1 - q0;)
         if (live != 0u) {
+            FPS_T(q_nupd++; q_npair += __builtin_popcount(live);)
             // the sample waits for the updating wave(s): ahead of the three waves that share the SIMD and are still
             // working through their own bound test / exchange read (oldest-first arbitration otherwise: tools/fps_timing.py
             // shows the fourth wave of a SIMD taking 2-3x as long for the same instructions)
@@ -585,18 +659,63 @@ __global__ __launch_bounds__(1024) void fps_slot_kernel(const float* __restrict_
             for (int g = 0; g < PPT / 2; g++) {
                 if ((live >> g) & 1u) {                          // wave-uniform
                     const int i = 2 * g;
+#if FPS_PAIR_ASM
+                    // the pair's two squared distances, hand-ordered: a packed fp32 result read by the NEXT instruction costs a wait
+                    // state; with three temporaries only the final sum waits (the compiler's two-temporary order needs three to four)
+                    f32x2 d, tb, tc;
+                    asm("v_pk_add_f32 %[a], %[px], %[qx] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                        "v_pk_add_f32 %[b], %[py], %[qy] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                        "v_pk_add_f32 %[c], %[pz], %[qz] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                        "v_pk_mul_f32 %[a], %[a], %[a]\n\t"
+                        "v_pk_mul_f32 %[b], %[b], %[b]\n\t"
+                        "v_pk_mul_f32 %[c], %[c], %[c]\n\t"
+                        "v_pk_add_f32 %[a], %[a], %[b]\n\t"
+                        "s_nop 0\n\t"
+                        "v_pk_add_f32 %[a], %[a], %[c]"
+                        : [a] "=&v"(d), [b] "=&v"(tb), [c] "=&v"(tc)
+                        : [px] "v"((f32x2){px[i], px[i + 1]}), [py] "v"((f32x2){py[i], py[i + 1]}), [pz] "v"((f32x2){pz[i], pz[i + 1]}),
+                          [qx] "s"(qx), [qy] "s"(qy), [qz] "s"(qz));
+#else
                     f32x2 dx = (f32x2){px[i], px[i + 1]} - qx;
                     f32x2 dy = (f32x2){py[i], py[i + 1]} - qy;
                     f32x2 dz = (f32x2){pz[i], pz[i + 1]} - qz;
                     f32x2 d = (dx * dx + dy * dy) + dz * dz;
+#endif
                     pt[i] = __builtin_fminf(pt[i], d.x); pt[i + 1] = __builtin_fminf(pt[i + 1], d.y);
                 }
             }
+            FPS_T(unsigned long long q2 = FPS_NOW(wave); q_dist += q2 - q1;)
+#if (FPS_V & 4)
+            float best;
+            if (PPT == 16) {                         // a tree: neighbouring instructions are independent (a chain waits ~6 cycles per link)
+                const float m0 = __builtin_fmaxf(__builtin_fmaxf(pt[0], pt[1]), pt[2]), m1 = __builtin_fmaxf(__builtin_fmaxf(pt[3], pt[4]), pt[5]);
+                const float m2 = __builtin_fmaxf(__builtin_fmaxf(pt[6], pt[7]), pt[8]), m3 = __builtin_fmaxf(__builtin_fmaxf(pt[9], pt[10]), pt[11]);
+                const float m4 = __builtin_fmaxf(__builtin_fmaxf(pt[12], pt[13]), pt[14]);
+                best = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), m2), __builtin_fmaxf(__builtin_fmaxf(m3, m4), pt[15]));
+            } else {
+                best = pt[0];
+#pragma unroll
+                for (int i = 1; i < PPT; i++) best = __builtin_fmaxf(best, pt[i]);
+            }
+#else
             float best = pt[0];
 #pragma unroll
             for (int i = 1; i < PPT; i++) best = __builtin_fmaxf(best, pt[i]);
+#endif
             unsigned eqbits;
-            const int wmax = WaveMaxEq<PPT>::run(pt, best, eqbits);
+#if (FPS_V & 4)
+            const int wvec = PPT == 16 ? wave_max_eq2_16(pt, best, eqbits) : WaveMaxEq<PPT>::run(pt, best, eqbits);
+#else
+            const int wvec = WaveMaxEq<PPT>::run(pt, best, eqbits);          // lane 63 = the wave maximum
+#endif
+            // every lane fetches the original index of ITS OWN candidate (lowest slot holding the lane's maximum) as soon as the slot
+            // masks exist; the owner's word is read out below, after the scalar search and the coordinate selects, so the LDS round
+            // trip is hidden (rounds 3-4 read s_po at the owner's address inside the fast path, after the search: an exposed round
+            // trip per update -- a load whose only use sits in a branch is sunk into it; the sched_barriers keep the order written)
+            const int myorig = s_po[__builtin_ctz(eqbits) * BLOCK + tid];
+            __builtin_amdgcn_sched_barrier(0);
+            const int wmax = __builtin_amdgcn_readlane(wvec, 63);
+            FPS_T(unsigned long long q3 = FPS_NOW(wave); q_max += q3 - q2;)
             const float wmaxf = __int_as_float(wmax);
             // candidates = (lane, slot) with t == wmax; the one with the LOWEST ORIGINAL index wins.  Fast path (a
             // unique maximum, the overwhelmingly common case).  An updating wave is usually ALONE on its SIMD and issues one
@@ -607,15 +726,20 @@ __global__ __launch_bounds__(1024) void fps_slot_kernel(const float* __restrict_
             const unsigned long long anym = __ballot(best == wmaxf);
             const int owner0 = __builtin_ctzll(anym);
             const unsigned ownbits = (unsigned)__builtin_amdgcn_readlane((int)eqbits, owner0);       // the owner lane's slots holding the maximum
+#if (FPS_V & 4)
+            const int total = (__popcll(anym) + __popc(ownbits) == 2) ? 1 : 2;        // both counts are >= 1
+#else
             const int total = (__popcll(anym) == 1 && __popc(ownbits) == 1) ? 1 : 2;
+#endif
             int istar = __builtin_ctz(ownbits);
+            // the fast path's selects, taken before the branch (wasted on the rare tie path) so that they too run under the load
+            const float fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[istar]), owner0));
+            const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[istar]), owner0));
+            const float fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[istar]), owner0));
+            __builtin_amdgcn_sched_barrier(0);
+            const int corig_fast = __builtin_amdgcn_readlane(myorig, owner0);
             if (total == 1) {
-                const int owner = owner0;
-                corig = s_po[istar * BLOCK + (wave << 6) + owner];          // own wave's entries: no barrier needed
-                float sx = px[istar], sy = py[istar], sz = pz[istar];
-                cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), owner));
-                cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), owner));
-                cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), owner));
+                corig = corig_fast; cx = fx; cy = fy; cz = fz;
             } else {                                  // exact ties (duplicated points, lattices): rare, any cost is fine
                 int bo = 0x7fffffff; float bx = 0.f, by = 0.f, bz = 0.f;
                 if (best == wmaxf) {
@@ -633,40 +757,31 @@ __global__ __launch_bounds__(1024) void fps_slot_kernel(const float* __restrict_
             }
             cval = wmaxf;
             first = false;
+            fps_cand_set(cand, wave, cx, cy, cz, cval, corig);
+            FPS_T(q_search += FPS_NOW(wave) - q3;)
             __builtin_amdgcn_s_setprio(2);
         }
-        // Exchange: every wave folds its candidate into ONE 64-bit LDS cell with an atomic max and parks the coordinates in
-        // its slot; after the barrier a wave reads the cell and the winner's slot -- two dependent LDS reads and ~20
-        // instructions, where reading all 16 candidates and reducing them twice by DPP (maximum, then lowest index among
-        // equals) was ~60 instructions per wave and sample.  key = [value, order-preserving | 2^28-1 - original index | wave]:
-        // the largest key is the largest value, ties -> lowest original index.  Cells rotate over three (the next one is
-        // cleared by wave 0 while nobody can still be reading it: its readers passed the previous barrier).
-        if (lane == 0) {
-            float* s = slot[j & 1][wave];
-            s[0] = cx; s[1] = cy; s[2] = cz;
-            const unsigned hi = (unsigned)__float_as_int(cval) ^ 0x80000000u;
-            const unsigned lo = ((0xFFFFFFFu - (unsigned)min(corig, 0xFFFFFFF)) << 4) | (unsigned)wave;
-            // (one lane, one instruction: atomicMax() would be wrapped in the compiler's wave-aggregation loop, ~25 more
-            //  instructions per wave and sample on the critical path)
-            const unsigned long long key = ((unsigned long long)hi << 32) | lo;
-            asm volatile("ds_max_u64 %0, %1" : : "v"((unsigned)(size_t)&cell[cb]), "v"(key) : "memory");
-            if (wave == 0) cell[cb == 2 ? 0 : cb + 1] = 0ULL;
-        }
+#if FPS_V & 2
+        else __builtin_amdgcn_s_setprio(2);
+#endif
+        // Exchange (fps_xt_publish / fps_xt_collect above): candidates folded into the sample's cell, one barrier, one LDS read
+        FPS_T(unsigned long long q4 = FPS_NOW(wave);)
+        if (lane == 0) fps_xt_publish(xt, cb, wave, cand);
         __syncthreads();
-        // the winner's coordinates without a second, dependent LDS round trip: every lane reads one word of the 16 x 4 slot table
-        // (lane = 4 * wave + component, 256 contiguous bytes) TOGETHER with the cell, and the winner's three words are picked out of
-        // the wave's registers by lane index
-        const float sv = (&slot[j & 1][0][0])[lane];
-        const unsigned long long kwin = cell[cb];
-        const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)kwin);
-        const int gorig = (int)(0xFFFFFFFu - (klo >> 4));
-        const int wl = (int)(klo & 15u) * 4;
-        x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl));
-        y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl + 1));
-        z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), wl + 2));
+        FPS_T(unsigned long long q5 = FPS_NOW(wave); q_pub += q5 - q4;)
+        int wwin;
+        const int gorig = fps_xt_collect(xt, cb, lane, x0, y0, z0, wwin);
+#if FPS_V & 2
+        // the winner's wave certainly updates next (the sample is one of its points) and its Morton neighbours (on the two adjacent SIMDs)
+        // probably do: they take their bound test ahead of the three waves they share a SIMD with instead of in arrival order
+        if ((unsigned)(__builtin_amdgcn_readfirstlane(wave) - wwin + 1) <= 2u) __builtin_amdgcn_s_setprio(3);          // scalar compare + branch
+#endif
         cb = cb == 2 ? 0 : cb + 1;
         if (tid == 0) out[j] = gorig;
+        FPS_T(q0 = FPS_NOW(wave); q_coll += q0 - q5;)
     }
+    FPS_T(if (b == 0 && lane == 0) { unsigned long long* d = prcnn_fps_dbg + 144 + wave * 16; d[0] = q_test; d[1] = q_dist; d[2] = q_max; d[3] = q_search; d[4] = q_pub;
+                                     d[5] = q_coll; d[6] = q_nupd; d[7] = q_npair; d[8] = FPS_NOW(wave) - q_begin; })
 }
 
 // =====================================================================================================
@@ -885,9 +1000,9 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
         const char* slots_env = getenv("PRCNN_FPS_SLOTS");              // read per call: the tests flip it in-process
         const bool slots = slots_env == nullptr || atoi(slots_env) != 0;
         static PrcnnLdsLimit slot_attr;
-        if (slots && N > 8192 && !slot_attr.raise((const void*)fps_slot_kernel<16>, 16 * 4096))
+        if (slots && N > 8192 && !slot_attr.raise((const void*)fps_slot_kernel<16, 16>, 16 * 4096))
             return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the slot kernel");
-        if (slots && N > 8192) hipLaunchKernelGGL((fps_slot_kernel<16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);
+        if (slots && N > 8192) hipLaunchKernelGGL((fps_slot_kernel<16, 16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);
         else if (N <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4>), dim3(B), dim3(1024), 4 * 4096, s, xyz, perm, N, npoint, idx);
         else if (N <= 8192) hipLaunchKernelGGL((fps_pruned_kernel<8>), dim3(B), dim3(1024), 8 * 4096, s, xyz, perm, N, npoint, idx);
         else hipLaunchKernelGGL((fps_pruned_kernel<16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);

@@ -20,7 +20,7 @@ def load(root, counter):
         d["v"] += float(r["Counter_Value"])
     ds = list(disp.values())
     # a step starts with SA1's FPS: fps_sort_kernel + fps_pruned_kernel<16> (default) or fps_reg_kernel<1024, 16>
-    firsts = [i - 1 for i, d in enumerate(ds) if ("fps_pruned_kernel<16>" in d["name"] or "fps_slot_kernel<16>" in d["name"])] or \
+    firsts = [i - 1 for i, d in enumerate(ds) if ("fps_pruned_kernel<16>" in d["name"] or "fps_slot_kernel<16" in d["name"])] or \
              [i for i, d in enumerate(ds) if "fps_reg_kernel<1024" in d["name"]]
     return ds[firsts[-1]:]        # the dispatches of the last full step
 

@@ -16,7 +16,7 @@ for r in csv.DictReader(open(f)):
     d = per.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"].split("(")[0].replace("void ", ""), "c": collections.Counter()})
     d["c"][r["Counter_Name"]] += float(r["Counter_Value"])
 ds = list(per.values())
-first = ([i - 1 for i, d in enumerate(ds) if ("fps_pruned_kernel<16>" in d["name"] or "fps_slot_kernel<16>" in d["name"])] or
+first = ([i - 1 for i, d in enumerate(ds) if ("fps_pruned_kernel<16>" in d["name"] or "fps_slot_kernel<16" in d["name"])] or
          [i for i, d in enumerate(ds) if "fps_reg_kernel<1024" in d["name"]])[-1]
 print("# MFMA pipe utilisation of the MLP launches of one bs32 RPN step (rocprofv3 PMC, single stream, eager)")
 print("# util = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES); MOPS_F32 x 512 = fp32 MFMA FLOPs issued; the split-bf16 kernels issue")

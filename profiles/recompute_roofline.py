@@ -54,7 +54,7 @@ def mfma_flops(path):
 
 def one(ks, f32, bf16, what):
     # steps in the trace = launches of a kernel that runs once per step (level-0 FPS)
-    once = [c for n, (c, _) in ks.items() if "fps_slot_kernel<16>" in n or "fps_pruned_kernel<16>" in n]
+    once = [c for n, (c, _) in ks.items() if "fps_slot_kernel<16" in n or "fps_pruned_kernel<16>" in n]
     steps = once[0] if once else None
     fam_us = sum(t for n, (_, t) in ks.items() if family(n))
     if not steps or fam_us <= 0:

@@ -13,7 +13,7 @@ for root in sys.argv[1:]:
             d = per.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"].split("(")[0].replace("void ", ""), "c": collections.Counter()})
             d["c"][r["Counter_Name"]] += float(r["Counter_Value"])
         ds = list(per.values())
-        last = ([i - 1 for i, d in enumerate(ds) if ("fps_pruned_kernel<16>" in d["name"] or "fps_slot_kernel<16>" in d["name"])] or
+        last = ([i - 1 for i, d in enumerate(ds) if ("fps_pruned_kernel<16>" in d["name"] or "fps_slot_kernel<16" in d["name"])] or
                 [i for i, d in enumerate(ds) if "fps_reg_kernel<1024" in d["name"]])[-1]
         for i, d in enumerate(ds[last:]):
             e = disp.setdefault(i, {"name": d["name"], "c": collections.Counter()})
