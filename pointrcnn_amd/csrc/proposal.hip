@@ -558,6 +558,176 @@ __global__ __launch_bounds__(NMS_THREADS) void greedy_nms_kernel(NmsParams P) {
     for (int k = nk + tid; k < K; k += NMS_THREADS) kept_out[k] = -1;
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Rotated greedy NMS with a PREFILTER (round 5).  On a driving scene almost every candidate is a vote for a car whose
+// best box is already kept: in greedy_nms_kernel every chunk of 64 such candidates costs the full serial step (load, A, B, C)
+// although none of them survives phase A -- ~40 steps of ~65 us before 70 boxes of a 24-car scene are kept.  Here a batch of
+// NMS_PB raw candidates (one per thread) is tested against the kept list first, every thread walking the kept list on its own
+// candidate: the nearest kept box that can overlap first, then the others in order -- the cheap circle test skips to the next
+// kept box that can overlap, then ALL threads that found one clip together (a round costs one polygon clip whatever the number
+// of lanes in it; a candidate leaves at its first suppressing box).  Only the survivors -- in score order -- go through the chunk step (A' against the boxes kept since the batch's
+// prefilter, B among themselves, C the serial resolve), so the serial steps are per 64 SURVIVORS, not per 64 candidates.
+// The decisions are the same IoU tests on the same operands as greedy_nms_kernel<ROTATED> makes (a candidate is dropped iff
+// some earlier kept box has IoU > thresh with it; kept boxes are never un-kept): identical keep lists (PRCNN_NMS_PREFILTER=0
+// selects the chunk kernel; tests/test_gpu_proposal.py compares both with the oracle).
+// ----------------------------------------------------------------------------------------------------
+#define NMS_RT 512           // threads of the prefiltered kernel: two waves per SIMD (the polygon clip waits on its private arrays)
+#define NMS_PB NMS_RT
+static size_t greedy_nms_rot_lds_bytes(int max_keep) {
+    return 64 * sizeof(u64) + 4 * sizeof(u64) + 16 * sizeof(int) + PAIR_CAP * sizeof(unsigned) + NMS_PB * sizeof(int) +
+           (size_t)(64 + NMS_PB + max_keep) * sizeof(RBox);
+}
+
+__global__ __launch_bounds__(NMS_RT) void greedy_nms_rot_kernel(NmsParams P) {
+    extern __shared__ u64 smem64[];
+    u64* m = smem64;                                    // [64] chunk suppression rows
+    u64* supw = m + 64;                                 // [0] phase-A' hits
+    int* sh = (int*)(supw + 4);                         // [0] running kept count, [1] pair-list length, [8..15] survivors per wave
+    unsigned* pairs = (unsigned*)(sh + 16);
+    int* surv = (int*)(pairs + PAIR_CAP);               // [NMS_PB] batch positions of the survivors, in score order
+    RBox* cand = (RBox*)(surv + NMS_PB);                // [64] the chunk
+    RBox* pre = cand + 64;                              // [NMS_PB] the batch
+    RBox* keptb = pre + NMS_PB;
+    const int seg = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = seg ? P.post2 : P.post1;
+    const size_t sb = (size_t)b * P.nseg + seg;
+    const int32_t* __restrict__ cl = P.cand + sb * P.cand_ld;
+    int32_t* kept_out = P.kept + sb * P.kept_ld;
+    const int n = P.cnt[sb];
+    const float* __restrict__ boxes = P.boxes3d + (size_t)b * P.N * 7;
+    const float thresh = P.thresh;
+    const bool prefilter = thresh >= 0.0f;              // a zero overlap can only suppress when thresh < 0
+    int nk = 0;
+    for (int p0 = 0; p0 < n && nk < K; p0 += NMS_PB) {
+        const int nb = min(NMS_PB, n - p0);
+        const int nk0 = nk;                             // the kept list this batch is prefiltered against
+        // ---- prefilter: my candidate against kept[0, nk0) ----
+        bool alive = tid < nb;
+        if (alive) {
+            float v[5];
+            to_bev(boxes + (size_t)cl[p0 + tid] * 7, v);
+            make_rbox(v, pre[tid]);
+        }
+        __syncthreads();                                // (also: the previous batch's last chunk is done with cand / m / sh)
+        {
+            const RBox& me = pre[tid < nb ? tid : 0];
+            // the nearest kept box that can overlap goes first: a vote for a car is almost always suppressed by the kept box closest to it,
+            // so most candidates leave after ONE clip (the outcome is an OR over the kept boxes: the order of the tests is free)
+            int kbest = -1;
+            if (alive) {
+                float dbest = 3.0e38f;
+                for (int k = 0; k < nk0; k++) {
+                    if (prefilter && far_apart(keptb[k], me)) continue;
+                    const float dx = sub(keptb[k].cx, me.cx), dy = sub(keptb[k].cy, me.cy);
+                    const float d = add(mul(dx, dx), mul(dy, dy));
+                    if (kbest < 0 || d < dbest) { dbest = d; kbest = k; }
+                }
+            }
+            if (kbest >= 0 && iou_bev(keptb[kbest], me) > thresh) alive = false;
+            int k = 0;
+            bool scanning = alive && kbest >= 0;
+            while (__any(scanning)) {
+                if (scanning) {
+                    while (k < nk0 && (k == kbest || (prefilter && far_apart(keptb[k], me)))) k++;
+                    scanning = k < nk0;
+                }
+                if (scanning) {
+                    if (iou_bev(keptb[k], me) > thresh) { alive = false; scanning = false; }
+                    k++;
+                }
+            }
+        }
+        // ---- survivors, in score order ----
+        const u64 am = __ballot(alive);
+        if (lane == 0) sh[8 + wave] = (int)__popcll(am);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; w++) base += sh[8 + w];
+        int ns = 0;
+        for (int w = 0; w < NMS_RT / 64; w++) ns += sh[8 + w];
+        if (alive) surv[base + (int)__popcll(am & ((1ULL << lane) - 1ULL))] = tid;
+        __syncthreads();
+        // ---- chunks of 64 survivors ----
+        for (int s0 = 0; s0 < ns && nk < K; s0 += 64) {
+            const int nc = min(64, ns - s0);
+            if (tid < nc) cand[tid] = pre[surv[s0 + tid]];
+            if (tid < 64) m[tid] = 0ULL;
+            if (tid == 0) { supw[0] = 0ULL; sh[1] = 0; }
+            __syncthreads();
+            // A': the chunk against the boxes kept since the prefilter (earlier chunks of this batch)
+            for (int k0 = nk0; k0 < nk; k0 += 32) {
+                const int nt = min(32, nk - k0);
+#pragma unroll 2
+                for (int q = tid; q < 64 * 32; q += NMS_RT) {
+                    const int c = q & 63, kk = q >> 6;
+                    bool pass = kk < nt && c < nc;
+                    if (pass && prefilter) pass = !far_apart(keptb[k0 + kk], cand[c]);
+                    push_pairs(pass, ((unsigned)(k0 + kk) << 6) | (unsigned)c, pairs, &sh[1]);
+                }
+                __syncthreads();
+                const int np = sh[1];
+                __syncthreads();
+                if (k0 + 32 >= nk || np > PAIR_CAP - 64 * 32) {
+                    for (int e = tid; e < np; e += NMS_RT) {
+                        const unsigned code = pairs[e];
+                        const int c = code & 63, k = code >> 6;
+                        if ((supw[0] >> c) & 1ULL) continue;
+                        if (iou_bev(keptb[k], cand[c]) > thresh) set_bit(&supw[0], c);
+                    }
+                    __syncthreads();
+                    if (tid == 0) sh[1] = 0;
+                    __syncthreads();
+                }
+            }
+            const u64 validm = nc == 64 ? ~0ULL : ((1ULL << nc) - 1ULL);
+            const u64 live = validm & ~supw[0];
+            // B: upper triangle among the chunk
+#pragma unroll 2
+            for (int q = tid; q < 64 * 64; q += NMS_RT) {
+                const int c = q & 63, r = q >> 6;
+                bool pass = r < c && ((live >> r) & 1ULL) && ((live >> c) & 1ULL);
+                if (pass && prefilter) pass = !far_apart(cand[r], cand[c]);
+                push_pairs(pass, ((unsigned)r << 6) | (unsigned)c, pairs, &sh[1]);   // <= 2016 entries
+            }
+            __syncthreads();
+            const int np = sh[1];
+            for (int e = tid; e < np; e += NMS_RT) {
+                const unsigned code = pairs[e];
+                const int c = code & 63, r = code >> 6;
+                if (iou_bev(cand[r], cand[c]) > thresh) set_bit(&m[r], c);
+            }
+            __syncthreads();
+            if (wave == 0) {                            // C: serial resolve on uniform masks
+                const u64 row = m[lane];
+                const unsigned rlo = (unsigned)row, rhi = (unsigned)(row >> 32);
+                u64 cur = ~live, keptm = 0ULL;
+                int num = nk;
+                for (int t = 0; t < nc; t++) {
+                    if (num == K) break;
+                    if (!((cur >> t) & 1ULL)) {
+                        keptm |= 1ULL << t;
+                        num++;
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)rlo, t);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)rhi, t);
+                        cur |= ((u64)hi << 32) | lo;
+                    }
+                }
+                if ((keptm >> lane) & 1ULL) {
+                    const int pos = nk + __popcll(keptm & ((1ULL << lane) - 1ULL));
+                    keptb[pos] = cand[lane];
+                    kept_out[pos] = cl[p0 + surv[s0 + lane]];
+                }
+                if (lane == 0) sh[0] = num;
+            }
+            __syncthreads();
+            nk = sh[0];
+        }
+    }
+    if (tid == 0) P.kept_cnt[sb] = nk;
+    for (int k = nk + tid; k < K; k += NMS_RT) kept_out[k] = -1;
+}
+
 // ====================================================================================================
 // output assembly (proposal_layer.py:38-56,114-117)
 // ====================================================================================================
@@ -688,8 +858,22 @@ static int launch_greedy_nms_kind(const char* op, const NmsParams& P, int B, hip
     return PRCNN_OK;
 }
 static int launch_greedy_nms(const char* op, int kind, const NmsParams& P, int B, hipStream_t s) {
-    return kind == PRCNN_NMS_ROTATED ? launch_greedy_nms_kind<PRCNN_NMS_ROTATED>(op, P, B, s)
-                                     : launch_greedy_nms_kind<PRCNN_NMS_NORMAL>(op, P, B, s);
+    if (kind == PRCNN_NMS_ROTATED) {
+        // the prefiltered kernel where its batch fits beside the kept list (it always does for the proposal layer's 70 / 30 and the
+        // detection select's 100); PRCNN_NMS_PREFILTER=0 is the A/B switch (same keep lists), read per call: the tests flip it in-process
+        const char* e = getenv("PRCNN_NMS_PREFILTER");
+        const size_t lds = greedy_nms_rot_lds_bytes(max(P.post1, P.post2));
+        if ((e == nullptr || atoi(e) != 0) && lds <= LDS_BUDGET) {
+            static PrcnnLdsLimit attr_set;
+            if (!attr_set.raise((const void*)greedy_nms_rot_kernel, LDS_BUDGET))
+                return prcnn_fail(PRCNN_EHIP, "%s: cannot raise the dynamic LDS limit", op);
+            hipLaunchKernelGGL(greedy_nms_rot_kernel, dim3(P.nseg, B), dim3(NMS_RT), lds, s, P);
+            PRCNN_LAUNCH_CHECK(op);
+            return PRCNN_OK;
+        }
+        return launch_greedy_nms_kind<PRCNN_NMS_ROTATED>(op, P, B, s);
+    }
+    return launch_greedy_nms_kind<PRCNN_NMS_NORMAL>(op, P, B, s);
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }

@@ -33,6 +33,13 @@ def test_mlp_rows_matches_oracle(dev, cpu, rows, K, Nout, relu, bias):
     got = ops.mlp_rows(T(a, dev), lin(dev, w, b, relu)).cpu().numpy()
     assert got.shape == want.shape
     np.testing.assert_allclose(got, want, atol=mlp_tol(want), rtol=0)
+    # the same contract PER ELEMENT (north_star's 1e-5 read literally): |err| <= 1e-5 * (sum_k |x_k||w_k| + |b|) against float64, in
+    # both arithmetics of the fused inference MLPs (conftest mlp_mode) -- the tensor-scale bound above is the looser of the two
+    exact = a.astype(np.float64) @ w.astype(np.float64).T + (0.0 if b is None else b.astype(np.float64))
+    if relu:
+        exact = np.maximum(exact, 0.0)
+    elem = 1e-5 * (np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T + (0.0 if b is None else np.abs(b).astype(np.float64))) + 1e-30
+    assert (np.abs(got.astype(np.float64) - exact) <= elem).all(), float((np.abs(got - exact) / elem).max())
 
 
 def test_mlp_rows_identity_is_transpose_safe(dev):

@@ -89,6 +89,36 @@ def test_score_ties_nan_and_small_frames(dev, cpu):
         assert np.array_equal(scores.cpu().numpy(), o[1], equal_nan=True), N
 
 
+@pytest.mark.parametrize("thresh", [0.8, 0.3, -1.0])
+def test_rotated_prefiltered_kernel_equals_chunk_kernel_and_oracle(dev, cpu, monkeypatch, thresh):
+    """greedy_nms_rot_kernel (round 5: a batch of 256 candidates is tested against the kept list before the serial chunk step) keeps
+    exactly what greedy_nms_kernel<ROTATED> (PRCNN_NMS_PREFILTER=0) and the oracle keep, on the scene it was written for: 24 cars,
+    40 % of the points voting for them in tight clusters, so that ~2 500 candidates are scanned before 70 survive; a low threshold
+    (few survivors per batch, several batches per kept box) and a negative one (every pair suppresses: the circle test is off)."""
+    from pointrcnn_amd import ops
+    xyz, sc, reg = rpn_like_scene(3, 16384, seed=21)
+    B, N = sc.shape
+    boxes = ops.decode_bbox_target(_t(xyz.reshape(-1, 3), dev), _t(reg.reshape(-1, 76), dev), 3.0, 0.5, 12, ANCHOR,
+                                   get_xz_fine=True, y_to_bottom=True).view(B, N, 7)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PRCNN_NMS_PREFILTER", flag)
+        rois, scores, cnt = ops.proposal_layer(_t(sc, dev), boxes, (6300, 2700), (70, 30), thresh, rotated=True)
+        got[flag] = (rois.cpu().numpy(), scores.cpu().numpy(), cnt.cpu().numpy())
+    for a, b in zip(got["1"], got["0"]):
+        assert np.array_equal(a, b)
+    o = cpu.proposal_layer(sc, boxes.cpu().numpy(), (6300, 2700), (70, 30), thresh, "rotated")
+    for a, b in zip(got["1"], o):
+        assert np.array_equal(a, b)
+    # the detection select's shape (eval_rcnn.py:600-614): 100 boxes per frame, every survivor kept
+    keep = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PRCNN_NMS_PREFILTER", flag)
+        k, n = ops.nms_batched(boxes[:, :300].contiguous(), _t(sc[:, :300], dev), None, 0.1, True)
+        keep[flag] = (k.cpu().numpy(), n.cpu().numpy())
+    assert np.array_equal(keep["1"][0], keep["0"][0]) and np.array_equal(keep["1"][1], keep["0"][1])
+
+
 def test_nms_batched_equals_oracle_and_sorted_nms(dev, cpu):
     """tools/eval_rcnn.py:600-614: score-threshold select + rotated NMS 0.1 on the refined boxes, whole batch at once"""
     from pointrcnn_amd import ops
