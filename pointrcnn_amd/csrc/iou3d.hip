@@ -44,15 +44,33 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     const int col_size = min(64, N - col_blk * 64);
     unsigned long long bits = 0;
     if (KIND == PRCNN_NMS_ROTATED) {
+        // Round 5: the tile's pairs that need the polygon clip are LISTED first (circumscribed circles not far apart: a dozen of the
+        // 4096 on scattered boxes) and then clipped one per lane.  Rounds 1-4 walked the 64 columns with every row's lane deciding for
+        // itself: whenever one lane of the wave needed a clip the other 63 waited for it -- ~32 one-lane clips per tile.  The listed
+        // pairs are the same pairs, the tests the same tests: same mask bits.
         __shared__ RBox srow[64], scol[64];
+        __shared__ unsigned short plist[64 * 64];
+        __shared__ unsigned rbits[64][2];
         if (row < N) make_rbox(boxes + (size_t)row * 5, srow[t]);
         if (col < N) make_rbox(boxes + (size_t)col * 5, scol[t]);
+        rbits[t][0] = 0u; rbits[t][1] = 0u;
         __syncthreads();
-        if (row < N) {
-            int start = (row_blk == col_blk) ? t + 1 : 0;    // iou3d_kernel.cu:281-283
-            for (int i = start; i < col_size; i++)
-                if (iou_bev(srow[t], scol[i]) > thresh) bits |= 1ULL << i;
+        const bool skip_far = thresh >= 0.0f;            // a zero overlap suppresses only under a negative threshold
+        const int start = (row_blk == col_blk) ? t + 1 : 0;    // iou3d_kernel.cu:281-283
+        int np = 0;                                      // uniform: one wave per workgroup
+        for (int i = 0; i < col_size; i++) {
+            const bool pass = row < N && i >= start && !(skip_far && far_apart(srow[t], scol[i]));
+            const unsigned long long bm = __ballot(pass);
+            if (pass) plist[np + (int)__popcll(bm & ((1ULL << t) - 1ULL))] = (unsigned short)((t << 6) | i);
+            np += (int)__popcll(bm);
         }
+        __syncthreads();
+        for (int e = t; e < np; e += 64) {
+            const int code = plist[e], r = code >> 6, i = code & 63;
+            if (iou_bev(srow[r], scol[i]) > thresh) atomicOr(&rbits[r][i >> 5], 1u << (i & 31));
+        }
+        __syncthreads();
+        bits = ((unsigned long long)rbits[t][1] << 32) | rbits[t][0];
     } else {
         __shared__ float scolb[64 * 5];
         if (col < N)
@@ -84,10 +102,26 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const unsigned
     for (int w = tid; w < W; w += SWEEP_THREADS) remv[w] = 0ULL;
     if (tid == 0) xchg[1] = 0ULL;
     __syncthreads();
+    unsigned long long diag_next = (wave == 0 && lane < N) ? mask[(size_t)lane * W] : 0ULL;
     for (int blk = 0; blk < W; blk++) {
+        const int nrows = min(64, N - blk * 64);
+        // Round 5: the 64 rows of this block's column words are requested BEFORE the serial resolve and whatever it keeps (the kept mask
+        // selects among them afterwards), all 64 at once: the loads fly while wave 0 resolves, one memory round trip per block where the
+        // kept-dependent fold took four dependent ones after the resolve (N = 6300: 99 blocks, 0.71 -> see profiles/r05_opbench.jsonl).
+        // the block's own (diagonal) word was requested a block ahead: the serial resolve starts without waiting for memory
+        const unsigned long long diag = diag_next;
+        if (wave == 0 && blk + 1 < W && (blk + 1) * 64 + lane < N) diag_next = mask[(size_t)((blk + 1) * 64 + lane) * W + blk + 1];
+        const int w0 = blk + 1 + tid;
+        unsigned long long part[64];
+        {
+            // straight-line loads from clamped addresses (a guarded load is a branch of its own), masked by the kept bits below: rows past
+            // the block's last one read its last row again and are never selected (kept has no bit there)
+            const unsigned long long* col = mask + (size_t)blk * 64 * W + (w0 < W ? w0 : W - 1);
+#pragma unroll
+            for (int u = 0; u < 64; u++) part[u] = col[(size_t)min(u, nrows - 1) * W];
+        }
         if (wave == 0) {
             const int row = blk * 64 + lane;
-            unsigned long long diag = row < N ? mask[(size_t)row * W + blk] : 0ULL;
             unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
             unsigned long long cur = remv[blk];
             // readfirstlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high one
@@ -95,7 +129,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const unsigned
                   (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur);
             int num = (int)xchg[1];
             num = __builtin_amdgcn_readfirstlane(num);
-            const int nrows = min(64, N - blk * 64);
             unsigned long long kept = 0ULL;
             for (int t = 0; t < nrows; t++) {            // serial inside the block, registers only
                 if (!((cur >> t) & 1ULL)) {
@@ -113,17 +146,23 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const unsigned
         const int num = (int)xchg[1];
         if (max_keep > 0 && num >= max_keep) break;       // uniform: every thread reads the same LDS word
         // fold the kept rows of this block into the suppression words of later blocks
-        for (int w = blk + 1 + tid; w < W; w += SWEEP_THREADS) {
+        if (w0 < W) {
+            unsigned long long acc = remv[w0];
+#pragma unroll
+            for (int u = 0; u < 64; u++) acc |= ((kept >> u) & 1ULL) ? part[u] : 0ULL;
+            remv[w0] = acc;
+        }
+        for (int w = w0 + SWEEP_THREADS; w < W; w += SWEEP_THREADS) {          // more than 256 later blocks (N > 16 384): the rest as before
             unsigned long long acc = remv[w];
             const unsigned long long* col = mask + (size_t)blk * 64 * W + w;
 #pragma unroll 1
             for (int t0 = 0; t0 < 64; t0 += 16) {
-                unsigned long long part[16];
+                unsigned long long q[16];
 #pragma unroll
                 for (int u = 0; u < 16; u++)               // 16 independent loads; `kept` is uniform
-                    part[u] = ((kept >> (t0 + u)) & 1ULL) ? col[(size_t)(t0 + u) * W] : 0ULL;
+                    q[u] = ((kept >> (t0 + u)) & 1ULL) ? col[(size_t)(t0 + u) * W] : 0ULL;
 #pragma unroll
-                for (int u = 0; u < 16; u++) acc |= part[u];
+                for (int u = 0; u < 16; u++) acc |= q[u];
             }
             remv[w] = acc;
         }
