@@ -1876,8 +1876,11 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_s_kernel(const ChainParams C
             if (st + 1 < NB0) sstage_store<NB1>(&Ws[(st + 1) & 1][0], tid, w1);
             __syncthreads();
         }
+        // ... or a finite layer-0 output whose layer-1 product overflows: the split of the overflowing sum holds NaN pieces where the fp32
+        // chain returns +-inf (round-4 advisor finding: only the layer-0 accumulators were tested)
+        const bool bad1 = bad || (P.wpack != nullptr && wave_has_nonfinite<NB1>(a1));
         bias_act<NB1>(a1, s_bias[1], C.relu1, h);
-        if (!bad) chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
+        if (!bad1) chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
         else schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, s_bias, false);
     }
 }

@@ -268,7 +268,9 @@ class PackedLinear:
 #                  `mlp_mode`), and by bench.py's max_diff_vs_f32_mfma on uniform, lidar and saturated clouds (contract 1e-5).
 #   0           -- fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout: PRCNN_MLP_SPLIT=0.
 #   3           -- three terms (drops below 2^-16 |x||w|): OUTSIDE the 1e-5 contract, dev / trade-off measurements only.
-# The choice never depends on row counts (a frame's bits are the same in a batch of 1 and of 32).  Training kernels are fp32 MFMA.
+# The choice never depends on row counts (a frame's bits are the same in a batch of 1 and of 32 -- with one exception: FINITE rows that
+# share a 64-row block (32 in the chain kernels) with a row holding inf / NaN are recomputed with it on the fp32 pipe and carry the
+# fp32-MFMA kernel's bits, within the same 1e-5 contract).  Training kernels are fp32 MFMA.
 MLP_SPLIT_TERMS = int(os.environ.get("PRCNN_MLP_SPLIT", "6") or 0)
 if MLP_SPLIT_TERMS not in (0, 3, 6):
     raise RuntimeError("PRCNN_MLP_SPLIT=%r: 6 (default) / 3 split-bf16 terms, 0 = fp32 MFMA" % os.environ.get("PRCNN_MLP_SPLIT"))

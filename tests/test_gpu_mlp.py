@@ -668,6 +668,30 @@ def test_split_bf16_chain_nonfinite_rows(dev, monkeypatch, n1, relu1):
 
 
 @pytest.mark.own_arithmetic
+def test_split_bf16_chain_layer1_overflow_is_the_fp32_chains_infinity(dev, monkeypatch):
+    """finite inputs, finite hidden units, but a layer-1 product that overflows fp32: the fp32 chain returns +-inf there; the split
+    of the overflowing accumulation holds NaN pieces, so the wave must notice it on the layer-1 accumulators too (round-4 advisor
+    finding: only layer 0 was tested) and redo its rows on the fp32 pipe -- same non-finite entries, same class, as the fp32 chain"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(77)
+    rows = 4096 + 5
+    x = np.abs(r.normal(size=(rows, 128))).astype(np.float32)
+    x[70] *= 1e18; x[3000] *= 1e18                                       # hidden units ~1e19 (finite), times weights ~1e20: overflow in layer 1
+    w0 = np.abs(r.normal(size=(128, 128)) * 0.1).astype(np.float32)
+    w1 = (r.normal(size=(76, 128)) * 1e20).astype(np.float32)
+    w1[:38] = np.abs(w1[:38])                                            # these outputs overflow to +inf, the mixed-sign ones to NaN
+    layers = [lin(dev, w0, np.zeros(128, np.float32), True), lin(dev, w1, np.zeros(76, np.float32), False)]
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 0)
+    ref = ops.mlp_chain_rows(T(x, dev), layers).cpu().numpy()
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
+    got = ops.mlp_chain_rows(T(x, dev), layers).cpu().numpy()
+    assert np.isinf(ref[70]).any() and np.isinf(ref[3000]).any()
+    assert _same_class(got, ref)
+    fin = np.isfinite(ref)
+    assert np.abs(got[fin] - ref[fin]).max() <= mlp_tol(ref[fin])
+
+
+@pytest.mark.own_arithmetic
 def test_split_bf16_hoisted_fp0_nonfinite_rows(dev, monkeypatch):
     """hoisted FP0 with an infinite known-point row: every row interpolating from it is relu(inf + b) = inf going into the layer"""
     from pointrcnn_amd import ops

@@ -2,7 +2,7 @@
 # copy the summaries produced by tools/refresh_profiles.sh (gpurun_out/refresh) into profiles/ (round tag = $1, default r02)
 set -e
 R=gpurun_out/refresh
-T=${1:-r04}
+T=${1:-r05}
 cp $R/bench_default.json profiles/${T}_final_bench.json
 cp $R/bench_driver_flags.json profiles/${T}_final_bench_steps20.json
 cp $R/bench_streams1.json profiles/${T}_final_bench_streams1.json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh'
-# Outputs land in gpurun_out/refresh/; copy the summaries into profiles/ afterwards (tools/collect_profiles.sh r04).
+# Outputs land in gpurun_out/refresh/; copy the summaries into profiles/ afterwards (tools/collect_profiles.sh r05).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
@@ -12,7 +12,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_FETCH_SI
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_WRITE_SIZE -- $B > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $O/pmc_mfma -- $B > /dev/null 2>&1
 python profiles/derive_hbm_traffic.py $O/pmc_ $O/hbm_traffic.json > $O/hbm_traffic.txt 2>&1
-cp $O/hbm_traffic.json profiles/r04_hbm_traffic.json
+cp $O/hbm_traffic.json profiles/r05_hbm_traffic.json
 python profiles/derive_mfma_util.py $O/pmc_mfma > $O/mfma_util.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2>> $O/bench_default.err
