@@ -102,10 +102,32 @@ __device__ __forceinline__ bool seg_intersection(Pt p1, Pt p0, Pt q1, Pt q0, Pt&
 // ordering key of the angular sort: atan2(dy, dx) exactly as the reference's host libm evaluates it (iou3d_kernel.cu:104-106)
 __device__ __forceinline__ float angle_key(float dx, float dy) { return prcnn_ref_atan2f(dy, dx); }
 
-// iou3d_kernel.cu:108-212
-__device__ float box_overlap(const RBox& A, const RBox& B) {
+// Storage of the clip's point list (up to 16 edge intersections + 8 contained corners, and their sort keys).  The reference keeps them in
+// thread-local arrays and bubble-sorts them there (iou3d_kernel.cu:110-111,188-196); on gfx950 dynamically indexed private arrays live in
+// scratch memory.  ClipLds keeps the same arrays in a lane-private column of an LDS block (element e of lane t at base[e * T + t]:
+// conflict-free whatever the lanes' indices) -- same algorithm, same operations in the same order, same bits.  Measured in round 5 and NOT
+// used by the NMS kernels: rotated NMS of 6300 boxes 777 vs 696 us, the proposal stage's rotated NMS 1586 (256 threads, LDS) vs 1346 us
+// (512 threads, scratch) -- the clip is not waiting for its arrays, it is ~5 k mostly dependent instructions (16 edge tests, correctly
+// rounded divisions, an atan2 per point) whatever the number of lanes that run it.
+struct ClipPrivate {
     Pt cp[24];
-    float key[24];
+    float k[24];
+    __device__ __forceinline__ float& x(int i) { return cp[i].x; }
+    __device__ __forceinline__ float& y(int i) { return cp[i].y; }
+    __device__ __forceinline__ float& key(int i) { return k[i]; }
+};
+#define CLIP_LDS_FLOATS 72          // per lane
+struct ClipLds {
+    float* b;                       // block base + the lane's index
+    int T;                          // lanes sharing the block (the stride between a lane's elements)
+    __device__ __forceinline__ float& x(int i) { return b[(size_t)(3 * i) * T]; }
+    __device__ __forceinline__ float& y(int i) { return b[(size_t)(3 * i + 1) * T]; }
+    __device__ __forceinline__ float& key(int i) { return b[(size_t)(3 * i + 2) * T]; }
+};
+
+// iou3d_kernel.cu:108-212
+template <class S>
+__device__ float box_overlap_s(const RBox& A, const RBox& B, S& st) {
     float pcx = 0.f, pcy = 0.f;
     int cnt = 0;
     for (int i = 0; i < 4; i++)
@@ -113,37 +135,44 @@ __device__ float box_overlap(const RBox& A, const RBox& B) {
             Pt ans;
             if (seg_intersection(A.p[i + 1], A.p[i], B.p[j + 1], B.p[j], ans)) {
                 pcx = add(pcx, ans.x); pcy = add(pcy, ans.y);
-                cp[cnt++] = ans;
+                st.x(cnt) = ans.x; st.y(cnt) = ans.y; cnt++;
             }
         }
     for (int k = 0; k < 4; k++) {
-        if (check_in_box2d(A, B.p[k])) { pcx = add(pcx, B.p[k].x); pcy = add(pcy, B.p[k].y); cp[cnt++] = B.p[k]; }
-        if (check_in_box2d(B, A.p[k])) { pcx = add(pcx, A.p[k].x); pcy = add(pcy, A.p[k].y); cp[cnt++] = A.p[k]; }
+        if (check_in_box2d(A, B.p[k])) { pcx = add(pcx, B.p[k].x); pcy = add(pcy, B.p[k].y); st.x(cnt) = B.p[k].x; st.y(cnt) = B.p[k].y; cnt++; }
+        if (check_in_box2d(B, A.p[k])) { pcx = add(pcx, A.p[k].x); pcy = add(pcy, A.p[k].y); st.x(cnt) = A.p[k].x; st.y(cnt) = A.p[k].y; cnt++; }
     }
     if (cnt == 0) return 0.0f;
     pcx = pcx / (float)cnt; pcy = pcy / (float)cnt;
-    for (int i = 0; i < cnt; i++) key[i] = angle_key(sub(cp[i].x, pcx), sub(cp[i].y, pcy));
+    for (int i = 0; i < cnt; i++) st.key(i) = angle_key(sub(st.x(i), pcx), sub(st.y(i), pcy));
     for (int j = 0; j < cnt - 1; j++)                                            // iou3d_kernel.cu:188-196
-        for (int i = 0; i < cnt - j - 1; i++)
-            if (key[i] > key[i + 1]) {
-                Pt t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
-                float tk = key[i]; key[i] = key[i + 1]; key[i + 1] = tk;
+        for (int i = 0; i < cnt - j - 1; i++) {
+            const float k0 = st.key(i), k1 = st.key(i + 1);
+            if (k0 > k1) {
+                const float x0 = st.x(i), y0 = st.y(i), x1 = st.x(i + 1), y1 = st.y(i + 1);
+                st.x(i) = x1; st.y(i) = y1; st.x(i + 1) = x0; st.y(i + 1) = y0;
+                st.key(i) = k1; st.key(i + 1) = k0;
             }
+        }
     float area = 0.f;
+    const float ox = st.x(0), oy = st.y(0);
     for (int k = 0; k < cnt - 1; k++) {                                          // iou3d_kernel.cu:206-211
-        float ux = sub(cp[k].x, cp[0].x), uy = sub(cp[k].y, cp[0].y);
-        float vx = sub(cp[k + 1].x, cp[0].x), vy = sub(cp[k + 1].y, cp[0].y);
+        float ux = sub(st.x(k), ox), uy = sub(st.y(k), oy);
+        float vx = sub(st.x(k + 1), ox), vy = sub(st.y(k + 1), oy);
         area = add(area, sub(mul(ux, vy), mul(uy, vx)));
     }
     return fabsf(area) / 2.0f;
 }
+__device__ float box_overlap(const RBox& A, const RBox& B) { ClipPrivate st; return box_overlap_s(A, B, st); }
 
-__device__ __forceinline__ float iou_bev(const RBox& a, const RBox& b) {         // iou3d_kernel.cu:214-221
+template <class S>
+__device__ __forceinline__ float iou_bev_s(const RBox& a, const RBox& b, S& st) {         // iou3d_kernel.cu:214-221
     float sa = mul(sub(a.x2, a.x1), sub(a.y2, a.y1));
     float sb = mul(sub(b.x2, b.x1), sub(b.y2, b.y1));
-    float ov = box_overlap(a, b);
+    float ov = box_overlap_s(a, b, st);
     return ov / fmaxf(sub(add(sa, sb), ov), 1e-8f);
 }
+__device__ __forceinline__ float iou_bev(const RBox& a, const RBox& b) { ClipPrivate st; return iou_bev_s(a, b, st); }
 
 __device__ __forceinline__ float iou_normal(const float* a, const float* b) {    // iou3d_kernel.cu:295-303
     float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);

@@ -78,7 +78,7 @@ RT_FN float prcnn_ref_sinf(float y) {
     rt_table(0, &p);
     int n;
     x = rt_reduce_fast(x, &p, &n);
-    const double s = p.sign[n & 3];
+    const double s = ((n + 1) & 2) ? -1.0 : 1.0;          // sign[n & 3] of {1, -1, -1, 1} without an indexed table (a dynamically indexed local array is scratch memory on the GPU)
     if (n & 2) rt_table(1, &p);
     return rt_poly(x * s, x * x, &p, n);
 }
@@ -95,7 +95,7 @@ RT_FN float prcnn_ref_cosf(float y) {
     rt_table(0, &p);
     int n;
     x = rt_reduce_fast(x, &p, &n);
-    const double s = p.sign[(n + 1) & 3];
+    const double s = ((n + 2) & 2) ? -1.0 : 1.0;          // sign[(n + 1) & 3]
     if ((n + 1) & 2) rt_table(1, &p);
     return rt_poly(x * s, x * x, &p, n ^ 1);
 }
@@ -130,7 +130,9 @@ RT_FN float rt_atanf(float x) {
     const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
     const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
     if (id < 0) return x - x * (s1 + s2);
-    const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    const float hi = id == 0 ? atanhi[0] : id == 1 ? atanhi[1] : id == 2 ? atanhi[2] : atanhi[3];          // (selects, not an indexed table)
+    const float lo = id == 0 ? atanlo[0] : id == 1 ? atanlo[1] : id == 2 ? atanlo[2] : atanlo[3];
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
     return hx < 0 ? -r : r;
 }
 
