@@ -575,7 +575,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
 template <int PPT, int NW>
 __global__ __launch_bounds__(NW * 64) void fps_slot_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ perm,
                                                           int N, int npoint, int32_t* __restrict__ idx_out) {
-    constexpr int BLOCK = NW * 64;          // NW waves x 64 lanes x PPT points (16 x 16 for 16 384 points; 8 x 8 for the 4 096-point level: 716 vs 659 us, not used)
+    constexpr int BLOCK = NW * 64;          // NW waves x 64 lanes x PPT points (16 x 16 for 16 384 points; the 4 096-point level on 8 x 8: 716, on 4 x 16: 748 vs 653 us for 16 waves x 4 points -- not used)
     typedef typename fvec_t<PPT>::type fvec;
     FPS_XT_DECL;
     // original indices of the points a lane holds: only the winner's is ever needed, so they live in LDS (slot-major:
