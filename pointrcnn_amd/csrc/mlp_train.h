@@ -886,30 +886,35 @@ static void launch_wgrad_lds(const TrainWgrad& Wg, dim3 grid, hipStream_t s) {
     else hipLaunchKernelGGL((train_wgrad_lds_kernel<POOL, MULT, false>), grid, dim3(256), 0, s, Wg);
 }
 
-// out[n, (k + k_unrot) % K] = sum over the partials, in order.  Block = 64 elements x 4 lanes over the partial index; k_unrot = 3
-// turns the kernel's [feat | dxyz] column order of a grouped first layer back into torch's [dxyz | feat].
+// out[n, (k + k_unrot) % K] = sum over the partials, in a fixed order (deterministic).  Block = 16 elements x 16 lanes over the partial
+// index, eight loads in flight per lane (round 5: narrow layers have up to 4096 partials -- 1024 row ranges x 4 row groups -- and the
+// round-3 form walked them 4 lanes x 4 loads at a time: 256 dependent L2 round trips, 24 us per call, 0.8 ms per training step);
+// k_unrot = 3 turns the kernel's [feat | dxyz] column order of a grouped first layer back into torch's [dxyz | feat].
+#define WRED_E 16
+#define WRED_Q 16
 __global__ __launch_bounds__(256) void train_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, long count, int K, int k_unrot,
                                                                  float* __restrict__ out) {
-    __shared__ float sm[4][64];
-    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const long e = (long)blockIdx.x * 64 + c;
+    __shared__ float sm[WRED_Q][WRED_E];
+    const int c = threadIdx.x & (WRED_E - 1), q = threadIdx.x / WRED_E;
+    const long e = (long)blockIdx.x * WRED_E + c;
     float s = 0.f;
     if (e < count) {
-        const int per = (nparts + 3) >> 2;
+        const int per = (nparts + WRED_Q - 1) / WRED_Q;
         const int t0 = q * per, t1 = min(nparts, t0 + per);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int t = t0;
-        for (; t + 4 <= t1; t += 4) {
-            s0 += part[(long)t * count + e]; s1 += part[(long)(t + 1) * count + e];
-            s2 += part[(long)(t + 2) * count + e]; s3 += part[(long)(t + 3) * count + e];
-        }
-        for (; t < t1; t++) s0 += part[(long)t * count + e];
-        s = (s0 + s1) + (s2 + s3);
+        for (; t + 8 <= t1; t += 8)
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] += part[(long)(t + u) * count + e];
+        for (; t < t1; t++) a[0] += part[(long)t * count + e];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     sm[q][c] = s;
     __syncthreads();
     if (q == 0 && e < count) {
-        const float tot = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+        float tot = 0.f;
+#pragma unroll
+        for (int u = 0; u < WRED_Q; u++) tot += sm[u][c];
         const long n = e / K;
         const int kk = (int)(e - n * K);
         out[n * K + (kk + k_unrot) % K] = tot;
@@ -1452,7 +1457,7 @@ PRCNN_API int prcnn_train_stack_bwd(const prcnn_train_src_t* src, const prcnn_tr
             else launch_wgrad_lds<2, true>(Wg, wg, s);
         } else launch_wgrad<2, 2, 2, 2>(Wg, p, s);
         const long count = (long)N * K;
-        hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3(prcnn_divup(count, 64)), dim3(256), 0, s, W.wpart, p.splits * p.WR, count, K,
+        hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3(prcnn_divup(count, WRED_E)), dim3(256), 0, s, W.wpart, p.splits * p.WR, count, K,
                            (l == 0 && src->mode == MODE_GROUP && K > 3) ? 3 : 0, L[l].dW);
         // dgrad
         if (l == 0 && !gin) break;
