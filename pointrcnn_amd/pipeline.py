@@ -2,12 +2,12 @@
 
 What tools/eval_rcnn.py:459-520 does per batch -- `inputs = torch.from_numpy(pts_input).cuda(non_blocking=True)`, `model(input_data)`,
 read the outputs -- keeps ONE batch in flight on one stream.  On this path that exposes the furthest-point-sampling chain: a serial
-4.5 ms chain on one workgroup per frame (32 of 256 CUs for a bs32 batch), during which the rest of the chip idles (4.8 k
+3.8 ms chain on one workgroup per frame (32 of 256 CUs for a bs32 batch), during which the rest of the chip idles (5.2 k
 frames/s).  Batches are independent, so the engine keeps `slots` of them in flight: slot s owns a HIP stream (and, with
 GPU_MAX_HW_QUEUES >= slots, a hardware queue), static device input buffers, and a hipGraph of one whole step captured on that
 stream.  `submit()` copies a batch's inputs into the slot's buffers (pinned host memory -> asynchronous H2D on the slot's stream, or, with
 copy_stream=True, on one copy stream shared by the slots, first come first served; either way overlapping the other slots' kernels) and replays the graph; results come back in submission order.  One batch's FPS then runs
-underneath other batches' MLP kernels (15.7 k frames/s on the same graph).
+underneath other batches' MLP kernels (16.2-17.8 k frames/s on the same graph).
 
     pipe = InferencePipeline(lambda inp, slot: model(inp), {"pts_input": example}, slots=20)
     for out in pipe.map(batches):          # batches: iterable of {"pts_input": pinned host or device tensor}
