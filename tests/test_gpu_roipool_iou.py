@@ -241,6 +241,20 @@ def test_iou3d_dropin_module(dev, cpu):
         iou3d_cuda.nms_gpu(torch.from_numpy(boxes), torch.LongTensor(500), 0.4)      # CPU boxes rejected
 
 
+def test_nms_more_than_256_blocks_and_rotated_at_rpn_scale(dev, cpu):
+    """the sweep folds a block's kept rows into the later blocks' suppression words one word per thread, 256 threads: more than 256
+    later blocks (N > 16 384) take the kernel's second loop; and the rotated mask kernel's pair lists at the RPN's scale (6 300
+    scattered boxes: a dozen listed pairs per 64 x 64 tile, some tiles none, the diagonal tiles their upper triangle only)"""
+    from pointrcnn_amd import ops
+    boxes = rand_bev(17000, 60.0, seed=170)
+    keep, num = ops.nms_sorted(T(boxes, dev), 0.5, rotated=False)
+    assert np.array_equal(keep[: int(num.item())].cpu().numpy(), cpu.nms(boxes, 0.5, "normal"))
+    boxes = rand_bev(6300, 30.0, seed=64)
+    for thr in (0.8, 0.05):
+        keep, num = ops.nms_sorted(T(boxes, dev), thr, rotated=True)
+        assert np.array_equal(keep[: int(num.item())].cpu().numpy(), cpu.nms(boxes, thr, "rotated"))
+
+
 def test_nms_max_keep_prefix(dev, cpu):
     """max_keep stops the sweep early: the kept list is the exact prefix of the full result (what
     proposal_layer.py:112 `keep_idx[:post_top_n]` consumes), for both kinds and across block boundaries"""
