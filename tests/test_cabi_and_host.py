@@ -230,3 +230,31 @@ def test_every_repo_path_cited_in_the_boundary_documents_exists():
                     if not re.search(r"def %s%s" % (re.escape(fn), r"\w*" if fn.endswith("_") else r"\b"), fh.read()):      # test_x_* = a family
                         missing.append("%s cites %s::%s" % (os.path.relpath(d, root), rel, fn))
     assert not missing, "\n".join(sorted(set(missing)))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc absent")
+def test_fps_workgroup_kernels_keep_their_register_budget():
+    """fps_slot_kernel<16,16> runs one 16-wave workgroup per frame for milliseconds under other batches' MLP kernels; at 88 allocated
+    VGPRs its four waves per SIMD leave 160 registers, which the cls-head chain (148) and the small kernels fit into ('where the
+    time goes').  The round-5 changes to the sample loop were held to that budget (the quad form at 90 registers was re-written to 86):
+    pin it, together with 'no scratch', on the ISA the build produces."""
+    import re
+    import subprocess
+    import tempfile
+    from pointrcnn_amd import build
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "fps.s")
+        subprocess.run([build.HIPCC] + build.FLAGS + build.EXTRA_FLAGS["fps.hip"] + ["--cuda-device-only", "-S", os.path.join(build.CSRC, "fps.hip"), "-o", out],
+                       check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    meta = text[text.index("amdhsa.kernels:"):]
+    seen = {}
+    for blk in meta.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        seen[name] = (int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)), int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)))
+    slot = [v for k, v in seen.items() if "fps_slot_kernelILi16ELi16E" in k]
+    assert len(slot) == 1, sorted(seen)
+    assert slot[0][0] <= 88 and slot[0][1] == 0, slot
+    for k, (vgpr, scratch) in seen.items():
+        if "fps_pruned_kernel" in k or "fps_reg_kernel" in k:
+            assert scratch == 0 and vgpr <= 88, (k, vgpr, scratch)
