@@ -1036,6 +1036,16 @@ def main():
     trace("model built; preparing %d slots" % nstreams)
     bench = InferenceBench(args, model, dev, rank, world, args.clouds, proposal_layer, raw).prepare()
     trace("slots captured; timed loop")
+    hbm = None
+    if dev.type == "cuda":
+        # what the in-flight batches hold: every slot keeps a whole step's worst-case-sized buffers alive (a captured graph's private pool).
+        # Beyond what fits the step rate falls off a cliff, not a slope (two-stage workload: 10 slots 7.2 k frames/s, 14 slots 47 -- DESIGN 8)
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        hbm = {"reserved_GB": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 1), "free_GB": round(free_b / 2 ** 30, 1),
+               "total_GB": round(total_b / 2 ** 30, 1), "slots": nstreams}
+        if free_b < 0.05 * total_b and rank == 0:
+            print("[bench] WARNING: %d slots leave %.1f of %.1f GB of HBM free; expect the step rate to collapse -- lower --streams"
+                  % (nstreams, free_b / 2 ** 30, total_b / 2 ** 30), file=sys.stderr, flush=True)
     elapsed = bench.timed(args.steps, args.warmup, dist, h2d=args.h2d)
     trace("timed loop done: %.3f ms/step" % (1e3 * elapsed / args.steps))
     out, clouds_cpu, graph = bench.out, bench.clouds_cpu, bench.graphs
@@ -1053,7 +1063,7 @@ def main():
                     "rotated NMS, tools/cfgs/default.yaml, %d pts/frame, batch %d per GPU, random-init weights" % (args.npoints, args.batch)),
                    "frames_per_gpu": args.batch, "npoints": args.npoints, "parallelism": "frames sharded, dp%d" % world,
                    "launch": "hipGraph replay" if graph is not None else "eager", "streams": nstreams,
-                   "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                   "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "hbm_held_by_the_slots": hbm,
                    "proposal_layer": args.proposals,
                    "inputs": ("raw velodyne scans (%d pts x 16 B per frame) in pinned host memory -> H2D -> prcnn_scene_prepare, all inside "
                               "the timed region" % args.raw_points) if args.input == "raw" else
