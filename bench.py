@@ -21,7 +21,8 @@ Besides the contract fields the line carries
                   processes that together use every core; median of 5 runs after a warm-up (oracle/cpu_baseline.py, run as a
                   subprocess so that it forks before any HIP state exists); plus the reference's own roipool3d_cpu.
   kernels      -- per-op-family GPU time of one step (ms) from the same event pass.
-  value_latency_mode -- one batch in flight (what a --batch_size-1-style caller sees: the FPS serial chain is exposed).
+  value_latency_mode -- one batch in flight (what a --batch_size-1-style caller sees: the FPS serial chain is exposed);
+                        value_by_batches_in_flight: the same at 2 / 4 / 8 batches in flight (a double-buffered eval loop is depth 2).
   value_h2d_inclusive, value_dedup_off, value_saturated -- the same command with every batch's clouds copied from pinned host
                   memory inside the timed region / with padding-free grouping switched off / on clouds whose every ball is
                   full: the throughput is data-dependent (exact first-layer hoisting + padding-free grouping remove most of the
@@ -548,6 +549,28 @@ class InferenceBench:
         for _ in range(steps):
             self.pipe.submit(None)
             self.pipe.result()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return reduce_elapsed(time.perf_counter() - t0, dist, self.dev)
+
+    def timed_depth(self, steps, depth, dist=None):
+        """`depth` batches in flight: what a caller sees that keeps a bounded number of batches outstanding (depth 1 = timed_single)"""
+        self.pipe.drain()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        inflight = 0
+        for _ in range(steps):
+            if inflight == depth:
+                self.pipe.result()
+                inflight -= 1
+            self.pipe.submit(None)
+            inflight += 1
+        while inflight:
+            self.pipe.result()
+            inflight -= 1
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -1086,6 +1109,14 @@ def main():
         e3 = bench.timed_single(lsteps, dist)
         line["value_latency_mode"] = round(whole_job_value(args.batch, world, lsteps, e3), 2)
         line["latency_mode_ms_per_batch"] = round(1e3 * e3 / lsteps, 3)
+        # between the one-batch caller and the 20-slot engine: the rate at a bounded number of batches in flight (a double-buffered
+        # eval loop is depth 2: the next batch's FPS chain runs under this batch's MLPs)
+        line["value_by_batches_in_flight"] = {"1": line["value_latency_mode"]}
+        for depth in (2, 4, 8):
+            if depth < nstreams:
+                ed = bench.timed_depth(lsteps, depth, dist)
+                line["value_by_batches_in_flight"][str(depth)] = round(whole_job_value(args.batch, world, lsteps, ed), 2)
+        line["value_by_batches_in_flight"][str(nstreams)] = line["value"]
 
     fam = None
     if rank == 0 and not args.no_roofline:

@@ -89,6 +89,9 @@ class StubBench:
     def timed_single(self, steps, dist=None):
         return self._timed(steps, dist)
 
+    def timed_depth(self, steps, depth, dist=None):
+        return self._timed(steps, dist)
+
     def release(self):
         pass
 
