@@ -240,6 +240,9 @@ class EventProfiler:
         if name == "prcnn_mlp_rows_addinterp_split":
             return (2.0 * (a[2] + 3) * a[7], a[13] * a[14], None, 1, "%d->%d + interpolated addend (bf16x%d)" % (a[2], a[7], a[5]), a[5],
                     2.0 * a[2] * pad(a[7]) * a[5])
+        if name == "prcnn_mlp_group_split":             # hoisted form: K = C
+            return (2.0 * a[9] * a[16], a[5] * a[7] * a[8], a[22], a[8], "%d->%d hoisted group (bf16x%d)" % (a[9], a[16], a[14]), a[14],
+                    2.0 * a[9] * pad(a[16]) * a[14])
         if name == "prcnn_mlp_group":
             k = a[9] + (0 if a[10] else 3)
             return 2.0 * k * a[14], a[5] * a[7] * a[8], a[20], a[8], "%d->%d" % (k, a[14]), 0, 2.0 * k * pad(a[14])

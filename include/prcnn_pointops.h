@@ -246,6 +246,14 @@ int prcnn_mlp_rows_addinterp_split(const float* in, int ld_in, int K, const floa
                                    const float* bias, int Nout, int relu, const float* y_cl, int ld_y, const int32_t* idx3,
                                    const float* w3, int B, int n, int m, float* out, int ld_out, int col_off,
                                    prcnn_stream_t stream);
+/* prcnn_mlp_group's HOISTED form (act_wx / act_bias given) on the split-bf16 layer kernel: the gathered row relu(Z[idx] + act_wx.dxyz +
+ * act_bias) is activated on its way into the split.  wsplit: the layer's prcnn_pack_weight_split image (chain = 0), terms 3 / 6; wpack: its
+ * fp32 image (rows holding inf / NaN are redone on the fp32 pipe).  Needs C % 32 == 0 and 16-byte aligned feature rows; any other shape
+ * (or act_wx NULL) runs the fp32 layer kernel exactly as prcnn_mlp_group does.  Replaces the same reference code as prcnn_mlp_group. */
+int prcnn_mlp_group_split(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl, int ld_feat, int B, int N,
+                          int M, int nsample, int C, const float* act_wx, const float* act_bias, const float* wpack,
+                          const void* wsplit, int terms, const float* bias, int Nout, int relu, float* out, int ld_out, int col_off,
+                          int pool_ns, const int32_t* groups_dev, prcnn_stream_t stream);
 
 /* Register-resident layer CHAIN: up to 3 consecutive layers (a whole SharedMLP) in ONE kernel; one wave owns 32
  * rows and carries them through every layer inside the register file (the MFMA accumulator layout of layer l is

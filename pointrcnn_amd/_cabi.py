@@ -62,6 +62,7 @@ SIGNATURES = {
     "prcnn_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
     "prcnn_mlp_rows": (_I, [_P, _I, _L, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P]),
     "prcnn_mlp_group": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P]),
+    "prcnn_mlp_group_split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _I, _I, _I, _P, _P]),
     "prcnn_mlp_interp": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P]),
     "prcnn_mlp_rows_addinterp": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
     "prcnn_wsplit_bytes": (_Z, [_I, _I]),

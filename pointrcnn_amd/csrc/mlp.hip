@@ -905,16 +905,24 @@ __device__ __forceinline__ bool wave_has_nonfinite(const f32x16 (&acc)[NR]) {
 // the wave's 64 x (32 WNB) block again, with fp32 MFMAs and operands read straight from global memory (rare path: a non-finite
 // operand).  Same products in the same order as mlp_layer_b_kernel: k-block by k-block, the four k-pairs of a block one after the
 // other -- bit-identical to the fp32 layer kernel.
-template <int WNB>
+template <int MODE, int WNB>
 __device__ __forceinline__ void split_redo_f32(const MlpParams& P, f32x16 (&acc)[2][WNB], long row0, int wm, int wn, int nb0, int lane) {
     const int h = lane >> 5, j = lane & 31;
     const float* ar[2];
     const float* bp[WNB];
+    float gd[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // MODE_GROUP: the rows' dxyz (hoisted form: row = relu(Z[idx] + wx . dxyz + b))
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         long g = row0 + wm * 64 + r * 32 + j;
         if (g >= P.rows) g = P.rows - 1;                 // clamped, never stored
-        ar[r] = P.in + g * P.ld_in + 4 * h;
+        if constexpr (MODE == MODE_GROUP) {
+            RowMeta<MODE_GROUP> gm;
+            make_meta<MODE_GROUP>(P, g, gm);
+            ar[r] = P.feat + gm.off + 4 * h;
+            gd[r][0] = gm.dx; gd[r][1] = gm.dy; gd[r][2] = gm.dz;
+        } else {
+            ar[r] = P.in + g * P.ld_in + 4 * h;
+        }
     }
 #pragma unroll
     for (int n = 0; n < WNB; n++) bp[n] = P.wpack + ((long)min(nb0 + wn * WNB + n, P.NB - 1) * P.KB) * 256 + lane * 4;
@@ -925,7 +933,10 @@ __device__ __forceinline__ void split_redo_f32(const MlpParams& P, f32x16 (&acc)
     for (int kb = 0; kb < P.KB; kb++) {
         float4 a[2], b[WNB];
 #pragma unroll
-        for (int r = 0; r < 2; r++) a[r] = ld4(ar[r] + kb * 8);
+        for (int r = 0; r < 2; r++) {
+            a[r] = ld4(ar[r] + kb * 8);
+            if constexpr (MODE == MODE_GROUP) a[r] = act_group4(P, a[r], kb * 8 + 4 * h, gd[r][0], gd[r][1], gd[r][2]);
+        }
 #pragma unroll
         for (int n = 0; n < WNB; n++) b[n] = ld4(bp[n] + (long)kb * 256);
 #pragma unroll
@@ -950,7 +961,10 @@ __device__ __forceinline__ void split_redo_f32(const MlpParams& P, f32x16 (&acc)
 // One 128-row tile of the split layer: the body of mlp_layer_s_kernel.  (bx, by) = the workgroup's grid position, or, in the
 // bounded-grid form, the position the tile loop stands in for; tid = the thread's index, passed in so that the tile loop can hand in
 // an opaque copy per tile (see mlp_layer_s_kernel).
-template <int WNB, int TERMS, bool ADDY>
+// MODE_GROUP (round 5, from docs/patches' round-4 form): the HOISTED grouped first layer -- the A row is relu(Z[idx] + act_wx . dxyz + act_bias)
+// with Z = W_f . feat per source point (K = C, a multiple of 32, 16-byte rows): the gathered chunk is activated on its way into the
+// split, everything else is the plain kernel (the RCNN stage's three grouped layers ran on the fp32 pipe until then).
+template <int MODE, int WNB, int TERMS, bool ADDY>
 __device__ __forceinline__ void layer_s_tile(const MlpParams& P, const long bx, const int by, const int tid, unsigned char* __restrict__ Ls) {
     constexpr int QN = 2 * WNB;
     constexpr int NP = TERMS == 6 ? 3 : 2;               // pieces in use
@@ -974,27 +988,39 @@ __device__ __forceinline__ void layer_s_tile(const MlpParams& P, const long bx, 
     const long row0 = tile_id * MLP_BM;
     const int nchunks = P.K / MLP_BK, KS = P.K / 16;
 
+    static_assert(MODE == MODE_PLAIN || (MODE == MODE_GROUP && !ADDY), "split layer kernel: plain rows or the hoisted grouped form");
     const int c4 = tid & 7, r0 = tid >> 3;
     const float* arow[4];
+    float gdx[4], gdy[4], gdz[4];                        // MODE_GROUP: the rows' dxyz
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         long grow = row0 + r0 + 32 * u;
         if (grow >= P.rows) grow = P.rows - 1;           // clamped, never stored
-        arow[u] = P.in + grow * P.ld_in + c4 * 4;
+        if constexpr (MODE == MODE_GROUP) {
+            RowMeta<MODE_GROUP> gm;
+            make_meta<MODE_GROUP>(P, grow, gm);
+            arow[u] = P.feat + gm.off + c4 * 4;
+            gdx[u] = gm.dx; gdy[u] = gm.dy; gdz[u] = gm.dz;
+        } else {
+            arow[u] = P.in + grow * P.ld_in + c4 * 4;
+            gdx[u] = gdy[u] = gdz[u] = 0.f;
+        }
     }
     float4 raA[4], raB[4];                               // two chunks of A rows in flight (see the main loop)
     auto load_chunk = [&](int c, float4 (&ra)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; u++) ra[u] = ld4(arow[u] + c * MLP_BK);
     };
-    auto store_chunk = [&](int buf, const float4 (&ra)[4]) {
+    auto store_chunk = [&](int buf, const float4 (&ra)[4], int c) {          // c: the chunk the values belong to (MODE_GROUP)
 #pragma unroll
         for (int u = 0; u < 4; u++) {
+            float4 v = ra[u];
+            if constexpr (MODE == MODE_GROUP) v = act_group4(P, v, c * MLP_BK + c4 * 4, gdx[u], gdy[u], gdz[u]);
             uint32_t b[3][4];
-            split3(ra[u].x, b[0][0], b[1][0], b[2][0]);
-            split3(ra[u].y, b[0][1], b[1][1], b[2][1]);
-            split3(ra[u].z, b[0][2], b[1][2], b[2][2]);
-            split3(ra[u].w, b[0][3], b[1][3], b[2][3]);
+            split3(v.x, b[0][0], b[1][0], b[2][0]);
+            split3(v.y, b[0][1], b[1][1], b[2][1]);
+            split3(v.z, b[0][2], b[1][2], b[2][2]);
+            split3(v.w, b[0][3], b[1][3], b[2][3]);
 #pragma unroll
             for (int p = 0; p < NP; p++)
                 *reinterpret_cast<uint2*>(Ls + (buf * 3 + p) * SPL_PLANE + (r0 + 32 * u) * SPL_LDB + c4 * 8) =
@@ -1075,7 +1101,7 @@ __device__ __forceinline__ void layer_s_tile(const MlpParams& P, const long bx, 
             addy_done = true;
         }
     }
-    store_chunk(0, raA);
+    store_chunk(0, raA, 0);
     __syncthreads();
     read_a(0, 0, a0);
     if (PRCNN_ABL & 256) read_a(0, 1, a1);
@@ -1101,7 +1127,7 @@ __device__ __forceinline__ void layer_s_tile(const MlpParams& P, const long bx, 
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(PRCNN_ABL & 64)) store_chunk(buf ^ 1, ra_split);
+        if (!(PRCNN_ABL & 64)) store_chunk(buf ^ 1, ra_split, min(c + 1, nchunks - 1));
         if (!(PRCNN_ABL & 128)) SPL_STEP(a1, 1);
         if (!(PRCNN_ABL & 32)) load_b(c * 2 + 3, 1);
 #pragma unroll
@@ -1145,10 +1171,10 @@ __device__ __forceinline__ void layer_s_tile(const MlpParams& P, const long bx, 
         //  non-finite ADDEND takes this path too and comes out as the fp32 kernel's sum)
         bool bad = wave_has_nonfinite<2 * WNB>(reinterpret_cast<const f32x16 (&)[2 * WNB]>(acc));
         if (ADDY && addy_done) bad = __syncthreads_or(bad) != 0;
-        if (bad && n_active) split_redo_f32<WNB>(P, acc, row0, wm, wn, nb0, lane);
+        if (bad && n_active) split_redo_f32<MODE, WNB>(P, acc, row0, wm, wn, nb0, lane);
         if (bad) addy_done = false;
     }
-    layer_epilogue<MODE_PLAIN, WNB, ADDY>(P, acc, reinterpret_cast<float*>(Ls), nullptr, tid, row0, nb0, n_active, addy_done);
+    layer_epilogue<MODE, WNB, ADDY>(P, acc, reinterpret_cast<float*>(Ls), nullptr, tid, row0, nb0, n_active, addy_done);
 }
 
 // LOOP = false: one workgroup per tile (the grid covers the launch's row count).
@@ -1158,7 +1184,7 @@ __device__ __forceinline__ void layer_s_tile(const MlpParams& P, const long bx, 
 // A plain loop around the body cost 20-48 VGPRs (round 4: the optimiser keeps every lane-derived address of the body live across
 // the back edge); here each trip derives everything from an OPAQUE copy of the thread index (a volatile v_mov the optimiser cannot
 // hoist or merge), so nothing but the loop counter lives across tiles and the body is allocated as in the one-tile form.
-template <int WNB, int TERMS, bool ADDY, bool LOOP>
+template <int MODE, int WNB, int TERMS, bool ADDY, bool LOOP>
 __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpParams Pin) {
     MlpParams P = Pin;
     P.rows = effective_rows(Pin);
@@ -1168,11 +1194,11 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_layer_s_kernel(const MlpPa
         for (long bid = blockIdx.x; bid < nbid; bid += gridDim.x) {
             int tid;
             asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"(threadIdx.x));
-            layer_s_tile<WNB, TERMS, ADDY>(P, bid, 0, tid, Ls);
+            layer_s_tile<MODE, WNB, TERMS, ADDY>(P, bid, 0, tid, Ls);
             __syncthreads();                             // the next tile's LDS writes vs this tile's last reads
         }
     } else {
-        layer_s_tile<WNB, TERMS, ADDY>(P, blockIdx.x, blockIdx.y, threadIdx.x, Ls);
+        layer_s_tile<MODE, WNB, TERMS, ADDY>(P, blockIdx.x, blockIdx.y, threadIdx.x, Ls);
     }
 }
 
@@ -2173,7 +2199,10 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
     // fewer tiles to the fp32 kernels, which have forms for few rows.
     const long split_tiles_wide = (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 4), split_tiles_narrow = (long)prcnn_divup(P.rows, MLP_BM) * prcnn_divup(P.NB, 2);
     static const long split_min = getenv("PRCNN_SPLIT_MIN_TILES") ? atol(getenv("PRCNN_SPLIT_MIN_TILES")) : 0;
-    if (P.wsplit && mode == MODE_PLAIN && P.K % MLP_BK == 0 && P.vec_a && split_tiles_narrow >= split_min) {
+    // the hoisted grouped form (prcnn_mlp_group_split); PRCNN_GROUP_SPLIT=0: A/B switch back to the fp32 layer kernel
+    static const bool group_split_on = !(getenv("PRCNN_GROUP_SPLIT") && atoi(getenv("PRCNN_GROUP_SPLIT")) == 0);
+    const bool split_group = group_split_on && mode == MODE_GROUP && P.act == 1 && P.C == P.K && !P.addY;
+    if (P.wsplit && (mode == MODE_PLAIN || split_group) && P.K % MLP_BK == 0 && P.vec_a && split_tiles_narrow >= split_min) {
         PRCNN_REQUIRE(aligned16(P.wsplit) && (P.split_terms == 3 || P.split_terms == 6), "prcnn_mlp: bad split image / terms=%d", P.split_terms);
         static const long split_wide_min = getenv("PRCNN_SPLIT_WIDE_MIN") ? atol(getenv("PRCNN_SPLIT_WIDE_MIN")) : 192;
         const bool wide = P.NB >= 4 && split_tiles_wide >= split_wide_min;
@@ -2189,9 +2218,11 @@ static int launch_mlp(int mode, MlpParams& P, hipStream_t s) {
         if (bounded) grid = dim3(2048u, 1);
 #define SPL_LAUNCH(W, T)                                                                                                  \
     do {                                                                                                                  \
-        if (P.addY) hipLaunchKernelGGL((mlp_layer_s_kernel<W, T, true, false>), grid, dim3(MLP_THREADS), 0, s, P);        \
-        else if (bounded) hipLaunchKernelGGL((mlp_layer_s_kernel<W, T, false, true>), grid, dim3(MLP_THREADS), 0, s, P);  \
-        else hipLaunchKernelGGL((mlp_layer_s_kernel<W, T, false, false>), grid, dim3(MLP_THREADS), 0, s, P);              \
+        if (split_group && bounded) hipLaunchKernelGGL((mlp_layer_s_kernel<MODE_GROUP, W, T, false, true>), grid, dim3(MLP_THREADS), 0, s, P);   \
+        else if (split_group) hipLaunchKernelGGL((mlp_layer_s_kernel<MODE_GROUP, W, T, false, false>), grid, dim3(MLP_THREADS), 0, s, P);        \
+        else if (P.addY) hipLaunchKernelGGL((mlp_layer_s_kernel<MODE_PLAIN, W, T, true, false>), grid, dim3(MLP_THREADS), 0, s, P);        \
+        else if (bounded) hipLaunchKernelGGL((mlp_layer_s_kernel<MODE_PLAIN, W, T, false, true>), grid, dim3(MLP_THREADS), 0, s, P);  \
+        else hipLaunchKernelGGL((mlp_layer_s_kernel<MODE_PLAIN, W, T, false, false>), grid, dim3(MLP_THREADS), 0, s, P);              \
     } while (0)
         if (wide) { if (P.split_terms == 6) SPL_LAUNCH(2, 6); else SPL_LAUNCH(2, 3); }
         else { if (P.split_terms == 6) SPL_LAUNCH(1, 6); else SPL_LAUNCH(1, 3); }
@@ -2419,6 +2450,33 @@ PRCNN_API int prcnn_mlp_group(const float* xyz, const float* new_xyz, const int3
     P.vec_a = C > 0 && aligned16(feat_cl) && (ld_feat % 4 == 0);
     int rc = set_group_act(P, act_wx, act_bias, C);
     if (rc) return rc;
+    return launch_mlp(MODE_GROUP, P, (hipStream_t)stream);
+}
+
+// prcnn_mlp_group's hoisted form on the split-bf16 layer kernel (wsplit = prcnn_pack_weight_split image of the layer, terms 3 / 6; wpack:
+// the fp32 image, read only by rows that hold inf / NaN).  C a multiple of 32, 16-byte aligned feature rows; otherwise, or with
+// PRCNN_GROUP_SPLIT=0, the call runs the fp32 layer kernel exactly as prcnn_mlp_group does.
+PRCNN_API int prcnn_mlp_group_split(const float* xyz, const float* new_xyz, const int32_t* idx, const float* feat_cl,
+                                    int ld_feat, int B, int N, int M, int nsample, int C, const float* act_wx,
+                                    const float* act_bias, const float* wpack, const void* wsplit, int terms, const float* bias, int Nout,
+                                    int relu, float* out, int ld_out, int col_off, int pool_ns, const int32_t* groups_dev,
+                                    prcnn_stream_t stream) {
+    PRCNN_REQUIRE(xyz && idx && wsplit, "prcnn_mlp_group_split: null pointer");
+    PRCNN_REQUIRE(C > 0 && feat_cl, "prcnn_mlp_group_split: the hoisted form needs features (C=%d)", C);
+    PRCNN_REQUIRE(B >= 0 && N > 0 && M > 0 && nsample > 0 && ld_feat >= C,
+                  "prcnn_mlp_group_split: bad shape B=%d N=%d M=%d ns=%d C=%d ld=%d", B, N, M, nsample, C, ld_feat);
+    PRCNN_REQUIRE(terms == 3 || terms == 6, "prcnn_mlp_group_split: terms=%d (3 or 6)", terms);
+    PRCNN_REQUIRE(ld_out >= col_off + Nout, "prcnn_mlp_group_split: ld_out=%d < col_off+Nout", ld_out);
+    MlpParams P = {};
+    P.rows = (long)B * M * nsample; P.K = C + 3; P.wpack = wpack; P.bias = bias; P.Nout = Nout; P.relu = relu;
+    P.out = out; P.ld_out = ld_out; P.col_off = col_off; P.pool_ns = pool_ns;
+    P.rows_dev = groups_dev; P.rows_unit = nsample;
+    P.xyz = xyz; P.new_xyz = new_xyz; P.idx = idx; P.feat = feat_cl; P.ld_feat = ld_feat;
+    P.N = N; P.M = M; P.ns = nsample; P.C = C;
+    P.vec_a = C > 0 && aligned16(feat_cl) && (ld_feat % 4 == 0);
+    int rc = set_group_act(P, act_wx, act_bias, C);
+    if (rc) return rc;
+    P.wsplit = wsplit; P.split_terms = terms;
     return launch_mlp(MODE_GROUP, P, (hipStream_t)stream);
 }
 

@@ -430,6 +430,12 @@ def mlp_group(xyz, new_xyz, idx, feat_cl, lin, out=None, pool_ns=0, act=None, gr
     rows_out = rows // pool_ns if pool_ns else rows
     buf, ld_out, col_off = _out_buf(out, rows_out, lin, xyz.device)
     awx, ab = (None, None) if act is None else act
+    if MLP_SPLIT_TERMS and act is not None and C % 32 == 0 and ld_feat % 4 == 0 and lin.wsplit() is not None:
+        # the hoisted grouped layer on the split-bf16 kernel (round 5; PRCNN_GROUP_SPLIT=0 inside the library is the A/B switch)
+        _cabi.check(_cabi.lib().prcnn_mlp_group_split(_p(xyz), _p(new_xyz), _p(idx), _p(feat_cl), ld_feat, B, N, M, ns, C, _p(awx), _p(ab),
+                                                      _p(lin.wpack), _p(lin.wsplit()), MLP_SPLIT_TERMS, _p(lin.bias), lin.nout, int(lin.relu),
+                                                      _p(buf), ld_out, col_off, pool_ns, _p(groups_dev), _stream()), "prcnn_mlp_group_split")
+        return buf
     _cabi.check(_cabi.lib().prcnn_mlp_group(_p(xyz), _p(new_xyz), _p(idx), _p(feat_cl), ld_feat, B, N, M, ns, C, _p(awx), _p(ab),
                                             _p(lin.wpack), _p(lin.bias), lin.nout, int(lin.relu), _p(buf), ld_out,
                                             col_off, pool_ns, _p(groups_dev), _stream()), "prcnn_mlp_group")

@@ -115,7 +115,10 @@ def test_reference_eval_rcnn_script_runs_unchanged_end_to_end(dev, mlp_mode, tmp
         for (cr, vr), (cm, vm) in zip(ref, mine):
             assert cr == cm == "Car"
             d = np.abs(np.array(vr) - np.array(vm))
-            assert d[:14].max() <= 2e-3 and d[14] <= 1e-3 * max(1.0, abs(vr[14])), (f, vr, vm)
+            # (2e-3 absolute on metres / radians, plus 1e-5 of the value for the image-plane corners: a pixel coordinate of 600-1200 carries the
+            #  1e-5 contract of the network outputs times the focal length -- the two routes may send a grouped layer to different kernel
+            #  families, e.g. the mirror's hoisted grouped layers run on the split-bf16 kernel since round 5)
+            assert (d[:14] <= 2e-3 + 1e-5 * np.abs(np.array(vr[:14]))).all() and d[14] <= 1e-3 * max(1.0, abs(vr[14])), (f, vr, vm)
         n_lines += len(ref)
     assert n_lines >= 3 * len(FRAMES), "an untrained detector should still emit detections: %d" % n_lines
     print("\n[eval_rcnn.py unchanged] %d detections in %d frames, %d lines string-identical between the two routes" % (n_lines, len(FRAMES), n_same))

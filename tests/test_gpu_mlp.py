@@ -668,6 +668,50 @@ def test_split_bf16_chain_nonfinite_rows(dev, monkeypatch, n1, relu1):
 
 
 @pytest.mark.own_arithmetic
+@pytest.mark.parametrize("ns,Nout,pool", [(16, 128, True), (32, 256, True), (64, 64, True), (32, 96, False)])
+def test_split_bf16_hoisted_group_layer(dev, cpu, monkeypatch, ns, Nout, pool):
+    """prcnn_mlp_group_split (round 5): the hoisted grouped layer -- rows relu(Z[idx] + W_x.dxyz + b) activated on their way into the bf16
+    split -- against the fp32 layer kernel on the same inputs (contract 1e-5 of the scale, and provably the other kernel), pooled over 16 /
+    32 / 64 samples and unpooled, with a device-side group count smaller than the launch's capacity (the bounded-grid form's row count),
+    and with a +inf in one source row of Z: the groups that gather it come out as the fp32 kernel's rows (same non-finite entries)."""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(ns + Nout)
+    B, N, M, C = 3, 700, 150, 64
+    xyz = unit_cloud(B, N, seed=ns)
+    new_xyz = xyz[:, :M].copy()
+    idx = cpu.ball_query(0.25, ns, xyz, new_xyz)
+    z = (r.normal(size=(B, N, C)) * 0.7).astype(np.float32)
+    wx = (r.normal(size=(C, 3)) * 0.5).astype(np.float32)
+    b0 = r.normal(size=(C,)).astype(np.float32)
+    w1 = (r.normal(size=(Nout, C)) * 0.15).astype(np.float32)
+    b1 = r.normal(size=(Nout,)).astype(np.float32)
+    layer = lin(dev, w1, b1, True)
+    act = (T(wx, dev), T(b0, dev))
+    live = torch.tensor([B * M - 37], dtype=torch.int32, device=dev)          # groups actually present (device-side count)
+    args = (T(xyz, dev), T(new_xyz, dev), T(idx, dev))
+
+    def run(zz, terms, groups_dev=None):
+        monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", terms)
+        return ops.mlp_group(*args, T(zz, dev), layer, pool_ns=ns if pool else 0, act=act, groups_dev=groups_dev).cpu().numpy()
+
+    ref, got = run(z, 0), run(z, 6)
+    assert got.shape == ref.shape == ((B * M if pool else B * M * ns), Nout)
+    np.testing.assert_allclose(got, ref, atol=mlp_tol(ref), rtol=0)
+    assert not np.array_equal(got, ref), "the split kernel did not run"
+    # device-side group count: the live groups' rows are the full launch's rows, bit for bit
+    part = run(z, 6, live)
+    nlive = (B * M - 37) * (1 if pool else ns)
+    assert np.array_equal(part[:nlive], got[:nlive])
+    # a non-finite source row
+    zb = z.copy()
+    zb[1, int(idx[1, 5, 0]), 7] = np.inf
+    refb, gotb = run(zb, 0), run(zb, 6)
+    assert not np.isfinite(refb).all() and _same_class(gotb, refb)
+    fin = np.isfinite(refb)
+    assert np.abs(gotb[fin] - refb[fin]).max() <= mlp_tol(refb[fin])
+
+
+@pytest.mark.own_arithmetic
 def test_split_bf16_chain_layer1_overflow_is_the_fp32_chains_infinity(dev, monkeypatch):
     """finite inputs, finite hidden units, but a layer-1 product that overflows fp32: the fp32 chain returns +-inf there; the split
     of the overflowing accumulation holds NaN pieces, so the wave must notice it on the layer-1 accumulators too (round-4 advisor
