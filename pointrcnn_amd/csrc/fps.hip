@@ -498,9 +498,9 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
             // masks exist; the owner's word is read out below, after the scalar search and the coordinate selects, so the LDS round
             // trip is hidden (rounds 3-4 read s_po at the owner's address inside the fast path, after the search: an exposed round
             // trip per update -- a load whose only use sits in a branch is sunk into it; the sched_barriers keep the order written)
+            const int wmax = __builtin_amdgcn_readlane(wvec, 63);          // first: the load's address arithmetic fills its wait states
             const int myorig = s_po[__builtin_ctz(eqbits) * BLOCK + tid];
             __builtin_amdgcn_sched_barrier(0);
-            const int wmax = __builtin_amdgcn_readlane(wvec, 63);
             const float wmaxf = __int_as_float(wmax);
             FPS_T(unsigned long long u2 = __builtin_readcyclecounter(); t_u2 += u2 - u1;)
             // candidates = (lane, slot) with t == wmax; the one with the LOWEST ORIGINAL index wins.  Fast path (a
@@ -712,9 +712,9 @@ __global__ __launch_bounds__(NW * 64) void fps_slot_kernel(const float* __restri
             // masks exist; the owner's word is read out below, after the scalar search and the coordinate selects, so the LDS round
             // trip is hidden (rounds 3-4 read s_po at the owner's address inside the fast path, after the search: an exposed round
             // trip per update -- a load whose only use sits in a branch is sunk into it; the sched_barriers keep the order written)
+            const int wmax = __builtin_amdgcn_readlane(wvec, 63);          // first: the load's address arithmetic fills its wait states
             const int myorig = s_po[__builtin_ctz(eqbits) * BLOCK + tid];
             __builtin_amdgcn_sched_barrier(0);
-            const int wmax = __builtin_amdgcn_readlane(wvec, 63);
             FPS_T(unsigned long long q3 = FPS_NOW(wave); q_max += q3 - q2;)
             const float wmaxf = __int_as_float(wmax);
             // candidates = (lane, slot) with t == wmax; the one with the LOWEST ORIGINAL index wins.  Fast path (a
