@@ -420,6 +420,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
     __builtin_amdgcn_s_setprio(2);     // the serial chain every batch waits for: its few instructions go first (3 while a wave updates)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);          // the wave's index in a scalar register (loop-invariant)
     const float* __restrict__ p = xyz + (size_t)b * N * 3;
     const int32_t* __restrict__ pm = perm + (size_t)b * N;
     int32_t* __restrict__ out = idx_out + (size_t)b * npoint;
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
         int wwin;
         const int gorig = fps_xt_collect(xt, cb, lane, x0, y0, z0, wwin);
 #if FPS_V & 2
-        if ((unsigned)(__builtin_amdgcn_readfirstlane(wave) - wwin + 1) <= 2u) __builtin_amdgcn_s_setprio(3);          // see fps_slot_kernel
+        if ((unsigned)(wave_u - wwin + 1) <= 2u) __builtin_amdgcn_s_setprio(3);          // see fps_slot_kernel
 #endif
         cb = cb == 2 ? 0 : cb + 1;
         if (tid == 0) out[j] = gorig;
@@ -585,6 +586,7 @@ __global__ __launch_bounds__(NW * 64) void fps_slot_kernel(const float* __restri
     __builtin_amdgcn_s_setprio(2);     // the serial chain every batch waits for: its few instructions go first (3 while a wave updates)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);          // the wave's index in a scalar register (loop-invariant)
     const float* __restrict__ p = xyz + (size_t)b * N * 3;
     const int32_t* __restrict__ pm = perm + (size_t)b * N;
     int32_t* __restrict__ out = idx_out + (size_t)b * npoint;
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(NW * 64) void fps_slot_kernel(const float* __restri
 #if FPS_V & 2
         // the winner's wave certainly updates next (the sample is one of its points) and its Morton neighbours (on the two adjacent SIMDs)
         // probably do: they take their bound test ahead of the three waves they share a SIMD with instead of in arrival order
-        if ((unsigned)(__builtin_amdgcn_readfirstlane(wave) - wwin + 1) <= 2u) __builtin_amdgcn_s_setprio(3);          // scalar compare + branch
+        if ((unsigned)(wave_u - wwin + 1) <= 2u) __builtin_amdgcn_s_setprio(3);          // scalar compare + branch
 #endif
         cb = cb == 2 ? 0 : cb + 1;
         if (tid == 0) out[j] = gorig;
