@@ -1069,6 +1069,11 @@ def main():
         free_b, total_b = torch.cuda.mem_get_info(dev)
         hbm = {"reserved_GB": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 1), "free_GB": round(free_b / 2 ** 30, 1),
                "total_GB": round(total_b / 2 ** 30, 1), "slots": nstreams}
+        if free_b < 0.01 * total_b and not os.environ.get("PRCNN_BENCH_ALLOW_OVERSUBSCRIPTION"):
+            # (the runtime pages oversubscribed memory instead of failing the allocation: a 14-slot two-stage run takes 680 ms per step)
+            raise SystemExit("bench.py: %d slots hold %.1f of %.1f GB of HBM (%.1f GB free): the in-flight batches do not fit and the step "
+                             "rate would collapse; lower --streams (PRCNN_BENCH_ALLOW_OVERSUBSCRIPTION=1 runs anyway)"
+                             % (nstreams, hbm["reserved_GB"], total_b / 2 ** 30, free_b / 2 ** 30))
         if free_b < 0.05 * total_b and rank == 0:
             print("[bench] WARNING: %d slots leave %.1f of %.1f GB of HBM free; expect the step rate to collapse -- lower --streams"
                   % (nstreams, free_b / 2 ** 30, total_b / 2 ** 30), file=sys.stderr, flush=True)
