@@ -78,7 +78,7 @@ def parse(argv=None):
     ap.add_argument("--proposals", choices=["off", "normal", "rotate"], default="normal",
                     help="also run the proposal layer (decode + sort + distance split + NMS + top-100, lib/rpn/proposal_layer.py) "
                          "inside every step, as tools/eval_rcnn.py --eval_mode rpn does after the heads")
-    ap.add_argument("--workload", choices=["rpn", "rcnn", "train", "train-rcnn"], default="rpn",
+    ap.add_argument("--workload", choices=["rpn", "rcnn", "train", "train-rcnn", "reference"], default="rpn",
                     help="rpn = the BASELINE metric (RPN inference end-to-end); rcnn = BASELINE config 3, the whole two-stage detector "
                          "(RPN -> proposals -> roipool3d -> RCNN -> box decode -> rotated NMS), 100 RoIs per frame; train = BASELINE "
                          "config 4, one RPN training iteration per step under DistributedDataParallel (RCCL); train-rcnn = one RCNN-stage "
@@ -106,9 +106,9 @@ def parse(argv=None):
     args = ap.parse_args(argv)
     train = args.workload in ("train", "train-rcnn")
     if args.steps is None:
-        args.steps = 20 if train else 320
+        args.steps = 20 if (train or args.workload == "reference") else 320
     if args.warmup is None:
-        args.warmup = 6 if train else 16
+        args.warmup = 6 if train else (3 if args.workload == "reference" else 16)
     if args.batch is None:
         args.batch = (16 if args.workload == "train" else 4) if train else 32
     return args
@@ -996,6 +996,47 @@ def run_train_rcnn(args, dev, rank, world, local_rank, dist):
                           "PRCNN_TRAIN_FUSED=0 = the composed torch path for A/B"}}
 
 
+def reference_route(dev, clouds_cpu, mirror, mirror_out, nms_type, steps, warmup, latency_value=None):
+    """frames/s of the reference's UNCHANGED lib/net + the loop body of tools/eval_rcnn.py on the drop-in (bench_reference.py), with the
+    ratio to the mirror's one-batch-in-flight figure; None when no reference tree is on this box"""
+    import bench_reference
+    if not bench_reference.available():
+        return None
+    ref = bench_reference.measure(dev, clouds_cpu, mirror, steps=steps, warmup=warmup, nms_type=nms_type, mirror_out=mirror_out)
+    if latency_value:
+        ref["mirror_value_latency_mode"] = latency_value
+        ref["eval_loop_vs_mirror_latency_mode"] = round(ref["value_eval_loop"] / latency_value, 3)
+        ref["model_only_vs_mirror_latency_mode"] = round(ref["value_model_only"] / latency_value, 3)
+    return ref
+
+
+def run_reference(args, dev, rank, world, dist):
+    """`--workload reference`: every rank runs the reference's own evaluation loop body on its shard of frames (no collective)"""
+    from pointrcnn_amd import rpn
+    torch.manual_seed(1234)
+    mirror = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
+    clouds = make_cloud_fn(args.clouds)(args.batch, args.npoints, seed0=shard_seed0(rank, world, 0, args.batch))
+    with torch.no_grad():
+        mo = mirror({"pts_input": clouds.to(dev)})
+    nms = args.proposals if args.proposals != "off" else "normal"
+    if dist is not None:
+        dist.barrier()
+    ref = reference_route(dev, clouds, mirror, mo, nms, args.steps, args.warmup)
+    if ref is None:
+        raise SystemExit("bench.py --workload reference: no reference tree on this box (oracle/_ref/reference_py.tar.gz is staged by "
+                         "__graft_entry__.build() in the build container)")
+    elapsed = reduce_elapsed(ref["eval_loop_ms_per_batch"] * 1e-3 * args.steps, dist, dev)
+    return {"metric": "KITTI frames/sec, RPN inference through the reference's unchanged lib/net + tools/eval_rcnn.py loop body on the drop-in "
+                      "(%d pts/frame, bs%d per GPU)" % (args.npoints, args.batch),
+            "value": round(whole_job_value(args.batch, world, args.steps, elapsed), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": arithmetic_label(__import__("pointrcnn_amd.ops", fromlist=["x"]).MLP_SPLIT_TERMS), "data": "synthetic",
+            "config": {"workload": "reference caller (lib/net/point_rcnn.py, lib/rpn/proposal_layer.py, unchanged) on pointrcnn_amd/dropin: H2D + "
+                                   "backbone + heads + sigmoid + proposal layer (%s NMS) + read-back, one batch in flight, eager" % nms,
+                       "frames_per_gpu": args.batch, "npoints": args.npoints, "clouds": args.clouds},
+            "reference_lib_net": ref}
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -1017,6 +1058,14 @@ def main():
 
     from pointrcnn_amd import _cabi, rpn
     _cabi.lib()
+    if args.workload == "reference":
+        line = run_reference(args, dev, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload in ("train", "train-rcnn"):
         line = (run_train if args.workload == "train" else run_train_rcnn)(args, dev, rank, world, local_rank, dist)
         if dist is not None:
@@ -1125,6 +1174,13 @@ def main():
                 ed = bench.timed_depth(lsteps, depth, dist)
                 line["value_by_batches_in_flight"][str(depth)] = round(whole_job_value(args.batch, world, lsteps, ed), 2)
         line["value_by_batches_in_flight"][str(nstreams)] = line["value"]
+        if world == 1:
+            # what an UNMODIFIED user of the reference gets: lib/net + the loop body of tools/eval_rcnn.py, unchanged, on the drop-in
+            trace("reference route")
+            ref = reference_route(dev, clouds_cpu, model, out, args.proposals if args.proposals != "off" else "normal", 12, 3,
+                                  line["value_latency_mode"])
+            line["value_reference_lib_net"] = ref["value_eval_loop"] if ref else None
+            line["reference_lib_net"] = ref if ref else "no reference tree on this box (oracle/_ref/reference_py.tar.gz not staged)"
 
     fam = None
     if rank == 0 and not args.no_roofline:

@@ -89,21 +89,36 @@ def build(force=False, verbose=True):
         os.makedirs(objdir, exist_ok=True)
         procs = []
         bid = source_id()
+        # an object is reused when its own source, every header and its flags are what it was compiled from (digest kept next to it);
+        # `force` recompiles everything (what __graft_entry__.build() asks for)
+        hdr = hashlib.sha1()
+        for d in sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "prcnn_pointops.h")]:
+            with open(d, "rb") as f:
+                hdr.update(f.read())
+        objs = []
         for src in sources():
             obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
+            objs.append(obj)
             extra = EXTRA_FLAGS.get(os.path.basename(src), [])
             if os.path.basename(src) == "cabi_common.hip":
                 extra = extra + ['-DPRCNN_BUILD_ID="%s%s"' % (BUILD_ID_TAG.decode(), bid)]
-            procs.append((src, obj, subprocess.Popen([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj],
-                                                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs = []
-        for src, obj, p in procs:
+            with open(src, "rb") as f:
+                digest = hashlib.sha1(f.read() + hdr.digest() + repr(FLAGS + extra).encode()).hexdigest()
+            stamp = obj + ".digest"
+            if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
+                continue
+            if os.path.exists(stamp):
+                os.remove(stamp)
+            procs.append((src, stamp, digest, subprocess.Popen([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj],
+                                                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        for src, stamp, digest, p in procs:
             out, _ = p.communicate()
             if p.returncode != 0:
                 raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
             if verbose and out.strip():
                 print(out.decode())
-            objs.append(obj)
+            with open(stamp, "w") as f:
+                f.write(digest)
         tmp = LIB + ".tmp.%d" % os.getpid()
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs, check=True)
         os.replace(tmp, LIB)

@@ -87,88 +87,147 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     if (row < N) mask[(size_t)row * W + col_blk] = bits;
 }
 
-// ---- NMS: greedy sweep on the device (iou3d.cpp:100-119), one 256-thread workgroup per problem ------
-// Per 64-box block: wave 0 resolves the block serially on the scalar unit (diag word per lane, v_readlane);
-// then all 4 waves fold the kept rows into the suppression words of later blocks, one word per thread with 16
-// independent loads in flight (the fold is latency-bound: a dependent load per kept row is what made the first
-// version slow).  max_keep > 0 ends the sweep as soon as enough boxes are kept.
-#define SWEEP_THREADS 256
+// ---- NMS: greedy sweep on the device (iou3d.cpp:100-119), one workgroup per problem ------------------
+// The sweep is a serial chain over the 64-box blocks (N = 6300: 99 of them) and a lone caller -- the reference's proposal layer
+// issues one NMS at a time and waits for each (lib/rpn/proposal_layer.py:100-105) -- sees its LATENCY: rounds 1-5 took ~4 us per
+// block (every thread issued its 64 row loads, wave 0 walked all 64 rows of the block, every thread folded 64 selects, two barriers;
+// 0.4-0.5 ms per call, half of the GPU time of the reference's unchanged evaluation loop).  Round 6 splits the roles:
+//   * wave 0, the RESOLVER, runs the chain alone.  Only rows whose diagonal word is non-zero can change the block's outcome, and a
+//     row's suppression state is final once every lower row is done (a row only suppresses higher ones), so the block resolves by
+//     walking the set bits of (non-zero rows & ~suppressed) -- a handful on scattered boxes, at most 64 -- and kept = ~cur.  The
+//     contribution of block i to the NEXT block's word is folded by the resolver itself (one word per lane, OR-reduced on the DPP
+//     network), so it never waits for the folders' result of the block it has just resolved;
+//   * waves 1-8, the FOLDERS, run one block behind: during iteration i they OR the kept rows of block i-1 into the suppression words
+//     >= i+1 (16 rows x one word per thread, rows requested an iteration ahead so no load sits on anybody's path, LDS ds_or).
+// One barrier per block, ~0.3 us per block on scattered boxes.  Same greedy order, same keep list; max_keep > 0 ends the sweep as soon
+// as enough boxes are kept.
+#define SWEEP_THREADS 576                                // resolver wave + 8 folder waves
+#define SWEEP_FOLD_ROWS 16
+
+// wave-wide OR of a 64-bit word per lane (DPP, the two halves interleaved so that one fills the other's wait states) -> uniform
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long x) {
+    int a = (int)(unsigned)x, b = (int)(unsigned)(x >> 32);
+#define SWEEP_OR_STEP(ctrl, rmask) { const int ta = PRCNN_DPP(a, ctrl, rmask), tb = PRCNN_DPP(b, ctrl, rmask); a |= ta; b |= tb; }
+    SWEEP_OR_STEP(0x111, 0xf) SWEEP_OR_STEP(0x112, 0xf) SWEEP_OR_STEP(0x114, 0xf) SWEEP_OR_STEP(0x118, 0xf)
+    SWEEP_OR_STEP(0x142, 0xa) SWEEP_OR_STEP(0x143, 0xc)
+#undef SWEEP_OR_STEP
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(b, 63) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane(a, 63);
+}
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    // readfirstlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high one
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
+           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+}
+
+struct SweepShared {
+    unsigned long long* remv;                            // W words: bit set = suppressed
+    unsigned long long* kslot;                           // [i & 1] = kept bits of block i
+    unsigned long long* stop;                            // [i & 1] != 0: enough boxes kept after block i
+};
+
+// Resolver, block i.  d / nr: word i / word i+1 of the block's rows (one row per lane), requested two blocks ago; they leave holding the
+// requests for block i+2 (issued after their last use, so they stay in the same registers: a register copy of a value in flight
+// would put the load's latency on the chain).  -> true when enough boxes are kept.
+__device__ __forceinline__ bool sweep_resolve(const unsigned long long* __restrict__ mask, int N, int W, int max_keep, int i, int lane,
+                                              const SweepShared& sh, unsigned long long& d, unsigned long long& nr,
+                                              unsigned long long& carry, int& num, int64_t* __restrict__ keep) {
+    const int nrows = min(64, N - i * 64);
+    unsigned long long cur = uniform_u64(sh.remv[i]) | carry;
+    const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
+    unsigned long long todo = __ballot(d != 0ULL) & ~cur;
+    while (todo) {                                       // ascending over the rows that can still suppress something
+        const int t = __builtin_ctzll(todo);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, t);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, t);
+        cur |= ((unsigned long long)hi << 32) | lo;
+        todo &= todo - 1ULL;
+        todo &= ~cur;
+    }
+    const int r2 = min((i + 2) * 64 + lane, N - 1);      // clamped: rows / words past the end are read again and never used
+    d = mask[(size_t)r2 * W + min(i + 2, W - 1)];
+    const unsigned long long valid = nrows == 64 ? ~0ULL : ((1ULL << nrows) - 1ULL);
+    const unsigned long long kept = ~cur & valid;
+    const bool mine = (kept >> lane) & 1ULL;
+    if (mine) keep[num + __popcll(kept & ((1ULL << lane) - 1ULL))] = i * 64 + lane;
+    num += __popcll(kept);
+    const bool enough = max_keep > 0 && num >= max_keep;
+    if (lane == 0) { sh.kslot[i & 1] = kept; sh.stop[i & 1] = enough ? 1ULL : 0ULL; }
+    __syncthreads();
+    carry = i + 1 < W ? wave_or_u64(mine ? nr : 0ULL) : 0ULL;
+    nr = mask[(size_t)r2 * W + min(i + 3, W - 1)];
+    return enough;
+}
+
+// Folder, iteration i: ORs the kept rows [c*16, c*16+16) of block i-1 (`part`, requested two iterations ago) into the suppression words
+// i+1 + g*64 + lane (+128, ...), then requests the same rows of block i+1 into `part`.  -> true when the resolver said stop.
+__device__ __forceinline__ bool sweep_fold(const unsigned long long* __restrict__ mask, int N, int W, int i, int lane, int c, int g,
+                                           const SweepShared& sh, unsigned long long (&part)[SWEEP_FOLD_ROWS]) {
+    if (i >= 1) {
+        const unsigned kb = (unsigned)(uniform_u64(sh.kslot[(i - 1) & 1]) >> (c * SWEEP_FOLD_ROWS)) & 0xffffu;
+        if (kb) {
+            const int w0 = i + 1 + g * 64 + lane;
+            if (w0 < W) {
+                unsigned long long acc = 0ULL;
+#pragma unroll
+                for (int r = 0; r < SWEEP_FOLD_ROWS; r++)
+                    if ((kb >> r) & 1u) acc |= part[r];
+                if (acc) atomicOr(&sh.remv[w0], acc);
+            }
+            for (int w = w0 + 128; w < W; w += 128) {          // more than 129 blocks (N > 8 256): the far words, not prefetched
+                unsigned long long acc = 0ULL;
+                const unsigned long long* col = mask + (size_t)((i - 1) * 64 + c * SWEEP_FOLD_ROWS) * W + w;
+#pragma unroll
+                for (int r = 0; r < SWEEP_FOLD_ROWS; r++)
+                    if ((kb >> r) & 1u) acc |= col[(size_t)r * W];
+                if (acc) atomicOr(&sh.remv[w], acc);
+            }
+        }
+    }
+    {   // block i+1 -> words >= i+3, consumed at iteration i+2.  Straight-line loads from clamped addresses (a guarded load is a branch of
+        // its own): words past the last one read the last word again and are never stored, rows past the last one read the last row
+        // again and are never selected (kept has no bit there)
+        const int w = min(i + 3 + g * 64 + lane, W - 1);
+#pragma unroll
+        for (int r = 0; r < SWEEP_FOLD_ROWS; r++) part[r] = mask[(size_t)min((i + 1) * 64 + c * SWEEP_FOLD_ROWS + r, N - 1) * W + w];
+    }
+    __syncthreads();
+    return sh.stop[i & 1] != 0ULL;
+}
+
 __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int N, int W,
                                                                   int max_keep, int64_t* __restrict__ keep,
                                                                   int32_t* __restrict__ num_keep) {
-    extern __shared__ unsigned long long remv[];         // W words: bit set = suppressed; then 2 words of exchange
-    unsigned long long* xchg = remv + W;                 // [0] = kept bits of the current block, [1] = running count
+    extern __shared__ unsigned long long sweep_lds[];    // W suppression words, then the exchange words
+    const SweepShared sh = {sweep_lds, sweep_lds + W, sweep_lds + W + 2};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int w = tid; w < W; w += SWEEP_THREADS) remv[w] = 0ULL;
-    if (tid == 0) xchg[1] = 0ULL;
+    for (int w = tid; w < W + 4; w += SWEEP_THREADS) sweep_lds[w] = 0ULL;
     __syncthreads();
-    unsigned long long diag_next = (wave == 0 && lane < N) ? mask[(size_t)lane * W] : 0ULL;
-    for (int blk = 0; blk < W; blk++) {
-        const int nrows = min(64, N - blk * 64);
-        // Round 5: the 64 rows of this block's column words are requested BEFORE the serial resolve and whatever it keeps (the kept mask
-        // selects among them afterwards), all 64 at once: the loads fly while wave 0 resolves, one memory round trip per block where the
-        // kept-dependent fold took four dependent ones after the resolve (N = 6300: 99 blocks, 0.71 -> see profiles/r05_opbench.jsonl).
-        // the block's own (diagonal) word was requested a block ahead: the serial resolve starts without waiting for memory
-        const unsigned long long diag = diag_next;
-        if (wave == 0 && blk + 1 < W && (blk + 1) * 64 + lane < N) diag_next = mask[(size_t)((blk + 1) * 64 + lane) * W + blk + 1];
-        const int w0 = blk + 1 + tid;
-        unsigned long long part[64];
-        {
-            // straight-line loads from clamped addresses (a guarded load is a branch of its own), masked by the kept bits below: rows past
-            // the block's last one read its last row again and are never selected (kept has no bit there)
-            const unsigned long long* col = mask + (size_t)blk * 64 * W + (w0 < W ? w0 : W - 1);
-#pragma unroll
-            for (int u = 0; u < 64; u++) part[u] = col[(size_t)min(u, nrows - 1) * W];
+    if (wave == 0) {
+        const int ra = min(lane, N - 1), rb = min(64 + lane, N - 1);
+        unsigned long long da = mask[(size_t)ra * W], na = mask[(size_t)ra * W + min(1, W - 1)];                     // block 0
+        unsigned long long db = mask[(size_t)rb * W + min(1, W - 1)], nb = mask[(size_t)rb * W + min(2, W - 1)];     // block 1
+        unsigned long long carry = 0ULL;
+        int num = 0;
+        for (int i = 0; i < W; i += 2) {
+            if (sweep_resolve(mask, N, W, max_keep, i, lane, sh, da, na, carry, num, keep)) break;
+            if (i + 1 >= W) break;
+            if (sweep_resolve(mask, N, W, max_keep, i + 1, lane, sh, db, nb, carry, num, keep)) break;
         }
-        if (wave == 0) {
-            const int row = blk * 64 + lane;
-            unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-            unsigned long long cur = remv[blk];
-            // readfirstlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high one
-            cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur >> 32)) << 32) |
-                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur);
-            int num = (int)xchg[1];
-            num = __builtin_amdgcn_readfirstlane(num);
-            unsigned long long kept = 0ULL;
-            for (int t = 0; t < nrows; t++) {            // serial inside the block, registers only
-                if (!((cur >> t) & 1ULL)) {
-                    kept |= 1ULL << t;
-                    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, t);
-                    unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, t);
-                    cur |= ((unsigned long long)hi << 32) | lo;
-                }
-            }
-            if ((kept >> lane) & 1ULL) keep[num + __popcll(kept & ((1ULL << lane) - 1ULL))] = row;
-            if (lane == 0) { xchg[0] = kept; xchg[1] = (unsigned long long)(num + __popcll(kept)); }
-        }
-        __syncthreads();
-        const unsigned long long kept = xchg[0];
-        const int num = (int)xchg[1];
-        if (max_keep > 0 && num >= max_keep) break;       // uniform: every thread reads the same LDS word
-        // fold the kept rows of this block into the suppression words of later blocks
-        if (w0 < W) {
-            unsigned long long acc = remv[w0];
+        if (lane == 0) *num_keep = (max_keep > 0 && num > max_keep) ? max_keep : num;
+    } else {
+        const int fw = wave - 1, c = fw & 3, g = fw >> 2;
+        unsigned long long p0[SWEEP_FOLD_ROWS], p1[SWEEP_FOLD_ROWS];
+        {   // block 0 -> words >= 2 (consumed at iteration 1); p1 is first requested at iteration 0
+            const int w = min(2 + g * 64 + lane, W - 1);
 #pragma unroll
-            for (int u = 0; u < 64; u++) acc |= ((kept >> u) & 1ULL) ? part[u] : 0ULL;
-            remv[w0] = acc;
+            for (int r = 0; r < SWEEP_FOLD_ROWS; r++) { p0[r] = mask[(size_t)min(c * SWEEP_FOLD_ROWS + r, N - 1) * W + w]; p1[r] = 0ULL; }
         }
-        for (int w = w0 + SWEEP_THREADS; w < W; w += SWEEP_THREADS) {          // more than 256 later blocks (N > 16 384): the rest as before
-            unsigned long long acc = remv[w];
-            const unsigned long long* col = mask + (size_t)blk * 64 * W + w;
-#pragma unroll 1
-            for (int t0 = 0; t0 < 64; t0 += 16) {
-                unsigned long long q[16];
-#pragma unroll
-                for (int u = 0; u < 16; u++)               // 16 independent loads; `kept` is uniform
-                    q[u] = ((kept >> (t0 + u)) & 1ULL) ? col[(size_t)(t0 + u) * W] : 0ULL;
-#pragma unroll
-                for (int u = 0; u < 16; u++) acc |= q[u];
-            }
-            remv[w] = acc;
+        for (int i = 0; i < W; i += 2) {
+            if (sweep_fold(mask, N, W, i, lane, c, g, sh, p1)) break;
+            if (i + 1 >= W) break;
+            if (sweep_fold(mask, N, W, i + 1, lane, c, g, sh, p0)) break;
         }
-        __syncthreads();
     }
-    if (tid == 0) *num_keep = (max_keep > 0 && (int)xchg[1] > max_keep) ? max_keep : (int)xchg[1];
 }
 
 static int pair_matrix(const char* op, bool iou, const float* a, int na, const float* b, int nb, float* out, hipStream_t s) {
@@ -219,7 +278,7 @@ PRCNN_API int prcnn_nms(const float* boxes, int N, float thresh, int kind, int m
     else
         hipLaunchKernelGGL(nms_mask_kernel<PRCNN_NMS_NORMAL>, grid, dim3(64), 0, s, boxes, N, thresh, W, mask);
     PRCNN_LAUNCH_CHECK("prcnn_nms(mask)");
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(SWEEP_THREADS), (size_t)(W + 2) * 8, s, mask, N, W, max_keep, keep, num_keep);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(SWEEP_THREADS), (size_t)(W + 4) * 8, s, mask, N, W, max_keep, keep, num_keep);
     PRCNN_LAUNCH_CHECK("prcnn_nms(sweep)");
     return PRCNN_OK;
 }

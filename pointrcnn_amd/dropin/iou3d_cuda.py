@@ -1,9 +1,9 @@
 """`iou3d_cuda` -- Python stand-in for the reference's pybind module (lib/utils/iou3d/src/iou3d.cpp:174-179):
 same four functions, same argument order and ownership (caller allocates; `keep` is a CPU int64 tensor for
 the nms functions, iou3d_utils.py:68,85), argument errors raise RuntimeError (AT_CHECK, iou3d.cpp:7-9).
-All computation is in libprcnn_pointops.so.  The NMS sweep runs on the device; the only host
-synchronisation is the copy of the kept indices into the caller's CPU `keep`, which this API shape forces
-(pointrcnn_amd.ops.nms_sorted is the sync-free form)."""
+All computation is in libprcnn_pointops.so.  The NMS sweep runs on the device and writes the kept indices and their count
+into a pinned, device-mapped staging buffer; the ONE host synchronisation per call is the wait for the stream that the API
+shape forces -- the count is the return value -- (pointrcnn_amd.ops.nms_sorted is the sync-free form)."""
 import torch
 
 from pointrcnn_amd import ops
@@ -46,11 +46,12 @@ def _nms(boxes, keep, thresh, rotated):
     _check_input(boxes, "boxes")
     if not keep.is_contiguous():
         raise RuntimeError("keep must be contiguous ")
-    keep_dev, num = ops.nms_sorted(_rows5(boxes, "boxes"), thresh, rotated=rotated)
-    n = int(num.item())
-    if n:
-        keep[:n].copy_(keep_dev[:n])
-    return n
+    if keep.is_cuda or keep.dtype != torch.int64:
+        raise RuntimeError("keep must be a CPU int64 tensor (iou3d_utils.py:68,85)")
+    boxes = _rows5(boxes, "boxes")
+    if keep.numel() < boxes.shape[0]:
+        raise RuntimeError("keep holds %d entries for %d boxes" % (keep.numel(), boxes.shape[0]))
+    return ops.nms_sorted_to_host(boxes, thresh, rotated, keep)
 
 
 def nms_gpu(boxes, keep, nms_overlap_thresh):

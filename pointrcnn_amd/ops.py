@@ -6,6 +6,7 @@ Shapes and argument meaning mirror the reference op surface (see each function's
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -695,6 +696,40 @@ def nms_sorted(boxes_sorted, thresh, rotated=True, max_keep=0):
     _cabi.check(L.prcnn_nms(_p(boxes_sorted), N, float(thresh), 0 if rotated else 1, int(max_keep), _p(keep), _p(num),
                             _p(ws), wsb, _stream()), "prcnn_nms")
     return keep, num
+
+
+_NMS_STAGE = threading.local()
+
+
+def nms_sorted_to_host(boxes_sorted, thresh, rotated, keep_cpu):
+    """The shape the reference's pybind functions force (iou3d.cpp:73-120: `keep` is a CPU int64 tensor, the return value the number of
+    kept boxes): greedy NMS over boxes sorted by descending score, the kept indices copied into `keep_cpu[:n]`, -> n (host int).
+    ONE host synchronisation: the kept indices and their count leave the device in one asynchronous copy into a pinned staging buffer
+    (one per host thread and device) queued behind the sweep, the host waits for the stream once and copies the n entries."""
+    _chk(boxes_sorted, "boxes", ndim=2)
+    N = boxes_sorted.shape[0]
+    if N == 0:
+        return 0
+    dev = boxes_sorted.device
+    stages = getattr(_NMS_STAGE, "buf", None)
+    if stages is None:
+        stages = _NMS_STAGE.buf = {}
+    stage = stages.get(dev.index)
+    if stage is None or stage.numel() < N + 1:
+        stage = stages[dev.index] = torch.empty((max(2 * N, 8192) + 1,), dtype=torch.int64).pin_memory()
+    L = _cabi.lib()
+    wsb = L.prcnn_nms_workspace_bytes(N)
+    ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=dev)
+    out = torch.empty((N + 1,), dtype=torch.int64, device=dev)          # [0, N): kept indices, [N]: their count (low int32)
+    stream = torch.cuda.current_stream(dev)
+    _cabi.check(L.prcnn_nms(_p(boxes_sorted), N, float(thresh), 0 if rotated else 1, 0, _p(out), _p(out) + 8 * N,
+                            _p(ws), wsb, stream.cuda_stream), "prcnn_nms")
+    stage[:N + 1].copy_(out, non_blocking=True)
+    stream.synchronize()
+    n = int(stage[N:N + 1].view(torch.int32)[0])
+    if n:
+        keep_cpu[:n].copy_(stage[:n])
+    return n
 
 
 # ---------------------------------------------------------------------------------------------------------

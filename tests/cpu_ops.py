@@ -95,6 +95,12 @@ def oracle_ops(trig_mode=2):
         keep[: len(k)] = _t(k)
         return keep, torch.tensor([len(k)], dtype=torch.int32)
 
+    def nms_sorted_to_host(boxes_sorted, thresh, rotated, keep_cpu):
+        keep, num = nms_sorted(boxes_sorted, thresh, rotated)
+        n = int(num[0])
+        keep_cpu[:n].copy_(keep[:n])
+        return n
+
     def overlap(boxes_a, boxes_b, out=None):
         r = _t(cpu.boxes_overlap_bev(_np(boxes_a), _np(boxes_b), trig_mode))
         return r if out is None else out.copy_(r)
@@ -109,6 +115,7 @@ def oracle_ops(trig_mode=2):
 
     patch(roipool3d_cuda, "forward", rp_forward)
     patch(ops, "nms_sorted", nms_sorted)
+    patch(ops, "nms_sorted_to_host", nms_sorted_to_host)
     patch(ops, "boxes_overlap_bev", overlap)
     patch(ops, "boxes_iou_bev", iou)
     patch(iou3d_cuda, "_check_input", check_input)

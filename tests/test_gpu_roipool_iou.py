@@ -255,6 +255,52 @@ def test_nms_more_than_256_blocks_and_rotated_at_rpn_scale(dev, cpu):
         assert np.array_equal(keep[: int(num.item())].cpu().numpy(), cpu.nms(boxes, thr, "rotated"))
 
 
+def _clustered_bev(n, clusters, spread, seed):
+    """n score-ordered boxes drawn around `clusters` centres: what a trained RPN hands the NMS (most boxes suppressed by a few kept ones,
+    every 64-box block full of in-block suppressions) -- the dense case of the sweep's resolver"""
+    r = np.random.default_rng(seed)
+    ctr = r.uniform(0, 40, (clusters, 2))
+    own = r.integers(0, clusters, n)
+    c = ctr[own] + r.normal(0, spread, (n, 2))
+    s = r.uniform(0.8, 1.2, (n, 2)) * [0.8, 2.0]
+    return np.concatenate([c - s, c + s, r.uniform(-3.14, 3.14, (n, 1))], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["rotated", "normal"])
+@pytest.mark.parametrize("N,clusters,thr", [(6300, 25, 0.8), (6300, 25, 0.3), (2700, 5, 0.5), (9000, 200, 0.7), (4097, 1, 0.9), (127, 3, 0.5)])
+def test_nms_sweep_dense_suppression_and_far_words(dev, cpu, kind, N, clusters, thr):
+    """round 6 sweep (resolver wave + folder waves one block behind): heavily overlapping proposals (the resolver walks many rows per
+    block, most blocks keep few or none, whole folder chunks have no kept row), more than 129 blocks (the folders' far-word loop), a
+    last block with one row, and the max_keep exit on the same boxes"""
+    from pointrcnn_amd import ops
+    boxes = _clustered_bev(N, clusters, 0.35, seed=N + clusters)
+    want = cpu.nms(boxes, thr, kind)
+    keep, num = ops.nms_sorted(T(boxes, dev), thr, rotated=(kind == "rotated"))
+    assert np.array_equal(keep[: int(num.item())].cpu().numpy(), want)
+    for mk in (1, 7, 64, 65):
+        keep, num = ops.nms_sorted(T(boxes, dev), thr, rotated=(kind == "rotated"), max_keep=mk)
+        n = int(num.item())
+        assert n == min(mk, len(want)) and np.array_equal(keep[:n].cpu().numpy(), want[:n])
+
+
+def test_nms_dropin_one_sync_path_repeated_calls(dev, cpu):
+    """iou3d_cuda.nms_*_gpu deliver through one pinned staging buffer per thread and device: back-to-back calls of different sizes (the
+    proposal layer's 6300 / 2700 pattern, proposal_layer.py:100-105) must not see each other's entries"""
+    import iou3d_cuda
+    for rep, (n, kind) in enumerate([(6300, "normal"), (2700, "normal"), (100, "rotated"), (6300, "rotated"), (1, "normal"), (9001, "normal")]):
+        boxes = _clustered_bev(n, 40, 0.5, seed=900 + rep)
+        keep = torch.LongTensor(n).fill_(-7)
+        fn = iou3d_cuda.nms_gpu if kind == "rotated" else iou3d_cuda.nms_normal_gpu
+        num = fn(T(boxes, dev), keep, 0.8)
+        want = cpu.nms(boxes, 0.8, kind)
+        assert num == len(want) and np.array_equal(keep[:num].numpy(), want)
+        assert (keep[num:] == -7).all()
+    with pytest.raises(RuntimeError):
+        iou3d_cuda.nms_gpu(T(boxes, dev), torch.LongTensor(5), 0.8)                  # keep shorter than the boxes
+    with pytest.raises(RuntimeError):
+        iou3d_cuda.nms_gpu(T(boxes, dev), torch.zeros(9001, dtype=torch.int32), 0.8)  # keep must be int64
+
+
 def test_nms_max_keep_prefix(dev, cpu):
     """max_keep stops the sweep early: the kept list is the exact prefix of the full result (what
     proposal_layer.py:112 `keep_idx[:post_top_n]` consumes), for both kinds and across block boundaries"""
