@@ -56,7 +56,9 @@ typedef void* prcnn_stream_t; /* hipStream_t */
 #define PRCNN_EHIP (-2)         /* HIP runtime / launch failure */
 #define PRCNN_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-int prcnn_abi_version(void);   /* 7: split-bf16 chain entry points take the fp32 pack images too (fp32 recomputation of rows with non-finite values); 6: + prcnn_fps_status, training-mode SharedMLP (prcnn_train_*), prcnn_boxes_iou3d, prcnn_proposal_target_sample, prcnn_ref_trig (box trigonometry = the reference's host libm, bit for bit); 5: + prcnn_gt_aug_edit;
+int prcnn_abi_version(void);   /* 9: + prcnn_fps_mode, prcnn_ball_query_arith, prcnn_three_nn_arith (comparison mode: the squared distance as nvcc contracts the
+                                 * upstream expression); prcnn_nms_workspace_bytes grew by one flag byte per 64 x 64 tile; 8: + prcnn_mlp_group_split;
+                                 * 7: split-bf16 chain entry points take the fp32 pack images too (fp32 recomputation of rows with non-finite values); 6: + prcnn_fps_status, training-mode SharedMLP (prcnn_train_*), prcnn_boxes_iou3d, prcnn_proposal_target_sample, prcnn_ref_trig (box trigonometry = the reference's host libm, bit for bit); 5: + prcnn_gt_aug_edit;
                                  * 4: + prcnn_host_* (host twins of the reference's *_cpu entry points), prcnn_build_id,
                                  * prcnn_fps_order (upstream tie order), prcnn_rpn_labels,
                                  * prcnn_ball_query2_grid takes xyz (dense-frame scan fallback);
@@ -99,6 +101,24 @@ int prcnn_fps_status(void);
 #define PRCNN_FPS_ORDER_CANONICAL 0
 #define PRCNN_FPS_ORDER_UPSTREAM 1
 int prcnn_fps_order(const float* xyz, int B, int N, int npoint, int order, float* tmp, int32_t* idx, prcnn_stream_t stream);
+
+/* COMPARISON MODE of the three index operators: selectable squared-distance arithmetic (and, for FPS, tie order).
+ *   PRCNN_ARITH_CANONICAL  three individually rounded products summed left to right -- the contract of prcnn_fps / prcnn_ball_query* /
+ *                          prcnn_three_nn* and of every test that pins an index;
+ *   PRCNN_ARITH_UPSTREAM   fma(dz,dz, fma(dy,dy, dx*dx)): what nvcc's default -fmad=true makes of the upstream kernels'
+ *                          (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)  (sshaoshuai/Pointnet2.PyTorch, not in the reference tree:
+ *                          .gitmodules:1-4) -- for index-by-index comparison against an upstream build, and for measuring how often
+ *                          the two arithmetics disagree (tools/arith_disagreement.py).
+ * Plain kernels (one workgroup per frame / one thread per query), bit-identical to the oracle's prcnn_cpu_fps_mode /
+ * prcnn_cpu_ball_query_arith / prcnn_cpu_three_nn_arith in both arithmetics; not a fast path, used by no module.
+ * prcnn_fps_mode: `tmp` (B,N) f32 is required.  prcnn_three_nn_arith returns SQUARED distances and no weights. */
+#define PRCNN_ARITH_CANONICAL 0
+#define PRCNN_ARITH_UPSTREAM 1
+int prcnn_fps_mode(const float* xyz, int B, int N, int npoint, int order, int arith, float* tmp, int32_t* idx, prcnn_stream_t stream);
+int prcnn_ball_query_arith(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample, int arith,
+                           int32_t* idx, prcnn_stream_t stream);
+int prcnn_three_nn_arith(const float* unknown, const float* known, int B, int n, int m, int arith, float* dist2, int32_t* idx,
+                         prcnn_stream_t stream);
 
 /* gather_points_wrapper(B,C,N,npoint,feat,idx,out): out[b,c,m] = feat[b,c,idx[b,m]] */
 int prcnn_gather(const float* feat, const int32_t* idx, int B, int C, int N, int M, float* out, prcnn_stream_t stream);
@@ -351,7 +371,7 @@ int prcnn_boxes_iou_bev(const float* boxes_a, int Na, const float* boxes_b, int 
 
 #define PRCNN_NMS_ROTATED 0
 #define PRCNN_NMS_NORMAL 1
-/* workspace bytes prcnn_nms needs for N boxes */
+/* workspace bytes prcnn_nms needs for N boxes (the N x ceil(N/64) suppression mask + one flag byte per 64 x 64 tile of it) */
 size_t prcnn_nms_workspace_bytes(int N);
 /* Greedy NMS over boxes ALREADY sorted by descending score (iou3d_utils.py:64-66): box i suppresses
  * j>i iff iou(i,j) > thresh.  Entirely on the device: keep (N) i64 receives the kept positions in

@@ -77,6 +77,31 @@ class _Cpu:
         self.lib.prcnn_cpu_fps_upstream(_p(xyz, _F), B, N, npoint, _p(idx, _I))
         return idx
 
+    # ---- comparison mode: tie order x distance arithmetic ("upstream" = nvcc's contraction of a*a + b*b + c*c, prcnn_oracle.c) ----
+    def fps_mode(self, xyz, npoint, order=0, arith=0):
+        xyz = _f32(xyz)
+        B, N, _ = xyz.shape
+        idx = np.zeros((B, npoint), np.int32)
+        self.lib.prcnn_cpu_fps_mode(_p(xyz, _F), B, N, npoint, int(order), int(arith), _p(idx, _I))
+        return idx
+
+    def ball_query_arith(self, radius, nsample, xyz, new_xyz, arith):
+        xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+        B, N, _ = xyz.shape
+        M = new_xyz.shape[1]
+        idx = np.zeros((B, M, nsample), np.int32)
+        self.lib.prcnn_cpu_ball_query_arith(_p(xyz, _F), _p(new_xyz, _F), B, N, M, ctypes.c_float(radius), nsample, int(arith), _p(idx, _I))
+        return idx
+
+    def three_nn_arith(self, unknown, known, arith):
+        unknown, known = _f32(unknown), _f32(known)
+        B, n, _ = unknown.shape
+        m = known.shape[1]
+        d2 = np.zeros((B, n, 3), np.float32)
+        idx = np.zeros((B, n, 3), np.int32)
+        self.lib.prcnn_cpu_three_nn_arith(_p(unknown, _F), _p(known, _F), B, n, m, int(arith), _p(d2, _F), _p(idx, _I))
+        return d2, idx
+
     def gt_aug_edit(self, pts, intensity, boxes3d, new_pts, new_intensity, num_pts=None, num_boxes=None, num_new=None,
                     extra_h=2.0, trig_mode=KERNEL_TRIG):
         """-> out_pts (B,N+P,3), out_intensity (B,N+P), count (B) i32, removed (B,N) i32"""

@@ -128,6 +128,103 @@ PRCNN_EXPORT void prcnn_cpu_fps_upstream(const float* xyz, int B, int N, int npo
     free(t);
 }
 
+/* ------------------------------------------------------------------ *
+ * "UPSTREAM ARITHMETIC" comparison mode (round 6; PARITY UNPINNED either way: the upstream source is absent, .gitmodules:1-4).
+ * The upstream kernels write the squared distance as  (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)  and are built by nvcc,
+ * whose default (-fmad=true) contracts a*a + b*b + c*c into  fma(c,c, fma(b,b, a*a)):  one rounding after dx*dx, then two fused
+ * steps -- not the three rounded products of the canonical contract above.  arith 0 = canonical (sqdist3), arith 1 = that contracted
+ * form.  The two differ in the last bit of some distances; indices differ only where that bit decides a comparison (a near-tie of two
+ * running min-distances in FPS, a point within an ulp of the ball radius, the 3rd / 4th neighbour at nearly the same distance).
+ * tests/test_gpu_arith_modes.py holds the kernels to these functions bit for bit in both modes and tools/arith_disagreement.py counts
+ * how often the modes disagree on the bench clouds.
+ * ------------------------------------------------------------------ */
+static inline float sqdist3_mode(int arith, float ax, float ay, float az, float bx, float by, float bz) {
+    if (!arith) return sqdist3(ax, ay, az, bx, by, bz);
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float xx = dx * dx;
+    return fmaf(dz, dz, fmaf(dy, dy, xx));       /* libm fmaf: correctly rounded whatever the host (-ffp-contract=off never fuses by itself) */
+}
+
+/* A.1 with selectable tie order (0 canonical: lowest point index; 1 upstream: argmin (k mod T, k), see prcnn_cpu_fps_upstream) and
+ * distance arithmetic */
+PRCNN_EXPORT void prcnn_cpu_fps_mode(const float* xyz, int B, int N, int npoint, int order, int arith, int* idx) {
+    int T = 1;
+    if (order) while (T * 2 <= N && T < 1024) T <<= 1;
+    float* t = (float*)malloc(sizeof(float) * (size_t)N);
+    for (int b = 0; b < B; b++) {
+        const float* p = xyz + (size_t)b * N * 3;
+        int* o = idx + (size_t)b * npoint;
+        for (int k = 0; k < N; k++) t[k] = 1e10f;
+        if (npoint <= 0) continue;
+        int old = 0;
+        o[0] = 0;
+        for (int j = 1; j < npoint; j++) {
+            float x0 = p[old * 3], y0 = p[old * 3 + 1], z0 = p[old * 3 + 2];
+            float best = -1.0f;
+            int besti = 0;
+            for (int th = 0; th < T; th++) {            /* T == 1: one pass in index order == the canonical rule */
+                float tb = -1.0f;
+                int ti = 0;
+                for (int k = th; k < N; k += T) {
+                    float d = sqdist3_mode(arith, p[k * 3], p[k * 3 + 1], p[k * 3 + 2], x0, y0, z0);
+                    float v = d < t[k] ? d : t[k];
+                    t[k] = v;
+                    if (v > tb) { tb = v; ti = k; }
+                }
+                if (tb > best) { best = tb; besti = ti; }
+            }
+            o[j] = besti;
+            old = besti;
+        }
+    }
+    free(t);
+}
+
+PRCNN_EXPORT void prcnn_cpu_ball_query_arith(const float* xyz, const float* new_xyz, int B, int N, int M, float radius, int nsample,
+                                             int arith, int* idx) {
+    float r2 = radius * radius;
+    for (int b = 0; b < B; b++) {
+        const float* p = xyz + (size_t)b * N * 3;
+        for (int m = 0; m < M; m++) {
+            const float* q = new_xyz + ((size_t)b * M + m) * 3;
+            int* o = idx + ((size_t)b * M + m) * nsample;
+            for (int s = 0; s < nsample; s++) o[s] = 0;
+            int cnt = 0;
+            for (int k = 0; k < N && cnt < nsample; k++) {
+                float d2 = sqdist3_mode(arith, q[0], q[1], q[2], p[k * 3], p[k * 3 + 1], p[k * 3 + 2]);
+                if (d2 < r2) {
+                    if (cnt == 0)
+                        for (int s = 0; s < nsample; s++) o[s] = k;
+                    o[cnt] = k;
+                    cnt++;
+                }
+            }
+        }
+    }
+}
+
+PRCNN_EXPORT void prcnn_cpu_three_nn_arith(const float* unknown, const float* known, int B, int n, int m, int arith, float* dist2,
+                                           int* idx) {
+    for (int b = 0; b < B; b++) {
+        const float* kn = known + (size_t)b * m * 3;
+        for (int i = 0; i < n; i++) {
+            const float* u = unknown + ((size_t)b * n + i) * 3;
+            float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+            int i1 = 0, i2 = 0, i3 = 0;
+            for (int k = 0; k < m; k++) {
+                float d = sqdist3_mode(arith, u[0], u[1], u[2], kn[k * 3], kn[k * 3 + 1], kn[k * 3 + 2]);
+                if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+                else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+                else if (d < b3) { b3 = d; i3 = k; }
+            }
+            float* od = dist2 + ((size_t)b * n + i) * 3;
+            int* oi = idx + ((size_t)b * n + i) * 3;
+            od[0] = b1; od[1] = b2; od[2] = b3;
+            oi[0] = i1; oi[1] = i2; oi[2] = i3;
+        }
+    }
+}
+
 /* A.2 gather_operation: out[b,c,m] = feat[b,c,idx[b,m]] */
 PRCNN_EXPORT void prcnn_cpu_gather(const float* feat, const int* idx, int B, int C, int N, int M, float* out) {
     for (int b = 0; b < B; b++)

@@ -36,6 +36,8 @@ class TrainLayer(ctypes.Structure):
                 ("dW", _P), ("dgamma", _P), ("dbeta", _P)]
 
 
+REQUIRED_ABI = 9                 # prcnn_abi_version() the signatures below describe
+
 # name -> (restype, argtypes); mirrors include/prcnn_pointops.h one for one
 SIGNATURES = {
     "prcnn_abi_version": (_I, []),
@@ -44,6 +46,9 @@ SIGNATURES = {
     "prcnn_fps": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "prcnn_fps_status": (_I, []),
     "prcnn_fps_order": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "prcnn_fps_mode": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "prcnn_ball_query_arith": (_I, [_P, _P, _I, _I, _I, _F, _I, _I, _P, _P]),
+    "prcnn_three_nn_arith": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "prcnn_rpn_labels": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "prcnn_gt_aug_edit": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "prcnn_host_pts_in_boxes3d": (_I, [_P, _P, _L, _L, _P]),
@@ -163,6 +168,10 @@ def lib():
         handle = ctypes.CDLL(path)
     except OSError as e:
         raise PointOpsError("cannot load %s: %s" % (path, e))
+    handle.prcnn_abi_version.restype = _I
+    if handle.prcnn_abi_version() < REQUIRED_ABI:      # an older library fails HERE, not at a missing symbol or a changed signature later
+        raise PointOpsError("%s implements ABI %d, this binding needs %d (include/prcnn_pointops.h)"
+                            % (path, handle.prcnn_abi_version(), REQUIRED_ABI))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)      # AttributeError here == header/library mismatch: fail loudly
         fn.restype = res

@@ -13,7 +13,7 @@ int prcnn_fail(int code, const char* fmt, ...) {
 }
 
 PRCNN_API const char* prcnn_last_error(void) { return g_err; }
-PRCNN_API int prcnn_abi_version(void) { return 7; }
+PRCNN_API int prcnn_abi_version(void) { return 9; }
 
 #ifndef PRCNN_BUILD_ID
 #define PRCNN_BUILD_ID "PRCNN_BUILD_ID=unknown"

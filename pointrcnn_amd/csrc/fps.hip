@@ -50,28 +50,54 @@ __device__ __forceinline__ int row0_max_i32_fused(int v) {          // first 16 
 }
 
 // Wave maximum of `best` AND, per lane, the bit mask of the slots holding the lane's own maximum (bit i = pt[i] == best), in one
-// hand-scheduled block (round 5).  A slot costs two VALU: v_cmp_eq into VCC, then v_addc_co acc = acc + acc + VCC, i.e. (acc << 1) | hit
-// -- where "lowest slot holding the maximum" + "how many slots hold it" cost three per slot each way before (compare, select the slot
-// number, count).  The slot steps are issued BETWEEN the six DPP steps of the maximum, whose VALU-write -> DPP-read hazard (two wait
-// states) they cover: no s_nop.  The owner lane's mask is read out with one v_readlane; its lowest set bit is the slot, its population
-// count says whether the maximum is unique in the lane.  An updating wave issues ~one instruction per 4-5 cycles, so this is latency
-// of every sample (fps_slot_kernel<16>: -24 VALU, -6 s_nop per update).
-#define FPS_EQ(p) "v_cmp_eq_f32 vcc, " p ", %[best]\n\tv_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+// hand-scheduled block (round 5).  A slot costs two VALU: v_cmp_eq into an SGPR pair, then v_addc_co acc = acc + acc + hit, i.e.
+// (acc << 1) | hit -- where "lowest slot holding the maximum" + "how many slots hold it" cost three per slot each way before (compare,
+// select the slot number, count).  The slot steps are issued BETWEEN the six DPP steps of the maximum, whose VALU-write -> DPP-read
+// hazard (two wait states) they cover: no s_nop.  The owner lane's mask is read out with one v_readlane; its lowest set bit is the slot,
+// its population count says whether the maximum is unique in the lane.  An updating wave issues ~one instruction per 4-5 cycles, so this
+// is latency of every sample (fps_slot_kernel<16>: -24 VALU, -6 s_nop per update).
+//
+// Round 6 (advisor finding): gfx940-class targets need TWO wait states between a VALU write of an SGPR / VCC and a VALU read of it
+// (hipcc pads exactly that with `s_nop 1` in its own code: v_cmp_*_e64 s[..] -> v_cndmask ... s[..]); nothing pads an asm string.
+// The round-5 blocks compared into VCC and consumed it in the very next instruction (no wait state), and the tail of the
+// two-accumulator form left one.  All 577 GPU tests passed on that code -- the hardware evidently forwards in the cases they hit --
+// but the ISA does not promise it.  Now every compare writes one of two (four in the tail of the two-accumulator form) SGPR pairs
+// and its v_addc is issued at least two instructions later:   C0 C1 D A0 C2 D A1 C3 D A2 ...   (C = compare, A = add-with-carry of
+// the compare two slots back, D = a DPP step of the maximum; a D is also two instructions after the previous D).  Same instruction
+// count as before except one s_nop 0 before the last A of the 8- and 16-slot forms.
+#define FPS_C(s, p) "v_cmp_eq_f32_e64 " s ", " p ", %[best]\n\t"
+#define FPS_A(s) "v_addc_co_u32_e64 %[acc], vcc, %[acc], %[acc], " s "\n\t"
 #define FPS_DPPS(ctrl) "v_max_i32_dpp %[t], %[t], %[t] " ctrl "\n\t"
+#define FPS_D1 FPS_DPPS("row_shr:1 row_mask:0xf bank_mask:0xf")
+#define FPS_D2 FPS_DPPS("row_shr:2 row_mask:0xf bank_mask:0xf")
+#define FPS_D3 FPS_DPPS("row_shr:4 row_mask:0xf bank_mask:0xf")
+#define FPS_D4 FPS_DPPS("row_shr:8 row_mask:0xf bank_mask:0xf")
+#define FPS_D5 FPS_DPPS("row_bcast:15 row_mask:0xa bank_mask:0xf")
+#define FPS_D6 FPS_DPPS("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#define FPS_SA "%[sa]"
+#define FPS_SB "%[sb]"
 template <int PPT> struct WaveMaxEq;
 template <> struct WaveMaxEq<16> {
     template <class V> static __device__ __forceinline__ int run(const V& pt, float best, unsigned& eqbits) {
-        int t; unsigned acc;
+        int t; unsigned acc; unsigned long long sa, sb;
         asm volatile("v_mov_b32 %[t], %[best]\n\tv_mov_b32 %[acc], 0\n\t"
-                     FPS_EQ("%[p15]") FPS_DPPS("row_shr:1 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p14]") FPS_DPPS("row_shr:2 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p13]") FPS_DPPS("row_shr:4 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p12]") FPS_DPPS("row_shr:8 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p11]") FPS_DPPS("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                     FPS_EQ("%[p10]") FPS_DPPS("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                     FPS_EQ("%[p9]") FPS_EQ("%[p8]") FPS_EQ("%[p7]") FPS_EQ("%[p6]") FPS_EQ("%[p5]")
-                     FPS_EQ("%[p4]") FPS_EQ("%[p3]") FPS_EQ("%[p2]") FPS_EQ("%[p1]") FPS_EQ("%[p0]")
-                     : [t] "=&v"(t), [acc] "=&v"(acc)
+                     FPS_C(FPS_SA, "%[p15]") FPS_C(FPS_SB, "%[p14]") FPS_D1
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p13]") FPS_D2
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p12]") FPS_D3
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p11]") FPS_D4
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p10]") FPS_D5
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p9]") FPS_D6
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p8]")
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p7]")
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p6]")
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p5]")
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p4]")
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p3]")
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p2]")
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p1]")
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p0]")
+                     FPS_A(FPS_SA) "s_nop 0\n\t" FPS_A(FPS_SB)
+                     : [t] "=&v"(t), [acc] "=&v"(acc), [sa] "=&s"(sa), [sb] "=&s"(sb)
                      : [best] "v"(best), [p0] "v"(pt[0]), [p1] "v"(pt[1]), [p2] "v"(pt[2]), [p3] "v"(pt[3]), [p4] "v"(pt[4]), [p5] "v"(pt[5]),
                        [p6] "v"(pt[6]), [p7] "v"(pt[7]), [p8] "v"(pt[8]), [p9] "v"(pt[9]), [p10] "v"(pt[10]), [p11] "v"(pt[11]),
                        [p12] "v"(pt[12]), [p13] "v"(pt[13]), [p14] "v"(pt[14]), [p15] "v"(pt[15])
@@ -82,16 +108,17 @@ template <> struct WaveMaxEq<16> {
 };
 template <> struct WaveMaxEq<8> {
     template <class V> static __device__ __forceinline__ int run(const V& pt, float best, unsigned& eqbits) {
-        int t; unsigned acc;
+        int t; unsigned acc; unsigned long long sa, sb;
         asm volatile("v_mov_b32 %[t], %[best]\n\tv_mov_b32 %[acc], 0\n\t"
-                     FPS_EQ("%[p7]") FPS_DPPS("row_shr:1 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p6]") FPS_DPPS("row_shr:2 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p5]") FPS_DPPS("row_shr:4 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p4]") FPS_DPPS("row_shr:8 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p3]") FPS_DPPS("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                     FPS_EQ("%[p2]") FPS_DPPS("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                     FPS_EQ("%[p1]") FPS_EQ("%[p0]")
-                     : [t] "=&v"(t), [acc] "=&v"(acc)
+                     FPS_C(FPS_SA, "%[p7]") FPS_C(FPS_SB, "%[p6]") FPS_D1
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p5]") FPS_D2
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p4]") FPS_D3
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p3]") FPS_D4
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p2]") FPS_D5
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p1]") FPS_D6
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p0]")
+                     FPS_A(FPS_SA) "s_nop 0\n\t" FPS_A(FPS_SB)
+                     : [t] "=&v"(t), [acc] "=&v"(acc), [sa] "=&s"(sa), [sb] "=&s"(sb)
                      : [best] "v"(best), [p0] "v"(pt[0]), [p1] "v"(pt[1]), [p2] "v"(pt[2]), [p3] "v"(pt[3]), [p4] "v"(pt[4]), [p5] "v"(pt[5]),
                        [p6] "v"(pt[6]), [p7] "v"(pt[7])
                      : "vcc");
@@ -101,16 +128,16 @@ template <> struct WaveMaxEq<8> {
 };
 template <> struct WaveMaxEq<4> {
     template <class V> static __device__ __forceinline__ int run(const V& pt, float best, unsigned& eqbits) {
-        int t; unsigned acc;
+        int t; unsigned acc; unsigned long long sa, sb;
         asm volatile("v_mov_b32 %[t], %[best]\n\tv_mov_b32 %[acc], 0\n\t"
-                     FPS_EQ("%[p3]") FPS_DPPS("row_shr:1 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p2]") FPS_DPPS("row_shr:2 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p1]") FPS_DPPS("row_shr:4 row_mask:0xf bank_mask:0xf")
-                     FPS_EQ("%[p0]") FPS_DPPS("row_shr:8 row_mask:0xf bank_mask:0xf")
-                     "s_nop 1\n\t" FPS_DPPS("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                     "s_nop 1\n\t" FPS_DPPS("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     FPS_C(FPS_SA, "%[p3]") FPS_C(FPS_SB, "%[p2]") FPS_D1
+                     FPS_A(FPS_SA) FPS_C(FPS_SA, "%[p1]") FPS_D2
+                     FPS_A(FPS_SB) FPS_C(FPS_SB, "%[p0]") FPS_D3
+                     FPS_A(FPS_SA) FPS_A(FPS_SB) FPS_D4
+                     "s_nop 1\n\t" FPS_D5
+                     "s_nop 1\n\t" FPS_D6
                      "s_nop 1\n\t"
-                     : [t] "=&v"(t), [acc] "=&v"(acc)
+                     : [t] "=&v"(t), [acc] "=&v"(acc), [sa] "=&s"(sa), [sb] "=&s"(sb)
                      : [best] "v"(best), [p0] "v"(pt[0]), [p1] "v"(pt[1]), [p2] "v"(pt[2]), [p3] "v"(pt[3])
                      : "vcc");
         eqbits = acc;
@@ -118,24 +145,27 @@ template <> struct WaveMaxEq<4> {
     }
 };
 
-// WaveMaxEq<16> with TWO accumulators and the compare results in two SGPR pairs instead of VCC (round 5): a v_addc then reads a
-// compare issued two to three instructions earlier and an accumulator written two instructions earlier -- the one-accumulator form is
-// a chain of 32 instructions each waiting for its predecessor's result (measured ~6 cycles per instruction on a lone wave against 4
-// for independent ones).  a0 collects slots 15..8, a1 slots 7..0.
+// WaveMaxEq<16> with TWO accumulators (round 5): a v_addc then reads a compare issued two to three instructions earlier and an
+// accumulator written two instructions earlier -- the one-accumulator form is a chain of instructions each waiting for its
+// predecessor's result (measured ~6 cycles per instruction on a lone wave against 4 for independent ones).  a0 collects slots 15..8,
+// a1 slots 7..0.  Every compare is two or more instructions ahead of the v_addc that reads its SGPR pair (see above): in the groups
+// around a DPP step by construction, in the tail (no DPP step left) by comparing the last four slots into four pairs first.
 #define FPS_EQ2(pa, pb) "v_cmp_eq_f32_e64 %[sa], " pa ", %[best]\n\tv_cmp_eq_f32_e64 %[sb], " pb ", %[best]\n\t"
 #define FPS_AC2 "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[sa]\n\tv_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[sb]\n\t"
 template <class V> __device__ __forceinline__ int wave_max_eq2_16(const V& pt, float best, unsigned& eqbits) {
-    int t; unsigned a0, a1; unsigned long long sa, sb;
+    int t; unsigned a0, a1; unsigned long long sa, sb, sc, sd;
     asm volatile("v_mov_b32 %[t], %[best]\n\tv_mov_b32 %[a0], 0\n\tv_mov_b32 %[a1], 0\n\t"
-                 FPS_EQ2("%[p15]", "%[p7]") FPS_DPPS("row_shr:1 row_mask:0xf bank_mask:0xf") FPS_AC2
-                 FPS_EQ2("%[p14]", "%[p6]") FPS_DPPS("row_shr:2 row_mask:0xf bank_mask:0xf") FPS_AC2
-                 FPS_EQ2("%[p13]", "%[p5]") FPS_DPPS("row_shr:4 row_mask:0xf bank_mask:0xf") FPS_AC2
-                 FPS_EQ2("%[p12]", "%[p4]") FPS_DPPS("row_shr:8 row_mask:0xf bank_mask:0xf") FPS_AC2
-                 FPS_EQ2("%[p11]", "%[p3]") FPS_DPPS("row_bcast:15 row_mask:0xa bank_mask:0xf") FPS_AC2
-                 FPS_EQ2("%[p10]", "%[p2]") FPS_DPPS("row_bcast:31 row_mask:0xc bank_mask:0xf") FPS_AC2
-                 FPS_EQ2("%[p9]", "%[p1]") FPS_AC2
-                 FPS_EQ2("%[p8]", "%[p0]") FPS_AC2
-                 : [t] "=&v"(t), [a0] "=&v"(a0), [a1] "=&v"(a1), [sa] "=&s"(sa), [sb] "=&s"(sb)
+                 FPS_EQ2("%[p15]", "%[p7]") FPS_D1 FPS_AC2
+                 FPS_EQ2("%[p14]", "%[p6]") FPS_D2 FPS_AC2
+                 FPS_EQ2("%[p13]", "%[p5]") FPS_D3 FPS_AC2
+                 FPS_EQ2("%[p12]", "%[p4]") FPS_D4 FPS_AC2
+                 FPS_EQ2("%[p11]", "%[p3]") FPS_D5 FPS_AC2
+                 FPS_EQ2("%[p10]", "%[p2]") FPS_D6 FPS_AC2
+                 FPS_EQ2("%[p9]", "%[p1]")
+                 "v_cmp_eq_f32_e64 %[sc], %[p8], %[best]\n\tv_cmp_eq_f32_e64 %[sd], %[p0], %[best]\n\t"
+                 FPS_AC2
+                 "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[sc]\n\tv_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[sd]\n\t"
+                 : [t] "=&v"(t), [a0] "=&v"(a0), [a1] "=&v"(a1), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc), [sd] "=&s"(sd)
                  : [best] "v"(best), [p0] "v"(pt[0]), [p1] "v"(pt[1]), [p2] "v"(pt[2]), [p3] "v"(pt[3]), [p4] "v"(pt[4]), [p5] "v"(pt[5]),
                    [p6] "v"(pt[6]), [p7] "v"(pt[7]), [p8] "v"(pt[8]), [p9] "v"(pt[9]), [p10] "v"(pt[10]), [p11] "v"(pt[11]),
                    [p12] "v"(pt[12]), [p13] "v"(pt[13]), [p14] "v"(pt[14]), [p15] "v"(pt[15])

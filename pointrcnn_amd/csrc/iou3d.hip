@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void pair_matrix_kernel(const float* __restric
 // ---- NMS: upper-triangle suppression mask (64x64 tiles) -----------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int N, float thresh, int W,
-                                                      unsigned long long* __restrict__ mask) {
+                                                      unsigned long long* __restrict__ mask, unsigned char* __restrict__ tflag) {
     const int row_blk = blockIdx.y, col_blk = blockIdx.x;
     if (col_blk < row_blk) return;                       // never read by the sweep
     const int t = threadIdx.x;
@@ -85,6 +85,10 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
         }
     }
     if (row < N) mask[(size_t)row * W + col_blk] = bits;
+    // one byte per tile: does any row of it suppress anything?  On scattered boxes nine tiles in ten are empty and the sweep's folders
+    // skip their rows (the fold of a block is bound by what one CU can pull from L2: 64 rows x (W - i) words per block)
+    const bool some = __ballot(row < N && bits != 0ULL) != 0ULL;
+    if (t == 0) tflag[(size_t)row_blk * W + col_blk] = some ? 1 : 0;
 }
 
 // ---- NMS: greedy sweep on the device (iou3d.cpp:100-119), one workgroup per problem ------------------
@@ -119,20 +123,41 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
 }
 
+// -DSWEEP_TIMING (tools/build_variant.py + tools/nms_timing.py): cycle counters of the resolver's and of folder wave 1's phases, written
+// over the head of the mask after the last block; never defined in the product build
+#ifdef SWEEP_TIMING
+#define SWEEP_T(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; }
+#else
+#define SWEEP_T(k)
+#endif
+
+#define SWEEP_DEPTH 4                                    // blocks between the request of a block's words and their use
+#define SWEEP_FLAGS_LDS_MAX_W 128                        // tile flags of up to 128 x 128 tiles (N <= 8 192) are staged in LDS
+
 struct SweepShared {
     unsigned long long* remv;                            // W words: bit set = suppressed
     unsigned long long* kslot;                           // [i & 1] = kept bits of block i
     unsigned long long* stop;                            // [i & 1] != 0: enough boxes kept after block i
+    const unsigned char* flags;                          // W x W tile flags: in LDS when they fit, else the mask kernel's array
 };
 
-// Resolver, block i.  d / nr: word i / word i+1 of the block's rows (one row per lane), requested two blocks ago; they leave holding the
-// requests for block i+2 (issued after their last use, so they stay in the same registers: a register copy of a value in flight
-// would put the load's latency on the chain).  -> true when enough boxes are kept.
+// The mask was written by workgroups on all eight XCDs and the sweep reads it on one: every word comes from the memory side
+// (~1 us), not from this XCD's L2.  Whatever the chain needs is therefore requested SWEEP_DEPTH blocks ahead into a ring of register
+// sets that the unrolled loop walks without ever copying a value in flight (a copy would wait for the load).
+
+// Resolver, block i.  d / nr: word i / word i+1 of the block's rows (one row per lane), requested SWEEP_DEPTH blocks ago; they leave
+// holding the requests for block i+SWEEP_DEPTH (issued after their last use, so they stay in the same registers).
+// -> true when enough boxes are kept.
 __device__ __forceinline__ bool sweep_resolve(const unsigned long long* __restrict__ mask, int N, int W, int max_keep, int i, int lane,
                                               const SweepShared& sh, unsigned long long& d, unsigned long long& nr,
-                                              unsigned long long& carry, int& num, int64_t* __restrict__ keep) {
+                                              unsigned long long& carry, int& num, int64_t* __restrict__ keep
+#ifdef SWEEP_TIMING
+                                              , unsigned long long (&tacc)[8], unsigned long long& tlast
+#endif
+                                              ) {
     const int nrows = min(64, N - i * 64);
     unsigned long long cur = uniform_u64(sh.remv[i]) | carry;
+    SWEEP_T(0)
     const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
     unsigned long long todo = __ballot(d != 0ULL) & ~cur;
     while (todo) {                                       // ascending over the rows that can still suppress something
@@ -143,8 +168,9 @@ __device__ __forceinline__ bool sweep_resolve(const unsigned long long* __restri
         todo &= todo - 1ULL;
         todo &= ~cur;
     }
-    const int r2 = min((i + 2) * 64 + lane, N - 1);      // clamped: rows / words past the end are read again and never used
-    d = mask[(size_t)r2 * W + min(i + 2, W - 1)];
+    SWEEP_T(1)
+    const int rn = min((i + SWEEP_DEPTH) * 64 + lane, N - 1);      // clamped: rows / words past the end are read again and never used
+    d = mask[(size_t)rn * W + min(i + SWEEP_DEPTH, W - 1)];
     const unsigned long long valid = nrows == 64 ? ~0ULL : ((1ULL << nrows) - 1ULL);
     const unsigned long long kept = ~cur & valid;
     const bool mine = (kept >> lane) & 1ULL;
@@ -152,21 +178,47 @@ __device__ __forceinline__ bool sweep_resolve(const unsigned long long* __restri
     num += __popcll(kept);
     const bool enough = max_keep > 0 && num >= max_keep;
     if (lane == 0) { sh.kslot[i & 1] = kept; sh.stop[i & 1] = enough ? 1ULL : 0ULL; }
+    SWEEP_T(2)
     __syncthreads();
+    SWEEP_T(3)
     carry = i + 1 < W ? wave_or_u64(mine ? nr : 0ULL) : 0ULL;
-    nr = mask[(size_t)r2 * W + min(i + 3, W - 1)];
+    nr = mask[(size_t)rn * W + min(i + SWEEP_DEPTH + 1, W - 1)];
+    SWEEP_T(4)
     return enough;
 }
 
-// Folder, iteration i: ORs the kept rows [c*16, c*16+16) of block i-1 (`part`, requested two iterations ago) into the suppression words
-// i+1 + g*64 + lane (+128, ...), then requests the same rows of block i+1 into `part`.  -> true when the resolver said stop.
-__device__ __forceinline__ bool sweep_fold(const unsigned long long* __restrict__ mask, int N, int W, int i, int lane, int c, int g,
-                                           const SweepShared& sh, unsigned long long (&part)[SWEEP_FOLD_ROWS]) {
+// Folder, iteration i: ORs the kept rows [c*16, c*16+16) of block i-1 (`part`, requested SWEEP_DEPTH iterations ago when the tile's flag
+// `has` said it holds anything) into the suppression words i+1 + g*64 + lane (+128, ...), then requests the same rows of block
+// i-1+SWEEP_DEPTH into `part`.  -> true when the resolver said stop.
+__device__ __forceinline__ bool sweep_tile_flag(const SweepShared& sh, int W, int blk, int w) {
+    return blk < W && w < W && sh.flags[(size_t)min(blk, W - 1) * W + min(w, W - 1)] != 0;          // clamped: no guarded load
+}
+__device__ __forceinline__ void sweep_request(const unsigned long long* __restrict__ mask, int N, int W, int blk, int lane, int c, int g,
+                                              const SweepShared& sh, unsigned long long (&part)[SWEEP_FOLD_ROWS], bool& has) {
+    // rows [c*16, c*16+16) of block `blk`, word blk+2 + g*64 + lane (the first word the folders own for that block); rows past the last
+    // one are clamped (read again, never selected: kept has no bit there)
+    const int w = blk + 2 + g * 64 + lane;
+    has = sweep_tile_flag(sh, W, blk, w);
+    if (has) {
+#pragma unroll
+        for (int r = 0; r < SWEEP_FOLD_ROWS; r++) {
+            const unsigned long long* rowp = mask + (size_t)min(blk * 64 + c * SWEEP_FOLD_ROWS + r, N - 1) * W;     // uniform
+            part[r] = rowp[w];
+        }
+    }
+}
+__device__ __forceinline__ bool sweep_fold(const unsigned long long* __restrict__ mask, int N, int W,
+                                           int i, int lane, int c, int g, const SweepShared& sh,
+                                           unsigned long long (&part)[SWEEP_FOLD_ROWS], bool& has
+#ifdef SWEEP_TIMING
+                                           , unsigned long long (&tacc)[8], unsigned long long& tlast
+#endif
+                                           ) {
     if (i >= 1) {
         const unsigned kb = (unsigned)(uniform_u64(sh.kslot[(i - 1) & 1]) >> (c * SWEEP_FOLD_ROWS)) & 0xffffu;
         if (kb) {
             const int w0 = i + 1 + g * 64 + lane;
-            if (w0 < W) {
+            if (has) {                                   // (has implies w0 < W)
                 unsigned long long acc = 0ULL;
 #pragma unroll
                 for (int r = 0; r < SWEEP_FOLD_ROWS; r++)
@@ -174,6 +226,7 @@ __device__ __forceinline__ bool sweep_fold(const unsigned long long* __restrict_
                 if (acc) atomicOr(&sh.remv[w0], acc);
             }
             for (int w = w0 + 128; w < W; w += 128) {          // more than 129 blocks (N > 8 256): the far words, not prefetched
+                if (!sh.flags[(size_t)(i - 1) * W + w]) continue;
                 unsigned long long acc = 0ULL;
                 const unsigned long long* col = mask + (size_t)((i - 1) * 64 + c * SWEEP_FOLD_ROWS) * W + w;
 #pragma unroll
@@ -183,50 +236,80 @@ __device__ __forceinline__ bool sweep_fold(const unsigned long long* __restrict_
             }
         }
     }
-    {   // block i+1 -> words >= i+3, consumed at iteration i+2.  Straight-line loads from clamped addresses (a guarded load is a branch of
-        // its own): words past the last one read the last word again and are never stored, rows past the last one read the last row
-        // again and are never selected (kept has no bit there)
-        const int w = min(i + 3 + g * 64 + lane, W - 1);
-#pragma unroll
-        for (int r = 0; r < SWEEP_FOLD_ROWS; r++) part[r] = mask[(size_t)min((i + 1) * 64 + c * SWEEP_FOLD_ROWS + r, N - 1) * W + w];
-    }
+    SWEEP_T(0)
+    sweep_request(mask, N, W, i - 1 + SWEEP_DEPTH, lane, c, g, sh, part, has);
+    SWEEP_T(1)
     __syncthreads();
-    return sh.stop[i & 1] != 0ULL;
+    SWEEP_T(2)
+    const bool stop_now = sh.stop[i & 1] != 0ULL;
+    SWEEP_T(3)
+    return stop_now;
 }
 
-__global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int N, int W,
+__global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
+                                                                  const unsigned char* __restrict__ tflag, int N, int W,
                                                                   int max_keep, int64_t* __restrict__ keep,
                                                                   int32_t* __restrict__ num_keep) {
-    extern __shared__ unsigned long long sweep_lds[];    // W suppression words, then the exchange words
-    const SweepShared sh = {sweep_lds, sweep_lds + W, sweep_lds + W + 2};
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ unsigned long long sweep_lds[];    // W suppression words, the exchange words, then the tile flags when they fit
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // in an SGPR: the folders' row addresses are scalar arithmetic
+    const bool flags_in_lds = W <= SWEEP_FLAGS_LDS_MAX_W;
+    const SweepShared sh = {sweep_lds, sweep_lds + W, sweep_lds + W + 2,
+                            flags_in_lds ? (const unsigned char*)(sweep_lds + W + 4) : tflag};
     for (int w = tid; w < W + 4; w += SWEEP_THREADS) sweep_lds[w] = 0ULL;
+    if (flags_in_lds) {
+        // (the flags of the tiles below the diagonal are never written and never used: whatever is there is copied and ignored)
+        unsigned char* fl = (unsigned char*)(sweep_lds + W + 4);
+        for (int e = tid; e < W * W; e += SWEEP_THREADS) fl[e] = tflag[e];
+    }
     __syncthreads();
+#ifdef SWEEP_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define SWEEP_TARGS , tacc, tlast
+#else
+#define SWEEP_TARGS
+#endif
     if (wave == 0) {
-        const int ra = min(lane, N - 1), rb = min(64 + lane, N - 1);
-        unsigned long long da = mask[(size_t)ra * W], na = mask[(size_t)ra * W + min(1, W - 1)];                     // block 0
-        unsigned long long db = mask[(size_t)rb * W + min(1, W - 1)], nb = mask[(size_t)rb * W + min(2, W - 1)];     // block 1
+        unsigned long long d0, d1, d2, d3, n0, n1, n2, n3;
+#define SWEEP_RQ(k, dk, nk) { const int r_ = min((k) * 64 + lane, N - 1); dk = mask[(size_t)r_ * W + min((k), W - 1)]; \
+                              nk = mask[(size_t)r_ * W + min((k) + 1, W - 1)]; }
+        SWEEP_RQ(0, d0, n0) SWEEP_RQ(1, d1, n1) SWEEP_RQ(2, d2, n2) SWEEP_RQ(3, d3, n3)
+#undef SWEEP_RQ
         unsigned long long carry = 0ULL;
         int num = 0;
-        for (int i = 0; i < W; i += 2) {
-            if (sweep_resolve(mask, N, W, max_keep, i, lane, sh, da, na, carry, num, keep)) break;
+        for (int i = 0; i < W; i += 4) {
+            if (sweep_resolve(mask, N, W, max_keep, i, lane, sh, d0, n0, carry, num, keep SWEEP_TARGS)) break;
             if (i + 1 >= W) break;
-            if (sweep_resolve(mask, N, W, max_keep, i + 1, lane, sh, db, nb, carry, num, keep)) break;
+            if (sweep_resolve(mask, N, W, max_keep, i + 1, lane, sh, d1, n1, carry, num, keep SWEEP_TARGS)) break;
+            if (i + 2 >= W) break;
+            if (sweep_resolve(mask, N, W, max_keep, i + 2, lane, sh, d2, n2, carry, num, keep SWEEP_TARGS)) break;
+            if (i + 3 >= W) break;
+            if (sweep_resolve(mask, N, W, max_keep, i + 3, lane, sh, d3, n3, carry, num, keep SWEEP_TARGS)) break;
         }
         if (lane == 0) *num_keep = (max_keep > 0 && num > max_keep) ? max_keep : num;
+#ifdef SWEEP_TIMING
+        if (lane == 0) for (int k = 0; k < 8; k++) ((unsigned long long*)mask)[k] = tacc[k];
+#endif
     } else {
         const int fw = wave - 1, c = fw & 3, g = fw >> 2;
-        unsigned long long p0[SWEEP_FOLD_ROWS], p1[SWEEP_FOLD_ROWS];
-        {   // block 0 -> words >= 2 (consumed at iteration 1); p1 is first requested at iteration 0
-            const int w = min(2 + g * 64 + lane, W - 1);
-#pragma unroll
-            for (int r = 0; r < SWEEP_FOLD_ROWS; r++) { p0[r] = mask[(size_t)min(c * SWEEP_FOLD_ROWS + r, N - 1) * W + w]; p1[r] = 0ULL; }
-        }
-        for (int i = 0; i < W; i += 2) {
-            if (sweep_fold(mask, N, W, i, lane, c, g, sh, p1)) break;
+        // set k holds the rows of the block consumed at iterations k, k+4, ...: iteration i consumes block i-1
+        unsigned long long p0[SWEEP_FOLD_ROWS], p1[SWEEP_FOLD_ROWS], p2[SWEEP_FOLD_ROWS], p3[SWEEP_FOLD_ROWS];
+        bool h0 = false, h1, h2, h3;
+        sweep_request(mask, N, W, 0, lane, c, g, sh, p1, h1);
+        sweep_request(mask, N, W, 1, lane, c, g, sh, p2, h2);
+        sweep_request(mask, N, W, 2, lane, c, g, sh, p3, h3);
+        for (int i = 0; i < W; i += 4) {
+            if (sweep_fold(mask, N, W, i, lane, c, g, sh, p0, h0 SWEEP_TARGS)) break;
             if (i + 1 >= W) break;
-            if (sweep_fold(mask, N, W, i + 1, lane, c, g, sh, p0)) break;
+            if (sweep_fold(mask, N, W, i + 1, lane, c, g, sh, p1, h1 SWEEP_TARGS)) break;
+            if (i + 2 >= W) break;
+            if (sweep_fold(mask, N, W, i + 2, lane, c, g, sh, p2, h2 SWEEP_TARGS)) break;
+            if (i + 3 >= W) break;
+            if (sweep_fold(mask, N, W, i + 3, lane, c, g, sh, p3, h3 SWEEP_TARGS)) break;
         }
+#ifdef SWEEP_TIMING
+        if (tid == 64) for (int k = 0; k < 8; k++) ((unsigned long long*)mask)[8 + k] = tacc[k];
+#endif
     }
 }
 
@@ -253,7 +336,7 @@ PRCNN_API int prcnn_boxes_iou_bev(const float* boxes_a, int Na, const float* box
 PRCNN_API size_t prcnn_nms_workspace_bytes(int N) {
     if (N <= 0) return 0;
     size_t W = (size_t)(N + 63) / 64;
-    return (size_t)N * W * sizeof(unsigned long long);
+    return (size_t)N * W * sizeof(unsigned long long) + W * W;      // suppression mask + one flag byte per 64 x 64 tile
 }
 
 PRCNN_API int prcnn_nms(const float* boxes, int N, float thresh, int kind, int max_keep, int64_t* keep, int32_t* num_keep,
@@ -272,13 +355,15 @@ PRCNN_API int prcnn_nms(const float* boxes, int N, float thresh, int kind, int m
     const int W = (N + 63) / 64;
     PRCNN_REQUIRE((size_t)W * 8 <= 60 * 1024, "prcnn_nms: N=%d too large for the LDS suppression bitmap", N);
     unsigned long long* mask = (unsigned long long*)workspace;
+    unsigned char* tflag = (unsigned char*)(mask + (size_t)N * W);
     dim3 grid(W, W);
     if (kind == PRCNN_NMS_ROTATED)
-        hipLaunchKernelGGL(nms_mask_kernel<PRCNN_NMS_ROTATED>, grid, dim3(64), 0, s, boxes, N, thresh, W, mask);
+        hipLaunchKernelGGL(nms_mask_kernel<PRCNN_NMS_ROTATED>, grid, dim3(64), 0, s, boxes, N, thresh, W, mask, tflag);
     else
-        hipLaunchKernelGGL(nms_mask_kernel<PRCNN_NMS_NORMAL>, grid, dim3(64), 0, s, boxes, N, thresh, W, mask);
+        hipLaunchKernelGGL(nms_mask_kernel<PRCNN_NMS_NORMAL>, grid, dim3(64), 0, s, boxes, N, thresh, W, mask, tflag);
     PRCNN_LAUNCH_CHECK("prcnn_nms(mask)");
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(SWEEP_THREADS), (size_t)(W + 4) * 8, s, mask, N, W, max_keep, keep, num_keep);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(SWEEP_THREADS), (size_t)(W + 4) * 8 + (W <= SWEEP_FLAGS_LDS_MAX_W ? (size_t)W * W : 0), s, mask, tflag, N, W, max_keep, keep,
+                       num_keep);
     PRCNN_LAUNCH_CHECK("prcnn_nms(sweep)");
     return PRCNN_OK;
 }

@@ -65,6 +65,44 @@ def furthest_point_sample(xyz, npoint, order="canonical"):
     return idx
 
 
+_ARITH = {"canonical": 0, "upstream": 1}
+_ORDER = {"canonical": 0, "upstream": 1}
+
+
+def furthest_point_sample_mode(xyz, npoint, order="canonical", arith="canonical"):
+    """COMPARISON MODE (prcnn_fps_mode): FPS with a selectable tie order and squared-distance arithmetic -- "upstream" arithmetic is
+    fma(dz,dz, fma(dy,dy, dx*dx)), what nvcc makes of the upstream kernel's expression.  Plain kernel, not a fast path."""
+    _chk(xyz, "xyz", ndim=3)
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, npoint), dtype=_INT, device=xyz.device)
+    tmp = torch.empty((B, N), dtype=_F32, device=xyz.device)
+    _cabi.check(_cabi.lib().prcnn_fps_mode(_p(xyz), B, N, npoint, _ORDER[order], _ARITH[arith], _p(tmp), _p(idx), _stream()), "prcnn_fps_mode")
+    return idx
+
+
+def ball_query_arith(radius, nsample, xyz, new_xyz, arith="upstream"):
+    """COMPARISON MODE (prcnn_ball_query_arith): ball_query by a plain scan under the chosen squared-distance arithmetic"""
+    _chk(xyz, "xyz", ndim=3); _chk(new_xyz, "new_xyz", ndim=3)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.empty((B, M, nsample), dtype=_INT, device=xyz.device)
+    _cabi.check(_cabi.lib().prcnn_ball_query_arith(_p(xyz), _p(new_xyz), B, N, M, float(radius), nsample, _ARITH[arith], _p(idx), _stream()),
+                "prcnn_ball_query_arith")
+    return idx
+
+
+def three_nn_arith(unknown, known, arith="upstream"):
+    """COMPARISON MODE (prcnn_three_nn_arith): -> dist2 (B,n,3) SQUARED, idx (B,n,3) under the chosen squared-distance arithmetic"""
+    _chk(unknown, "unknown", ndim=3); _chk(known, "known", ndim=3)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = torch.empty((B, n, 3), dtype=_F32, device=unknown.device)
+    idx = torch.empty((B, n, 3), dtype=_INT, device=unknown.device)
+    _cabi.check(_cabi.lib().prcnn_three_nn_arith(_p(unknown), _p(known), B, n, m, _ARITH[arith], _p(d2), _p(idx), _stream()),
+                "prcnn_three_nn_arith")
+    return d2, idx
+
+
 def fps_status():
     """Raise if a multi-workgroup furthest_point_sample launch (N > 16384) timed out waiting for a partner slice since the
     last check (its output then holds -1 indices).  Does not synchronise: call after the stream has (end of a step / test)."""

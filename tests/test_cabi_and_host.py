@@ -36,10 +36,10 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_pure_host_queries():
     from pointrcnn_amd import _cabi
     lib = _cabi.lib()
-    assert lib.prcnn_abi_version() >= 6
+    assert lib.prcnn_abi_version() >= 9
     assert lib.prcnn_wpack_floats(64, 99) == 2 * 13 * 256
     assert lib.prcnn_wpack_floats(0, 5) == 0
-    assert lib.prcnn_nms_workspace_bytes(6300) == 6300 * 99 * 8
+    assert lib.prcnn_nms_workspace_bytes(6300) == 6300 * 99 * 8 + 99 * 99      # mask + one flag byte per 64 x 64 tile
     assert lib.prcnn_nms_workspace_bytes(0) == 0
 
 

@@ -224,6 +224,44 @@ def test_fps_pruned_and_plain_variants_are_bit_identical(dev, cpu, monkeypatch, 
         ops.FPS_PRUNED = old
 
 
+@pytest.mark.parametrize("busy", [False, True])
+def test_fps_slot_masks_on_ties_in_every_slot_alone_and_under_co_resident_waves(dev, cpu, busy):
+    """round-5 advisor finding: the hand-scheduled slot-mask blocks (csrc/fps.hip WaveMaxEq / wave_max_eq2_16) read a compare's
+    SGPR pair from a v_addc the hazard recognizer cannot see.  Directed at them: clouds on which the maximum is held by SEVERAL slots of
+    one lane in every sample -- each point 16 / 8 / 2 times (equal Morton keys: the copies are consecutive in the sorted order, so they
+    sit in the slots of one lane, 0/1/8/9 included) and a 32 x 16 x 32 lattice -- on the 16-slot kernel (16384 -> 4096), the 4-slot kernel
+    (4096 -> 1024) and the single-wave kernels, once on an idle chip and once while matrix products from another stream share the CUs
+    (the VALU co-issue conditions differ).  Indices must equal the oracle's (ties -> lowest original index)."""
+    from pointrcnn_amd import ops
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=dev)
+    stop = [False]
+
+    def spin():
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                torch.mm(a, a)
+
+    rng = np.random.default_rng(5)
+    cases = []
+    for N, npoint, copies in ((16384, 4096, 16), (16384, 1024, 8), (16384, 2048, 2), (4096, 1024, 4), (4096, 700, 2), (1024, 256, 16), (256, 64, 4)):
+        base = rng.uniform([-40, -1, 0], [40, 3, 70.4], (2, N // copies, 3)).astype(np.float32)
+        xyz = np.repeat(base, copies, axis=1)
+        perm = rng.permutation(N)
+        cases.append((xyz[:, perm], npoint))
+    g = np.stack(np.meshgrid(np.arange(32), np.arange(16), np.arange(32), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+    cases.append((np.tile(g, (2, 1, 1)), 4096))
+    cases.append((np.tile(g[:, :4096] * 0.5, (2, 1, 1)), 1024))
+    for xyz, npoint in cases:
+        want = cpu.fps(xyz, npoint)
+        if busy:
+            spin()
+        got = ops.furthest_point_sample(T(xyz, dev), npoint).cpu().numpy()
+        assert np.array_equal(got, want), (xyz.shape, npoint, int((got != want).sum()))
+    torch.cuda.synchronize()
+    del stop
+
+
 def test_backward_kernels_at_training_shapes(dev, cpu):
     """group_grad: the padding-aware kernel (nsample 16 / 32 / 64, one lane per group) on real ball-query index tensors (first
     hit repeated), on arbitrary indices and on ragged M / C; three_interpolate_grad: the channels-last accumulator path

@@ -194,3 +194,41 @@ def test_iou_identities(cpu):
     ov = cpu.boxes_overlap_bev(sq, sq, 1)
     np.testing.assert_allclose(ov[0, 1], 1.0, atol=1e-6)                       # unit square overlap
     np.testing.assert_allclose(ov[0, 2], 8 * (np.sqrt(2) - 1), atol=1e-5)      # regular octagon of two 2x2 squares
+
+
+def test_arith_modes_of_the_index_operators(cpu):
+    """round 6 comparison mode (prcnn_oracle.c sqdist3_mode): arith 0 == the canonical functions; arith 1 == an independent numpy
+    restatement of nvcc's contraction fma(dz,dz, fma(dy,dy, dx*dx)) in exact rational arithmetic (each fused step rounds the EXACT
+    a*b + c once, to the nearest float32, ties to even); the two arithmetics give different last bits on some distances"""
+    from fractions import Fraction
+    r = np.random.default_rng(12)
+    xyz = r.uniform([-40, -1, 0], [40, 3, 70.4], (2, 1500, 3)).astype(np.float32)
+    ctr = xyz[:, ::5].copy()
+    assert np.array_equal(cpu.fps_mode(xyz, 300, 0, 0), cpu.fps(xyz, 300))
+    assert np.array_equal(cpu.fps_mode(xyz, 300, 1, 0), cpu.fps_upstream(xyz, 300))
+    assert np.array_equal(cpu.ball_query_arith(1.0, 16, xyz, ctr, 0), cpu.ball_query(1.0, 16, xyz, ctr))
+    d0, i0 = cpu.three_nn_arith(xyz, ctr, 0)
+    rd, ri = cpu.three_nn(xyz, ctr)
+    assert np.array_equal(d0, rd) and np.array_equal(i0, ri)
+    d1, i1 = cpu.three_nn_arith(xyz, ctr, 1)
+
+    def f32(x):
+        """the float32 nearest to the exact rational x (ties to even): candidates around the double-rounded guess, compared exactly"""
+        g = np.float32(float(x))
+        cands = [np.nextafter(g, np.float32(-np.inf)), g, np.nextafter(g, np.float32(np.inf))]
+        best = min(cands, key=lambda c: (abs(Fraction(float(c)) - x), int(np.float32(c).view(np.uint32)) & 1))
+        return np.float32(best)
+
+    def contracted(u, k):            # fma rounds the EXACT a*b + c once
+        dx, dy, dz = (np.float32(u[c] - k[c]) for c in range(3))
+        xx = f32(Fraction(float(dx)) * Fraction(float(dx)))
+        t = f32(Fraction(float(dy)) * Fraction(float(dy)) + Fraction(float(xx)))
+        return f32(Fraction(float(dz)) * Fraction(float(dz)) + Fraction(float(t)))
+
+    for b in range(2):
+        for i in range(0, 1500, 37):
+            for s in range(3):
+                assert contracted(xyz[b, i], ctr[b, i1[b, i, s]]) == d1[b, i, s], (b, i, s)
+    same = (i0 == i1).all(2)
+    assert (d0[same] != d1[same]).any(), "no distance differs between the arithmetics"
+    assert (np.abs(d0[same].astype(np.float64) - d1[same]) <= 2 * np.spacing(np.maximum(d0[same], d1[same]))).all()
