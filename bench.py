@@ -398,7 +398,8 @@ def arithmetic_label(terms):
     if terms == 0:
         return "f32 (fp32 MFMA: v_mfma_f32_32x32x2_f32; PRCNN_MLP_SPLIT=0)"
     return ("f32 via split-bf16x%d MFMA (every fp32 operand cut exactly into 3 bf16 pieces, %d bf16 MFMA products per fp32 product, fp32 "
-            "accumulate: %s; grouped SA stacks on fp32 MFMA; PRCNN_MLP_SPLIT=0 selects fp32 MFMA throughout)" %
+            "accumulate: %s; hoisted grouped layers on the split kernel too, unhoisted grouped first layers (xyz-only input) and training on "
+            "fp32 MFMA; PRCNN_MLP_SPLIT=0 selects fp32 MFMA throughout)" %
             (terms, terms, "fp32-grade, measured error 2.9e-7 of sum|x||w| vs 3.0e-7 for the fp32-MFMA kernel" if terms == 6 else
              "error 1e-5 of sum|x||w|: outside the 1e-5 output contract, dev only"))
 
@@ -1118,9 +1119,20 @@ def main():
         free_b, total_b = torch.cuda.mem_get_info(dev)
         hbm = {"reserved_GB": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 1), "free_GB": round(free_b / 2 ** 30, 1),
                "total_GB": round(total_b / 2 ** 30, 1), "slots": nstreams}
-        if free_b < 0.01 * total_b and not os.environ.get("PRCNN_BENCH_ALLOW_OVERSUBSCRIPTION"):
+        # every rank decides on the SAME flag (max over ranks): one rank leaving while the others enter the timed loop's barrier would hang
+        # them until the collective times out
+        too_full = free_b < 0.01 * total_b and not os.environ.get("PRCNN_BENCH_ALLOW_OVERSUBSCRIPTION")
+        if dist is not None:
+            flag = torch.tensor([int(too_full)], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            too_full_any = bool(flag.item())
+        else:
+            too_full_any = too_full
+        if too_full_any and not too_full:
+            raise SystemExit(1 if rank else "bench.py: another rank's in-flight batches do not fit its HBM; lower --streams")
+        if too_full:
             # (the runtime pages oversubscribed memory instead of failing the allocation: a 14-slot two-stage run takes 680 ms per step)
-            raise SystemExit("bench.py: %d slots hold %.1f of %.1f GB of HBM (%.1f GB free): the in-flight batches do not fit and the step "
+            raise SystemExit(1 if rank else "bench.py: %d slots hold %.1f of %.1f GB of HBM (%.1f GB free): the in-flight batches do not fit and the step "
                              "rate would collapse; lower --streams (PRCNN_BENCH_ALLOW_OVERSUBSCRIPTION=1 runs anyway)"
                              % (nstreams, hbm["reserved_GB"], total_b / 2 ** 30, free_b / 2 ** 30))
         if free_b < 0.05 * total_b and rank == 0:

@@ -961,7 +961,7 @@ __device__ __forceinline__ void split_redo_f32(const MlpParams& P, f32x16 (&acc)
 // One 128-row tile of the split layer: the body of mlp_layer_s_kernel.  (bx, by) = the workgroup's grid position, or, in the
 // bounded-grid form, the position the tile loop stands in for; tid = the thread's index, passed in so that the tile loop can hand in
 // an opaque copy per tile (see mlp_layer_s_kernel).
-// MODE_GROUP (round 5, from docs/patches' round-4 form): the HOISTED grouped first layer -- the A row is relu(Z[idx] + act_wx . dxyz + act_bias)
+// MODE_GROUP (round 5): the HOISTED grouped first layer -- the A row is relu(Z[idx] + act_wx . dxyz + act_bias)
 // with Z = W_f . feat per source point (K = C, a multiple of 32, 16-byte rows): the gathered chunk is activated on its way into the
 // split, everything else is the plain kernel (the RCNN stage's three grouped layers ran on the fp32 pipe until then).
 template <int MODE, int WNB, int TERMS, bool ADDY>
@@ -1714,18 +1714,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == MO
 // =====================================================================================================
 template <int NBO> struct SStage { static constexpr int U4 = 2 * NBO * 3 * 64; static constexpr int PT = (U4 + 255) / 256; };
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // staging registers as a first-class vector (not HIP's uint4 struct)
 template <int NBO>
-__device__ __forceinline__ void sstage_load(const uint4* __restrict__ img, int st, int tid, uint4 (&r)[SStage<NBO>::PT]) {
+__device__ __forceinline__ void sstage_load(const uint4* __restrict__ img, int st, int tid, u32x4 (&r)[SStage<NBO>::PT]) {
 #pragma unroll
     for (int u = 0; u < SStage<NBO>::PT; u++) {
         const int e = min(tid + 256 * u, SStage<NBO>::U4 - 1);        // clamped, not guarded: straight-line loads (a ragged last
-        r[u] = img[(long)st * SStage<NBO>::U4 + e];                   // round re-reads / re-writes the stage's last element)
+        r[u] = reinterpret_cast<const u32x4*>(img)[(long)st * SStage<NBO>::U4 + e];   // round re-reads / re-writes the stage's last element)
     }
 }
 template <int NBO>
-__device__ __forceinline__ void sstage_store(uint4* ws, int tid, const uint4 (&r)[SStage<NBO>::PT]) {
+__device__ __forceinline__ void sstage_store(uint4* ws, int tid, const u32x4 (&r)[SStage<NBO>::PT]) {
 #pragma unroll
-    for (int u = 0; u < SStage<NBO>::PT; u++) ws[min(tid + 256 * u, SStage<NBO>::U4 - 1)] = r[u];
+    for (int u = 0; u < SStage<NBO>::PT; u++) reinterpret_cast<u32x4*>(ws)[min(tid + 256 * u, SStage<NBO>::U4 - 1)] = r[u];
 }
 // eight fp32 values (one lane half's k-step) -> the three bf16 operand pieces
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&piece)[3]) {
@@ -1751,6 +1752,25 @@ __device__ __forceinline__ void schain_step(f32x16 (&out)[NBO], const uint4* ws,
     if constexpr (TERMS == 6) { SCH_TERM(2, 0); SCH_TERM(0, 2); SCH_TERM(1, 1); }
     SCH_TERM(1, 0); SCH_TERM(0, 1); SCH_TERM(0, 0);
 #undef SCH_TERM
+}
+
+// the same k-step two output blocks at a time: 24 operand registers alive instead of 48 (each accumulator sees its terms in the same
+// order: same bits); for the persistent kernel's interpolation variant, which is at the register limit of two waves per SIMD
+template <int NBO, int TERMS>
+__device__ __forceinline__ void schain_step_pairs(f32x16 (&out)[NBO], const uint4* ws, int ksl, int lane, const bf16x8 (&bp)[3]) {
+    static_assert(NBO % 2 == 0 && TERMS == 6, "pairs of output blocks, six terms");
+#pragma unroll
+    for (int o2 = 0; o2 < NBO; o2 += 2) {
+        bf16x8 w[2][3];
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) w[ob][p] = __builtin_bit_cast(bf16x8, ws[((ksl * NBO + o2 + ob) * 3 + p) * 64 + lane]);
+#define SCH_TERM2(PA, PB)                                                                                                         \
+        _Pragma("unroll") for (int ob = 0; ob < 2; ob++) out[o2 + ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ob][PA], bp[PB], out[o2 + ob], 0, 0, 0)
+        SCH_TERM2(2, 0); SCH_TERM2(0, 2); SCH_TERM2(1, 1); SCH_TERM2(1, 0); SCH_TERM2(0, 1); SCH_TERM2(0, 0);
+#undef SCH_TERM2
+    }
 }
 
 // The wave's 32 rows through the whole chain again on the fp32 pipe (rare path: a non-finite value among the rows' inputs, see
@@ -1837,7 +1857,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_s_kernel(const ChainParams C
     Raw<MODE> xa[KS], xb[KS];
 #pragma unroll
     for (int ks = 0; ks < RD; ks++) { fast_fetch<MODE>(P, meta, 16 * ks + 4 * h, xa[ks]); fast_fetch<MODE>(P, meta, 16 * ks + 8 + 4 * h, xb[ks]); }
-    uint4 wr[SStage<NB0>::PT];
+    u32x4 wr[SStage<NB0>::PT];
     sstage_load<NB0>(img0, 0, tid, wr);
     sstage_store<NB0>(Ws[0], tid, wr);
     __syncthreads();
@@ -1879,7 +1899,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_s_kernel(const ChainParams C
         else schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, s_bias, false);
     }
     if constexpr (NB1 > 1) {
-        uint4 w1[SStage<NB1>::PT];
+        u32x4 w1[SStage<NB1>::PT];
         uint4* W1s = &Ws[0][0];                              // (a stage of NB1 <= 4 blocks fits a stage of four)
         sstage_load<NB1>(img1, 0, tid, w1);
         sstage_store<NB1>(W1s, tid, w1);
@@ -1909,6 +1929,467 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_s_kernel(const ChainParams C
         if (!bad1) chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
         else schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, s_bias, false);
     }
+}
+
+// =====================================================================================================
+// mlp_chain_s_kernel with COOPERATIVE row access (round 6).  Same arithmetic, same products in the same order, same results bit for
+// bit; what changes is who touches memory.  In the transposed formulation a lane IS a row: it used to fetch its own row 16 bytes
+// at a time, so one wave-wide load touched 32-64 different cache lines for 32 bytes each, and the vector L1 processes a wave's load
+// line by line -- the hoisted FP0 launch kept the L1 busy 76 % of its time (TCP_TOTAL_CACHE_ACCESSES / SQ_BUSY_CU_CYCLES, 74 M
+// accesses for 1.2 GB of useful traffic) while the matrix pipe was busy 24 %; the heads the same way at 53 %.  Here eight lanes
+// fetch 128 contiguous bytes of one row (one full line), a wave-wide load covers 8 rows x one line, 4 x fewer L1 accesses; the
+// interpolation / bias / ReLU of the hoisted FP first layer happens in THAT layout (the three neighbours' values of a k-quad are in
+// one lane), the finished 32-row x 32-k chunk goes through a 4.5 KB per-wave LDS tile and comes back in the lane-is-a-row layout the
+// MFMA B operand wants (conflict-free both ways: row stride 36 dwords).  The output takes the same route backwards: D registers ->
+// LDS tile -> 8 rows x 128 contiguous bytes per store.  A chunk is exactly one weight stage (two k-steps), so the stage loop and its
+// barriers are unchanged.  PRCNN_CHAIN_COOP=0 selects the round-5 kernel (A/B switch).
+// =====================================================================================================
+#define CC_LD 36
+// -DMLP_TIMING (tools/build_variant.py mlp.hip mlptiming -DMLP_TIMING; tools/mlp_timing.py): cycle counters of wave 0 of every workgroup of
+// mlp_chain_c_kernel by phase, summed into a device array read back through prcnn_debug_mlp_timing; never defined in the product build
+#ifdef MLP_TIMING
+__device__ unsigned long long g_mlp_t[16];
+#define MLP_T(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; }
+#else
+#define MLP_T(k)
+#endif
+
+template <int MODE> struct CoopRows;
+template <> struct CoopRows<MODE_PLAIN> { const float* p[4]; };
+template <> struct CoopRows<MODE_INTERP> { const float* p0[4]; const float* p1[4]; const float* p2[4]; float w0[4], w1[4], w2[4]; };
+template <int MODE> struct CoopRaw;
+template <> struct CoopRaw<MODE_PLAIN> { float4 a[4]; };
+template <> struct CoopRaw<MODE_INTERP> { float4 a[4], b[4], c[4]; };
+
+// rows rw0 + 8u + g (u = 0..3) of the wave's 32, k-quad q of every 32-float chunk: rows past the end are clamped (read, never stored)
+__device__ __forceinline__ void coop_rows(const MlpParams& P, long rw0, int g, int q, CoopRows<MODE_PLAIN>& cr) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long r = min(rw0 + 8 * u + g, P.rows - 1);
+        cr.p[u] = P.in + r * (long)P.ld_in + 4 * q;
+    }
+}
+__device__ __forceinline__ void coop_rows(const MlpParams& P, long rw0, int g, int q, CoopRows<MODE_INTERP>& cr) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long r = min(rw0 + 8 * u + g, P.rows - 1);
+        const long base = (r / P.n) * (long)P.m;
+        const int32_t* id = P.idx3 + r * 3;
+        const float* w = P.w3 + r * 3;
+        cr.p0[u] = P.known + (base + id[0]) * (long)P.ld_known + 4 * q;
+        cr.p1[u] = P.known + (base + id[1]) * (long)P.ld_known + 4 * q;
+        cr.p2[u] = P.known + (base + id[2]) * (long)P.ld_known + 4 * q;
+        cr.w0[u] = w[0]; cr.w1[u] = w[1]; cr.w2[u] = w[2];
+    }
+}
+__device__ __forceinline__ void coop_fetch(const CoopRows<MODE_PLAIN>& cr, int c, CoopRaw<MODE_PLAIN>& v) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) v.a[u] = ld4(cr.p[u] + 32 * c);
+}
+__device__ __forceinline__ void coop_fetch(const CoopRows<MODE_INTERP>& cr, int c, CoopRaw<MODE_INTERP>& v) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) { v.a[u] = ld4(cr.p0[u] + 32 * c); v.b[u] = ld4(cr.p1[u] + 32 * c); v.c[u] = ld4(cr.p2[u] + 32 * c); }
+}
+// the finished A values of row 8u + g, k = 32 c + 4 q .. + 4 (the expressions of fast_finish, element for element)
+__device__ __forceinline__ float4 coop_finish(const CoopRows<MODE_PLAIN>&, const CoopRaw<MODE_PLAIN>& v, int u, float4) { return v.a[u]; }
+__device__ __forceinline__ float4 coop_finish(const CoopRows<MODE_INTERP>& cr, const CoopRaw<MODE_INTERP>& v, int u, float4 b) {
+    float4 o;
+    o.x = fmaxf(interp1(cr.w0[u], v.a[u].x, cr.w1[u], v.b[u].x, cr.w2[u], v.c[u].x) + b.x, 0.f);
+    o.y = fmaxf(interp1(cr.w0[u], v.a[u].y, cr.w1[u], v.b[u].y, cr.w2[u], v.c[u].y) + b.y, 0.f);
+    o.z = fmaxf(interp1(cr.w0[u], v.a[u].z, cr.w1[u], v.b[u].z, cr.w2[u], v.c[u].z) + b.z, 0.f);
+    o.w = fmaxf(interp1(cr.w0[u], v.a[u].w, cr.w1[u], v.b[u].w, cr.w2[u], v.c[u].w) + b.w, 0.f);
+    return o;
+}
+
+// D registers -> the wave's LDS tile -> 8 rows x 128 contiguous bytes per store instruction (32 channels at a time)
+template <int NB>
+__device__ __forceinline__ void coop_store(const ChainParams& C, f32x16 (&acc)[NB], int Nlast, long rw0, int lane, float* Tw) {
+    const MlpParams& P = C.a;
+    const int h = lane >> 5, j = lane & 31, g = lane >> 3, q = lane & 7;
+#pragma unroll
+    for (int ob = 0; ob < NB; ob++) {
+        if (ob * 32 >= Nlast) continue;                  // (no break: the loop must unroll, acc[ob] is a register index)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++)
+            *reinterpret_cast<float4*>(Tw + j * CC_LD + 8 * qq + 4 * h) =
+                make_float4(acc[ob][4 * qq], acc[ob][4 * qq + 1], acc[ob][4 * qq + 2], acc[ob][4 * qq + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float4 v = *reinterpret_cast<const float4*>(Tw + (8 * u + g) * CC_LD + 4 * q);
+            const long r = rw0 + 8 * u + g;
+            const int c = ob * 32 + 4 * q;
+            if (r < P.rows && c < Nlast) *reinterpret_cast<float4*>(P.out + r * (long)P.ld_out + P.col_off + c) = v;
+        }
+    }
+}
+
+template <int MODE, int NB1, int TERMS>
+__global__ __launch_bounds__(256, 2) void mlp_chain_c_kernel(const ChainParams Cin) {
+    constexpr int NB0 = 4, NST = 4;                          // K = 128 -> 128 (-> N1); four stages of two k-steps = four 32-float chunks
+    ChainParams C = Cin;
+    C.a.rows = effective_rows(Cin.a);
+    const MlpParams& P = C.a;
+    const long tile_id = tile_of_block(P, blockIdx.x);
+    if (tile_id * 128 >= P.rows) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31, g = lane >> 3, q = lane & 7;
+    const long rw0 = (tile_id * 4 + wave) * 32;              // the wave's first row
+    const long row = rw0 + j;
+    const bool valid = row < P.rows;
+
+    __shared__ __attribute__((aligned(16))) uint4 Ws[2][SStage<NB0>::U4];
+    __shared__ __attribute__((aligned(16))) float Tbuf[4][32 * CC_LD];
+    __shared__ __attribute__((aligned(16))) float s_bias[2][128];
+    __shared__ __attribute__((aligned(16))) float s_b[128];
+    float* Tw = Tbuf[wave];
+    if (tid < 128) {
+        s_bias[0][tid] = P.bias ? P.bias[tid] : 0.f;
+        s_bias[1][tid] = (NB1 > 0 && C.bias1 && tid < NB1 * 32) ? C.bias1[tid] : 0.f;
+        s_b[tid] = MODE != MODE_PLAIN ? P.act_bias[tid] : 0.f;
+    }
+    const uint4* img0 = reinterpret_cast<const uint4*>(P.wsplit);
+    const uint4* img1 = reinterpret_cast<const uint4*>(C.wsplit1);
+    const bool out1 = chain_out1_applies<NB1, 0>(C);
+
+#ifdef MLP_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+    CoopRows<MODE> cr;
+    coop_rows(P, rw0, g, q, cr);
+    CoopRaw<MODE> x[NST];
+    constexpr int RD = MODE == MODE_PLAIN ? 2 : 1;           // chunks requested ahead (a chunk of interpolation sources is 48 registers)
+#pragma unroll
+    for (int c = 0; c < RD; c++) coop_fetch(cr, c, x[c]);
+    u32x4 wr[SStage<NB0>::PT];
+    sstage_load<NB0>(img0, 0, tid, wr);
+    sstage_store<NB0>(Ws[0], tid, wr);
+    __syncthreads();
+    MLP_T(0)
+
+    f32x16 a0[NB0];
+#pragma unroll
+    for (int ob = 0; ob < NB0; ob++) a0[ob] = (f32x16){0};
+#pragma unroll
+    for (int st = 0; st < NST; st++) {
+        if (st + 1 < NST) sstage_load<NB0>(img0, st + 1, tid, wr);
+        if (st + RD < NST) coop_fetch(cr, st + RD, x[st + RD]);
+        const float4 b4 = MODE != MODE_PLAIN ? ld4(s_b + 32 * st + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; u++) *reinterpret_cast<float4*>(Tw + (8 * u + g) * CC_LD + 4 * q) = coop_finish(cr, x[st], u, b4);
+        MLP_T(1)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ksl = 0; ksl < 2; ksl++) {
+            const float4 va = *reinterpret_cast<const float4*>(Tw + j * CC_LD + 16 * ksl + 4 * h);
+            const float4 vb = *reinterpret_cast<const float4*>(Tw + j * CC_LD + 16 * ksl + 8 + 4 * h);
+            const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+            bf16x8 bp[3];
+            split8(v, bp);
+            schain_step<NB0, TERMS>(a0, Ws[st & 1], ksl, lane, bp);
+        }
+        MLP_T(2)
+        __builtin_amdgcn_wave_barrier();
+        if (st + 1 < NST) sstage_store<NB0>(Ws[(st + 1) & 1], tid, wr);
+        MLP_T(3)
+        __syncthreads();
+        MLP_T(4)
+    }
+    const bool coop_out = P.pool_ns == 0 && ((P.ld_out | P.col_off) % 4 == 0) && aligned16(P.out);
+    const bool bad = P.wpack != nullptr && wave_has_nonfinite<NB0>(a0);
+    bias_act<NB0>(a0, s_bias[0], P.relu, h);
+    if (out1) {
+        chain_out1<NB0>(C, a0, row, valid, lane, h);
+        if (bad) schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, s_bias, true);
+        return;
+    }
+    if constexpr (NB1 == 0) {
+        if (bad) schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, s_bias, false);
+        else if (coop_out && P.Nout % 4 == 0) coop_store<NB0>(C, a0, P.Nout, rw0, lane, Tw);
+        else chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
+    }
+    if constexpr (NB1 > 1) {
+        u32x4 w1[SStage<NB1>::PT];
+        uint4* W1s = &Ws[0][0];                              // (a stage of NB1 <= 4 blocks fits a stage of four)
+        sstage_load<NB1>(img1, 0, tid, w1);
+        sstage_store<NB1>(W1s, tid, w1);
+        __syncthreads();
+        MLP_T(5)
+        f32x16 a1[NB1];
+#pragma unroll
+        for (int ob = 0; ob < NB1; ob++) a1[ob] = (f32x16){0};
+#pragma unroll
+        for (int st = 0; st < NB0 * 2 / 2; st++) {
+            if (st + 1 < NB0) sstage_load<NB1>(img1, st + 1, tid, w1);
+#pragma unroll
+            for (int sh = 0; sh < 2; sh++) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = a0[st][8 * sh + e];
+                bf16x8 bp[3];
+                split8(v, bp);
+                schain_step<NB1, TERMS>(a1, &Ws[st & 1][0], sh, lane, bp);
+            }
+            MLP_T(6)
+            if (st + 1 < NB0) sstage_store<NB1>(&Ws[(st + 1) & 1][0], tid, w1);
+            __syncthreads();
+            MLP_T(4)
+        }
+        const bool bad1 = bad || (P.wpack != nullptr && wave_has_nonfinite<NB1>(a1));
+        bias_act<NB1>(a1, s_bias[1], C.relu1, h);
+        if (bad1) schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, s_bias, false);
+        else if (coop_out && C.N1 % 4 == 0) coop_store<NB1>(C, a1, C.N1, rw0, lane, Tw);
+        else chain_store<NB1>(C, a1, C.N1, row, valid, lane, h);
+    }
+#ifdef MLP_TIMING
+    MLP_T(7)
+    if (tid == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_mlp_t[k], tacc[k]);
+    if (tid == 0) atomicAdd(&g_mlp_t[8], 1ULL);
+#endif
+}
+#ifdef MLP_TIMING
+PRCNN_API int prcnn_debug_mlp_timing(unsigned long long* out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mlp_t), sizeof(unsigned long long) * 16) != hipSuccess) return PRCNN_EHIP;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_t), z, sizeof(z)) != hipSuccess) return PRCNN_EHIP; }
+    return PRCNN_OK;
+}
+#endif
+// =====================================================================================================
+// PERSISTENT form of the cooperative-row split chain (round 6): ONE layer 128 -> 128 (+ the single-channel dot product of the
+// classification head) with the WHOLE split weight image resident in LDS (96 KB) for the lifetime of an 8-wave workgroup, one per CU.
+// Cycle counters of mlp_chain_c_kernel (tools/mlp_timing.py, FP0): of 55.8 k cycles a workgroup spends on its 128 rows, the matrix pipe
+// is busy 6.1 k per wave; 13 k go to the prologue -- neighbour indices from HBM, then the rows they point to, then the first weight
+// stage, three dependent round trips before the first product -- and every stage ends in a barrier.  Here each WAVE walks its own
+// sequence of 32-row tiles with no barrier at all (weights never move), and the next tile's neighbour indices, addresses and first
+// chunk are requested while the current tile multiplies, so the round trips of tile t+1 run under the products of tile t.
+// Same chunks, same transposition tile, same products in the same order as mlp_chain_c_kernel / mlp_chain_s_kernel: same bits.
+// Tile order: with xcd_tpf > 0 (gather mode, frames a multiple of 8) XCD x takes frames x, x+8, ... one after the other and spreads
+// each frame's tiles over its workgroups' waves, so a frame's gather source stays in that XCD's L2 (as tile_of_block does for the
+// per-tile kernels).  Row offsets are 32-bit (host-checked: the source array is smaller than 4 GB).
+// =====================================================================================================
+#define CP_WAVES 8
+template <int MODE> struct CoopRows32;                   // per-lane: rows 8u + g of the wave's tile, as float offsets from the source base
+template <> struct CoopRows32<MODE_PLAIN> { unsigned o[4]; };
+template <> struct CoopRows32<MODE_INTERP> { unsigned o0[4], o1[4], o2[4]; float w0[4], w1[4], w2[4]; };
+template <int MODE> struct CoopMeta;                     // the raw words a tile's addresses are computed from (requested a tile ahead)
+template <> struct CoopMeta<MODE_PLAIN> { int unused; };
+template <> struct CoopMeta<MODE_INTERP> { int i0[4], i1[4], i2[4]; float w0[4], w1[4], w2[4]; };
+
+__device__ __forceinline__ void coop_meta_fetch(const MlpParams&, long, int, CoopMeta<MODE_PLAIN>&) {}
+__device__ __forceinline__ void coop_meta_fetch(const MlpParams& P, long rw0, int g, CoopMeta<MODE_INTERP>& mt) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long r = min(rw0 + 8 * u + g, P.rows - 1);
+        const int32_t* id = P.idx3 + r * 3;
+        const float* w = P.w3 + r * 3;
+        mt.i0[u] = id[0]; mt.i1[u] = id[1]; mt.i2[u] = id[2];
+        mt.w0[u] = w[0]; mt.w1[u] = w[1]; mt.w2[u] = w[2];
+    }
+}
+__device__ __forceinline__ void coop_rows32(const MlpParams& P, long rw0, int g, int q, const CoopMeta<MODE_PLAIN>&, CoopRows32<MODE_PLAIN>& cr) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) cr.o[u] = (unsigned)(min(rw0 + 8 * u + g, P.rows - 1) * (long)P.ld_in) + 4u * q;
+}
+__device__ __forceinline__ void coop_rows32(const MlpParams& P, long rw0, int g, int q, const CoopMeta<MODE_INTERP>& mt, CoopRows32<MODE_INTERP>& cr) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long r = min(rw0 + 8 * u + g, P.rows - 1);
+        const long base = (r / P.n) * (long)P.m;
+        cr.o0[u] = (unsigned)((base + mt.i0[u]) * (long)P.ld_known) + 4u * q;
+        cr.o1[u] = (unsigned)((base + mt.i1[u]) * (long)P.ld_known) + 4u * q;
+        cr.o2[u] = (unsigned)((base + mt.i2[u]) * (long)P.ld_known) + 4u * q;
+        cr.w0[u] = mt.w0[u]; cr.w1[u] = mt.w1[u]; cr.w2[u] = mt.w2[u];
+    }
+}
+__device__ __forceinline__ void coop_fetch32(const MlpParams& P, const CoopRows32<MODE_PLAIN>& cr, int c, CoopRaw<MODE_PLAIN>& v) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) v.a[u] = ld4(P.in + cr.o[u] + 32 * c);
+}
+__device__ __forceinline__ void coop_fetch32(const MlpParams& P, const CoopRows32<MODE_INTERP>& cr, int c, CoopRaw<MODE_INTERP>& v) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        v.a[u] = ld4(P.known + cr.o0[u] + 32 * c); v.b[u] = ld4(P.known + cr.o1[u] + 32 * c); v.c[u] = ld4(P.known + cr.o2[u] + 32 * c);
+    }
+}
+__device__ __forceinline__ float4 coop_finish32(const CoopRows32<MODE_PLAIN>&, const CoopRaw<MODE_PLAIN>& v, int u, float4) { return v.a[u]; }
+__device__ __forceinline__ float4 coop_finish32(const CoopRows32<MODE_INTERP>& cr, const CoopRaw<MODE_INTERP>& v, int u, float4 b) {
+    float4 o;
+    o.x = fmaxf(interp1(cr.w0[u], v.a[u].x, cr.w1[u], v.b[u].x, cr.w2[u], v.c[u].x) + b.x, 0.f);
+    o.y = fmaxf(interp1(cr.w0[u], v.a[u].y, cr.w1[u], v.b[u].y, cr.w2[u], v.c[u].y) + b.y, 0.f);
+    o.z = fmaxf(interp1(cr.w0[u], v.a[u].z, cr.w1[u], v.b[u].z, cr.w2[u], v.c[u].z) + b.z, 0.f);
+    o.w = fmaxf(interp1(cr.w0[u], v.a[u].w, cr.w1[u], v.b[u].w, cr.w2[u], v.c[u].w) + b.w, 0.f);
+    return o;
+}
+
+// the wave's tile sequence (32-row tiles)
+struct CoopTiles {
+    long t;                 // current tile, -1: none left
+    long step, end;         // plain order: t += step while t < end
+    long f, i, tpf, wx, WX, nframes;   // XCD order: frame f (step 8), tile i of the frame (step WX)
+    bool xcd;
+};
+__device__ __forceinline__ void coop_tiles_init(CoopTiles& it, const MlpParams& P, int wave) {
+    const long ntiles = (P.rows + 31) / 32;
+    it.xcd = P.xcd_tpf > 0 && (gridDim.x & 7) == 0;
+    if (it.xcd) {
+        it.tpf = 4L * P.xcd_tpf; it.nframes = ntiles / it.tpf;
+        it.WX = (long)(gridDim.x >> 3) * CP_WAVES; it.wx = (long)(blockIdx.x >> 3) * CP_WAVES + wave;
+        it.f = blockIdx.x & 7; it.i = it.wx;
+        it.t = (it.i < it.tpf && it.f < it.nframes) ? it.f * it.tpf + it.i : -1;
+    } else {
+        it.step = (long)gridDim.x * CP_WAVES; it.end = ntiles;
+        it.t = (long)blockIdx.x * CP_WAVES + wave;
+        if (it.t >= it.end) it.t = -1;
+    }
+}
+__device__ __forceinline__ long coop_tiles_next(CoopTiles& it) {        // -> the tile after the current one (-1: none); advances
+    if (it.t < 0) return -1;
+    if (it.xcd) {
+        it.i += it.WX;
+        if (it.i >= it.tpf) { it.i = it.wx; it.f += 8; }
+        it.t = (it.f < it.nframes) ? it.f * it.tpf + it.i : -1;
+    } else {
+        it.t += it.step;
+        if (it.t >= it.end) it.t = -1;
+    }
+    return it.t;
+}
+
+template <int MODE, int NB1, int TERMS>
+__global__ __launch_bounds__(CP_WAVES * 64, 1) void mlp_chain_p_kernel(const ChainParams Cin) {
+    static_assert(NB1 == 0 || NB1 == 1, "one layer, or one layer + the single-channel output");
+    constexpr int NB0 = 4, NST = 4;
+    constexpr int RD = MODE == MODE_PLAIN ? 2 : 1;           // chunks requested ahead
+    ChainParams C = Cin;
+    C.a.rows = effective_rows(Cin.a);
+    const MlpParams& P = C.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31, g = lane >> 3, q = lane & 7;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_lds[];
+    uint4* Wl = reinterpret_cast<uint4*>(cp_lds);                                            // [NST][U4]: the whole layer-0 image
+    float* Tw = reinterpret_cast<float*>(cp_lds + (size_t)NST * SStage<NB0>::U4 * 16) + wave * 32 * CC_LD;
+    float* s_bias = reinterpret_cast<float*>(cp_lds + (size_t)NST * SStage<NB0>::U4 * 16) + CP_WAVES * 32 * CC_LD;   // [128]
+    float* s_b = s_bias + 128;                                                               // [128]
+    {
+        const u32x4* img = reinterpret_cast<const u32x4*>(P.wsplit);
+        for (int e = tid; e < NST * SStage<NB0>::U4; e += CP_WAVES * 64) reinterpret_cast<u32x4*>(Wl)[e] = img[e];
+        if (tid < 128) { s_bias[tid] = P.bias ? P.bias[tid] : 0.f; s_b[tid] = MODE != MODE_PLAIN ? P.act_bias[tid] : 0.f; }
+    }
+    __syncthreads();                                         // the only barrier of the kernel
+    const bool out1 = NB1 == 1;
+    const bool coop_out = P.pool_ns == 0 && ((P.ld_out | P.col_off) % 4 == 0) && aligned16(P.out) && P.Nout % 4 == 0;
+
+    CoopTiles it;
+    coop_tiles_init(it, P, wave);
+    if (it.t < 0) return;
+    long cur = it.t;
+    CoopMeta<MODE> mt;
+    CoopRows32<MODE> cr;
+    CoopRaw<MODE> x[NST];
+    coop_meta_fetch(P, cur * 32, g, mt);
+    coop_rows32(P, cur * 32, g, q, mt, cr);
+#pragma unroll
+    for (int c = 0; c < RD; c++) coop_fetch32(P, cr, c, x[c]);
+
+    while (cur >= 0) {
+        const long rw0 = cur * 32;
+        const long nxt = coop_tiles_next(it);
+        const long nrw0 = (nxt >= 0 ? nxt : cur) * 32;       // (no next tile: the requests repeat this tile's, results unused)
+        CoopRows32<MODE> crn;
+        f32x16 a0[NB0];
+#pragma unroll
+        for (int ob = 0; ob < NB0; ob++) a0[ob] = (f32x16){0};
+#pragma unroll
+        for (int st = 0; st < NST; st++) {
+            if (st == 0) coop_meta_fetch(P, nrw0, g, mt);                      // next tile's neighbour indices / weights: in flight for >= 2 chunks
+            // (the offset goes through an opaque asm so that the four bias quads are re-read from LDS every tile: hoisted out of the
+            //  tile loop they are 16 more live registers in a kernel at the limit of two waves per SIMD)
+            int qo = 4 * q;
+            asm volatile("" : "+v"(qo));
+            const float4 b4 = MODE != MODE_PLAIN ? ld4(s_b + 32 * st + qo) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // PLAIN (16 registers a chunk): the request runs two chunks ahead, issued before this chunk is consumed; INTERP (48 a chunk):
+            // one chunk ahead and issued AFTER this chunk's values are finished into the LDS tile, so that only one chunk of raw
+            // neighbour rows is alive at a time (with two the kernel spilled 46 registers at two waves per SIMD)
+            if (MODE == MODE_PLAIN) {
+                if (st + RD == NST) coop_rows32(P, nrw0, g, q, mt, crn);
+                if (st + RD < NST) coop_fetch32(P, cr, st + RD, x[st + RD]);
+                else coop_fetch32(P, crn, st + RD - NST, x[st + RD - NST]);    // the next tile's first chunks, under this tile's last products
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) *reinterpret_cast<float4*>(Tw + (8 * u + g) * CC_LD + 4 * q) = coop_finish32(cr, x[st], u, b4);
+            if (MODE != MODE_PLAIN) {
+                if (st + RD == NST) coop_rows32(P, nrw0, g, q, mt, crn);       // the next tile's addresses, just before its first chunk is requested
+                if (st + RD < NST) coop_fetch32(P, cr, st + RD, x[st + RD]);
+                else coop_fetch32(P, crn, st + RD - NST, x[st + RD - NST]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ksl = 0; ksl < 2; ksl++) {
+                const float4 va = *reinterpret_cast<const float4*>(Tw + j * CC_LD + 16 * ksl + 4 * h);
+                const float4 vb = *reinterpret_cast<const float4*>(Tw + j * CC_LD + 16 * ksl + 8 + 4 * h);
+                const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+                bf16x8 bp[3];
+                split8(v, bp);
+                // the stage's lane-adjusted base goes through an opaque asm: one address register + immediate offsets per stage; left to
+                // itself the compiler hoists one address register per weight tile beyond the 64 KB immediate range out of the tile loop
+                // (~20 registers: spills at two waves per SIMD)
+                unsigned wo = (unsigned)(st * SStage<NB0>::U4 + lane) * 16u;
+                asm volatile("" : "+v"(wo));
+                const uint4* wst = reinterpret_cast<const uint4*>(cp_lds + wo);
+                if (MODE == MODE_PLAIN) schain_step<NB0, TERMS>(a0, wst, ksl, 0, bp);
+                else schain_step_pairs<NB0, TERMS>(a0, wst, ksl, 0, bp);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const long row = rw0 + j;
+        const bool valid = row < P.rows;
+        const bool bad = P.wpack != nullptr && wave_has_nonfinite<NB0>(a0);
+        bias_act<NB0>(a0, s_bias, P.relu, h);
+        if (out1) {
+            chain_out1<NB0>(C, a0, row, valid, lane, h);
+            if (bad) schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, reinterpret_cast<const float (*)[128]>(s_bias), true);
+        } else {
+            if (bad) schain_redo_f32<MODE, NB1>(C, row, valid, lane, h, s_b, reinterpret_cast<const float (*)[128]>(s_bias), false);
+            else if (coop_out) coop_store<NB0>(C, a0, P.Nout, rw0, lane, Tw);
+            else chain_store<NB0>(C, a0, P.Nout, row, valid, lane, h);
+        }
+        cr = crn;
+        cur = nxt;
+    }
+}
+template <int MODE, int NB1> static constexpr size_t chain_p_lds_bytes() {
+    return (size_t)4 * SStage<4>::U4 * 16 + (size_t)CP_WAVES * 32 * CC_LD * 4 + 2 * 128 * 4;
+}
+static int chain_p_grid() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n & ~7;                                        // a multiple of 8: the XCD-aware tile order counts on it
+    }();
+    return cus > 0 ? cus : 8;
+}
+// PRCNN_CHAIN_PERSIST=0: the per-tile kernels (A/B switch, same bits)
+static bool chain_persist_on() {
+    static const bool on = !(getenv("PRCNN_CHAIN_PERSIST") && atoi(getenv("PRCNN_CHAIN_PERSIST")) == 0);
+    return on;
+}
+template <int MODE, int NB1>
+static int launch_chain_p(const ChainParams& C, hipStream_t s) {
+    constexpr size_t lds = chain_p_lds_bytes<MODE, NB1>();
+    static PrcnnLdsLimit attr;
+    if (!attr.raise((const void*)mlp_chain_p_kernel<MODE, NB1, 6>, (int)lds))
+        return prcnn_fail(PRCNN_EHIP, "prcnn_mlp_chain(persistent split): cannot raise the dynamic LDS limit");
+    const long tiles = (C.a.rows + 31) / 32;
+    const int grid = (int)min((long)chain_p_grid(), (tiles + CP_WAVES - 1) / CP_WAVES);
+    hipLaunchKernelGGL((mlp_chain_p_kernel<MODE, NB1, 6>), dim3(grid), dim3(CP_WAVES * 64), lds, s, C);
+    return PRCNN_OK;
+}
+static bool chain_coop_on() {
+    static const bool on = !(getenv("PRCNN_CHAIN_COOP") && atoi(getenv("PRCNN_CHAIN_COOP")) == 0);
+    return on;
 }
 
 // =====================================================================================================
@@ -2335,10 +2816,14 @@ PRCNN_API int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t row
     const hipStream_t s = (hipStream_t)stream;
 #define SCH_LAUNCH(NB1)                                                                                        \
     do {                                                                                                       \
-        if (terms == 6) hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_PLAIN, NB1, 6>), grid, dim3(256), 0, s, C); \
+        if (terms == 6 && chain_coop_on()) hipLaunchKernelGGL((mlp_chain_c_kernel<MODE_PLAIN, NB1, 6>), grid, dim3(256), 0, s, C); \
+        else if (terms == 6) hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_PLAIN, NB1, 6>), grid, dim3(256), 0, s, C); \
         else hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_PLAIN, NB1, 3>), grid, dim3(256), 0, s, C);            \
     } while (0)
-    if (nout[1] == 1) SCH_LAUNCH(1);
+    if (nout[1] == 1 && terms == 6 && chain_coop_on() && chain_persist_on() && (long)rows * ld_in < (1L << 30)) {
+        const int rc = launch_chain_p<MODE_PLAIN, 1>(C, s);                     // (row offsets in floats fit 32 bits)
+        if (rc) return rc;
+    } else if (nout[1] == 1) SCH_LAUNCH(1);
     else if (nout[1] <= 96) SCH_LAUNCH(3);
     else SCH_LAUNCH(4);
 #undef SCH_LAUNCH
@@ -3087,7 +3572,11 @@ PRCNN_API int prcnn_mlp_chain_interp_split(const float* known_cl, int ld_known, 
     C.nlayers = 1;
     if (B % 8 == 0 && n % 128 == 0 && getenv("PRCNN_NO_XCD_ORDER") == nullptr) P.xcd_tpf = n / 128;
     const dim3 grid(prcnn_divup(P.rows, 128));
-    if (terms == 6) hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_INTERP, 0, 6>), grid, dim3(256), 0, (hipStream_t)stream, C);
+    if (terms == 6 && chain_coop_on() && chain_persist_on() && (long)B * m * ld_known < (1L << 30)) {
+        const int rc = launch_chain_p<MODE_INTERP, 0>(C, (hipStream_t)stream);
+        if (rc) return rc;
+    } else if (terms == 6 && chain_coop_on()) hipLaunchKernelGGL((mlp_chain_c_kernel<MODE_INTERP, 0, 6>), grid, dim3(256), 0, (hipStream_t)stream, C);
+    else if (terms == 6) hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_INTERP, 0, 6>), grid, dim3(256), 0, (hipStream_t)stream, C);
     else hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_INTERP, 0, 3>), grid, dim3(256), 0, (hipStream_t)stream, C);
     PRCNN_LAUNCH_CHECK("prcnn_mlp_chain_interp_split");
     return PRCNN_OK;
