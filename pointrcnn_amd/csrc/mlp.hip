@@ -1990,15 +1990,20 @@ __device__ __forceinline__ void coop_fetch(const CoopRows<MODE_INTERP>& cr, int 
 #pragma unroll
     for (int u = 0; u < 4; u++) { v.a[u] = ld4(cr.p0[u] + 32 * c); v.b[u] = ld4(cr.p1[u] + 32 * c); v.c[u] = ld4(cr.p2[u] + 32 * c); }
 }
+// relu(interp1(w, a, b, c) + bias) on a quad, two components per instruction (v_pk_mul_f32 / v_pk_add_f32: the only fp32 VALU forms that
+// issue at full rate on gfx950; every component goes through the same individually rounded operations as interp1 -- no FMA: the
+// library is built with -ffp-contract=off -- so the values are those of fast_finish bit for bit)
+typedef float mlp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 interp_bias_relu4(float w0, float w1, float w2, float4 a, float4 b, float4 c, float4 bias) {
+    const mlp_f32x2 W0 = {w0, w0}, W1 = {w1, w1}, W2 = {w2, w2};
+    const mlp_f32x2 lo = ((mlp_f32x2){a.x, a.y} * W0 + (mlp_f32x2){b.x, b.y} * W1) + (mlp_f32x2){c.x, c.y} * W2 + (mlp_f32x2){bias.x, bias.y};
+    const mlp_f32x2 hi = ((mlp_f32x2){a.z, a.w} * W0 + (mlp_f32x2){b.z, b.w} * W1) + (mlp_f32x2){c.z, c.w} * W2 + (mlp_f32x2){bias.z, bias.w};
+    return make_float4(fmaxf(lo.x, 0.f), fmaxf(lo.y, 0.f), fmaxf(hi.x, 0.f), fmaxf(hi.y, 0.f));
+}
 // the finished A values of row 8u + g, k = 32 c + 4 q .. + 4 (the expressions of fast_finish, element for element)
 __device__ __forceinline__ float4 coop_finish(const CoopRows<MODE_PLAIN>&, const CoopRaw<MODE_PLAIN>& v, int u, float4) { return v.a[u]; }
 __device__ __forceinline__ float4 coop_finish(const CoopRows<MODE_INTERP>& cr, const CoopRaw<MODE_INTERP>& v, int u, float4 b) {
-    float4 o;
-    o.x = fmaxf(interp1(cr.w0[u], v.a[u].x, cr.w1[u], v.b[u].x, cr.w2[u], v.c[u].x) + b.x, 0.f);
-    o.y = fmaxf(interp1(cr.w0[u], v.a[u].y, cr.w1[u], v.b[u].y, cr.w2[u], v.c[u].y) + b.y, 0.f);
-    o.z = fmaxf(interp1(cr.w0[u], v.a[u].z, cr.w1[u], v.b[u].z, cr.w2[u], v.c[u].z) + b.z, 0.f);
-    o.w = fmaxf(interp1(cr.w0[u], v.a[u].w, cr.w1[u], v.b[u].w, cr.w2[u], v.c[u].w) + b.w, 0.f);
-    return o;
+    return interp_bias_relu4(cr.w0[u], cr.w1[u], cr.w2[u], v.a[u], v.b[u], v.c[u], b);
 }
 
 // D registers -> the wave's LDS tile -> 8 rows x 128 contiguous bytes per store instruction (32 channels at a time)
@@ -2214,12 +2219,7 @@ __device__ __forceinline__ void coop_fetch32(const MlpParams& P, const CoopRows3
 }
 __device__ __forceinline__ float4 coop_finish32(const CoopRows32<MODE_PLAIN>&, const CoopRaw<MODE_PLAIN>& v, int u, float4) { return v.a[u]; }
 __device__ __forceinline__ float4 coop_finish32(const CoopRows32<MODE_INTERP>& cr, const CoopRaw<MODE_INTERP>& v, int u, float4 b) {
-    float4 o;
-    o.x = fmaxf(interp1(cr.w0[u], v.a[u].x, cr.w1[u], v.b[u].x, cr.w2[u], v.c[u].x) + b.x, 0.f);
-    o.y = fmaxf(interp1(cr.w0[u], v.a[u].y, cr.w1[u], v.b[u].y, cr.w2[u], v.c[u].y) + b.y, 0.f);
-    o.z = fmaxf(interp1(cr.w0[u], v.a[u].z, cr.w1[u], v.b[u].z, cr.w2[u], v.c[u].z) + b.z, 0.f);
-    o.w = fmaxf(interp1(cr.w0[u], v.a[u].w, cr.w1[u], v.b[u].w, cr.w2[u], v.c[u].w) + b.w, 0.f);
-    return o;
+    return interp_bias_relu4(cr.w0[u], cr.w1[u], cr.w2[u], v.a[u], v.b[u], v.c[u], b);
 }
 
 // the wave's tile sequence (32-row tiles)
@@ -2282,6 +2282,9 @@ __global__ __launch_bounds__(CP_WAVES * 64, 1) void mlp_chain_p_kernel(const Cha
     const bool out1 = NB1 == 1;
     const bool coop_out = P.pool_ns == 0 && ((P.ld_out | P.col_off) % 4 == 0) && aligned16(P.out) && P.Nout % 4 == 0;
 
+#ifdef MLP_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     CoopTiles it;
     coop_tiles_init(it, P, wave);
     if (it.t < 0) return;
@@ -2293,6 +2296,7 @@ __global__ __launch_bounds__(CP_WAVES * 64, 1) void mlp_chain_p_kernel(const Cha
     coop_rows32(P, cur * 32, g, q, mt, cr);
 #pragma unroll
     for (int c = 0; c < RD; c++) coop_fetch32(P, cr, c, x[c]);
+    MLP_T(0)
 
     while (cur >= 0) {
         const long rw0 = cur * 32;
@@ -2325,6 +2329,7 @@ __global__ __launch_bounds__(CP_WAVES * 64, 1) void mlp_chain_p_kernel(const Cha
                 if (st + RD < NST) coop_fetch32(P, cr, st + RD, x[st + RD]);
                 else coop_fetch32(P, crn, st + RD - NST, x[st + RD - NST]);
             }
+            MLP_T(1)
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int ksl = 0; ksl < 2; ksl++) {
@@ -2342,6 +2347,7 @@ __global__ __launch_bounds__(CP_WAVES * 64, 1) void mlp_chain_p_kernel(const Cha
                 if (MODE == MODE_PLAIN) schain_step<NB0, TERMS>(a0, wst, ksl, 0, bp);
                 else schain_step_pairs<NB0, TERMS>(a0, wst, ksl, 0, bp);
             }
+            MLP_T(2)
             __builtin_amdgcn_wave_barrier();
         }
         const long row = rw0 + j;
@@ -2358,7 +2364,14 @@ __global__ __launch_bounds__(CP_WAVES * 64, 1) void mlp_chain_p_kernel(const Cha
         }
         cr = crn;
         cur = nxt;
+        MLP_T(7)
+#ifdef MLP_TIMING
+        if (lane == 0 && wave == 0) atomicAdd(&g_mlp_t[8], 1ULL);
+#endif
     }
+#ifdef MLP_TIMING
+    if (lane == 0 && wave == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_mlp_t[k], tacc[k]);
+#endif
 }
 template <int MODE, int NB1> static constexpr size_t chain_p_lds_bytes() {
     return (size_t)4 * SStage<4>::U4 * 16 + (size_t)CP_WAVES * 32 * CC_LD * 4 + 2 * 128 * 4;
@@ -2372,9 +2385,9 @@ static int chain_p_grid() {
     return cus > 0 ? cus : 8;
 }
 // PRCNN_CHAIN_PERSIST=0: the per-tile kernels (A/B switch, same bits)
-static bool chain_persist_on() {
-    static const bool on = !(getenv("PRCNN_CHAIN_PERSIST") && atoi(getenv("PRCNN_CHAIN_PERSIST")) == 0);
-    return on;
+static bool chain_persist_on() {                           // (read per launch: the tests flip it inside one process)
+    const char* e = getenv("PRCNN_CHAIN_PERSIST");
+    return !(e && atoi(e) == 0);
 }
 template <int MODE, int NB1>
 static int launch_chain_p(const ChainParams& C, hipStream_t s) {
@@ -2387,9 +2400,9 @@ static int launch_chain_p(const ChainParams& C, hipStream_t s) {
     hipLaunchKernelGGL((mlp_chain_p_kernel<MODE, NB1, 6>), dim3(grid), dim3(CP_WAVES * 64), lds, s, C);
     return PRCNN_OK;
 }
-static bool chain_coop_on() {
-    static const bool on = !(getenv("PRCNN_CHAIN_COOP") && atoi(getenv("PRCNN_CHAIN_COOP")) == 0);
-    return on;
+static bool chain_coop_on() {                              // (read per launch: the tests flip it inside one process)
+    const char* e = getenv("PRCNN_CHAIN_COOP");
+    return !(e && atoi(e) == 0);
 }
 
 // =====================================================================================================

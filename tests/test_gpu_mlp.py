@@ -758,3 +758,57 @@ def test_split_bf16_hoisted_fp0_nonfinite_rows(dev, monkeypatch):
     assert np.isinf(ref).any() and _same_class(got, ref)
     fin = np.isfinite(ref)
     assert np.abs(got[fin] - ref[fin]).max() <= mlp_tol(ref[fin])
+
+
+@pytest.mark.own_arithmetic
+def test_split_chain_forms_are_bit_identical(dev, monkeypatch):
+    """round 6: the split-bf16 chain runs in three forms -- lane-is-a-row loads (mlp_chain_s_kernel, PRCNN_CHAIN_COOP=0), cooperative
+    row access through an LDS transposition tile (mlp_chain_c_kernel, PRCNN_CHAIN_PERSIST=0) and the persistent weights-resident form
+    (mlp_chain_p_kernel: hoisted FP0 and the single-channel head).  Same products in the same order: the outputs must be the same
+    BITS, on ragged row counts (last tile partly empty, fewer tiles than waves), frames a multiple of 8 (XCD-aware tile order) and
+    not, and with a non-finite input row (every form redoes the wave's rows on the fp32 pipe)."""
+    from pointrcnn_amd import ops
+    monkeypatch.setattr(ops, "MLP_SPLIT_TERMS", 6)
+    r = np.random.default_rng(77)
+    w0 = (r.normal(size=(128, 128)) * 0.1).astype(np.float32)
+    b0 = r.normal(size=(128,)).astype(np.float32)
+    l0 = lin(dev, w0, b0, True)
+    heads = [lin(dev, (r.normal(size=(n1, 128)) * 0.1).astype(np.float32), r.normal(size=(n1,)).astype(np.float32), False) for n1 in (1, 76, 128)]
+
+    def forms(fn):
+        outs = []
+        for coop, persist in (("0", "0"), ("1", "0"), ("1", "1")):
+            monkeypatch.setenv("PRCNN_CHAIN_COOP", coop)
+            monkeypatch.setenv("PRCNN_CHAIN_PERSIST", persist)
+            outs.append(fn().clone())
+        monkeypatch.delenv("PRCNN_CHAIN_COOP")
+        monkeypatch.delenv("PRCNN_CHAIN_PERSIST")
+        return outs
+
+    for rows in (40000 + 17, 300, 31, 128 * 2048):
+        x = _scaled_rows(r, rows, 128)
+        if rows > 1000:
+            x[1234, 5] = np.inf                               # one non-finite row: its wave takes the fp32 redo path in every form
+        xt = T(x, dev)
+        for l1 in heads:
+            a, b, c = forms(lambda: ops.mlp_chain_rows(xt, [l0, l1]))
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(a.view(torch.int32), c.view(torch.int32)), (rows, l1.nout)
+    for B, n, m in ((8, 4096, 1024), (3, 1000, 250), (16, 256, 64), (1, 40, 7)):
+        y = T(r.normal(size=(B, m, 128)).astype(np.float32), dev)
+        idx3 = T(r.integers(0, m, size=(B, n, 3)).astype(np.int32), dev)
+        w3 = r.random(size=(B, n, 3)).astype(np.float32)
+        w3 = T(w3 / w3.sum(-1, keepdims=True), dev)
+        bb = T(r.normal(size=(128,)).astype(np.float32), dev)
+        a, b, c = forms(lambda: ops.mlp_chain_interp(y, idx3, w3, None, [l0], act_bias=bb))
+        assert torch.equal(a, b) and torch.equal(a, c), (B, n, m)
+        # strided output: the chain writes into a column window of a wider buffer
+        wide = [torch.zeros((B * n, 160), device=dev) for _ in range(3)]
+        k = [0]
+
+        def into():
+            o = wide[k[0]]
+            k[0] += 1
+            ops.mlp_chain_interp(y, idx3, w3, None, [l0], out=(o, 32), act_bias=bb)
+            return o
+        a, b, c = forms(into)
+        assert torch.equal(a, b) and torch.equal(a, c) and float(a[:, :32].abs().max()) == 0.0
