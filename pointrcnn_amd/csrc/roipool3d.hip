@@ -357,7 +357,7 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(const float* __re
     const int total_e = S * W, live_e = total * W;
     const int qstep = RP_THREADS / W, rstep = RP_THREADS - qstep * W;
     int srow = tid / W, scol = tid - srow * W;
-    constexpr int U = 8;
+    constexpr int U = 16;
     // (starting every workgroup at its own chunk / replica, in case blocks 1064 x 256 bytes apart camp on memory channels: no effect)
     for (int e = tid; e < live_e; e += U * RP_THREADS) {
         float v[U];
@@ -370,10 +370,15 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(const float* __re
             srow += qstep; scol += rstep;
             if (scol >= W) { scol -= W; srow++; }
         }
+        // replica-major: the workgroup writes its U x 256 consecutive elements of one copy of the block, then the same elements of the
+        // next copy (u-major order spread every 1 KB piece over all the copies before the next piece)
+        for (int rep = 0; rep < total_e; rep += live_e) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            if (e + u * RP_THREADS < live_e)
-                for (int q = e + u * RP_THREADS; q < total_e; q += live_e) o[q] = v[u];
+            for (int u = 0; u < U; u++) {
+                const int q = rep + e + u * RP_THREADS;
+                if (e + u * RP_THREADS < live_e && q < total_e) o[q] = v[u];
+            }
+        }
     }
 }
 

@@ -71,6 +71,19 @@ def main():
     xyz = rpn.synthetic_clouds(B, N, device=dev)
     g = torch.Generator(device="cpu").manual_seed(0)
 
+    # ---- what plain streams reach on THIS box (1 GiB buffers): the ceilings the gather ops are read against, next to the 8 TB/s headline.
+    # A pure write stream (roipool3d's 1 GB of pooled rows written once) and a read + write copy are different ceilings.
+    buf_a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    buf_b = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    t_fill = timeit(lambda: buf_a.fill_(1.0), 10, 2)
+    t_copy = timeit(lambda: buf_b.copy_(buf_a), 10, 2)
+    print(json.dumps({"op": "stream ceilings", "shape": "1 GiB fp32", "write_only_GBps": round(buf_a.numel() * 4 / t_fill / 1e9, 1),
+                      "copy_read_plus_write_GBps": round(2 * buf_a.numel() * 4 / t_copy / 1e9, 1),
+                      "note": "torch fill_ / copy_ on this box; an op that writes W bytes and reads R cannot finish before W / write_only (R << W) or "
+                              "(R + W) / copy (R ~ W)"}), flush=True)
+    del buf_a, buf_b
+    torch.cuda.empty_cache()
+
     # ---- search ops
     emit("fps", "B%d %d->4096" % (B, N), timeit(lambda: ops.furthest_point_sample(xyz, 4096), 5, 1), pairs=B * N * 4096)
     new_xyz = ops.gather_rows(xyz, ops.furthest_point_sample(xyz, 4096))
