@@ -98,45 +98,105 @@ __global__ __launch_bounds__(TI_THREADS) void three_interp_lds_kernel(const floa
 // values are one or two 16-byte LDS reads instead of CGT scalar reads at a 4 m-byte stride (24 -> 6 LDS instructions per output
 // point at CGT = 8, on random addresses either way), and the next point's index / weight triple is requested before the current
 // point's arithmetic.  Same individually rounded arithmetic, same bits.
-template <int CGT>
+template <int CGT, bool VEC>
 __global__ __launch_bounds__(TI_THREADS) void three_interp_pm_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx,
                                                                      const float* __restrict__ w, int C, int m, int n,
                                                                      float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float spm[];     // m rows of CGT floats
     const int b = blockIdx.y, c0 = blockIdx.x * CGT;
     const float* f = feat + ((size_t)b * C + c0) * m;
-    for (int i = threadIdx.x; i < m; i += TI_THREADS) {
-        float v[CGT];
+    // staging: four source points per thread and trip, all 4 x CGT loads requested before the first LDS write (round 6: with one point
+    // per trip the 128 KB came in as eight dependent round trips)
+    for (int i0 = threadIdx.x; i0 < m; i0 += 4 * TI_THREADS) {
+        float v[4][CGT];
 #pragma unroll
-        for (int c = 0; c < CGT; c++) v[c] = f[(size_t)c * m + i];
+        for (int p = 0; p < 4; p++) {
+            const int i = min(i0 + p * TI_THREADS, m - 1);
 #pragma unroll
-        for (int q = 0; q < CGT / 4; q++)
-            *reinterpret_cast<float4*>(spm + (size_t)i * CGT + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            for (int c = 0; c < CGT; c++) v[p][c] = f[(size_t)c * m + i];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int i = i0 + p * TI_THREADS;
+            if (i < m)
+#pragma unroll
+                for (int q = 0; q < CGT / 4; q++)
+                    *reinterpret_cast<float4*>(spm + (size_t)i * CGT + 4 * q) = make_float4(v[p][4 * q], v[p][4 * q + 1], v[p][4 * q + 2], v[p][4 * q + 3]);
+        }
     }
     __syncthreads();
     float* o = out + ((size_t)b * C + c0) * n;
-    int i = threadIdx.x;
-    if (i >= n) return;
     const int32_t* __restrict__ ib = idx + (size_t)b * n * 3;
     const float* __restrict__ wb = w + (size_t)b * n * 3;
-    int i0 = ib[i * 3], i1 = ib[i * 3 + 1], i2 = ib[i * 3 + 2];
-    float w0 = wb[i * 3], w1 = wb[i * 3 + 1], w2 = wb[i * 3 + 2];
-    while (true) {
-        const int nx = i + TI_THREADS, nc = min(nx, n - 1);
-        const int j0 = ib[nc * 3], j1 = ib[nc * 3 + 1], j2 = ib[nc * 3 + 2];
-        const float u0 = wb[nc * 3], u1 = wb[nc * 3 + 1], u2 = wb[nc * 3 + 2];
+    // PP output points per thread and trip: the workgroup owns 128 KB of LDS, so it is alone on its CU and nothing else hides the
+    // latency of the index / weight triples -- with one point per trip (rounds 2-5) every trip waited a memory round trip for the
+    // triple requested one trip earlier (~1.5 us x 32 trips per thread).  Now 4 triples are requested together, a trip ahead.
+    // VEC (n a multiple of 4, 16-byte aligned bases): the four points are CONSECUTIVE, their 12 indices / 12 weights are three 16-byte
+    // loads each and every channel's four results one 16-byte store (the output is 4/5 of the op's traffic: 32 dword stores -> 8).
+    constexpr int PP = 4;
+    const int stride = VEC ? 1 : TI_THREADS, step = PP * TI_THREADS;
+    int id[PP][3];
+    float wt[PP][3];
+    auto request = [&](int base, int (&di)[PP][3], float (&dw)[PP][3]) {
+        if (VEC) {
+            const int4* ip = reinterpret_cast<const int4*>(ib + (size_t)base * 3);
+            const float4* wp = reinterpret_cast<const float4*>(wb + (size_t)base * 3);
+            const int4 a0 = ip[0], a1 = ip[1], a2 = ip[2];
+            const float4 b0 = wp[0], b1 = wp[1], b2 = wp[2];
+            di[0][0] = a0.x; di[0][1] = a0.y; di[0][2] = a0.z; di[1][0] = a0.w; di[1][1] = a1.x; di[1][2] = a1.y;
+            di[2][0] = a1.z; di[2][1] = a1.w; di[2][2] = a2.x; di[3][0] = a2.y; di[3][1] = a2.z; di[3][2] = a2.w;
+            dw[0][0] = b0.x; dw[0][1] = b0.y; dw[0][2] = b0.z; dw[1][0] = b0.w; dw[1][1] = b1.x; dw[1][2] = b1.y;
+            dw[2][0] = b1.z; dw[2][1] = b1.w; dw[2][2] = b2.x; dw[3][0] = b2.y; dw[3][1] = b2.z; dw[3][2] = b2.w;
+        } else {
 #pragma unroll
-        for (int q = 0; q < CGT / 4; q++) {
-            const float4 a = *reinterpret_cast<const float4*>(spm + (size_t)i0 * CGT + 4 * q);
-            const float4 bq = *reinterpret_cast<const float4*>(spm + (size_t)i1 * CGT + 4 * q);
-            const float4 cq = *reinterpret_cast<const float4*>(spm + (size_t)i2 * CGT + 4 * q);
-            o[(size_t)(4 * q + 0) * n + i] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.x), __fmul_rn(w1, bq.x)), __fmul_rn(w2, cq.x));
-            o[(size_t)(4 * q + 1) * n + i] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.y), __fmul_rn(w1, bq.y)), __fmul_rn(w2, cq.y));
-            o[(size_t)(4 * q + 2) * n + i] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.z), __fmul_rn(w1, bq.z)), __fmul_rn(w2, cq.z));
-            o[(size_t)(4 * q + 3) * n + i] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.w), __fmul_rn(w1, bq.w)), __fmul_rn(w2, cq.w));
+            for (int p = 0; p < PP; p++) {
+                const int i = min(base + p * stride, n - 1);
+                di[p][0] = ib[i * 3]; di[p][1] = ib[i * 3 + 1]; di[p][2] = ib[i * 3 + 2];
+                dw[p][0] = wb[i * 3]; dw[p][1] = wb[i * 3 + 1]; dw[p][2] = wb[i * 3 + 2];
+            }
         }
-        if (nx >= n) break;
-        i = nx; i0 = j0; i1 = j1; i2 = j2; w0 = u0; w1 = u1; w2 = u2;
+    };
+    int base = VEC ? PP * threadIdx.x : threadIdx.x;
+    if (base >= n) return;
+    request(base, id, wt);
+    while (true) {
+        const int nbase = base + step;
+        int nid[PP][3];
+        float nwt[PP][3];
+        request(nbase < n ? nbase : base, nid, nwt);      // (no next trip: the request repeats this one, unused)
+        float r[CGT][PP];
+#pragma unroll
+        for (int p = 0; p < PP; p++) {
+#pragma unroll
+            for (int q = 0; q < CGT / 4; q++) {
+                const float4 a = *reinterpret_cast<const float4*>(spm + (size_t)id[p][0] * CGT + 4 * q);
+                const float4 bq = *reinterpret_cast<const float4*>(spm + (size_t)id[p][1] * CGT + 4 * q);
+                const float4 cq = *reinterpret_cast<const float4*>(spm + (size_t)id[p][2] * CGT + 4 * q);
+                const float w0 = wt[p][0], w1 = wt[p][1], w2 = wt[p][2];
+                r[4 * q + 0][p] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.x), __fmul_rn(w1, bq.x)), __fmul_rn(w2, cq.x));
+                r[4 * q + 1][p] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.y), __fmul_rn(w1, bq.y)), __fmul_rn(w2, cq.y));
+                r[4 * q + 2][p] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.z), __fmul_rn(w1, bq.z)), __fmul_rn(w2, cq.z));
+                r[4 * q + 3][p] = __fadd_rn(__fadd_rn(__fmul_rn(w0, a.w), __fmul_rn(w1, bq.w)), __fmul_rn(w2, cq.w));
+            }
+        }
+        if (VEC) {
+#pragma unroll
+            for (int c = 0; c < CGT; c++) *reinterpret_cast<float4*>(o + (size_t)c * n + base) = make_float4(r[c][0], r[c][1], r[c][2], r[c][3]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < PP; p++) {
+                const int i = base + p * stride;
+                if (i < n)
+#pragma unroll
+                    for (int c = 0; c < CGT; c++) o[(size_t)c * n + i] = r[c][p];
+            }
+        }
+        if (nbase >= n) break;
+        base = nbase;
+#pragma unroll
+        for (int p = 0; p < PP; p++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) { id[p][k] = nid[p][k]; wt[p][k] = nwt[p][k]; }
     }
 }
 
@@ -348,17 +408,22 @@ PRCNN_API int prcnn_three_interp(const float* feat, const int32_t* idx, const fl
     if (CG > C) CG = C;
     if (CG > 16) CG = 16;                                                                 // (more workgroups beat longer rows)
     const char* lay = getenv("PRCNN_INTERP_LAYOUT");                                       // "rows": channel-major LDS rows (A/B switch)
-    const int CGT = CG >= 8 ? 8 : 4;
+    const char* cge = getenv("PRCNN_INTERP_CGT");                                          // A/B switch: channels per workgroup (same bits)
+    const int CGT = (cge && atoi(cge) == 4) ? 4 : (CG >= 8 ? 8 : 4);
     if (!no_lds && !(lay && lay[0] == 'r') && CG >= 4 && C % CGT == 0 && n >= 2 * m && (long)B * (C / CGT) >= 16) {
-        static PrcnnLdsLimit lim4, lim8;
+        static PrcnnLdsLimit lim[4];
         const size_t bytes = (size_t)CGT * m * sizeof(float);
-        if (CGT == 8) {
-            if (!lim8.raise((const void*)three_interp_pm_kernel<8>, 128 * 1024)) return prcnn_fail(PRCNN_EHIP, "prcnn_three_interp: cannot raise the dynamic LDS limit");
-            hipLaunchKernelGGL(three_interp_pm_kernel<8>, dim3(C / 8, B), dim3(TI_THREADS), bytes, (hipStream_t)stream, feat, idx, weight, C, m, n, out);
-        } else {
-            if (!lim4.raise((const void*)three_interp_pm_kernel<4>, 128 * 1024)) return prcnn_fail(PRCNN_EHIP, "prcnn_three_interp: cannot raise the dynamic LDS limit");
-            hipLaunchKernelGGL(three_interp_pm_kernel<4>, dim3(C / 4, B), dim3(TI_THREADS), bytes, (hipStream_t)stream, feat, idx, weight, C, m, n, out);
-        }
+        const bool vec = (n % 4 == 0) && (((uintptr_t)idx | (uintptr_t)weight | (uintptr_t)out) & 15) == 0;
+#define TI_LAUNCH(G, V, L)                                                                                                        \
+        do {                                                                                                                      \
+            if (!lim[L].raise((const void*)three_interp_pm_kernel<G, V>, 128 * 1024))                                             \
+                return prcnn_fail(PRCNN_EHIP, "prcnn_three_interp: cannot raise the dynamic LDS limit");                          \
+            hipLaunchKernelGGL((three_interp_pm_kernel<G, V>), dim3(C / G, B), dim3(TI_THREADS), bytes, (hipStream_t)stream, feat, idx, weight, \
+                               C, m, n, out);                                                                                     \
+        } while (0)
+        if (CGT == 8) { if (vec) TI_LAUNCH(8, true, 0); else TI_LAUNCH(8, false, 1); }
+        else { if (vec) TI_LAUNCH(4, true, 2); else TI_LAUNCH(4, false, 3); }
+#undef TI_LAUNCH
         PRCNN_LAUNCH_CHECK("prcnn_three_interp(point-major lds)");
         return PRCNN_OK;
     }
