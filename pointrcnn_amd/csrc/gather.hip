@@ -28,6 +28,78 @@ __global__ __launch_bounds__(G_THREADS) void gather_kernel(const float* __restri
     for (int c = 0; c < C; c++) o[(size_t)c * J] = f[(size_t)c * N];
 }
 
+// grouping_operation / gather_operation with the source rows staged in LDS (round 6; the three_interpolate kernel's plan, one source point
+// per output instead of three): in the op surface's (B, C, N) layout the plain kernel above reads 64 unrelated addresses of one 4 N-byte
+// row per load instruction -- 64 separate cache accesses for 256 bytes.  A workgroup here owns CGT consecutive channels of one frame,
+// staged POINT-major (CGT floats per source point, contiguous: one or two 16-byte LDS reads fetch all of a point's channels), and a slice
+// of the J outputs: four consecutive outputs per thread (one 16-byte index load, one 16-byte store per channel).  Pure copies: exact.
+#define GP_THREADS 1024
+template <int CGT>
+__global__ __launch_bounds__(GP_THREADS) void gather_pm_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, int C, int N,
+                                                               int J, int jslices, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float gpm[];     // N rows of CGT floats
+    const int b = blockIdx.y, cgi = blockIdx.x / jslices, js = blockIdx.x - cgi * jslices, c0 = cgi * CGT;
+    const float* f = feat + ((size_t)b * C + c0) * N;
+    for (int i0 = threadIdx.x; i0 < N; i0 += 4 * GP_THREADS) {
+        float v[4][CGT];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int i = min(i0 + p * GP_THREADS, N - 1);
+#pragma unroll
+            for (int c = 0; c < CGT; c++) v[p][c] = f[(size_t)c * N + i];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int i = i0 + p * GP_THREADS;
+            if (i < N)
+#pragma unroll
+                for (int q = 0; q < CGT / 4; q++)
+                    *reinterpret_cast<float4*>(gpm + (size_t)i * CGT + 4 * q) = make_float4(v[p][4 * q], v[p][4 * q + 1], v[p][4 * q + 2], v[p][4 * q + 3]);
+        }
+    }
+    __syncthreads();
+    float* o = out + ((size_t)b * C + c0) * J;
+    const int32_t* __restrict__ ib = idx + (size_t)b * J;
+    // this workgroup's slice of the outputs, in units of 4: [q0, q1)
+    const int quads = J / 4, per = (quads + jslices - 1) / jslices;
+    const int q0 = js * per, q1 = min(quads, q0 + per);
+    int qd = q0 + threadIdx.x;
+    if (qd >= q1) return;
+    int4 id = *reinterpret_cast<const int4*>(ib + 4 * (size_t)qd);
+    while (true) {
+        const int nq = qd + GP_THREADS;
+        const int4 nid = *reinterpret_cast<const int4*>(ib + 4 * (size_t)(nq < q1 ? nq : qd));
+        float r[CGT][4];
+        const int ii[4] = {id.x, id.y, id.z, id.w};
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int q = 0; q < CGT / 4; q++) {
+                const float4 a = *reinterpret_cast<const float4*>(gpm + (size_t)ii[p] * CGT + 4 * q);
+                r[4 * q][p] = a.x; r[4 * q + 1][p] = a.y; r[4 * q + 2][p] = a.z; r[4 * q + 3][p] = a.w;
+            }
+#pragma unroll
+        for (int c = 0; c < CGT; c++) *reinterpret_cast<float4*>(o + (size_t)c * J + 4 * (size_t)qd) = make_float4(r[c][0], r[c][1], r[c][2], r[c][3]);
+        if (nq >= q1) break;
+        qd = nq; id = nid;
+    }
+}
+// -> true when the staged kernel took the call
+static bool launch_gather_pm(const float* feat, const int32_t* idx, int B, int C, int N, long J, float* out, hipStream_t s) {
+    if (getenv("PRCNN_GATHER_DIRECT") != nullptr) return false;                          // A/B switch (same values)
+    const int CGT = 8;
+    if (C % CGT || J % 4 || (long)N * CGT * 4 > 128 * 1024 || J < 4L * N || J > 0x7fffffffL) return false;    // (staging must pay: >= 4 outputs per source point)
+    if ((((uintptr_t)idx | (uintptr_t)out) & 15) != 0) return false;
+    static PrcnnLdsLimit lim;
+    if (!lim.raise((const void*)gather_pm_kernel<8>, 128 * 1024)) return false;
+    // enough workgroups for the chip: slices of the outputs when B x C / 8 alone is short of ~4 per CU
+    int jslices = 1;
+    while ((long)B * (C / CGT) * jslices < 1024 && (J / 4) / (jslices * 2) >= 2 * GP_THREADS) jslices *= 2;
+    hipLaunchKernelGGL(gather_pm_kernel<8>, dim3((C / CGT) * jslices, B), dim3(GP_THREADS), (size_t)CGT * N * sizeof(float), s, feat, idx, C, N,
+                       (int)J, jslices, out);
+    return true;
+}
+
 __global__ __launch_bounds__(G_THREADS) void gather_grad_kernel(const float* __restrict__ grad_out,
                                                                 const int32_t* __restrict__ idx, int C, int N, int J,
                                                                 float* __restrict__ grad_feat) {
@@ -371,8 +443,9 @@ PRCNN_API int prcnn_group(const float* feat, const int32_t* idx, int B, int C, i
     int rc = check_bcn("prcnn_group", feat, idx, out, B, C, N, J);
     if (rc) return rc;
     if (B == 0 || C == 0 || J == 0) return PRCNN_OK;
-    hipLaunchKernelGGL(gather_kernel, dim3(prcnn_divup(J, G_THREADS), B), dim3(G_THREADS), 0, (hipStream_t)stream, feat,
-                       idx, C, N, (int)J, out);
+    if (!launch_gather_pm(feat, idx, B, C, N, J, out, (hipStream_t)stream))
+        hipLaunchKernelGGL(gather_kernel, dim3(prcnn_divup(J, G_THREADS), B), dim3(G_THREADS), 0, (hipStream_t)stream, feat,
+                           idx, C, N, (int)J, out);
     PRCNN_LAUNCH_CHECK("prcnn_group");
     return PRCNN_OK;
 }

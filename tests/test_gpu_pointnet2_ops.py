@@ -287,3 +287,21 @@ def test_backward_kernels_at_training_shapes(dev, cpu):
         want = cpu.three_interp_grad(go, i3, w3, m)
         got = ops.three_interpolate_grad(T(go, dev), T(i3, dev), T(w3, dev), m).cpu().numpy()
         assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("B,C,N,M,ns", [(2, 96, 4096, 1024, 32), (3, 16, 1000, 260, 16), (1, 8, 64, 64, 4), (2, 24, 4096, 512, 64)])
+def test_grouping_lds_staged_kernel_is_exact(dev, cpu, monkeypatch, B, C, N, M, ns):
+    """round 6: grouping_operation with the source rows staged point-major in LDS (C a multiple of 8, at least four outputs per source
+    point) == the plain gather kernel (PRCNN_GATHER_DIRECT=1) == the oracle, element for element (pure copies); output slices per
+    workgroup when B x C / 8 alone would not fill the chip"""
+    from pointrcnn_amd import ops
+    r = np.random.default_rng(B * 1000 + C)
+    feat = r.normal(size=(B, C, N)).astype(np.float32)
+    idx = r.integers(0, N, size=(B, M, ns)).astype(np.int32)
+    idx[:, 0] = N - 1
+    idx[:, -1] = 0
+    want = cpu.group(feat, idx)
+    got = ops.group(T(feat, dev), T(idx, dev)).cpu().numpy()
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("PRCNN_GATHER_DIRECT", "1")
+    assert np.array_equal(ops.group(T(feat, dev), T(idx, dev)).cpu().numpy(), want)
