@@ -1084,8 +1084,8 @@ def main():
         args.proposals = "off"                     # the two-stage model runs its own proposal layer
     else:
         model = rpn.randomize_bn_stats(rpn.RPN(), seed=7).to(dev).eval()
-    if args.streams is None:      # rcnn: each in-flight batch holds several GB of worst-case-sized RoI-stage buffers
-        args.streams = 20 if args.workload == "rpn" else 10
+    if args.streams is None:      # rcnn: each in-flight batch holds ~9 GB of worst-case-sized RoI-stage buffers (20 GB until round 6: 10 slots)
+        args.streams = 20 if args.workload == "rpn" else 16
     nstreams = max(1, args.streams)
 
     raw = None

@@ -32,6 +32,8 @@ GROUP_DEDUP = os.environ.get("PRCNN_GROUP_DEDUP", "1") != "0"       # padding-fr
 DEDUP_SPARSE_DIV = int(os.environ.get("PRCNN_DEDUP_SPARSE_DIV", "4"))  # groups with <= nsample/DIV hits run as flat rows
 STACK_ALL_FLAT = os.environ.get("PRCNN_STACK_ALL_FLAT", "1") != "0"      # A/B switch: stack-kernel scales keep a dense list when off
 STACK_ALL_FLAT_MAX_ROWS = 1 << 20
+# largest layer-to-layer intermediate of a padding-free scale's dense list allocated at once (see _run_scale); 0 = never slice (A/B)
+DENSE_CHUNK_BYTES = int(float(os.environ.get("PRCNN_DENSE_CHUNK_MB", "2048")) * 2 ** 20) or (1 << 62)
 TRAIN_FUSED = os.environ.get("PRCNN_TRAIN_FUSED", "1") != "0"          # hand-written training-mode SharedMLP (train_mlp.py)
 TRAIN_DEDUP = os.environ.get("PRCNN_TRAIN_DEDUP", "1") != "0"          # ... on padding-free rows (exact; A/B switch)
 
@@ -78,8 +80,30 @@ def _run_scale(xyz, ctr, idx, src, layers, act, out, ns, pool, groups_dev):
         return ops.mlp_chain_group(xyz, ctr, idx, src, layers, out=out, pool_ns=pool_ns, act=act, groups_dev=groups_dev)
     if len(layers) == 1:
         return ops.mlp_group(xyz, ctr, idx, src, layers[0], out=out, pool_ns=pool_ns, act=act, groups_dev=groups_dev)
-    x = ops.mlp_group(xyz, ctr, idx, src, layers[0], act=act, groups_dev=groups_dev)
     n = len(layers)
+    G = idx.shape[1] if idx.shape[0] == 1 else 0
+    inter_bytes = idx.numel() * max(l.nout for l in layers[:-1]) * 4
+    if groups_dev is not None and (pool or ns == 1) and out is not None and G > 1 and inter_bytes > DENSE_CHUNK_BYTES:
+        # The dense list of a padding-free scale has a device-side length, but the layer-to-layer intermediate is allocated for the
+        # host-side bound: every group dense, G x nsample rows (the RCNN stage's first level: 409 600 groups x 64 x 128 floats =
+        # 13.4 GB, for a list that holds 0-200 groups on the benchmark clouds) -- 20 GB per in-flight batch capped the two-stage
+        # pipeline at 10 slots.  The list is walked in slices of at most DENSE_CHUNK_BYTES of intermediate instead: slice k covers
+        # groups [g0, g1) and runs with the device-side count clamp(count - g0, 0, g1 - g0), so slices beyond the list's end are
+        # launches of zero rows.  The flat list of the sparse groups (nsample 1, un-pooled: a "group" is a row) is walked the same way.
+        # Same rows through the same kernels: same bits (tests/test_gpu_round2.py, PRCNN_DENSE_CHUNK_MB).
+        nchunk = -(-inter_bytes // DENSE_CHUNK_BYTES)
+        gc = -(-G // nchunk)
+        dst, col = out
+        for g0 in range(0, G, gc):
+            g1 = min(G, g0 + gc)
+            cnt = (groups_dev - g0).clamp_(0, g1 - g0)
+            x = ops.mlp_group(xyz, None if ctr is None else ctr[:, g0:g1], idx[:, g0:g1], src, layers[0], act=act, groups_dev=cnt)
+            for li in range(1, n):
+                last = li == n - 1
+                x = ops.mlp_rows(x, layers[li], out=(dst[g0:g1], col) if last else None, pool_ns=pool_ns if last else 0, rows_dev=cnt, rows_unit=ns)
+            del x
+        return dst
+    x = ops.mlp_group(xyz, ctr, idx, src, layers[0], act=act, groups_dev=groups_dev)
     for li in range(1, n):
         last = li == n - 1
         x = ops.mlp_rows(x, layers[li], out=out if last else None, pool_ns=pool_ns if last else 0, rows_dev=groups_dev, rows_unit=ns)
@@ -262,6 +286,7 @@ class _PointnetSAModuleBase(nn.Module):
                 t1 = torch.empty((sp.max_rows, c_outs[i]), dtype=torch.float32, device=xyz.device)
                 _run_scale(xyz_f, sp.rnx, sp.ridx, src_f, layers, act, (t1, 0), 1, False, sp.rows)
                 ops.segmax_scatter(t1, sp, dst[0], col)
+                del t1                                        # (worst-case sized: gone before the dense list's intermediates are allocated)
                 if not all_flat:
                     tn = torch.empty((sp.G, c_outs[i]), dtype=torch.float32, device=xyz.device)
                     _run_scale(xyz_f, sp.nxn, sp.idxn, src_f, layers, act, (tn, 0), ns, True, sp.count_dense)
