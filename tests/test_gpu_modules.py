@@ -328,3 +328,25 @@ def test_rcnn_roi_duplicate_elimination_is_bit_identical(dev, cpu, mlp_mode):
     assert np.array_equal(empty.cpu().numpy(), (want == 0).astype(np.int32))
     assert np.array_equal(distinct.cpu().numpy(), np.maximum(want, 1))
     assert want.max() == 512 and want.min() == 0 and ((want > 0) & (want < 128)).any() and ((want > 128) & (want < 512)).any()
+
+
+def test_padding_free_lists_walked_in_slices_are_bit_identical(dev, monkeypatch):
+    """round 6 (two-stage detector memory): the dense and the flat list of a padding-free scale are walked in slices with a device-side
+    count per slice (pointnet2_modules._run_scale) so that their worst-case-sized intermediates never exist at once.  Slices of a few
+    hundred kilobytes (dozens of them, most past the lists' ends: zero-row launches) == one slice, bit for bit, on a cloud whose groups
+    are part dense, part sparse -- the RCNN stage's first level in miniature (nsample 64, three 128-wide layers, no BatchNorm)."""
+    from pointnet2_lib.pointnet2 import pointnet2_modules as pm
+    r = np.random.default_rng(4)
+    B, N = 6, 512
+    # half of every frame in a tight cluster (dense balls), half scattered (sparse balls)
+    xyz = np.concatenate([r.normal(0, 0.08, (B, N // 2, 3)), r.uniform(-3, 3, (B, N // 2, 3))], 1).astype(np.float32)
+    feat = r.normal(size=(B, 128, N)).astype(np.float32)
+    sa = pm.PointnetSAModule(npoint=128, radius=0.2, nsample=64, mlp=[128, 128, 128, 128], use_xyz=True, bn=False).to(dev).eval()
+    x, f = torch.from_numpy(xyz).to(dev), torch.from_numpy(feat).to(dev)
+    outs = []
+    for chunk in (1 << 62, 300 * 1024, 64 * 1024):
+        monkeypatch.setattr(pm, "DENSE_CHUNK_BYTES", chunk)
+        with torch.no_grad():
+            outs.append(sa(x, f)[1].clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert float(outs[0].abs().max()) > 0
