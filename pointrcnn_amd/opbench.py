@@ -98,7 +98,7 @@ def main():
     idx = ops.ball_query(1.0, 32, xyz1, nx2)
     emit("grouping_operation", "B%d C96 N4096 M1024 ns32" % B, timeit(lambda: ops.group(feat, idx)),
          bytes=B * (1024 * 32 * 4 + 2 * 96 * 1024 * 32 * 4), compulsory=B * (1024 * 32 * 4 + 96 * 4096 * 4 + 96 * 1024 * 32 * 4),
-         kernels=[("gather_kernel", B * 1024 * 32)])
+         kernels=[("gather_pm_kernel", 0)])
     fidx = ops.furthest_point_sample(xyz1, 1024)
     emit("gather_operation", "B%d C96 N4096 M1024" % B, timeit(lambda: ops.gather(feat, fidx)),
          bytes=B * (1024 * 4 + 2 * 96 * 1024 * 4), compulsory=B * (1024 * 4 + 2 * 96 * 1024 * 4), kernels=[("gather_kernel", B * 1024)])

@@ -2,7 +2,7 @@
 # copy the summaries produced by tools/refresh_profiles.sh (gpurun_out/refresh) into profiles/ (round tag = $1, default r02)
 set -e
 R=gpurun_out/refresh
-T=${1:-r05}
+T=${1:-r06}
 cp $R/bench_default.json profiles/${T}_final_bench.json
 cp $R/bench_driver_flags.json profiles/${T}_final_bench_steps20.json
 cp $R/bench_streams1.json profiles/${T}_final_bench_streams1.json
@@ -21,4 +21,10 @@ cp $R/kernel_stats_f32_mfma.txt profiles/${T}_final_kernel_stats_f32_mfma.txt
 cp $R/hbm_traffic.json profiles/${T}_hbm_traffic.json
 cp $R/mfma_util.txt profiles/${T}_mfma_util.txt
 cp $R/opbench.jsonl profiles/${T}_opbench.jsonl
+cp $R/bench_reference.json profiles/${T}_final_bench_reference.json
+cp $R/bench_reference_rotate.json profiles/${T}_final_bench_reference_rotate.json
+cp $R/kernel_stats_reference.txt profiles/${T}_final_kernel_stats_reference.txt
+cp $R/arith_disagreement.json profiles/${T}_arith_disagreement.json
+[ -s $R/mlp_chain_timing.txt ] && cp $R/mlp_chain_timing.txt profiles/${T}_mlp_chain_timing.txt
+[ -s $R/nms_sweep_timing.txt ] && cp $R/nms_sweep_timing.txt profiles/${T}_nms_sweep_timing.txt
 ls -la profiles

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh'
-# Outputs land in gpurun_out/refresh/; copy the summaries into profiles/ afterwards (tools/collect_profiles.sh r05).
+# Outputs land in gpurun_out/refresh/; copy the summaries into profiles/ afterwards (tools/collect_profiles.sh r06).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
@@ -12,7 +12,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_FETCH_SI
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_WRITE_SIZE -- $B > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $O/pmc_mfma -- $B > /dev/null 2>&1
 python profiles/derive_hbm_traffic.py $O/pmc_ $O/hbm_traffic.json > $O/hbm_traffic.txt 2>&1
-cp $O/hbm_traffic.json profiles/r05_hbm_traffic.json
+cp $O/hbm_traffic.json profiles/r06_hbm_traffic.json
 python profiles/derive_mfma_util.py $O/pmc_mfma > $O/mfma_util.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2>> $O/bench_default.err
@@ -33,6 +33,15 @@ PRCNN_MLP_SPLIT=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts
 python profiles/summarize_rocprof.py $O/kts "PRCNN_MLP_SPLIT=0 python bench.py (fp32-MFMA arithmetic throughout; 20 batches in flight, hipGraph replay)" > $O/kernel_stats_f32_mfma.txt
 python profiles/summarize_rocprof.py $O/ktr "python bench.py --workload train-rcnn --steps 16 (RCNN-stage training step, bs4, eager, fused training path)" > $O/kernel_stats_train_rcnn.txt
 python -m pointrcnn_amd.opbench > $O/opbench_raw.jsonl 2> $O/opbench.err
+# the reference's unchanged lib/net + evaluation loop body on the drop-in (bench.py --workload reference), its kernel trace, and the rate
+# at which the canonical and the upstream (nvcc-contracted) squared-distance arithmetics disagree
+python bench.py --workload reference --steps 20 --warmup 3 > $O/bench_reference.json 2>> $O/bench_default.err
+python bench.py --workload reference --proposals rotate --steps 20 --warmup 3 > $O/bench_reference_rotate.json 2>> $O/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktref -- python bench_reference.py 12 > /dev/null 2>&1
+python profiles/summarize_rocprof.py $O/ktref "python bench_reference.py 12 (the reference's unchanged lib/net + tools/eval_rcnn.py loop body on the drop-in, eager, one batch in flight)" > $O/kernel_stats_reference.txt
+python tools/arith_disagreement.py --out $O/arith_disagreement.json > /dev/null 2>> $O/bench_default.err
+PRCNN_POINTOPS_LIB=pointrcnn_amd/lib/libprcnn_mlptiming.so python tools/mlp_timing.py > $O/mlp_chain_timing.txt 2>/dev/null
+PRCNN_POINTOPS_LIB=pointrcnn_amd/lib/libprcnn_sweeptiming.so python tools/nms_timing.py 6300 > $O/nms_sweep_timing.txt 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/op_FETCH_SIZE -- python -m pointrcnn_amd.opbench > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/op_WRITE_SIZE -- python -m pointrcnn_amd.opbench > /dev/null 2>&1
 python profiles/join_op_traffic.py $O/opbench_raw.jsonl /tmp/op_ $O/opbench.jsonl > /dev/null 2>> $O/opbench.err
