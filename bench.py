@@ -280,6 +280,8 @@ class EventProfiler:
             c = sp.counts.cpu().tolist()
             for k, v in enumerate(c):
                 dev_counts[sp.counts.data_ptr() + 4 * k] = v
+            if getattr(sp, "slice_count", False):       # the device-side count of one slice of a list walked in slices (pointnet2_modules._run_scale)
+                continue
             # rows the list's launch stands for in the graph without padding-free grouping: all G * nsample rows of the
             # scale, minus what the dense list (its own launches) carries
             undedup[sp.counts.data_ptr()] = sp.G * sp.ns - c[1] * sp.ns

@@ -69,6 +69,14 @@ def _stack_scale(layers, act, src):
             and src.shape[-1] % 8 == 0 and ops.chain_supported(1, layers, 0))
 
 
+class _SliceCount:
+    """what bench.py's instrumented pass needs of a slice's device-side count: the tensor, kept alive until it is read"""
+    slice_count = True
+
+    def __init__(self, counts):
+        self.counts = counts
+
+
 def _run_scale(xyz, ctr, idx, src, layers, act, out, ns, pool, groups_dev):
     """One grouping scale: gather + SharedMLP (+ max-pool over the nsample rows when `pool`), the register-resident chain
     kernel where an instance exists, LDS-tiled layer kernels otherwise.  groups_dev: device-side group count (dedup)."""
@@ -97,6 +105,8 @@ def _run_scale(xyz, ctr, idx, src, layers, act, out, ns, pool, groups_dev):
         for g0 in range(0, G, gc):
             g1 = min(G, g0 + gc)
             cnt = (groups_dev - g0).clamp_(0, g1 - g0)
+            if ops._split_log is not None:                    # (bench.py's instrumented pass reads the device-side counts afterwards)
+                ops._split_log.append(_SliceCount(cnt))
             x = ops.mlp_group(xyz, None if ctr is None else ctr[:, g0:g1], idx[:, g0:g1], src, layers[0], act=act, groups_dev=cnt)
             for li in range(1, n):
                 last = li == n - 1

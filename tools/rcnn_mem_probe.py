@@ -24,6 +24,8 @@ with torch.no_grad():
     torch.cuda.synchronize()
     print("clouds %s: peak memory of one batch above the resident state: %.2f GB" % (kind, (torch.cuda.max_memory_allocated() - base) / 2 ** 30))
     for sp in ops._split_log:
+        if getattr(sp, 'slice_count', False):
+            continue
         c = sp.counts.cpu().tolist()
         print("  GroupSplit G=%7d ns=%2d flat cap %9d rows: flat rows %9d (%.3f), dense groups %7d (%.3f of G), sparse groups %7d"
               % (sp.G, sp.ns, sp.max_rows, c[0], c[0] / sp.max_rows, c[1], c[1] / sp.G, c[2]))
