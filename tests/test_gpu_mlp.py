@@ -19,6 +19,29 @@ def lin(dev, w, b, relu, k_rot=0):
     return ops.PackedLinear(T(w, dev), None if b is None else T(b, dev), relu=relu, k_rot=k_rot)
 
 
+def assert_elementwise(got, rows, layers, pool_ns=0, eps=1e-5, rows_err=None):
+    """north_star's 1e-5 read PER ELEMENT for a stack of layers (round 6: the review asked for the bound of test_mlp_rows_matches_oracle
+    on the chain / grouped / interpolated launches too).  rows: the fp32 input rows of the first layer (as the kernel builds them: gathered /
+    interpolated values are exact copies or exactly specified fp32 expressions); layers: [(w, b, relu), ...].  The stack is evaluated in
+    float64; a layer's own rounding is allowed eps * (sum_k |h_k||w_k| + |b|) per output, the error it inherits from its input is pushed
+    through |W| (ReLU and max are 1-Lipschitz).  rows_err: per-element error already in the rows (interpolated rows: a few fp32 roundings)."""
+    h = rows.astype(np.float64)
+    err = np.zeros_like(h) if rows_err is None else rows_err.astype(np.float64)
+    for w, b, relu in layers:
+        wd = w.astype(np.float64)
+        bd = 0.0 if b is None else b.astype(np.float64)
+        s_ = np.abs(h) @ np.abs(wd).T + (0.0 if b is None else np.abs(bd))
+        err = err @ np.abs(wd).T + eps * s_
+        h = h @ wd.T + bd
+        if relu:
+            h = np.maximum(h, 0.0)
+    if pool_ns:
+        h = h.reshape(-1, pool_ns, h.shape[-1]).max(1)
+        err = err.reshape(-1, pool_ns, err.shape[-1]).max(1)
+    d = np.abs(got.astype(np.float64) - h)
+    assert d.shape == err.shape and (d <= err + 1e-30).all(), float((d / (err + 1e-30)).max())
+
+
 @pytest.mark.parametrize("rows,K,Nout,relu,bias", [(128, 32, 64, True, True), (1000, 3, 16, True, False),
                                                    (77, 5, 1, False, True), (300, 99, 76, False, True),
                                                    (513, 131, 196, True, True), (256, 515, 512, True, True),
@@ -103,6 +126,7 @@ def test_mlp_group_matches_oracle(dev, cpu, C, Nout, ns):
     feat_cl = None if feat is None else T(feat.transpose(0, 2, 1), dev)
     got = ops.mlp_group(T(xyz, dev), T(new_xyz, dev), T(idx, dev), feat_cl, lin(dev, w, b, True, k_rot=3 if C else 0))
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=mlp_tol(want), rtol=0)
+    assert_elementwise(got.cpu().numpy(), rows, [(w, b, True)])
 
 
 def test_mlp_group_gathered_rows_are_exact(dev, cpu):
@@ -142,6 +166,8 @@ def test_mlp_interp_matches_oracle(dev, cpu, C2, C1, Nout):
     got = ops.mlp_interp(T(kf.transpose(0, 2, 1), dev), T(idx3, dev), T(w3, dev),
                          None if sf is None else T(sf.transpose(0, 2, 1), dev), lin(dev, w, b, True))
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=mlp_tol(want), rtol=0)
+    # (the kernel's interpolated rows ARE the oracle's three_interp values bit for bit: test_gather_group_interp_forward_exact)
+    assert_elementwise(got.cpu().numpy(), cat.transpose(0, 2, 1).reshape(-1, C2 + C1), [(w, b, True)])
 
 
 # ------------------------------------------------------------------ register-resident layer chains
@@ -166,6 +192,7 @@ def test_chain_group_equals_oracle_and_per_layer(dev, cpu, C, widths, ns):
     gx = cpu.group(xyz.transpose(0, 2, 1), idx) - new_xyz.transpose(0, 2, 1)[..., None]
     g = gx if feat is None else np.concatenate([gx, cpu.group(feat, idx)], 1)
     rows = g.transpose(0, 2, 3, 1).reshape(-1, C + 3)
+    rows0 = rows
     for w, b in zip(ws, bs):
         rows = cpu.linear_rows(rows, w, b, True)
     want = rows.reshape(B * M, ns, -1).max(1)
@@ -176,6 +203,7 @@ def test_chain_group_equals_oracle_and_per_layer(dev, cpu, C, widths, ns):
     ops.mlp_chain_group(T(xyz, dev), T(new_xyz, dev), T(idx, dev), feat_cl, layers, out=(out, 4), pool_ns=ns)
     got = out.cpu().numpy()
     np.testing.assert_allclose(got[:, 4:4 + widths[-1]], want, atol=mlp_tol(want), rtol=0)
+    assert_elementwise(got[:, 4:4 + widths[-1]], rows0, [(w, b, True) for w, b in zip(ws, bs)], pool_ns=ns)
     assert (got[:, :4] == -3.0).all() and (got[:, 4 + widths[-1]:] == -3.0).all()
     x = ops.mlp_group(T(xyz, dev), T(new_xyz, dev), T(idx, dev), feat_cl, layers[0])
     x = ops.mlp_rows(x, layers[1])
@@ -199,6 +227,7 @@ def test_chain_interp_and_rows_equal_oracle(dev, cpu):
     assert ops.chain_supported(2, layers, 0)
     got = ops.mlp_chain_interp(T(kf.transpose(0, 2, 1), dev), T(idx3, dev), T(w3, dev), None, layers).cpu().numpy()
     np.testing.assert_allclose(got, want, atol=mlp_tol(want), rtol=0)
+    assert_elementwise(got, rows, [(ws[0], bs[0], True), (ws[1], bs[1], True)])
     feats = want                                            # (602,128) rows feed the heads
     for nout in (1, 76, 128):
         hw, hb = _stack(r, (128, 128, nout), 0.1)
@@ -208,6 +237,7 @@ def test_chain_interp_and_rows_equal_oracle(dev, cpu):
         out = ops.mlp_chain_rows(T(feats, dev), hl).cpu().numpy()
         assert out.shape == (602, nout)
         np.testing.assert_allclose(out, ref, atol=mlp_tol(ref), rtol=0)
+        assert_elementwise(out, feats, [(hw[0], hb[0], True), (hw[1], hb[1], False)])
 
 
 def test_chain_unsupported_shapes_are_reported_not_guessed(dev):
