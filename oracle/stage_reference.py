@@ -61,15 +61,23 @@ def stage(verbose=False):
     return ARCHIVE
 
 
+_UNPACKED = None        # one unpacked copy per process: the reference's modules can only be imported from ONE place
+
+
 def locate(tmpdir=None):
     """-> a directory holding the reference tree (lib/, tools/cfgs/): $PRCNN_REFERENCE or /root/reference when present, else the
-    staged archive unpacked into `tmpdir`; None when neither exists"""
+    staged archive unpacked into `tmpdir` (the first caller's; later callers of the same process get that directory again, whatever
+    they pass: `lib.*` is importable from one location only); None when neither exists"""
+    global _UNPACKED
     if have_reference():
         return REFERENCE
+    if _UNPACKED is not None and os.path.isdir(os.path.join(_UNPACKED, "lib", "net")):
+        return _UNPACKED
     if os.path.exists(ARCHIVE) and tmpdir is not None:
         with tarfile.open(ARCHIVE, "r:gz") as tar:
             tar.extractall(tmpdir, filter="data")      # plain files under tmpdir only: no links, devices, absolute or .. paths
-        return str(tmpdir)
+        _UNPACKED = str(tmpdir)
+        return _UNPACKED
     return None
 
 
