@@ -1191,10 +1191,15 @@ def main():
         if world == 1:
             # what an UNMODIFIED user of the reference gets: lib/net + the loop body of tools/eval_rcnn.py, unchanged, on the drop-in
             trace("reference route")
-            ref = reference_route(dev, clouds_cpu, model, out, args.proposals if args.proposals != "off" else "normal", 12, 3,
-                                  line["value_latency_mode"])
-            line["value_reference_lib_net"] = ref["value_eval_loop"] if ref else None
-            line["reference_lib_net"] = ref if ref else "no reference tree on this box (oracle/_ref/reference_py.tar.gz not staged)"
+            try:
+                ref = reference_route(dev, clouds_cpu, model, out, args.proposals if args.proposals != "off" else "normal", 12, 3,
+                                      line["value_latency_mode"])
+                line["value_reference_lib_net"] = ref["value_eval_loop"] if ref else None
+                line["reference_lib_net"] = ref if ref else "no reference tree on this box (oracle/_ref/reference_py.tar.gz not staged)"
+            except Exception as e:  # noqa: BLE001  (a side measurement must not cost the line; `--workload reference` raises)
+                line["value_reference_lib_net"] = None
+                line["reference_lib_net"] = "failed: %s: %s" % (type(e).__name__, str(e).split("\n")[0][:300])
+                torch.cuda.synchronize()
 
     fam = None
     if rank == 0 and not args.no_roofline:
