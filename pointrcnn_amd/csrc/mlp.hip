@@ -2404,6 +2404,10 @@ static bool chain_coop_on() {                              // (read per launch: 
     const char* e = getenv("PRCNN_CHAIN_COOP");
     return !(e && atoi(e) == 0);
 }
+static bool chain_coop_forced() {                          // 2: the cooperative form also where the lane-is-a-row kernel is the default
+    const char* e = getenv("PRCNN_CHAIN_COOP");
+    return e && atoi(e) == 2;
+}
 
 // =====================================================================================================
 // PERSISTENT chain: the fast chain's arithmetic with ALL layers' packed weights resident in LDS for the lifetime of the
@@ -2829,7 +2833,9 @@ PRCNN_API int prcnn_mlp_chain_rows_split(const float* in, int ld_in, int64_t row
     const hipStream_t s = (hipStream_t)stream;
 #define SCH_LAUNCH(NB1)                                                                                        \
     do {                                                                                                       \
-        if (terms == 6 && chain_coop_on()) hipLaunchKernelGGL((mlp_chain_c_kernel<MODE_PLAIN, NB1, 6>), grid, dim3(256), 0, s, C); \
+        /* plain rows, two layers: the lane-is-a-row kernel stays the default (its 32 rows are 16 contiguous KB that the 16 k-steps */ \
+        /* re-read from L1: 168 vs 179 us for the reg head); PRCNN_CHAIN_COOP=2 selects the cooperative form (same bits)            */ \
+        if (terms == 6 && chain_coop_forced()) hipLaunchKernelGGL((mlp_chain_c_kernel<MODE_PLAIN, NB1, 6>), grid, dim3(256), 0, s, C); \
         else if (terms == 6) hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_PLAIN, NB1, 6>), grid, dim3(256), 0, s, C); \
         else hipLaunchKernelGGL((mlp_chain_s_kernel<MODE_PLAIN, NB1, 3>), grid, dim3(256), 0, s, C);            \
     } while (0)

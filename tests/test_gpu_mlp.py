@@ -793,7 +793,7 @@ def test_split_bf16_hoisted_fp0_nonfinite_rows(dev, monkeypatch):
 @pytest.mark.own_arithmetic
 def test_split_chain_forms_are_bit_identical(dev, monkeypatch):
     """round 6: the split-bf16 chain runs in three forms -- lane-is-a-row loads (mlp_chain_s_kernel, PRCNN_CHAIN_COOP=0), cooperative
-    row access through an LDS transposition tile (mlp_chain_c_kernel, PRCNN_CHAIN_PERSIST=0) and the persistent weights-resident form
+    row access through an LDS transposition tile (mlp_chain_c_kernel, PRCNN_CHAIN_PERSIST=0; PRCNN_CHAIN_COOP=2 also for the two-layer heads) and the persistent weights-resident form
     (mlp_chain_p_kernel: hoisted FP0 and the single-channel head).  Same products in the same order: the outputs must be the same
     BITS, on ragged row counts (last tile partly empty, fewer tiles than waves), frames a multiple of 8 (XCD-aware tile order) and
     not, and with a non-finite input row (every form redoes the wave's rows on the fp32 pipe)."""
@@ -807,7 +807,7 @@ def test_split_chain_forms_are_bit_identical(dev, monkeypatch):
 
     def forms(fn):
         outs = []
-        for coop, persist in (("0", "0"), ("1", "0"), ("1", "1")):
+        for coop, persist in (("0", "0"), ("1", "0"), ("2", "0"), ("1", "1")):
             monkeypatch.setenv("PRCNN_CHAIN_COOP", coop)
             monkeypatch.setenv("PRCNN_CHAIN_PERSIST", persist)
             outs.append(fn().clone())
@@ -821,18 +821,18 @@ def test_split_chain_forms_are_bit_identical(dev, monkeypatch):
             x[1234, 5] = np.inf                               # one non-finite row: its wave takes the fp32 redo path in every form
         xt = T(x, dev)
         for l1 in heads:
-            a, b, c = forms(lambda: ops.mlp_chain_rows(xt, [l0, l1]))
-            assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(a.view(torch.int32), c.view(torch.int32)), (rows, l1.nout)
+            outs = forms(lambda: ops.mlp_chain_rows(xt, [l0, l1]))
+            assert all(torch.equal(outs[0].view(torch.int32), o.view(torch.int32)) for o in outs[1:]), (rows, l1.nout)
     for B, n, m in ((8, 4096, 1024), (3, 1000, 250), (16, 256, 64), (1, 40, 7)):
         y = T(r.normal(size=(B, m, 128)).astype(np.float32), dev)
         idx3 = T(r.integers(0, m, size=(B, n, 3)).astype(np.int32), dev)
         w3 = r.random(size=(B, n, 3)).astype(np.float32)
         w3 = T(w3 / w3.sum(-1, keepdims=True), dev)
         bb = T(r.normal(size=(128,)).astype(np.float32), dev)
-        a, b, c = forms(lambda: ops.mlp_chain_interp(y, idx3, w3, None, [l0], act_bias=bb))
-        assert torch.equal(a, b) and torch.equal(a, c), (B, n, m)
+        outs = forms(lambda: ops.mlp_chain_interp(y, idx3, w3, None, [l0], act_bias=bb))
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (B, n, m)
         # strided output: the chain writes into a column window of a wider buffer
-        wide = [torch.zeros((B * n, 160), device=dev) for _ in range(3)]
+        wide = [torch.zeros((B * n, 160), device=dev) for _ in range(4)]
         k = [0]
 
         def into():
@@ -840,5 +840,5 @@ def test_split_chain_forms_are_bit_identical(dev, monkeypatch):
             k[0] += 1
             ops.mlp_chain_interp(y, idx3, w3, None, [l0], out=(o, 32), act_bias=bb)
             return o
-        a, b, c = forms(into)
-        assert torch.equal(a, b) and torch.equal(a, c) and float(a[:, :32].abs().max()) == 0.0
+        outs = forms(into)
+        assert all(torch.equal(outs[0], o) for o in outs[1:]) and float(outs[0][:, :32].abs().max()) == 0.0
