@@ -371,7 +371,7 @@ int prcnn_boxes_iou_bev(const float* boxes_a, int Na, const float* boxes_b, int 
 
 #define PRCNN_NMS_ROTATED 0
 #define PRCNN_NMS_NORMAL 1
-/* workspace bytes prcnn_nms needs for N boxes (the N x ceil(N/64) suppression mask + one flag byte per 64 x 64 tile of it) */
+/* workspace bytes prcnn_nms needs for N boxes (the suppression mask in whole blocks of 64 rows, 64 ceil(N/64) x ceil(N/64) words, + one flag byte per 64 x 64 tile of it) */
 size_t prcnn_nms_workspace_bytes(int N);
 /* Greedy NMS over boxes ALREADY sorted by descending score (iou3d_utils.py:64-66): box i suppresses
  * j>i iff iou(i,j) > thresh.  Entirely on the device: keep (N) i64 receives the kept positions in

@@ -200,10 +200,15 @@ __device__ __forceinline__ void sweep_request(const unsigned long long* __restri
     const int w = blk + 2 + g * 64 + lane;
     has = sweep_tile_flag(sh, W, blk, w);
     if (has) {
+        // (the mask is allocated in whole blocks of 64 rows: rows past the last box are never written and never selected -- kept has no
+        //  bit there -- so a row address is the first row's plus r row strides, no clamp: 16 x 7 scalar instructions less per request)
+        const char* rowb = reinterpret_cast<const char*>(mask + (size_t)(blk * 64 + c * SWEEP_FOLD_ROWS) * W);   // uniform
+        const size_t stride = (size_t)W * 8;
+        const unsigned voff = (unsigned)w * 8u;          // uniform base + 32-bit lane offset: the saddr form of the load, one scalar add per row
 #pragma unroll
         for (int r = 0; r < SWEEP_FOLD_ROWS; r++) {
-            const unsigned long long* rowp = mask + (size_t)min(blk * 64 + c * SWEEP_FOLD_ROWS + r, N - 1) * W;     // uniform
-            part[r] = rowp[w];
+            part[r] = *reinterpret_cast<const unsigned long long*>(rowb + voff);
+            rowb += stride;
         }
     }
 }
@@ -219,10 +224,14 @@ __device__ __forceinline__ bool sweep_fold(const unsigned long long* __restrict_
         if (kb) {
             const int w0 = i + 1 + g * 64 + lane;
             if (has) {                                   // (has implies w0 < W)
-                unsigned long long acc = 0ULL;
+                unsigned lo = 0u, hi = 0u;               // kept rows folded with uniform masks: (row & mask) | acc is one v_and_or_b32 per half
 #pragma unroll
-                for (int r = 0; r < SWEEP_FOLD_ROWS; r++)
-                    if ((kb >> r) & 1u) acc |= part[r];
+                for (int r = 0; r < SWEEP_FOLD_ROWS; r++) {
+                    const unsigned mk = 0u - ((kb >> r) & 1u);
+                    lo |= (unsigned)part[r] & mk;
+                    hi |= (unsigned)(part[r] >> 32) & mk;
+                }
+                const unsigned long long acc = ((unsigned long long)hi << 32) | lo;
                 if (acc) atomicOr(&sh.remv[w0], acc);
             }
             for (int w = w0 + 128; w < W; w += 128) {          // more than 129 blocks (N > 8 256): the far words, not prefetched
@@ -336,7 +345,7 @@ PRCNN_API int prcnn_boxes_iou_bev(const float* boxes_a, int Na, const float* box
 PRCNN_API size_t prcnn_nms_workspace_bytes(int N) {
     if (N <= 0) return 0;
     size_t W = (size_t)(N + 63) / 64;
-    return (size_t)N * W * sizeof(unsigned long long) + W * W;      // suppression mask + one flag byte per 64 x 64 tile
+    return W * 64 * W * sizeof(unsigned long long) + W * W;         // suppression mask (whole blocks of 64 rows) + one flag byte per 64 x 64 tile
 }
 
 PRCNN_API int prcnn_nms(const float* boxes, int N, float thresh, int kind, int max_keep, int64_t* keep, int32_t* num_keep,
@@ -355,7 +364,7 @@ PRCNN_API int prcnn_nms(const float* boxes, int N, float thresh, int kind, int m
     const int W = (N + 63) / 64;
     PRCNN_REQUIRE((size_t)W * 8 <= 60 * 1024, "prcnn_nms: N=%d too large for the LDS suppression bitmap", N);
     unsigned long long* mask = (unsigned long long*)workspace;
-    unsigned char* tflag = (unsigned char*)(mask + (size_t)N * W);
+    unsigned char* tflag = (unsigned char*)(mask + (size_t)W * 64 * W);
     dim3 grid(W, W);
     if (kind == PRCNN_NMS_ROTATED)
         hipLaunchKernelGGL(nms_mask_kernel<PRCNN_NMS_ROTATED>, grid, dim3(64), 0, s, boxes, N, thresh, W, mask, tflag);

@@ -39,7 +39,7 @@ def test_abi_version_and_pure_host_queries():
     assert lib.prcnn_abi_version() >= 9
     assert lib.prcnn_wpack_floats(64, 99) == 2 * 13 * 256
     assert lib.prcnn_wpack_floats(0, 5) == 0
-    assert lib.prcnn_nms_workspace_bytes(6300) == 6300 * 99 * 8 + 99 * 99      # mask + one flag byte per 64 x 64 tile
+    assert lib.prcnn_nms_workspace_bytes(6300) == 99 * 64 * 99 * 8 + 99 * 99      # mask (whole 64-row blocks) + one flag byte per 64 x 64 tile
     assert lib.prcnn_nms_workspace_bytes(0) == 0
 
 
