@@ -817,6 +817,272 @@ __global__ __launch_bounds__(NW * 64) void fps_slot_kernel(const float* __restri
 }
 
 // =====================================================================================================
+// Two samples per exchange (fps_batch_kernel, round 6).  The sample loop is a serial chain -- update, publish, barrier, collect -- of
+// ~1 700 cycles, and only the 2-4 waves a sample reaches do anything in it.  But the table of candidates already holds the NEXT sample
+// in most rounds: let W1 be the wave of the largest candidate (sample j) and W2 the wave of the largest among the other fifteen,
+// value v2.  Sample j + 1 is W2's candidate, provably and before any update has run, when
+//   (a) sample j cannot change W2's points: W2 is not in the REACH MASK published with W1's candidate -- the waves whose box bound
+//       against the candidate was below their maximum when the candidate was found (maxima only shrink: a superset of today's);
+//   (b) v2 > s(W1), an upper bound of the SECOND largest min-distance of W1's points (published too): once sample j is taken W1's
+//       best point drops to 0 and every other only shrinks, so W1's next candidate is <= s(W1);
+//   (c) no third wave holds v2 too (every other wave's next candidate is <= its current one <= v2; a tie would go to the index rule).
+// Distances only shrink, so these are exact: the sample SEQUENCE is the one-at-a-time sequence (tools/fps_batch_sim.py replays the rule
+// on the host against plain FPS: 1.74 samples per exchange on the uniform and the LiDAR-like clouds).  When the proof fails the round
+// carries one sample, as before.  A wave in neither sample's reach mask skips the round with scalar work only; a reached wave tests
+// its own pairs, applies both samples to the pairs each can reach, then finds its new candidate, second value and reach mask ONCE --
+// and not at all when its candidate's own distance did not shrink (then it is still the maximum, and its mask and bound still hold).
+// Every wave runs the proof after the barrier (same table, same decision).
+// MEASURED (16 384 -> 4 096, bs32, tools/fps_timing.py): exact -- every FPS test passes on it -- and 1.74 samples per round as predicted,
+// but a round costs 3 200 cycles against 1 775 for a one-sample round of fps_slot_kernel: 3.09 vs 3.02 ms.  A wave that shares its SIMD
+// with three others issues one instruction per 8-16 cycles whatever its kind, so the ~30 instructions of the proof cost every wave
+// 500-700 cycles per round, and the second value + reach mask + survival test add ~700 to a full update (1 750 vs 970).  Two other
+// arrangements of the same idea: the wave-box test inside the proof instead of a published mask (47 VALU in the proof, nothing added to
+// the update): 2.94 ms, -2.5 %; the last wave to publish running the proof alone for everybody (a returning LDS add as the arrival
+// count, result through the buffer): 730 cycles of a lone wave's dependent instructions on the critical path, 3.15 ms, +4 %.  Opt-in
+// (PRCNN_FPS_BATCH=1), kept as the worked-out form of "more than one sample per barrier".
+// Exchange buffer (three rotate): words 4w.. = {x, y, z, value} of wave w, 64+4w.. = {second value, original index, reach mask, -},
+// 128-129 = the 64-bit maximum cell of fps_slot_kernel.
+// =====================================================================================================
+struct fps_bcand_t { float x, y, z, v, s; unsigned orig, mask; unsigned long long key; };
+__device__ __forceinline__ void fps_bcand_set(fps_bcand_t& c, int wave, float cx, float cy, float cz, float cval, float csec, int corig, unsigned cmask) {
+    const unsigned hi = (unsigned)__float_as_int(cval) ^ 0x80000000u;
+    const unsigned o = (unsigned)min(corig, 0xFFFFFFF);
+    c.x = cx; c.y = cy; c.z = cz; c.v = cval; c.s = csec; c.orig = o; c.mask = cmask; c.key = ((unsigned long long)hi << 32) | ((0xFFFFFFFu - o) << 4) | (unsigned)wave;
+    asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.v), "+v"(c.s), "+v"(c.orig), "+v"(c.mask), "+v"(c.key));
+}
+#define FPS_BT_WORDS 160
+
+template <int PPT, int NW>
+__global__ __launch_bounds__(NW * 64) void fps_batch_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ perm,
+                                                           int N, int npoint, int32_t* __restrict__ idx_out) {
+    static_assert(NW == 16 && PPT == 16, "rows of 16 lanes = the 16 waves; 8 pair boxes");
+    constexpr int BLOCK = NW * 64;
+    typedef typename fvec_t<PPT>::type fvec;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(256))) unsigned xt[3][FPS_BT_WORDS];
+    __shared__ __attribute__((aligned(32))) float wbox[16][8];          // {lo x y z, hi x y z, -, -} of every wave
+    extern __shared__ int s_po[];
+    __builtin_amdgcn_s_setprio(2);
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const float* __restrict__ p = xyz + (size_t)b * N * 3;
+    const int32_t* __restrict__ pm = perm + (size_t)b * N;
+    int32_t* __restrict__ out = idx_out + (size_t)b * npoint;
+
+    fvec px, py, pz, pt;
+    float lox = FPS_BIG, loy = FPS_BIG, loz = FPS_BIG, hix = -FPS_BIG, hiy = -FPS_BIG, hiz = -FPS_BIG;
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        int s = (wave * PPT + i) * 64 + lane;
+        bool ok = s < N;
+        int o = ok ? pm[s] : 0x7fffffff;
+        s_po[i * BLOCK + tid] = o;
+        px[i] = ok ? p[o * 3 + 0] : 0.f;
+        py[i] = ok ? p[o * 3 + 1] : 0.f;
+        pz[i] = ok ? p[o * 3 + 2] : 0.f;
+        pt[i] = ok ? 1e10f : -1.0f;
+        if (ok) {
+            lox = fminf(lox, px[i]); hix = fmaxf(hix, px[i]);
+            loy = fminf(loy, py[i]); hiy = fmaxf(hiy, py[i]);
+            loz = fminf(loz, pz[i]); hiz = fmaxf(hiz, pz[i]);
+        }
+    }
+    lox = wave_min_f32_fused(lox); loy = wave_min_f32_fused(loy); loz = wave_min_f32_fused(loz);
+    hix = wave_max_f32_fused(hix); hiy = wave_max_f32_fused(hiy); hiz = wave_max_f32_fused(hiz);
+    if (lane == 0) { float* wb = wbox[wave]; wb[0] = lox; wb[1] = loy; wb[2] = loz; wb[3] = hix; wb[4] = hiy; wb[5] = hiz; }
+
+    // the pair box a lane tests after the barrier: lanes 0-7 pair l15 against sample 1, lanes 16-23 against sample 2 (the rest: an empty box)
+    float glx = FPS_BIG, gly = FPS_BIG, glz = FPS_BIG, ghx = -FPS_BIG, ghy = -FPS_BIG, ghz = -FPS_BIG;
+#pragma unroll
+    for (int g = 0; g < PPT / 2; g++) {
+        float ax_ = FPS_BIG, ay_ = FPS_BIG, az_ = FPS_BIG, bx_ = -FPS_BIG, by_ = -FPS_BIG, bz_ = -FPS_BIG;
+#pragma unroll
+        for (int i = 2 * g; i < 2 * g + 2; i++)
+            if (pt[i] >= 0.f) {
+                ax_ = fminf(ax_, px[i]); bx_ = fmaxf(bx_, px[i]);
+                ay_ = fminf(ay_, py[i]); by_ = fmaxf(by_, py[i]);
+                az_ = fminf(az_, pz[i]); bz_ = fmaxf(bz_, pz[i]);
+            }
+        ax_ = wave_min_f32_fused(ax_); ay_ = wave_min_f32_fused(ay_); az_ = wave_min_f32_fused(az_);
+        bx_ = wave_max_f32_fused(bx_); by_ = wave_max_f32_fused(by_); bz_ = wave_max_f32_fused(bz_);
+        if (lane < 32 && l15 == g) { glx = ax_; gly = ay_; glz = az_; ghx = bx_; ghy = by_; ghz = bz_; }
+    }
+    if (tid == 0 && npoint > 0) out[0] = 0;
+    // every buffer starts with value 1e10 for every wave (the reach mask of the first candidates is taken against "the previous table")
+    if (tid < 3 * FPS_BT_WORDS) (&xt[0][0])[tid] = (tid % FPS_BT_WORDS < 64 && (tid & 3) == 3) ? __float_as_uint(1e10f) : 0u;
+    __syncthreads();
+    const bool row_s2 = (lane & 16) != 0;          // odd rows look at sample 2
+
+    float x1 = p[0], y1 = p[1], z1 = p[2], x2 = 0.f, y2 = 0.f, z2 = 0.f;
+    float cval = 1e10f, csec = 1e10f; int corig = 0x7fffffff; float cx = 0.f, cy = 0.f, cz = 0.f;
+    fps_bcand_t cand; fps_bcand_set(cand, wave, cx, cy, cz, cval, csec, corig, 0xFFFFu);
+    unsigned live1 = (1u << (PPT / 2)) - 1u, live2 = 0u;          // round 0: sample 0 reaches everything
+    bool second = false, winner = false;          // winner: one of this round's samples is this wave's candidate
+    FPS_T(unsigned long long q_test = 0, q_dist = 0, q_max = 0, q_search = 0, q_pub = 0, q_coll = 0, q_nupd = 0, q_npair = 0, q_rounds = 0, q_proof = 0, q_nproof = 0, q_nfull = 0; unsigned long long q0 = FPS_NOW(wave); const unsigned long long q_begin = q0;)
+    int cb = 1;
+    int j = 1;
+    while (j < npoint) {
+        FPS_T(unsigned long long q1 = FPS_NOW(wave); q_rounds++;)
+        if ((live1 | live2) != 0u) {
+            FPS_T(q_nupd++; q_npair += __builtin_popcount(live1) + __builtin_popcount(live2);)
+#define FPS_BATCH_PAIRS(LIVE, QX, QY, QZ)                                                                                          \
+            {                                                                                                                      \
+                const f32x2 qx = {QX, QX}, qy = {QY, QY}, qz = {QZ, QZ};                                                           \
+                _Pragma("unroll") for (int g = 0; g < PPT / 2; g++) {                                                              \
+                    if (((LIVE) >> g) & 1u) {                                                                                      \
+                        const int i = 2 * g;                                                                                       \
+                        f32x2 d, tb, tc;                                                                                           \
+                        asm("v_pk_add_f32 %[a], %[px], %[qx] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                       \
+                            "v_pk_add_f32 %[b], %[py], %[qy] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                       \
+                            "v_pk_add_f32 %[c], %[pz], %[qz] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                       \
+                            "v_pk_mul_f32 %[a], %[a], %[a]\n\t"                                                                    \
+                            "v_pk_mul_f32 %[b], %[b], %[b]\n\t"                                                                    \
+                            "v_pk_mul_f32 %[c], %[c], %[c]\n\t"                                                                    \
+                            "v_pk_add_f32 %[a], %[a], %[b]\n\t"                                                                    \
+                            "s_nop 0\n\t"                                                                                          \
+                            "v_pk_add_f32 %[a], %[a], %[c]"                                                                        \
+                            : [a] "=&v"(d), [b] "=&v"(tb), [c] "=&v"(tc)                                                           \
+                            : [px] "v"((f32x2){px[i], px[i + 1]}), [py] "v"((f32x2){py[i], py[i + 1]}), [pz] "v"((f32x2){pz[i], pz[i + 1]}), \
+                              [qx] "s"(qx), [qy] "s"(qy), [qz] "s"(qz));                                                           \
+                        pt[i] = __builtin_fminf(pt[i], d.x); pt[i + 1] = __builtin_fminf(pt[i + 1], d.y);                          \
+                    }                                                                                                              \
+                }                                                                                                                  \
+            }
+            if (live1 != 0u) FPS_BATCH_PAIRS(live1, x1, y1, z1)
+            if (live2 != 0u) FPS_BATCH_PAIRS(live2, x2, y2, z2)
+#undef FPS_BATCH_PAIRS
+            FPS_T(unsigned long long q2 = FPS_NOW(wave); q_dist += q2 - q1;)
+            // did the candidate's own distance shrink?  (the pair update's arithmetic, operation for operation, on the candidate's
+            // coordinates; a pair that was not live cannot have changed it: its bound is >= cval)  If not it is still the wave's maximum --
+            // every other distance only shrank -- and the published second value and reach mask still bound what they bound.
+            const float e1x = __fsub_rn(cx, x1), e1y = __fsub_rn(cy, y1), e1z = __fsub_rn(cz, z1);
+            const float e1 = __fadd_rn(__fadd_rn(__fmul_rn(e1x, e1x), __fmul_rn(e1y, e1y)), __fmul_rn(e1z, e1z));
+            const float e2x = __fsub_rn(cx, x2), e2y = __fsub_rn(cy, y2), e2z = __fsub_rn(cz, z2);
+            const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(e2x, e2x), __fmul_rn(e2y, e2y)), __fmul_rn(e2z, e2z));
+            const bool shrunk = winner || (e1 < cval) || (second && e2 < cval) || cval >= 1e10f;
+            if (shrunk) {
+            FPS_T(q_nfull++;)
+            // operands of the reach mask, consumed after the search: the waves' boxes and their values in the PREVIOUS table (the one
+            // this round's samples came from; today's values are <= those)
+            const f32x4 wlo = *reinterpret_cast<const f32x4*>(&wbox[l15][0]);
+            const f32x2 whi = *reinterpret_cast<const f32x2*>(&wbox[l15][4]);
+            const float pval = __uint_as_float(xt[cb == 0 ? 2 : cb - 1][l15 * 4 + 3]);
+            const float m0 = __builtin_fmaxf(__builtin_fmaxf(pt[0], pt[1]), pt[2]), m1 = __builtin_fmaxf(__builtin_fmaxf(pt[3], pt[4]), pt[5]);
+            const float m2 = __builtin_fmaxf(__builtin_fmaxf(pt[6], pt[7]), pt[8]), m3 = __builtin_fmaxf(__builtin_fmaxf(pt[9], pt[10]), pt[11]);
+            const float m4 = __builtin_fmaxf(__builtin_fmaxf(pt[12], pt[13]), pt[14]);
+            const float best = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), m2), __builtin_fmaxf(__builtin_fmaxf(m3, m4), pt[15]));
+            unsigned eqbits;
+            const int wvec = wave_max_eq2_16(pt, best, eqbits);
+            const int wmax = __builtin_amdgcn_readlane(wvec, 63);
+            const int myorig = s_po[__builtin_ctz(eqbits) * BLOCK + tid];
+            __builtin_amdgcn_sched_barrier(0);
+            FPS_T(unsigned long long q3 = FPS_NOW(wave); q_max += q3 - q2;)
+            const float wmaxf = __int_as_float(wmax);
+            const unsigned long long anym = __ballot(best == wmaxf);
+            const int owner0 = __builtin_ctzll(anym);
+            const unsigned ownbits = (unsigned)__builtin_amdgcn_readlane((int)eqbits, owner0);
+            const int total = (__popcll(anym) + __popc(ownbits) == 2) ? 1 : 2;
+            int istar = __builtin_ctz(ownbits);
+            const float fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[istar]), owner0));
+            const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[istar]), owner0));
+            const float fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[istar]), owner0));
+            __builtin_amdgcn_sched_barrier(0);
+            const int corig_fast = __builtin_amdgcn_readlane(myorig, owner0);
+            if (total == 1) {
+                corig = corig_fast; cx = fx; cy = fy; cz = fz;
+                // the second value: the lane maxima of the other lanes, and the owner lane's with its slot istar left out
+                const float keep = pt[istar];
+                pt[istar] = -2.0f;
+                const float n0 = __builtin_fmaxf(__builtin_fmaxf(pt[0], pt[1]), pt[2]), n1 = __builtin_fmaxf(__builtin_fmaxf(pt[3], pt[4]), pt[5]);
+                const float n2 = __builtin_fmaxf(__builtin_fmaxf(pt[6], pt[7]), pt[8]), n3 = __builtin_fmaxf(__builtin_fmaxf(pt[9], pt[10]), pt[11]);
+                const float n4 = __builtin_fmaxf(__builtin_fmaxf(pt[12], pt[13]), pt[14]);
+                const float lane2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(n0, n1), n2), __builtin_fmaxf(__builtin_fmaxf(n3, n4), pt[15]));
+                pt[istar] = keep;
+                csec = wave_max_f32_fused(lane == owner0 ? lane2 : best);
+            } else {
+                int bo = 0x7fffffff; float bx = 0.f, by = 0.f, bz = 0.f;
+                if (best == wmaxf) {
+#pragma unroll
+                    for (int i = PPT - 1; i >= 0; i--) {
+                        const int oi = s_po[i * BLOCK + tid];
+                        if (pt[i] == wmaxf && oi <= bo) { bo = oi; bx = px[i]; by = py[i]; bz = pz[i]; }
+                    }
+                }
+                corig = wave_min_i32_fused(bo);
+                const int owner = __builtin_ctzll(__ballot(bo == corig));
+                cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), owner));
+                cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), owner));
+                cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), owner));
+                csec = wmaxf;                      // several points hold the maximum: the wave's next candidate may equal this one
+            }
+            cval = wmaxf;
+            // the candidate's reach mask: lane w tests wave w's box against it (the bound fps_slot_kernel uses for its own wave)
+            const float hx = fmaxf(fmaxf(wlo.x - cx, cx - wlo.w), 0.f), hy = fmaxf(fmaxf(wlo.y - cy, cy - whi.x), 0.f), hz = fmaxf(fmaxf(wlo.z - cz, cz - whi.y), 0.f);
+            const float Lw = __fadd_rn(__fadd_rn(__fmul_rn(hx, hx), __fmul_rn(hy, hy)), __fmul_rn(hz, hz));
+            const unsigned cmask = ((unsigned)__ballot(Lw < pval) & 0xFFFFu) | (1u << wave_u);
+            fps_bcand_set(cand, wave, cx, cy, cz, cval, csec, corig, cmask);
+            FPS_T(q_search += FPS_NOW(wave) - q3;)
+            }
+            __builtin_amdgcn_s_setprio(2);
+        }
+        FPS_T(unsigned long long q4 = FPS_NOW(wave);)
+        unsigned* t = xt[cb];
+        if (lane == 0) {
+            *reinterpret_cast<f32x4*>(t + wave * 4) = (f32x4){cand.x, cand.y, cand.z, cand.v};
+            *reinterpret_cast<u32x4*>(t + 64 + wave * 4) = (u32x4){__float_as_uint(cand.s), cand.orig, cand.mask, 0u};
+            asm volatile("ds_max_u64 %0, %1 offset:512" : : "v"((unsigned)(size_t)&t[0]), "v"(cand.key) : "memory");
+            if (wave == 0) *(unsigned long long*)&xt[cb == 2 ? 0 : cb + 1][128] = 0ULL;
+        }
+        __syncthreads();
+        FPS_T(unsigned long long q5 = FPS_NOW(wave); q_pub += q5 - q4;)
+        // ---- collect + the proof for a second sample (every wave, the same table: the same decision) ----
+        const f32x4 ta = *reinterpret_cast<const f32x4*>(t + l15 * 4);                 // {x, y, z, value} of wave l15
+        const u32x4 tb = *reinterpret_cast<const u32x4*>(t + 64 + l15 * 4);            // {second value, original index, reach mask, -}
+        const unsigned klo = (unsigned)__builtin_amdgcn_readfirstlane((int)t[128]);
+        const int w1 = (int)(klo & 15u);
+        const int gorig1 = (int)(0xFFFFFFFu - (klo >> 4));
+        if ((unsigned)(wave_u - w1 + 1) <= 2u) __builtin_amdgcn_s_setprio(3);          // the winner's wave and its Morton neighbours go first
+        const int s1 = __builtin_amdgcn_readlane((int)tb.x, w1);
+        const unsigned mask1 = (unsigned)__builtin_amdgcn_readlane((int)tb.z, w1);
+        // the largest value among the other fifteen waves (float bits compare as integers: values are >= 0, or -1 for an all-padding wave)
+        const int tv = (l15 == w1) ? (int)0x80000000 : __float_as_int(ta.w);
+        const int v2 = row0_max_i32_fused(tv);
+        const unsigned m2nd = (unsigned)__ballot(tv == v2) & 0xFFFFu;
+        const int w2 = __builtin_ctz(m2nd);
+        const int gorig2 = __builtin_amdgcn_readlane((int)tb.y, w2);
+        const unsigned mask2 = (unsigned)__builtin_amdgcn_readlane((int)tb.z, w2);
+        second = (__builtin_popcount(m2nd) == 1) && (v2 > s1) && (v2 > 0) && (j + 1 < npoint) && ((mask1 >> w2) & 1u) == 0u;
+        const unsigned reached = mask1 | (second ? mask2 : 0u);
+        winner = wave_u == w1 || (second && wave_u == w2);
+        live1 = 0u; live2 = 0u;
+        if ((reached >> wave_u) & 1u) {
+            __builtin_amdgcn_s_setprio(3);
+            x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta.x), w1));
+            y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta.y), w1));
+            z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta.z), w1));
+            x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta.x), w2));
+            y2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta.y), w2));
+            z2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta.z), w2));
+            const float qx = row_s2 ? x2 : x1, qy = row_s2 ? y2 : y1, qz = row_s2 ? z2 : z1;
+            const float hx = fmaxf(fmaxf(glx - qx, qx - ghx), 0.f), hy = fmaxf(fmaxf(gly - qy, qy - ghy), 0.f), hz = fmaxf(fmaxf(glz - qz, qz - ghz), 0.f);
+            const float Lg = __fadd_rn(__fadd_rn(__fmul_rn(hx, hx), __fmul_rn(hy, hy)), __fmul_rn(hz, hz));
+            const unsigned reach = (unsigned)__ballot(Lg < cval);
+            live1 = reach & 0xFFu;
+            live2 = second ? (reach >> 16) & 0xFFu : 0u;
+            if ((live1 | live2) == 0u) __builtin_amdgcn_s_setprio(2);
+        } else __builtin_amdgcn_s_setprio(2);
+        cb = cb == 2 ? 0 : cb + 1;
+        if (tid == 0) { out[j] = gorig1; if (second) out[j + 1] = gorig2; }
+        j += second ? 2 : 1;
+        FPS_T(q0 = FPS_NOW(wave); q_coll += q0 - q5;)
+    }
+    FPS_T(if (b == 0 && lane == 0) { unsigned long long* d = prcnn_fps_dbg + 144 + wave * 16; d[0] = q_test; d[1] = q_dist; d[2] = q_max; d[3] = q_search; d[4] = q_pub;
+                                     d[5] = q_coll; d[6] = q_nupd; d[7] = q_npair; d[8] = FPS_NOW(wave) - q_begin; d[9] = q_rounds; d[10] = q_proof; d[11] = q_nproof; d[12] = q_nfull; })
+}
+
+// =====================================================================================================
 // N > 16384 (BASELINE config 5: 65 536 points per frame): the frame does not fit one workgroup's registers (1024 threads x
 // 16 points), and re-reading it from L2 every iteration (fps_mem_kernel below) costs ~12 us per sample.  Here a frame is
 // owned by S = ceil(N / 16384) workgroups, each keeping its 16384-point slice and running min-distances in VGPRs exactly
@@ -1034,7 +1300,15 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
         static PrcnnLdsLimit slot_attr;
         if (slots && N > 8192 && !slot_attr.raise((const void*)fps_slot_kernel<16, 16>, 16 * 4096))
             return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the slot kernel");
-        if (slots && N > 8192) hipLaunchKernelGGL((fps_slot_kernel<16, 16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);
+        // two samples per exchange where the second is provable (fps_batch_kernel; same bits): measured 2-3 % SLOWER than the slot kernel
+        // (DESIGN.md 8), so it is opt-in, PRCNN_FPS_BATCH=1
+        const char* batch_env = getenv("PRCNN_FPS_BATCH");
+        const bool batch = batch_env != nullptr && atoi(batch_env) != 0;
+        static PrcnnLdsLimit batch_attr;
+        if (slots && batch && N > 8192 && !batch_attr.raise((const void*)fps_batch_kernel<16, 16>, 16 * 4096))
+            return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the batch kernel");
+        if (slots && batch && N > 8192) hipLaunchKernelGGL((fps_batch_kernel<16, 16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);
+        else if (slots && N > 8192) hipLaunchKernelGGL((fps_slot_kernel<16, 16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);
         else if (N <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4>), dim3(B), dim3(1024), 4 * 4096, s, xyz, perm, N, npoint, idx);
         else if (N <= 8192) hipLaunchKernelGGL((fps_pruned_kernel<8>), dim3(B), dim3(1024), 8 * 4096, s, xyz, perm, N, npoint, idx);
         else hipLaunchKernelGGL((fps_pruned_kernel<16>), dim3(B), dim3(1024), 16 * 4096, s, xyz, perm, N, npoint, idx);

@@ -196,7 +196,7 @@ def test_op_argument_errors(dev):
         ops.furthest_point_sample(torch.zeros(1, 10, 3, device=dev), 11)          # npoint > N
 
 
-@pytest.mark.parametrize("pruned", [True, "one-level", False])
+@pytest.mark.parametrize("pruned", [True, "one-level", "batch", False])
 @pytest.mark.parametrize("B,N,npoint", [(2, 16384, 2048), (2, 12000, 1500), (2, 4096, 1024), (1, 8192, 700), (2, 5000, 333), (1, 2049, 64)])
 def test_fps_pruned_and_plain_variants_are_bit_identical(dev, cpu, monkeypatch, B, N, npoint, pruned):
     """the FPS kernels for 2048 < N <= 16384 -- the spatially pruned ones (Morton pre-sort + exact bounding-box skip, csrc/fps.hip:
@@ -208,6 +208,8 @@ def test_fps_pruned_and_plain_variants_are_bit_identical(dev, cpu, monkeypatch, 
     ops.FPS_PRUNED = bool(pruned)
     if pruned == "one-level":
         monkeypatch.setenv("PRCNN_FPS_SLOTS", "0")
+    if pruned == "batch":                                             # two samples per exchange where the second is provable (opt-in)
+        monkeypatch.setenv("PRCNN_FPS_BATCH", "1")
     try:
         clouds = [kitti_cloud(B, N, seed=N)]
         dup = clouds[0].copy()
@@ -224,8 +226,8 @@ def test_fps_pruned_and_plain_variants_are_bit_identical(dev, cpu, monkeypatch, 
         ops.FPS_PRUNED = old
 
 
-@pytest.mark.parametrize("busy", [False, True])
-def test_fps_slot_masks_on_ties_in_every_slot_alone_and_under_co_resident_waves(dev, cpu, busy):
+@pytest.mark.parametrize("busy", [False, True, "batch"])
+def test_fps_slot_masks_on_ties_in_every_slot_alone_and_under_co_resident_waves(dev, cpu, busy, monkeypatch):
     """round-5 advisor finding: the hand-scheduled slot-mask blocks (csrc/fps.hip WaveMaxEq / wave_max_eq2_16) read a compare's
     SGPR pair from a v_addc the hazard recognizer cannot see.  Directed at them: clouds on which the maximum is held by SEVERAL slots of
     one lane in every sample -- each point 16 / 8 / 2 times (equal Morton keys: the copies are consecutive in the sorted order, so they
@@ -233,6 +235,9 @@ def test_fps_slot_masks_on_ties_in_every_slot_alone_and_under_co_resident_waves(
     (4096 -> 1024) and the single-wave kernels, once on an idle chip and once while matrix products from another stream share the CUs
     (the VALU co-issue conditions differ).  Indices must equal the oracle's (ties -> lowest original index)."""
     from pointrcnn_amd import ops
+    if busy == "batch":                      # the same clouds through fps_batch_kernel (ties fail its proof: one sample per round)
+        monkeypatch.setenv("PRCNN_FPS_BATCH", "1")
+        busy = False
     side = torch.cuda.Stream()
     a = torch.randn(4096, 4096, device=dev)
     stop = [False]

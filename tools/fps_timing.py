@@ -47,7 +47,12 @@ if "--run" in sys.argv:
               (u[0] / d[3], u[1] / d[3], u[2] / d[3], u[3] / d[3], (d[0] - sum(u)) / max(1, 4095 - d[3])))
     print("fps_slot_kernel<16> (the default at this size), frame 0, cycles per sample: bound test | publish+barrier | collect  ;  per UPDATE: distances | max+slot masks | search+selects+candidate ; updates, live pairs per update")
     for w in ([int(tw[0])] if tw else range(16)):
-        d = buf[144 + w * 16:144 + w * 16 + 9]
+        d = buf[144 + w * 16:144 + w * 16 + 13]
         n = max(1, d[6])
+        if d[9]:             # fps_batch_kernel: per exchange ROUND (one or two samples)
+            r = d[9]
+            print("%4d  batch kernel: rounds %d (%.2f samples per round) | per round: update-phase %5.0f  pub+barrier %5.0f  collect+proof+test %5.0f  total %6.0f | per UPDATE: dist %5.0f  max %5.0f  search+second %5.0f | updates %5d (%.2f of rounds)  live pairs/update %.2f | full updates %d | proofs run by this wave %d, %5.0f cycles each" %
+                  (w, r, 4095.0 / r, (d[1] + d[2] + d[3]) / r, d[4] / r, d[5] / r, d[8] / r, d[1] / n, d[2] / max(1, d[12]), d[3] / max(1, d[12]), d[6], d[6] / r, d[7] / n, d[12], d[11], d[10] / max(1, d[11])))
+            continue
         print("%4d  test %5.0f  pub+barrier %5.0f  collect %5.0f | dist %5.0f  max %5.0f  search %5.0f | updates %5d (%.2f of samples)  pairs/update %.2f | loop total/sample %6.0f" %
               (w, d[0] / 4095, d[4] / 4095, d[5] / 4095, d[1] / n, d[2] / n, d[3] / n, d[6], d[6] / 4095.0, d[7] / n, d[8] / 4095))
