@@ -485,6 +485,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
     float cval = 1e10f; int corig = 0x7fffffff; float cx = 0.f, cy = 0.f, cz = 0.f;
     fps_cand_t cand; fps_cand_set(cand, wave, cx, cy, cz, cval, corig);
     bool first = true;
+    int wprev = -1;                            // the wave whose candidate is the current sample
 
     FPS_T(unsigned long long t_upd = 0, t_wait = 0, t_red = 0, n_upd = 0, t_u1 = 0, t_u2 = 0, t_u3 = 0, t_u4 = 0; unsigned long long t0 = __builtin_readcyclecounter();)
     FPS_T(const unsigned long long t_begin = t0;)
@@ -523,6 +524,13 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
                 pt[0] = t; best = t;
             }
             FPS_T(unsigned long long u1 = __builtin_readcyclecounter(); t_u1 += u1 - u0;)
+            // Round 6: a candidate whose own distance did not shrink is still the wave's maximum (see fps_slot_kernel): republish it as it is
+            bool shrunk = wave_u == wprev || first;
+            if (!shrunk) {
+                const float ex = __fsub_rn(cx, x0), ey = __fsub_rn(cy, y0), ez = __fsub_rn(cz, z0);
+                shrunk = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)) < cval;
+            }
+            if (shrunk) {
             unsigned eqbits;
             const int wvec = WaveMaxEq<PPT>::run(pt, best, eqbits);          // lane 63 = the wave maximum
             // every lane fetches the original index of ITS OWN candidate (lowest slot holding the lane's maximum) as soon as the slot
@@ -572,8 +580,9 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
             cval = wmaxf;
             first = false;
             fps_cand_set(cand, wave, cx, cy, cz, cval, corig);
-            __builtin_amdgcn_s_setprio(2);
             FPS_T(t_u4 += __builtin_readcyclecounter() - u3;)
+            }
+            __builtin_amdgcn_s_setprio(2);
         }
 #if FPS_V & 2
         else __builtin_amdgcn_s_setprio(2);
@@ -588,6 +597,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(const float* __restric
 #if FPS_V & 2
         if ((unsigned)(wave_u - wwin + 1) <= 2u) __builtin_amdgcn_s_setprio(3);          // see fps_slot_kernel
 #endif
+        wprev = wwin;
         cb = cb == 2 ? 0 : cb + 1;
         if (tid == 0) out[j] = gorig;
         FPS_T(t0 = __builtin_readcyclecounter(); t_red += t0 - t2;)
@@ -667,6 +677,7 @@ __global__ __launch_bounds__(NW * 64) void fps_slot_kernel(const float* __restri
     float cval = 1e10f; int corig = 0x7fffffff; float cx = 0.f, cy = 0.f, cz = 0.f;
     fps_cand_t cand; fps_cand_set(cand, wave, cx, cy, cz, cval, corig);
     bool first = true;
+    int wprev = -1;                            // the wave whose candidate is the current sample
     FPS_T(unsigned long long q_test = 0, q_dist = 0, q_max = 0, q_search = 0, q_pub = 0, q_coll = 0, q_nupd = 0, q_npair = 0; unsigned long long q0 = FPS_NOW(wave); const unsigned long long q_begin = q0;)
     int cb = 1;                                // exchange cell of sample j: j % 3
     for (int j = 1; j < npoint; j++) {
@@ -717,6 +728,17 @@ __global__ __launch_bounds__(NW * 64) void fps_slot_kernel(const float* __restri
                 }
             }
             FPS_T(unsigned long long q2 = FPS_NOW(wave); q_dist += q2 - q1;)
+            // Round 6: did the candidate's own distance shrink?  (the pair update's arithmetic, operation for operation, on the candidate's
+            // coordinates; a pair that was not live cannot have changed it: its bound is >= cval.)  If not, it is still the wave's maximum --
+            // every other distance only shrank, and it beat its equals on the index rule already -- and the wave republishes it as it is:
+            // no lane maximum, slot masks, wave maximum or owner search (2/3 of the updates of the waves next to the winner's; the
+            // winner's own wave always recomputes: its candidate IS the sample).
+            bool shrunk = wave_u == wprev || first;
+            if (!shrunk) {
+                const float ex = __fsub_rn(cx, x0), ey = __fsub_rn(cy, y0), ez = __fsub_rn(cz, z0);
+                shrunk = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)) < cval;
+            }
+            if (shrunk) {
 #if (FPS_V & 4)
             float best;
             if (PPT == 16) {                         // a tree: neighbouring instructions are independent (a chain waits ~6 cycles per link)
@@ -791,6 +813,7 @@ __global__ __launch_bounds__(NW * 64) void fps_slot_kernel(const float* __restri
             first = false;
             fps_cand_set(cand, wave, cx, cy, cz, cval, corig);
             FPS_T(q_search += FPS_NOW(wave) - q3;)
+            }
             __builtin_amdgcn_s_setprio(2);
         }
 #if FPS_V & 2
@@ -808,6 +831,7 @@ __global__ __launch_bounds__(NW * 64) void fps_slot_kernel(const float* __restri
         // probably do: they take their bound test ahead of the three waves they share a SIMD with instead of in arrival order
         if ((unsigned)(wave_u - wwin + 1) <= 2u) __builtin_amdgcn_s_setprio(3);          // scalar compare + branch
 #endif
+        wprev = wwin;
         cb = cb == 2 ? 0 : cb + 1;
         if (tid == 0) out[j] = gorig;
         FPS_T(q0 = FPS_NOW(wave); q_coll += q0 - q5;)
