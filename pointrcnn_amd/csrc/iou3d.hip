@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
         const int start = (row_blk == col_blk) ? t + 1 : 0;    // iou3d_kernel.cu:281-283
         int np = 0;                                      // uniform: one wave per workgroup
         for (int i = 0; i < col_size; i++) {
-            const bool pass = row < N && i >= start && !(skip_far && far_apart(srow[t], scol[i]));
+            const bool pass = row < N && i >= start && !(skip_far && decided_without_clip(srow[t], scol[i], thresh));
             const unsigned long long bm = __ballot(pass);
             if (pass) plist[np + (int)__popcll(bm & ((1ULL << t) - 1ULL))] = (unsigned short)((t << 6) | i);
             np += (int)__popcll(bm);

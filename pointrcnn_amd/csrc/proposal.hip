@@ -387,7 +387,7 @@ __device__ __forceinline__ void make_box(const float (&v)[5], NBox& r) {
 }
 // does the earlier (higher-score) box suppress the later one?  iou3d_kernel.cu:284-286 / :339-341
 __device__ __forceinline__ bool suppresses(const RBox& earlier, const RBox& later, float thresh) {
-    if (thresh >= 0.0f && far_apart(earlier, later)) return false;       // overlap is exactly 0 there
+    if (thresh >= 0.0f && decided_without_clip(earlier, later, thresh)) return false;       // overlap exactly 0, or provably below the threshold
     return iou_bev(earlier, later) > thresh;
 }
 __device__ __forceinline__ bool suppresses(const NBox& earlier, const NBox& later, float thresh) {
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(NMS_THREADS) void greedy_nms_kernel(NmsParams P) {
                 for (int q = tid; q < 64 * 32; q += NMS_THREADS) {
                     const int c = q & 63, kk = q >> 6;
                     bool pass = kk < nt && c < nc;
-                    if (pass && prefilter) pass = !far_apart(keptb[k0 + kk], cand[c]);
+                    if (pass && prefilter) pass = !decided_without_clip(keptb[k0 + kk], cand[c], thresh);
                     push_pairs(pass, ((unsigned)(k0 + kk) << 6) | (unsigned)c, pairs, &sh[1]);
                 }
                 __syncthreads();
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(NMS_THREADS) void greedy_nms_kernel(NmsParams P) {
             for (int q = tid; q < 64 * 64; q += NMS_THREADS) {
                 const int c = q & 63, r = q >> 6;
                 bool pass = r < c && ((alive >> r) & 1ULL) && ((alive >> c) & 1ULL);
-                if (pass && prefilter) pass = !far_apart(cand[r], cand[c]);
+                if (pass && prefilter) pass = !decided_without_clip(cand[r], cand[c], thresh);
                 push_pairs(pass, ((unsigned)r << 6) | (unsigned)c, pairs, &sh[1]);   // <= 2016 entries
             }
             __syncthreads();
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(NMS_RT) void greedy_nms_rot_kernel(NmsParams P) {
             if (alive) {
                 float dbest = 3.0e38f;
                 for (int k = 0; k < nk0; k++) {
-                    if (prefilter && far_apart(keptb[k], me)) continue;
+                    if (prefilter && decided_without_clip(keptb[k], me, thresh)) continue;
                     const float dx = sub(keptb[k].cx, me.cx), dy = sub(keptb[k].cy, me.cy);
                     const float d = add(mul(dx, dx), mul(dy, dy));
                     if (kbest < 0 || d < dbest) { dbest = d; kbest = k; }
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(NMS_RT) void greedy_nms_rot_kernel(NmsParams P) {
             bool scanning = alive && kbest >= 0;
             while (__any(scanning)) {
                 if (scanning) {
-                    while (k < nk0 && (k == kbest || (prefilter && far_apart(keptb[k], me)))) k++;
+                    while (k < nk0 && (k == kbest || (prefilter && decided_without_clip(keptb[k], me, thresh)))) k++;
                     scanning = k < nk0;
                 }
                 if (scanning) {
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(NMS_RT) void greedy_nms_rot_kernel(NmsParams P) {
                 for (int q = tid; q < 64 * 32; q += NMS_RT) {
                     const int c = q & 63, kk = q >> 6;
                     bool pass = kk < nt && c < nc;
-                    if (pass && prefilter) pass = !far_apart(keptb[k0 + kk], cand[c]);
+                    if (pass && prefilter) pass = !decided_without_clip(keptb[k0 + kk], cand[c], thresh);
                     push_pairs(pass, ((unsigned)(k0 + kk) << 6) | (unsigned)c, pairs, &sh[1]);
                 }
                 __syncthreads();
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(NMS_RT) void greedy_nms_rot_kernel(NmsParams P) {
             for (int q = tid; q < 64 * 64; q += NMS_RT) {
                 const int c = q & 63, r = q >> 6;
                 bool pass = r < c && ((live >> r) & 1ULL) && ((live >> c) & 1ULL);
-                if (pass && prefilter) pass = !far_apart(cand[r], cand[c]);
+                if (pass && prefilter) pass = !decided_without_clip(cand[r], cand[c], thresh);
                 push_pairs(pass, ((unsigned)r << 6) | (unsigned)c, pairs, &sh[1]);   // <= 2016 entries
             }
             __syncthreads();
