@@ -27,4 +27,6 @@ cp $R/kernel_stats_reference.txt profiles/${T}_final_kernel_stats_reference.txt
 cp $R/arith_disagreement.json profiles/${T}_arith_disagreement.json
 [ -s $R/mlp_chain_timing.txt ] && cp $R/mlp_chain_timing.txt profiles/${T}_mlp_chain_timing.txt
 [ -s $R/nms_sweep_timing.txt ] && cp $R/nms_sweep_timing.txt profiles/${T}_nms_sweep_timing.txt
+[ -s $R/fps_timing_all_waves.txt ] && cp $R/fps_timing_all_waves.txt profiles/${T}_fps_timing_all_waves.txt
+[ -s $R/fps_batch_vs_slot.txt ] && cp $R/fps_batch_vs_slot.txt profiles/${T}_fps_batch_vs_slot.txt
 ls -la profiles

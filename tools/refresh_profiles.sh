@@ -42,6 +42,8 @@ python profiles/summarize_rocprof.py $O/ktref "python bench_reference.py 12 (the
 python tools/arith_disagreement.py --out $O/arith_disagreement.json > /dev/null 2>> $O/bench_default.err
 PRCNN_POINTOPS_LIB=pointrcnn_amd/lib/libprcnn_mlptiming.so python tools/mlp_timing.py > $O/mlp_chain_timing.txt 2>/dev/null
 PRCNN_POINTOPS_LIB=pointrcnn_amd/lib/libprcnn_sweeptiming.so python tools/nms_timing.py 6300 > $O/nms_sweep_timing.txt 2>/dev/null
+[ -f pointrcnn_amd/lib/libprcnn_fpstiming.so ] && python tools/fps_timing.py --no-build --run 2>/dev/null | grep -v amdgpu.ids > $O/fps_timing_all_waves.txt
+python tools/fps_batch_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/fps_batch_vs_slot.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/op_FETCH_SIZE -- python -m pointrcnn_amd.opbench > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/op_WRITE_SIZE -- python -m pointrcnn_amd.opbench > /dev/null 2>&1
 python profiles/join_op_traffic.py $O/opbench_raw.jsonl /tmp/op_ $O/opbench.jsonl > /dev/null 2>> $O/opbench.err
