@@ -292,20 +292,23 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float* __restrict_
 #define FPS_PAIR_ASM 1          // 0: the compiler's order of the pair update (A/B switch of the build)
 #endif
 
-__device__ __forceinline__ unsigned morton_spread10(unsigned v) {       // 10 bits -> every third bit
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
+__device__ __forceinline__ unsigned morton_spread6(unsigned v) {       // 6 bits -> every third bit
+    v &= 0x3fu;
+    v = (v | (v << 8)) & 0x0000300fu;
+    v = (v | (v << 4)) & 0x000030c3u;
+    v = (v | (v << 2)) & 0x00009249u;
     return v;
 }
 
 // One workgroup per frame: perm[s] = original index of the s-th point in Morton order (stable on the index).
-// 64-bit keys (morton << 32 | index) sorted by the shared LDS bitonic sort (lds_sort.h: strides <= 8 in registers);
-// NP = power of two >= N (<= 16384 -> 136 KB of LDS); blockDim = max(64, NP / 16) threads.
+// 32-bit keys (18-bit Morton code << 14 | index; N <= 16 384) sorted by the shared LDS bitonic sort (lds_sort.h: strides <= 8 in
+// registers); NP = power of two >= N (<= 16384 -> 68 KB of LDS); blockDim = max(64, NP / 16) threads.
+// Round 6: the keys were 64 bits (30-bit code, 32-bit index) -- the sort is bound by LDS bandwidth (55 passes over the keys), so half
+// the key is half the time (95 -> ~50 us per 16 384-point frame set) and half the LDS (136 -> 68 KB, which kept every other
+// workgroup off the CU).  The order only decides how compact a slot's 64 points are, never a result (ties go to the ORIGINAL index
+// inside the FPS kernels): 64 cells per axis leave ~1 point per occupied cell at 16 384 points.
 __global__ __launch_bounds__(1024) void fps_sort_kernel(const float* __restrict__ xyz, int N, int NP, int32_t* __restrict__ perm) {
-    extern __shared__ u64 keys[];
+    extern __shared__ unsigned keys[];
     __shared__ float red[6][16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const float* __restrict__ p = xyz + (size_t)b * N * 3;
@@ -325,20 +328,20 @@ __global__ __launch_bounds__(1024) void fps_sort_kernel(const float* __restrict_
         float l = red[a][0], h = red[3 + a][0];
         for (int w = 1; w < nw; w++) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
         lo[a] = l;
-        scale[a] = (h > l) ? 1023.0f / (h - l) : 0.f;
+        scale[a] = (h > l) ? 63.0f / (h - l) : 0.f;
     }
-    u64 v[16];
+    unsigned v[16];
     if (tid * 16 < NP) {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int k = tid * 16 + e;
-            u64 key = ~0ULL;                                // padding sorts to the end
+            unsigned key = ~0u;                             // padding sorts to the end
             if (k < N) {
                 unsigned qx = (unsigned)((p[k * 3 + 0] - lo[0]) * scale[0]);
                 unsigned qy = (unsigned)((p[k * 3 + 1] - lo[1]) * scale[1]);
                 unsigned qz = (unsigned)((p[k * 3 + 2] - lo[2]) * scale[2]);
-                unsigned m = (morton_spread10(qx) << 2) | (morton_spread10(qz) << 1) | morton_spread10(qy);
-                key = ((u64)m << 32) | (unsigned)k;
+                unsigned m = (morton_spread6(qx) << 2) | (morton_spread6(qz) << 1) | morton_spread6(qy);
+                key = (m << 14) | (unsigned)k;
             }
             v[e] = key;
         }
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(1024) void fps_sort_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int k = tid * 16 + e;
-            if (k < N) perm[(size_t)b * N + k] = (int32_t)(unsigned)v[e];
+            if (k < N) perm[(size_t)b * N + k] = (int32_t)(v[e] & 0x3fffu);
         }
     }
 }
@@ -1309,10 +1312,10 @@ PRCNN_API int prcnn_fps(const float* xyz, int B, int N, int npoint, float* tmp, 
         while (NP < N) NP <<= 1;
         int32_t* perm = reinterpret_cast<int32_t*>(tmp);
         static PrcnnLdsLimit sort_attr;
-        if (!sort_attr.raise((const void*)fps_sort_kernel, 150 * 1024))
+        if (!sort_attr.raise((const void*)fps_sort_kernel, 80 * 1024))
             return prcnn_fail(PRCNN_EHIP, "prcnn_fps: cannot raise the dynamic LDS limit of the sort kernel");
         const int sort_threads = NP / 16 < 64 ? 64 : NP / 16;
-        hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(sort_threads), lds_sort_bytes(NP), s, xyz, N, NP, perm);
+        hipLaunchKernelGGL(fps_sort_kernel, dim3(B), dim3(sort_threads), lds_sort_bytes(NP, sizeof(unsigned)), s, xyz, N, NP, perm);
         PRCNN_LAUNCH_CHECK("prcnn_fps(sort)");
         static PrcnnLdsLimit pruned_attr;
         if (!pruned_attr.raise((const void*)fps_pruned_kernel<16>, 16 * 4096))

@@ -1,4 +1,4 @@
-// lds_sort.h -- workgroup-wide bitonic sort of 64-bit keys held in LDS, 16 keys per owning thread.
+// lds_sort.h -- workgroup-wide bitonic sort of 64-bit (or 32-bit) keys held in LDS, 16 keys per owning thread.
 //
 // Strides >= 16 are compare-exchanged through LDS (one barrier per stride), strides 8..1 and the first four stages
 // entirely in the owning thread's registers: 16 384 keys take 55 LDS passes + 10 register phases instead of the 105
@@ -12,13 +12,15 @@ typedef unsigned long long u64;
 
 __device__ __forceinline__ int lds_phys(int i) { return i + (i >> 4); }     // one pad word per 16 keys
 
-__device__ __forceinline__ void cswap(u64& a, u64& b, bool up) {
+template <class K>
+__device__ __forceinline__ void cswap(K& a, K& b, bool up) {
     const bool gt = a > b;
-    if (gt == up) { u64 t = a; a = b; b = t; }
+    if (gt == up) { K t = a; a = b; b = t; }
 }
 
 // strides 8,4,2,1 of one merge stage on the 16 keys a thread owns (all 16 share the direction once k >= 32)
-__device__ __forceinline__ void merge16(u64 (&v)[16], bool up) {
+template <class K>
+__device__ __forceinline__ void merge16(K (&v)[16], bool up) {
 #pragma unroll
     for (int j = 8; j >= 1; j >>= 1)
 #pragma unroll
@@ -27,12 +29,13 @@ __device__ __forceinline__ void merge16(u64 (&v)[16], bool up) {
 }
 
 // bytes of LDS `keys` needs for Npad keys (Npad a power of two >= 16)
-static inline size_t lds_sort_bytes(int Npad) { return ((size_t)(Npad + (Npad >> 4)) + 1) * sizeof(u64); }
+static inline size_t lds_sort_bytes(int Npad, size_t key_bytes = sizeof(u64)) { return ((size_t)(Npad + (Npad >> 4)) + 1) * key_bytes; }
 
 // Sort Npad keys ascending.  Thread t < Npad/16 owns positions 16t .. 16t+15: it passes their keys in v and receives the
 // sorted keys of the same positions back in v (the sorted sequence is also left in LDS, lds_phys layout).  EVERY thread of
 // the workgroup must call this (barriers inside); threads with t >= Npad/16 only take part in the barriers.
-__device__ __forceinline__ void block_sort16(u64 (&v)[16], u64* keys, int Npad, int t) {
+template <class K>
+__device__ __forceinline__ void block_sort16(K (&v)[16], K* keys, int Npad, int t) {
     const int nact = Npad >> 4;
     const bool active = t < nact;
     if (active) {
@@ -56,7 +59,7 @@ __device__ __forceinline__ void block_sort16(u64 (&v)[16], u64* keys, int Npad, 
                     const int p = q * nact + t;
                     const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
                     const int pa = lds_phys(i), pb = lds_phys(i + j);
-                    u64 a = keys[pa], c = keys[pb];
+                    K a = keys[pa], c = keys[pb];
                     const bool up = (i & k) == 0;
                     if ((a > c) == up) { keys[pa] = c; keys[pb] = a; }
                 }

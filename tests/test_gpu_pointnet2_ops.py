@@ -230,8 +230,8 @@ def test_fps_pruned_and_plain_variants_are_bit_identical(dev, cpu, monkeypatch, 
 def test_fps_slot_masks_on_ties_in_every_slot_alone_and_under_co_resident_waves(dev, cpu, busy, monkeypatch):
     """round-5 advisor finding: the hand-scheduled slot-mask blocks (csrc/fps.hip WaveMaxEq / wave_max_eq2_16) read a compare's
     SGPR pair from a v_addc the hazard recognizer cannot see.  Directed at them: clouds on which the maximum is held by SEVERAL slots of
-    one lane in every sample -- each point 16 / 8 / 2 times (equal Morton keys: the copies are consecutive in the sorted order, so they
-    sit in the slots of one lane, 0/1/8/9 included) and a 32 x 16 x 32 lattice -- on the 16-slot kernel (16384 -> 4096), the 4-slot kernel
+    one lane in every sample -- each point 16 / 8 / 2 times (equal Morton codes: the copies are neighbours in the sorted order, so they
+    sit in the slots of one lane or of adjacent lanes, 0/1/8/9 included) and a 32 x 16 x 32 lattice -- on the 16-slot kernel (16384 -> 4096), the 4-slot kernel
     (4096 -> 1024) and the single-wave kernels, once on an idle chip and once while matrix products from another stream share the CUs
     (the VALU co-issue conditions differ).  Indices must equal the oracle's (ties -> lowest original index)."""
     from pointrcnn_amd import ops
