@@ -28,6 +28,42 @@ __device__ __forceinline__ void merge16(K (&v)[16], bool up) {
             if ((e & j) == 0) cswap(v[e], v[e | j], up);
 }
 
+// One compare-exchange pass of stride j >= 16 inside merge stage k: the thread's 8 pairs are p = q * nact + t, element
+// i = ((p & ~(j-1)) << 1) | (p & (j-1)).  While j <= nact (all but the last few passes of the largest stages) the low bits of p are t's,
+// so i = i0(t, j) + q * 2 nact and, 2 nact being a multiple of 16, its padded address is lds_phys(i0) + q * (2 nact + nact / 8): one
+// address computation per pass instead of eight (round 6: a pass was ~160 instructions per thread of mostly index arithmetic -- the
+// sort is issue-bound, not LDS-bound: halving the keys had bought 11 %).  All 16 keys are read before any is written back.
+template <class K>
+__device__ __forceinline__ void lds_pass(K* keys, int nact, int t, int j, int k) {
+    K a[8], c[8];
+    if (j <= nact && nact >= 8) {
+        const int i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int D = 2 * nact, DP = D + (D >> 4);
+        K* pa = keys + lds_phys(i0);
+        K* pb = keys + lds_phys(i0 + j);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { a[q] = pa[q * DP]; c[q] = pb[q * DP]; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const bool up = ((i0 + q * D) & k) == 0;
+            if ((a[q] > c[q]) == up) { pa[q * DP] = c[q]; pb[q * DP] = a[q]; }
+        }
+    } else {
+        int ia[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int p = q * nact + t;
+            ia[q] = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+            a[q] = keys[lds_phys(ia[q])]; c[q] = keys[lds_phys(ia[q] + j)];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const bool up = (ia[q] & k) == 0;
+            if ((a[q] > c[q]) == up) { keys[lds_phys(ia[q])] = c[q]; keys[lds_phys(ia[q] + j)] = a[q]; }
+        }
+    }
+}
+
 // bytes of LDS `keys` needs for Npad keys (Npad a power of two >= 16)
 static inline size_t lds_sort_bytes(int Npad, size_t key_bytes = sizeof(u64)) { return ((size_t)(Npad + (Npad >> 4)) + 1) * key_bytes; }
 
@@ -53,17 +89,7 @@ __device__ __forceinline__ void block_sort16(K (&v)[16], K* keys, int Npad, int 
     __syncthreads();
     for (int k = 32; k <= Npad; k <<= 1) {
         for (int j = k >> 1; j >= 16; j >>= 1) {        // strides >= 16 through LDS: 8 pairs per owning thread
-            if (active) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int p = q * nact + t;
-                    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                    const int pa = lds_phys(i), pb = lds_phys(i + j);
-                    K a = keys[pa], c = keys[pb];
-                    const bool up = (i & k) == 0;
-                    if ((a > c) == up) { keys[pa] = c; keys[pb] = a; }
-                }
-            }
+            if (active) lds_pass(keys, nact, t, j, k);
             __syncthreads();
         }
         if (active) {                                   // strides 8..1 in registers
@@ -88,16 +114,7 @@ __device__ __forceinline__ void block_merge16(u64 (&v)[16], u64* keys, int Npad,
     }
     __syncthreads();
     for (int j = Npad >> 1; j >= 16; j >>= 1) {
-        if (active) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int p = q * nact + t;
-                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                const int pa = lds_phys(i), pb = lds_phys(i + j);
-                u64 a = keys[pa], c = keys[pb];
-                if (a > c) { keys[pa] = c; keys[pb] = a; }
-            }
-        }
+        if (active) lds_pass(keys, nact, t, j, 1 << 30);          // (i & 2^30) == 0: ascending everywhere
         __syncthreads();
     }
     if (active) {
