@@ -119,6 +119,37 @@ def test_rotated_prefiltered_kernel_equals_chunk_kernel_and_oracle(dev, cpu, mon
     assert np.array_equal(keep["1"][0], keep["0"][0]) and np.array_equal(keep["1"][1], keep["0"][1])
 
 
+@pytest.mark.parametrize("thresh", [0.8, 0.3, -1.0])
+def test_normal_prefiltered_kernel_equals_chunk_kernel_and_oracle(dev, cpu, monkeypatch, thresh):
+    """greedy_nms_pre_kernel (round 6: growing batches of candidates are tested against the kept list before the serial chunk step, on the
+    default axis-aligned path) keeps exactly what greedy_nms_kernel<NORMAL> (PRCNN_NMS_PREFILTER=0) and the oracle keep, on the 24-car
+    scene, at the RPN's threshold, a low one and a negative one (every pair suppresses: one box survives per range)."""
+    from pointrcnn_amd import ops
+    xyz, sc, reg = rpn_like_scene(3, 16384, seed=22)
+    B, N = sc.shape
+    boxes = ops.decode_bbox_target(_t(xyz.reshape(-1, 3), dev), _t(reg.reshape(-1, 76), dev), 3.0, 0.5, 12, ANCHOR,
+                                   get_xz_fine=True, y_to_bottom=True).view(B, N, 7)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PRCNN_NMS_PREFILTER", flag)
+        rois, scores, cnt = ops.proposal_layer(_t(sc, dev), boxes, (6300, 2700), (70, 30), thresh, rotated=False)
+        got[flag] = (rois.cpu().numpy(), scores.cpu().numpy(), cnt.cpu().numpy())
+    for a, b in zip(got["1"], got["0"]):
+        assert np.array_equal(a, b)
+    o = cpu.proposal_layer(sc, boxes.cpu().numpy(), (6300, 2700), (70, 30), thresh, "normal")
+    for a, b in zip(got["1"], o):
+        assert np.array_equal(a, b)
+    # small problems (fewer candidates than the first batch; more kept than one chunk) through nms_batched
+    keep = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PRCNN_NMS_PREFILTER", flag)
+        k, n = ops.nms_batched(boxes[:, :300].contiguous(), _t(sc[:, :300], dev), None, 0.1, False)
+        k2, n2 = ops.nms_batched(boxes[:, :40].contiguous(), _t(sc[:, :40], dev), None, 0.5, False)
+        keep[flag] = (k.cpu().numpy(), n.cpu().numpy(), k2.cpu().numpy(), n2.cpu().numpy())
+    for a, b in zip(keep["1"], keep["0"]):
+        assert np.array_equal(a, b)
+
+
 def test_nms_batched_equals_oracle_and_sorted_nms(dev, cpu):
     """tools/eval_rcnn.py:600-614: score-threshold select + rotated NMS 0.1 on the refined boxes, whole batch at once"""
     from pointrcnn_amd import ops
