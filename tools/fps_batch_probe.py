@@ -12,7 +12,9 @@ dev = torch.device("cuda:0")
 
 
 def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
+    for _ in range(4):          # (a launch right after a host-side pause runs at the idle clocks: warm up past it)
+        fn()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
         fn()
